@@ -1,0 +1,536 @@
+"""TEST INFRASTRUCTURE ONLY -- generate ``tests/golden/*.npz`` from the reference.
+
+Runs only in the build container (needs ``/root/reference``; see
+``oracle/ref_loader.py``).  Usage::
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+What runs is the reference's *own* ``Environment.take_turn`` /
+``Agent.transition`` / ``Gridworld.move`` / ``visual_field`` / ``shift`` /
+``OneHotObservationSpec`` / ``Buffer`` code (sorrel/environment.py:81-93 and
+everything under it).  Only the plugin points a Sorrel user is expected to
+write are supplied here: an ``Entity.transition`` and a ``BaseModel.take_action``
+that draw from the build's counter generator, and ``setup_agents`` /
+``populate_environment``.  Each fixture stores inputs (spec, seeds, scripted
+actions) and the reference's outputs (initial grid, per-turn float32
+observations as the reference's replay ``Buffer`` stored them, actions,
+rewards, ``world.total_reward``, grid and agent locations after every turn).
+
+Fixtures are data only; no reference source text is stored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from oracle import gridstep_oracle as O
+from oracle import ref_loader
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _import_reference():
+    ref_loader.install()
+    import sorrel.action.action_spec as action_spec
+    import sorrel.agents as agents
+    import sorrel.entities as entities
+    import sorrel.environment as environment
+    import sorrel.examples.treasurehunt.agents as th_agents
+    import sorrel.examples.treasurehunt.entities as th_entities
+    import sorrel.examples.treasurehunt.world as th_world
+    import sorrel.models.base_model as base_model
+    import sorrel.observation.observation_spec as observation_spec
+    import sorrel.worlds as worlds
+
+    return dict(action_spec=action_spec, agents=agents, entities=entities, environment=environment,
+                th_agents=th_agents, th_entities=th_entities, th_world=th_world,
+                base_model=base_model, observation_spec=observation_spec, worlds=worlds)
+
+
+class Ctx:
+    """Harness state the plugin classes read (the reference passes only `world`)."""
+    seed = 0
+    env = 0
+    epoch = 0
+    turn = 0
+    spec: O.Spec = None  # type: ignore
+    scripted = None      # optional [turn][agent] action script
+
+
+def build_plugins(R):
+    """Plugin classes, written against the reference's public plugin API."""
+    th = R["th_entities"]
+    BaseModel = R["base_model"].BaseModel
+    Entity = R["entities"].Entity
+
+    class CounterEmpty(th.EmptyEntity):
+        """Treasurehunt EmptyEntity whose two draws come from the counter RNG."""
+
+        def __init__(self):
+            super().__init__()
+            self.kind = "EmptyEntity"
+
+        def transition(self, world):
+            sp = Ctx.spec
+            y, x, z = self.location
+            idx = int(O.cell_index(sp, y, x, z))
+            u = int(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, O.STREAM_SPAWN, idx))
+            if u < O.prob_threshold(world.spawn_prob):
+                u2 = O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, O.STREAM_SPAWN_KIND, idx)
+                k = int(O.categorical(u2, 3))
+                ent = [th.Gem(world.values["gem"]), th.Food(world.values["food"]), th.Bone(world.values["bone"])][k]
+                world.add(self.location, ent)
+
+    class CounterModel(BaseModel):
+        """take_action = counter RNG keyed by the agent's slot (or a script)."""
+
+        def __init__(self, input_size, action_space, memory_size, slot):
+            super().__init__(input_size, action_space, memory_size)
+            self.slot = slot
+
+        def take_action(self, state):
+            if Ctx.scripted is not None:
+                return int(Ctx.scripted[Ctx.turn - 1][self.slot])
+            u = O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, O.STREAM_ACTION, self.slot)
+            return int(O.categorical(u, self.action_space))
+
+    class InertEmpty(Entity):
+        """Passable, no transitions, appears as EmptyEntity (like Sand)."""
+
+        def __init__(self):
+            super().__init__()
+            self.passable = True
+            self.kind = "EmptyEntity"
+
+    return CounterEmpty, CounterModel, InertEmpty
+
+
+# --------------------------------------------------------------------------- #
+# harness environments (user-side subclasses of the reference Environment)
+# --------------------------------------------------------------------------- #
+def make_treasurehunt_env(R, spec: O.Spec, turns: int, actions_names=("up", "down", "left", "right"),
+                          entity_map_override=None):
+    CounterEmpty, CounterModel, _ = build_plugins(R)
+    Environment = R["environment"].Environment
+    th, tha, thw = R["th_entities"], R["th_agents"], R["th_world"]
+    OneHot = R["observation_spec"].OneHotObservationSpec
+    ActionSpec = R["action_spec"].ActionSpec
+    entity_list = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+
+    class HarnessEnv(Environment):
+        def setup_agents(self):
+            agents = []
+            for slot in range(spec.num_agents):
+                ospec = OneHot(entity_list, full_view=False, vision_radius=spec.vision_radius)
+                if entity_map_override is not None:
+                    ospec.override_entity_map(entity_map_override)
+                ospec.override_input_size((int(np.prod(ospec.input_size)),))
+                aspec = ActionSpec(list(actions_names))
+                model = CounterModel(ospec.input_size, aspec.n_actions, memory_size=turns + 1, slot=slot)
+                agents.append(tha.TreasurehuntAgent(observation_spec=ospec, action_spec=aspec, model=model))
+            self.agents = agents
+
+        def populate_environment(self):
+            H, W = self.world.height, self.world.width
+            for index in np.ndindex(self.world.map.shape):
+                y, x, z = index
+                if (y in [0, H - 1] or x in [0, W - 1]) and z == 1:
+                    self.world.add(index, th.Wall())
+                elif z == 0:
+                    self.world.add(index, th.Sand())
+            # optional pre-seeding ("dense entities"), same draws as oracle reset_env
+            if spec.dense_prob > 0.0:
+                for y in range(1, H - 1):
+                    for x in range(1, W - 1):
+                        idx = int(O.cell_index(spec, y, x, 1))
+                        if int(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, O.STREAM_DENSE, idx)) < O.prob_threshold(spec.dense_prob):
+                            k = int(O.categorical(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, O.STREAM_DENSE_KIND, idx), 3))
+                            v = self.world.values
+                            self.world.add((y, x, 1), [th.Gem(v["gem"]), th.Food(v["food"]), th.Bone(v["bone"])][k])
+            pos = O.place_agents(spec, Ctx.env, Ctx.epoch)
+            for (y, x), agent in zip(pos, self.agents):
+                self.world.add((int(y), int(x), 1), agent)
+
+    cfg = {"world": {"height": spec.height, "width": spec.width,
+                     "gem_value": spec.type_value[3], "food_value": spec.type_value[5],
+                     "bone_value": spec.type_value[4], "spawn_prob": spec.spawn_prob[1]},
+           "experiment": {"epochs": 1, "max_turns": turns, "record_period": 1}}
+    world = thw.TreasurehuntWorld(config=cfg, default_entity=CounterEmpty())
+    return HarnessEnv(world, cfg), CounterEmpty
+
+
+def type_ids_treasurehunt(R, world, CounterEmpty) -> np.ndarray:
+    th = R["th_entities"]
+    Agent = R["agents"].Agent
+    H, W, L = world.map.shape
+    g = np.zeros((L, H, W), dtype=np.uint8)
+    for (y, x, z), e in np.ndenumerate(world.map):
+        if isinstance(e, Agent):
+            t = 6
+        elif type(e) is th.Sand:
+            t = 0
+        elif type(e) is CounterEmpty or type(e) is th.EmptyEntity:
+            t = 1
+        elif type(e) is th.Wall:
+            t = 2
+        elif type(e) is th.Gem:
+            t = 3
+        elif type(e) is th.Bone:
+            t = 4
+        elif type(e) is th.Food:
+            t = 5
+        else:
+            raise RuntimeError(f"unmapped entity {e!r}")
+        assert tuple(e.location) == (y, x, z), "entity.location out of sync with the map"
+        g[z, y, x] = t
+    return g
+
+
+def run_reference_treasurehunt(R, spec: O.Spec, env_ids, turns, scripted=None, epoch=0,
+                               actions_names=("up", "down", "left", "right"), entity_map_override=None):
+    E, A, C, V = len(env_ids), spec.num_agents, spec.num_channels, spec.window
+    out = dict(
+        grid0=np.zeros((E, spec.layers, spec.height, spec.width), np.uint8),
+        pos0=np.zeros((E, A, 2), np.uint8),
+        obs=np.zeros((turns, E, A, C, V, V), np.float32),
+        actions=np.zeros((turns, E, A), np.uint8),
+        rewards=np.zeros((turns, E, A), np.float32),
+        dones=np.zeros((turns, E, A), np.float32),
+        total_reward=np.zeros((turns, E), np.float64),
+        grid=np.zeros((turns, E, spec.layers, spec.height, spec.width), np.uint8),
+        pos=np.zeros((turns, E, A, 2), np.uint8),
+    )
+    for n, env_id in enumerate(env_ids):
+        Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec = spec.seed, int(env_id), epoch, 0, spec
+        Ctx.scripted = None if scripted is None else scripted[:, n]
+        env, CounterEmpty = make_treasurehunt_env(R, spec, turns, actions_names, entity_map_override)
+        out["grid0"][n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
+        out["pos0"][n] = [a.location[:2] for a in env.agents]
+        for t in range(turns):
+            Ctx.turn = env.turn + 1                     # Environment.turn after its increment
+            env.take_turn()                             # <- the reference's hot path
+            assert env.turn == Ctx.turn
+            for a, agent in enumerate(env.agents):
+                mem = agent.model.memory
+                out["obs"][t, n, a] = mem.states[t].reshape(C, V, V)
+                out["actions"][t, n, a] = mem.actions[t]
+                out["rewards"][t, n, a] = mem.rewards[t]
+                out["dones"][t, n, a] = mem.dones[t]
+                out["pos"][t, n, a] = agent.location[:2]
+                assert agent.location[2] == 1
+            out["total_reward"][t, n] = env.world.total_reward
+            out["grid"][t, n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# a second family: basic entities, arbitrary layers, walls on every layer
+# --------------------------------------------------------------------------- #
+def basic_spec(height, width, layers, num_agents, vision_radius, seed, dense_prob, actions_names,
+               appearance=None) -> O.Spec:
+    """Types: 0 InertEmpty (kind EmptyEntity), 1 Wall, 2 Gem(3.5), 3 Gem(-2), 4 MovingAgent-subclass 'Walker'.
+    Border walls on EVERY layer (the iowa layout, examples/iowa/env.py:105-107)."""
+    C = 4  # entity_list = ["EmptyEntity", "Wall", "Gem", "Walker"]
+    if appearance is None:
+        appearance = np.zeros((5, C))
+        appearance[1, 1] = 1.0
+        appearance[2, 2] = 1.0
+        appearance[3, 2] = 1.0
+        appearance[4, 3] = 1.0
+    moves = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
+    return O.Spec(
+        height=height, width=width, layers=layers, num_agents=num_agents, vision_radius=vision_radius,
+        num_types=5, num_channels=C, agent_layer=layers - 1, default_type=0, fill_type=1,
+        action_dy=[moves.get(n, (0, 0))[0] for n in actions_names],
+        action_dx=[moves.get(n, (0, 0))[1] for n in actions_names],
+        agent_type=[4] * num_agents, type_value=[0, -1, 3.5, -2, 0], type_passable=[1, 0, 1, 1, 0],
+        type_rule=[0] * 5, spawn_prob=[0.0] * 5, spawn_choices=[[]] * 5, appearance=appearance, seed=seed,
+        layer_fill_type=[0] * layers, layer_border_type=[1] * layers, dense_prob=dense_prob, dense_choices=[2, 3],
+    )
+
+
+def run_reference_basic(R, spec: O.Spec, env_ids, turns, actions_names, entity_map_override=None, epoch=0):
+    _, CounterModel, InertEmpty = build_plugins(R)
+    Environment = R["environment"].Environment
+    Gridworld = R["worlds"].Gridworld
+    ent = R["entities"]
+    MovingAgent = R["agents"].MovingAgent
+    OneHot = R["observation_spec"].OneHotObservationSpec
+    ActionSpec = R["action_spec"].ActionSpec
+    entity_list = ["EmptyEntity", "Wall", "Gem", "Walker"]
+    L, zA = spec.layers, spec.agent_layer
+
+    class Walker(MovingAgent):
+        """Concrete MovingAgent: the abstract hooks only (agents/agent.py:57-111)."""
+
+        def reset(self):
+            pass
+
+        def pov(self, world):
+            return self.observation_spec.observe(world, self.location).reshape(1, -1)
+
+        def get_action(self, state):
+            return self.model.take_action(state)
+
+        def is_done(self, world):
+            return world.is_done
+
+    class BasicEnv(Environment):
+        def setup_agents(self):
+            self.agents = []
+            for slot in range(spec.num_agents):
+                ospec = OneHot(entity_list, full_view=False, vision_radius=spec.vision_radius)
+                if entity_map_override is not None:
+                    ospec.override_entity_map(entity_map_override)
+                ospec.override_input_size((int(np.prod(ospec.input_size)),))
+                aspec = ActionSpec(list(actions_names))
+                model = CounterModel(ospec.input_size, aspec.n_actions, memory_size=turns + 1, slot=slot)
+                self.agents.append(Walker(ospec, aspec, model))
+
+        def populate_environment(self):
+            H, W = self.world.height, self.world.width
+            for index in np.ndindex(self.world.map.shape):
+                y, x, z = index
+                if y in [0, H - 1] or x in [0, W - 1]:
+                    self.world.add(index, ent.Wall())
+            if spec.dense_prob > 0.0:
+                for y in range(1, H - 1):
+                    for x in range(1, W - 1):
+                        idx = int(O.cell_index(spec, y, x, zA))
+                        if int(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, O.STREAM_DENSE, idx)) < O.prob_threshold(spec.dense_prob):
+                            k = int(O.categorical(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, O.STREAM_DENSE_KIND, idx), 2))
+                            self.world.add((y, x, zA), ent.Gem([3.5, -2][k]))
+            pos = O.place_agents(spec, Ctx.env, Ctx.epoch)
+            for (y, x), agent in zip(pos, self.agents):
+                self.world.add((int(y), int(x), zA), agent)
+
+    def type_ids(world):
+        H, W, Ls = world.map.shape
+        g = np.zeros((Ls, H, W), dtype=np.uint8)
+        for (y, x, z), e in np.ndenumerate(world.map):
+            if isinstance(e, Walker):
+                t = 4
+            elif type(e) is InertEmpty:
+                t = 0
+            elif type(e) is ent.Wall:
+                t = 1
+            elif type(e) is ent.Gem:
+                t = 2 if e.value == 3.5 else 3
+            else:
+                raise RuntimeError(f"unmapped entity {e!r}")
+            g[z, y, x] = t
+        return g
+
+    E, A, C, V = len(env_ids), spec.num_agents, spec.num_channels, spec.window
+    out = dict(
+        grid0=np.zeros((E, L, spec.height, spec.width), np.uint8), pos0=np.zeros((E, A, 2), np.uint8),
+        obs=np.zeros((turns, E, A, C, V, V), np.float32), actions=np.zeros((turns, E, A), np.uint8),
+        rewards=np.zeros((turns, E, A), np.float32), dones=np.zeros((turns, E, A), np.float32),
+        total_reward=np.zeros((turns, E), np.float64),
+        grid=np.zeros((turns, E, L, spec.height, spec.width), np.uint8), pos=np.zeros((turns, E, A, 2), np.uint8),
+    )
+    cfg = {"experiment": {"epochs": 1, "max_turns": turns, "record_period": 1}}
+    for n, env_id in enumerate(env_ids):
+        Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec, Ctx.scripted = spec.seed, int(env_id), epoch, 0, spec, None
+        env = BasicEnv(Gridworld(spec.height, spec.width, L, InertEmpty()), cfg)
+        out["grid0"][n] = type_ids(env.world)
+        out["pos0"][n] = [a.location[:2] for a in env.agents]
+        for t in range(turns):
+            Ctx.turn = env.turn + 1
+            env.take_turn()
+            for a, agent in enumerate(env.agents):
+                mem = agent.model.memory
+                out["obs"][t, n, a] = mem.states[t].reshape(C, V, V)
+                out["actions"][t, n, a] = mem.actions[t]
+                out["rewards"][t, n, a] = mem.rewards[t]
+                out["dones"][t, n, a] = mem.dones[t]
+                out["pos"][t, n, a] = agent.location[:2]
+            out["total_reward"][t, n] = env.world.total_reward
+            out["grid"][t, n] = type_ids(env.world)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# stock Treasurehunt with the reference's own global np.random stream
+# --------------------------------------------------------------------------- #
+def run_reference_stock(R, height, width, num_agents, radius, spawn_prob, turns, np_seed):
+    """Unmodified Treasurehunt entities/agents/world + RandomModel; only
+    setup_agents is replaced (the stock one builds a PyTorch IQN)."""
+    Environment = R["environment"].Environment
+    th, tha, thw = R["th_entities"], R["th_agents"], R["th_world"]
+    RandomModel = R["base_model"].RandomModel
+    OneHot = R["observation_spec"].OneHotObservationSpec
+    ActionSpec = R["action_spec"].ActionSpec
+    import sorrel.examples.treasurehunt.env as th_env_mod
+    entity_list = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+
+    class StockEnv(th_env_mod.TreasurehuntEnv):
+        def setup_agents(self):
+            self.agents = []
+            for _ in range(num_agents):
+                ospec = OneHot(entity_list, full_view=False, vision_radius=radius)
+                ospec.override_input_size((int(np.prod(ospec.input_size)),))
+                aspec = ActionSpec(["up", "down", "left", "right"])
+                model = RandomModel(ospec.input_size, aspec.n_actions, memory_size=turns + 1)
+                self.agents.append(tha.TreasurehuntAgent(ospec, aspec, model))
+
+    cfg = {"world": {"height": height, "width": width, "gem_value": 10, "food_value": 5,
+                     "bone_value": -10, "spawn_prob": spawn_prob},
+           "model": {"agent_vision_radius": radius, "num_agents": num_agents},
+           "experiment": {"epochs": 1, "max_turns": turns, "record_period": 1}}
+    np.random.seed(np_seed)
+    world = thw.TreasurehuntWorld(config=cfg, default_entity=th.EmptyEntity())
+    env = StockEnv(world, cfg)
+    A, C, V = num_agents, 6, 2 * radius + 1
+    out = dict(
+        grid0=type_ids_treasurehunt(R, env.world, th.EmptyEntity)[None],
+        pos0=np.array([[a.location[:2] for a in env.agents]], np.uint8),
+        obs=np.zeros((turns, 1, A, C, V, V), np.float32), actions=np.zeros((turns, 1, A), np.uint8),
+        rewards=np.zeros((turns, 1, A), np.float32), total_reward=np.zeros((turns, 1), np.float64),
+        grid=np.zeros((turns, 1, 2, height, width), np.uint8), pos=np.zeros((turns, 1, A, 2), np.uint8),
+    )
+    for t in range(turns):
+        env.take_turn()
+        for a, agent in enumerate(env.agents):
+            mem = agent.model.memory
+            out["obs"][t, 0, a] = mem.states[t].reshape(C, V, V)
+            out["actions"][t, 0, a] = mem.actions[t]
+            out["rewards"][t, 0, a] = mem.rewards[t]
+            out["pos"][t, 0, a] = agent.location[:2]
+        out["total_reward"][t, 0] = env.world.total_reward
+        out["grid"][t, 0] = type_ids_treasurehunt(R, env.world, th.EmptyEntity)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+def spec_to_json(spec: O.Spec) -> str:
+    d = {k: getattr(spec, k) for k in spec.__dataclass_fields__ if k != "appearance"}
+    d = {k: (list(map(lambda v: list(v) if isinstance(v, (list, tuple)) else v, v)) if isinstance(v, (list, tuple)) else v)
+         for k, v in d.items()}
+    d["appearance"] = np.asarray(spec.appearance, dtype=np.float64).tolist()
+    return json.dumps(d)
+
+
+def save(name, spec, env_ids, ref, extra=None):
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    payload = dict(ref)
+    payload["spec_json"] = np.array(spec_to_json(spec))
+    payload["env_ids"] = np.asarray(env_ids, dtype=np.int64)
+    if extra:
+        payload.update(extra)
+    np.savez_compressed(path, **payload)
+    print(f"  wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+def check_against_oracle(spec, env_ids, turns, ref, scripted=None, epoch=0):
+    mine = O.rollout(spec, env_ids, turns, epoch=epoch, actions=scripted)
+    for k in ("grid0", "pos0", "obs", "actions", "rewards", "total_reward", "grid", "pos"):
+        if not np.array_equal(mine[k], ref[k]):
+            bad = np.argwhere(mine[k] != ref[k])[0]
+            raise AssertionError(f"restatement differs from the reference in {k} at {bad}")
+    assert not ref["dones"].any(), "reference stored done != 0 inside an epoch"
+
+
+def main() -> int:
+    if not ref_loader.reference_available():
+        print("reference not available; fixtures cannot be regenerated here", file=sys.stderr)
+        return 1
+    R = _import_reference()
+    t0 = time.time()
+    moves = ("up", "down", "left", "right")
+
+    print("c1_treasurehunt_10x10: BASELINE config 1 (10x10, 2 agents, r=2, 100 turns)")
+    spec = O.treasurehunt_spec(10, 10, 2, 2, spawn_prob=0.005, seed=0)
+    ref = run_reference_treasurehunt(R, spec, [0], 100)
+    check_against_oracle(spec, [0], 100, ref)
+    save("c1_treasurehunt_10x10", spec, [0], ref)
+
+    print("c2_treasurehunt_16x16: config-2 shape, 4 envs x 16 turns")
+    spec = O.treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.02, seed=1)
+    ids = [0, 1, 2, 4095]
+    ref = run_reference_treasurehunt(R, spec, ids, 16)
+    check_against_oracle(spec, ids, 16, ref)
+    save("c2_treasurehunt_16x16", spec, ids, ref)
+
+    print("c3_treasurehunt_32x32: headline shape, 2 envs x 8 turns")
+    spec = O.treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=0)
+    ids = [0, 65535]
+    ref = run_reference_treasurehunt(R, spec, ids, 8)
+    check_against_oracle(spec, ids, 8, ref)
+    save("c3_treasurehunt_32x32", spec, ids, ref)
+
+    print("crowded_6x6: 6 agents on a 4x4 interior, p=0.2 (contention, bumps, pickups)")
+    spec = O.treasurehunt_spec(6, 6, 6, 2, spawn_prob=0.2, seed=11)
+    ids = [3, 9]
+    ref = run_reference_treasurehunt(R, spec, ids, 40)
+    check_against_oracle(spec, ids, 40, ref)
+    save("crowded_6x6", spec, ids, ref)
+
+    print("ragged_9x13_rmax: non-square odd grid, r = (min-1)//2 = 4, dense pre-seeding, epoch 3")
+    spec = O.treasurehunt_spec(9, 13, 3, 4, spawn_prob=0.03, seed=5, dense_prob=0.25)
+    ids = [7]
+    ref = run_reference_treasurehunt(R, spec, ids, 25, epoch=3)
+    check_against_oracle(spec, ids, 25, ref, epoch=3)
+    save("ragged_9x13_rmax", spec, ids, ref, extra={"epoch": np.array(3)})
+
+    print("c5_small_dense: config-5 flavour scaled down (24x24, 12 agents, r=5, dense)")
+    spec = O.treasurehunt_spec(24, 24, 12, 5, spawn_prob=0.05, seed=2, dense_prob=0.25)
+    ids = [0, 16383]
+    ref = run_reference_treasurehunt(R, spec, ids, 6)
+    check_against_oracle(spec, ids, 6, ref)
+    save("c5_small_dense", spec, ids, ref)
+
+    print("scripted_noop: 5 actions incl. a non-move name -> stay in place, reward = own value")
+    names = ("up", "down", "left", "right", "noop")
+    spec = O.treasurehunt_spec(8, 8, 2, 2, spawn_prob=0.1, seed=4)
+    spec.action_dy, spec.action_dx = [-1, 1, 0, 0, 0], [0, 0, -1, 1, 0]
+    rng = np.random.default_rng(0)
+    scripted = rng.integers(0, 5, size=(20, 1, 2))
+    scripted[3] = 4
+    ref = run_reference_treasurehunt(R, spec, [1], 20, scripted=scripted, actions_names=names)
+    check_against_oracle(spec, [1], 20, ref, scripted=scripted)
+    save("scripted_noop", spec, [1], ref, extra={"scripted": scripted.astype(np.uint8)})
+
+    print("basic_doublewall: basic entities, 2 layers, walls on both (layer sum = 2.0), float values")
+    spec = basic_spec(11, 8, 2, 3, 3, seed=8, dense_prob=0.3, actions_names=moves)
+    ids = [0, 5]
+    ref = run_reference_basic(R, spec, ids, 25, moves)
+    check_against_oracle(spec, ids, 25, ref)
+    assert ref["obs"].max() == 2.0
+    save("basic_doublewall", spec, ids, ref)
+
+    print("basic_1layer: single-layer world (agents and items share the only layer)")
+    spec = basic_spec(9, 9, 1, 2, 2, seed=9, dense_prob=0.4, actions_names=moves)
+    ref = run_reference_basic(R, spec, [2], 30, moves)
+    check_against_oracle(spec, [2], 30, ref)
+    save("basic_1layer", spec, [2], ref)
+
+    print("float_appearance_3layer: override_entity_map with arbitrary floats, 3 layers (f64 layer sum)")
+    rng = np.random.default_rng(42)
+    emap = {k: (rng.standard_normal(4) * 10.0 ** rng.integers(-3, 4, 4)) for k in ["EmptyEntity", "Wall", "Gem", "Walker"]}
+    app = np.stack([emap["EmptyEntity"], emap["Wall"], emap["Gem"], emap["Gem"], emap["Walker"]])
+    spec = basic_spec(10, 12, 3, 3, 2, seed=10, dense_prob=0.3, actions_names=moves, appearance=app)
+    ref = run_reference_basic(R, spec, [4], 12, moves, entity_map_override=emap)
+    check_against_oracle(spec, [4], 12, ref)
+    save("float_appearance_3layer", spec, [4], ref)
+
+    print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
+    ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)
+    spec = O.treasurehunt_spec(10, 10, 2, 2, spawn_prob=0.05, seed=0)
+    from oracle import numpy_order
+    mine = numpy_order.rollout_numpy_order(spec, 60, np_seed=0)
+    for k in ("grid0", "pos0", "obs", "actions", "rewards", "total_reward", "grid", "pos"):
+        assert np.array_equal(mine[k], ref[k]), f"numpy-order restatement differs in {k}"
+    save("stock_np_random", spec, [0], ref, extra={"np_seed": np.array(0)})
+
+    print(f"done in {time.time() - t0:.1f}s")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/s of the batched take_turn hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N=1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``Environment.take_turn`` over the whole env batch (entity sweep,
+A sequential agent transitions with egocentric observations, rewards, moves) with
+random actions drawn on device.  Workload at N=1 = BASELINE.json configs[2]
+(headline): 32x32 grid, 8 agents, 7x7 window, 65 536 envs; for N>1 each rank owns
+65 536 envs of a global batch of N*65 536 (weak scaling; N=8 is configs[3]).  Envs
+shard with no data-path collective; the only collective is one all-reduce (RCCL)
+of the 4-double metric vector at the end of the rollout.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+CONFIGS = {
+    # name: (H, W, agents, radius, envs per GPU, spawn_prob, dense_prob)
+    "c2": (16, 16, 4, 2, 4096, 0.005, 0.0),
+    "c3": (32, 32, 8, 3, 65536, 0.005, 0.0),
+    "c5": (128, 128, 64, 5, 2048, 0.05, 0.25),
+}
+
+
+def cpu_baseline(spec, seconds_target: float = 12.0):
+    """The C oracle ("port") timed on this host's cores on a bounded sample of the
+    same workload.  Only the checker is used here, never as the thing measured above."""
+    import ctypes as C
+
+    import numpy as np
+
+    import __graft_entry__ as g
+
+    lib = C.CDLL(g.build_oracle())
+    lib.sgo_threads.argtypes = [C.c_int]
+    cores = int(lib.sgo_threads(0))
+    A = spec.num_agents
+    E = 4096 if spec.grid_bytes_per_env() <= 4096 else 256
+    cfg = spec.to_config(E, 0)
+    grid = np.zeros((E, spec.layers, spec.height, spec.width), np.uint8)
+    pos = np.zeros((E, A, 2), np.uint8)
+    act = np.zeros((E, A), np.uint8)
+    obs = np.zeros((E,) + spec.obs_shape, np.float32)
+    rew = np.zeros((E, A), np.float32)
+    tot = np.zeros((E,), np.float64)
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    lib.sgo_reset(C.byref(cfg), p(grid), p(pos), p(tot), C.c_uint32(0), C.c_int(0))
+
+    def run(t0, n):
+        for t in range(t0, t0 + n):
+            lib.sgo_step(C.byref(cfg), p(grid), p(pos), p(act), p(obs), p(rew), p(tot), C.c_uint32(0), C.c_uint32(t),
+                         C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(0))
+
+    run(1, 2)                                   # warm-up + page-in
+    t = time.perf_counter()
+    run(3, 3)
+    per_turn = (time.perf_counter() - t) / 3
+    turns = max(3, min(2000, int(seconds_target / max(per_turn, 1e-6))))
+    t = time.perf_counter()
+    run(6, turns)
+    dt = time.perf_counter() - t
+    return {
+        "value": E * A * turns / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+        "sample": f"oracle/gridstep_oracle.c (OpenMP, {cores} threads), {E} envs x {turns} turns of the same "
+                  f"{spec.height}x{spec.width}x{A}-agent workload, {dt:.1f} s",
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip observation stores (NOT a valid bench line)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from sorrel_amd.engine import GridEngine
+    from sorrel_amd.spec import treasurehunt_spec
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device; the hot path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    H, W, A, r, E_cfg, p_spawn, p_dense = CONFIGS[args.config]
+    E = args.envs or E_cfg
+    spec = treasurehunt_spec(H, W, A, r, spawn_prob=p_spawn, seed=0, dense_prob=p_dense)
+    eng = GridEngine(spec, E, device=dev, first_env_id=rank * E)   # global env ids: re-sharding is bit-exact
+    eng.reset(epoch=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    write_obs = not args.no_obs
+    for _ in range(args.warmup):
+        eng.step(random_actions=True, write_obs=write_obs)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                   # on the stream sgw_step launches on
+    for _ in range(args.steps):
+        eng.step(random_actions=True, write_obs=write_obs)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events over the timed region, per launch
+
+    # end-of-rollout metrics: on-device reduction + the one collective
+    metrics = eng.reduce_metrics().clone()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    status = eng.status()
+
+    if rank == 0:
+        total_envs = E * world
+        value = total_envs * A * args.steps / dt
+        alg_bytes = spec.algorithmic_bytes_per_env_step() * E          # per launch (one rank's kernel)
+        if not write_obs:
+            alg_bytes -= E * A * spec.num_channels * spec.window ** 2 * 4
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {H}x{W} grid x {spec.layers} layers, {A} agents, {spec.window}x{spec.window} window, "
+                            f"{E} envs/GPU x {world} GPU = {total_envs} envs, treasurehunt rules, random actions, f32 one-hot obs",
+                "envs_per_gpu": E, "global_envs": total_envs, "agents": A, "grid": [H, W, spec.layers],
+                "window": spec.window, "channels": spec.num_channels, "spawn_prob": p_spawn, "dense_prob": p_dense,
+                "sharding": f"env-batch x{world}, no data-path collective; one 32-byte all-reduce at end of rollout",
+                "obs_written": write_obs,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
+            },
+            "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

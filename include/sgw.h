@@ -1,0 +1,182 @@
+/*
+ * sgw.h -- C ABI of the MI355X batched gridworld step/observation engine.
+ *
+ * Sorrel (social-ai-uoft/sorrel v1.4.0) is pure Python and has no FFI; the
+ * interface a maintainer would bind is its class-based plugin API.  Each entry
+ * point below names the reference interface it replaces for a batch of E
+ * independent environments (paths relative to the reference root):
+ *
+ *   sgw_create      Environment.__init__ / setup_agents       sorrel/environment.py:36-54
+ *                   + OneHotObservationSpec.__init__/generate_map
+ *                                                             sorrel/observation/observation_spec.py:128-173
+ *                   + Entity attribute table                  sorrel/entities/entity.py:29-39
+ *                   + ActionSpec / MovingAgent.movement table sorrel/action/action_spec.py:23-26,
+ *                                                             sorrel/agents/agent.py:187-213
+ *   sgw_reset       Environment.reset -> Gridworld.create_world + populate_environment
+ *                                                             sorrel/environment.py:72-79,
+ *                                                             sorrel/worlds/gridworld.py:47-65,
+ *                                                             sorrel/examples/treasurehunt/env.py:114-147
+ *   sgw_observe     OneHotObservationSpec.observe -> visual_field -> shift
+ *                                                             sorrel/observation/observation_spec.py:175-205,
+ *                                                             sorrel/observation/visual_field.py:9-101,
+ *                                                             sorrel/utils/helpers.py:48-77
+ *   sgw_step        Environment.take_turn                     sorrel/environment.py:81-93
+ *                   -> Entity.transition sweep                sorrel/examples/treasurehunt/entities.py:69-85
+ *                   -> Agent.transition (pov, act, reward)    sorrel/agents/agent.py:155-173
+ *                   -> MovingAgent.act -> Gridworld.move      sorrel/agents/agent.py:215-225,
+ *                                                             sorrel/worlds/gridworld.py:95-122
+ *   sgw_reduce_metrics  world.total_reward read-out           sorrel/environment.py:193-199
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SGW_E* code and never
+ *     throws; sgw_last_error() returns the message of the calling thread's
+ *     last failure;
+ *   - all array arguments are DEVICE pointers owned by the caller (PyTorch);
+ *     the library owns only the engine handle, its constant tables and a small
+ *     reduction workspace;
+ *   - all work is enqueued asynchronously on the HIP stream passed as `stream`
+ *     (a hipStream_t, NULL = default stream); no call synchronises except
+ *     sgw_get_status;
+ *   - one engine per device, not thread-safe per engine (the reference is
+ *     single-threaded);
+ *   - there is no CPU fallback: without a HIP device every launch fails.
+ *
+ * Tensor layouts (C order, per-env contiguous)
+ *   grid          uint8  [E][L][H][W]   entity TYPE id per cell
+ *   agent_pos     uint8  [E][A][2]      (y, x) of each agent on `agent_layer`
+ *   actions       uint8  [E][A]         action index per agent
+ *   obs           float  [E][A][C][V][V], V = 2*vision_radius+1
+ *   rewards       float  [E][A]
+ *   total_reward  double [E]            world.total_reward (float64, agent order)
+ */
+#ifndef SGW_H
+#define SGW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGW_MAX_TYPES 32
+#define SGW_MAX_CHANNELS 16
+#define SGW_MAX_CHOICES 8
+#define SGW_MAX_ACTIONS 16
+#define SGW_MAX_AGENTS 64
+#define SGW_MAX_LAYERS 7   /* numpy sums <= 7 layers left to right; 8+ pairwise */
+#define SGW_MAX_DIM 256    /* positions are uint8 */
+
+/* entity transition rules (Entity.transition plugins the device can run) */
+#define SGW_RULE_NONE 0
+#define SGW_RULE_SPAWN 1   /* w.p. p replace own cell by one of n types, uniformly */
+
+#define SGW_NO_BORDER 255
+
+/* counter-RNG stream ids: u32 = Philox4x32-10(ctr = {index>>2, turn, env, epoch<<4|stream},
+ * key = {seed lo, seed hi})[index & 3] */
+#define SGW_STREAM_SPAWN 0
+#define SGW_STREAM_SPAWN_KIND 1
+#define SGW_STREAM_ACTION 2
+#define SGW_STREAM_PLACE 3
+#define SGW_STREAM_DENSE 4
+#define SGW_STREAM_DENSE_KIND 5
+
+/* sgw_step flags */
+#define SGW_STEP_SWEEP 1u           /* run the entity-transition sweep first */
+#define SGW_STEP_RANDOM_ACTIONS 2u  /* draw actions from STREAM_ACTION and STORE them to `actions` */
+#define SGW_STEP_NO_OBS 4u          /* do not write observations (obs may be NULL) */
+#define SGW_STEP_DEFAULT (SGW_STEP_SWEEP)
+
+/* error codes */
+#define SGW_OK 0
+#define SGW_EINVAL (-1)   /* rejected configuration / argument */
+#define SGW_EHIP (-2)     /* HIP runtime error */
+#define SGW_ENOMEM (-3)
+
+/* bits of the device status word (sgw_get_status) */
+#define SGW_STATUS_OOB_MOVE 1   /* an agent targeted a cell outside the grid (reference: IndexError / wrap) */
+#define SGW_STATUS_BAD_ACTION 2 /* action index >= num_actions */
+#define SGW_STATUS_BAD_TYPE 4   /* grid holds a type id >= num_types */
+
+typedef struct sgw_config {
+    int32_t height, width, layers;
+    int32_t num_agents, vision_radius;
+    int32_t num_types, num_channels, num_actions;
+    int32_t agent_layer;   /* layer (z) every agent lives on */
+    int32_t default_type;  /* Gridworld.default_entity: refills vacated cells */
+    int32_t fill_type;     /* ObservationSpec.fill_entity_kind: out-of-bounds appearance */
+    int32_t reserved0;
+    int8_t action_dy[SGW_MAX_ACTIONS]; /* in {-1,0,1}; (0,0) for non-move action names */
+    int8_t action_dx[SGW_MAX_ACTIONS];
+    uint8_t agent_type[SGW_MAX_AGENTS];
+    double type_value[SGW_MAX_TYPES];     /* Entity.value */
+    uint8_t type_passable[SGW_MAX_TYPES]; /* Entity.passable */
+    uint8_t type_rule[SGW_MAX_TYPES];     /* SGW_RULE_* (Entity.has_transitions + transition) */
+    double spawn_prob[SGW_MAX_TYPES];
+    uint8_t spawn_count[SGW_MAX_TYPES];
+    uint8_t spawn_choice[SGW_MAX_TYPES][SGW_MAX_CHOICES];
+    double appearance[SGW_MAX_TYPES][SGW_MAX_CHANNELS]; /* ObservationSpec.entity_map[kind of type] */
+    /* reset layout (populate_environment): per-layer fill and border types,
+     * optional Bernoulli pre-seeding of the agent layer's interior, agents on
+     * distinct interior cells */
+    uint8_t layer_fill_type[8];
+    uint8_t layer_border_type[8]; /* SGW_NO_BORDER = none */
+    double dense_prob;
+    uint8_t dense_count;
+    uint8_t dense_choice[SGW_MAX_CHOICES];
+    uint8_t reserved1[7];
+    uint64_t seed;
+    uint64_t first_env_id; /* global id of local env 0 (multi-GPU sharding) */
+    int64_t num_envs;      /* E on this device */
+} sgw_config;
+
+typedef struct sgw_engine sgw_engine;
+
+int sgw_create(const sgw_config* cfg, sgw_engine** out);
+void sgw_destroy(sgw_engine* eng);
+
+int sgw_reset(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, double* total_reward,
+              uint32_t epoch, void* stream);
+
+/* Stateless observation of agents [agent_begin, agent_end) from the current
+ * grid; obs rows of other agents are left untouched. */
+int sgw_observe(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_pos, float* obs,
+                int32_t agent_begin, int32_t agent_end, void* stream);
+
+/* One take_turn for every env.  `turn` is Environment.turn AFTER its increment
+ * (1 for the first turn of an epoch).  Agents [agent_begin, agent_end) are
+ * stepped sequentially; pass (0, num_agents) for a whole turn.  A policy-driven
+ * loop that must reproduce "agent i+1 observes agent i's move" calls
+ * sgw_step once per agent with SGW_STEP_SWEEP only on the first call. */
+int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs,
+             float* rewards, double* total_reward, uint32_t epoch, uint32_t turn,
+             int32_t agent_begin, int32_t agent_end, uint32_t flags, void* stream);
+
+/* out (device, 4 doubles) = { sum(total_reward), sum(total_reward^2), E, 0 },
+ * summed in a fixed order (bitwise reproducible). */
+int sgw_reduce_metrics(sgw_engine* eng, const double* total_reward, double* out, void* stream);
+
+/* Fill `actions` from STREAM_ACTION without stepping (what a RandomModel would choose). */
+int sgw_random_actions(sgw_engine* eng, uint8_t* actions, uint32_t epoch, uint32_t turn, void* stream);
+
+/* Synchronising: copies and clears the device status word (SGW_STATUS_* bits). */
+int sgw_get_status(sgw_engine* eng, int32_t* status_out, void* stream);
+
+/* Shape helpers (pure host arithmetic). */
+int64_t sgw_obs_elems_per_env(const sgw_config* cfg);
+int64_t sgw_grid_bytes_per_env(const sgw_config* cfg);
+/* Algorithmic HBM bytes of one env-step (SURVEY.md 8d formula). */
+int64_t sgw_algorithmic_bytes_per_env_step(const sgw_config* cfg);
+
+/* Name and duration (ms, HIP events on `stream`) bookkeeping for the LAST
+ * sgw_step launch when timing is enabled with sgw_set_timing(eng, 1). */
+int sgw_set_timing(sgw_engine* eng, int enable);
+int sgw_get_step_time_ms(sgw_engine* eng, double* total_ms, int64_t* launches);
+
+const char* sgw_last_error(void);
+const char* sgw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGW_H */

@@ -1,0 +1,134 @@
+"""ctypes binding of the C ABI in ``include/sgw.h`` (``sorrel_amd/csrc/libsgw.so``).
+
+There is no CPU fallback: if the HIP library is missing, or a second HIP runtime
+gets mapped next to PyTorch's, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
+RULE_NONE, RULE_SPAWN = 0, 1
+NO_BORDER = 255
+STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS = 1, 2, 4
+STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE = 1, 2, 4
+OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
+
+
+class SgwConfig(C.Structure):
+    """Mirror of ``struct sgw_config`` (include/sgw.h); layout checked by tests/test_abi.py."""
+
+    _fields_ = [
+        ("height", C.c_int32), ("width", C.c_int32), ("layers", C.c_int32),
+        ("num_agents", C.c_int32), ("vision_radius", C.c_int32),
+        ("num_types", C.c_int32), ("num_channels", C.c_int32), ("num_actions", C.c_int32),
+        ("agent_layer", C.c_int32), ("default_type", C.c_int32), ("fill_type", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("action_dy", C.c_int8 * MAX_ACTIONS), ("action_dx", C.c_int8 * MAX_ACTIONS),
+        ("agent_type", C.c_uint8 * MAX_AGENTS),
+        ("type_value", C.c_double * MAX_TYPES),
+        ("type_passable", C.c_uint8 * MAX_TYPES),
+        ("type_rule", C.c_uint8 * MAX_TYPES),
+        ("spawn_prob", C.c_double * MAX_TYPES),
+        ("spawn_count", C.c_uint8 * MAX_TYPES),
+        ("spawn_choice", (C.c_uint8 * MAX_CHOICES) * MAX_TYPES),
+        ("appearance", (C.c_double * MAX_CHANNELS) * MAX_TYPES),
+        ("layer_fill_type", C.c_uint8 * 8),
+        ("layer_border_type", C.c_uint8 * 8),
+        ("dense_prob", C.c_double),
+        ("dense_count", C.c_uint8),
+        ("dense_choice", C.c_uint8 * MAX_CHOICES),
+        ("reserved1", C.c_uint8 * 7),
+        ("seed", C.c_uint64),
+        ("first_env_id", C.c_uint64),
+        ("num_envs", C.c_int64),
+    ]
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgw.so")
+
+# every symbol include/sgw.h declares
+EXPORTS = (
+    "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_reduce_metrics",
+    "sgw_random_actions", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
+    "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms",
+    "sgw_last_error", "sgw_version",
+)
+
+_lib = None
+
+
+class SgwError(RuntimeError):
+    pass
+
+
+def _hip_runtimes_mapped():
+    paths = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def load():
+    """Load libsgw.so (after torch, so that it binds to torch's HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SgwError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the step/observe path."
+        )
+    import torch  # noqa: F401  (maps torch's libamdhip64 first; libsgw.so then resolves to the same soname)
+
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise SgwError(f"two HIP runtimes are mapped in this process ({rts}); stream handles would not be shared")
+    vp, u8p, f32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    cfgp = C.POINTER(SgwConfig)
+    lib.sgw_create.argtypes = [cfgp, C.POINTER(vp)]
+    lib.sgw_create.restype = C.c_int
+    lib.sgw_destroy.argtypes = [vp]
+    lib.sgw_destroy.restype = None
+    lib.sgw_reset.argtypes = [vp, u8p, u8p, f64p, C.c_uint32, vp]
+    lib.sgw_reset.restype = C.c_int
+    lib.sgw_observe.argtypes = [vp, u8p, u8p, f32p, C.c_int32, C.c_int32, vp]
+    lib.sgw_observe.restype = C.c_int
+    lib.sgw_step.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, f64p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                             C.c_uint32, vp]
+    lib.sgw_step.restype = C.c_int
+    lib.sgw_reduce_metrics.argtypes = [vp, f64p, f64p, vp]
+    lib.sgw_reduce_metrics.restype = C.c_int
+    lib.sgw_random_actions.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]
+    lib.sgw_random_actions.restype = C.c_int
+    lib.sgw_get_status.argtypes = [vp, C.POINTER(C.c_int32), vp]
+    lib.sgw_get_status.restype = C.c_int
+    for name in ("sgw_obs_elems_per_env", "sgw_grid_bytes_per_env", "sgw_algorithmic_bytes_per_env_step"):
+        getattr(lib, name).argtypes = [cfgp]
+        getattr(lib, name).restype = C.c_int64
+    lib.sgw_set_timing.argtypes = [vp, C.c_int]
+    lib.sgw_set_timing.restype = C.c_int
+    lib.sgw_get_step_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.sgw_get_step_time_ms.restype = C.c_int
+    lib.sgw_last_error.argtypes = []
+    lib.sgw_last_error.restype = C.c_char_p
+    lib.sgw_version.argtypes = []
+    lib.sgw_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        msg = load().sgw_last_error().decode("utf-8", "replace")
+        if rc == EINVAL:
+            raise ValueError(msg)   # the reference raises ValueError/TypeError for bad specs
+        raise SgwError(f"sgw error {rc}: {msg}")

@@ -1,0 +1,939 @@
+// sgw.hip -- MI355X (gfx950 / CDNA4) batched gridworld step + observation engine.
+//
+// Hand-written HIP behind the C ABI of include/sgw.h.  One thread GROUP owns
+// one environment for a whole take_turn:
+//   * <= 4 KiB worlds (e.g. 32x32x2): one 64-lane wavefront per env, four envs
+//     per 256-thread workgroup, wave-level ordering only (no s_barrier);
+//   * larger worlds (e.g. 128x128x2): one 256-thread workgroup per env.
+// The env's grid (uint8 type ids, [L][H][W]) is staged once into LDS with
+// 16-byte loads, the entity sweep and all sequential agent phases run against
+// LDS, observation windows are gathered from LDS and streamed to HBM as
+// contiguous dword stores (lane = window cell, loop over channels), and the
+// grid is written back once with 16-byte stores.  Integer / indexing work only:
+// no MFMA, bound = HBM bandwidth (observation stores dominate).
+//
+// Semantics follow the reference Python step loop bit for bit; see
+// include/sgw.h for the reference file:line each entry point replaces and
+// oracle/gridstep_oracle.py for the line-by-line CPU restatement the kernels
+// are tested against.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/sgw.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+constexpr int kMaxPass = 2;  // window cells per thread held in registers
+
+// ---------------------------------------------------------------- tables
+// Constant per-engine tables: built on the host in sgw_create, kept in device
+// memory, copied into LDS at the start of every workgroup.
+struct DevTables {
+    uint32_t thr_lo[SGW_MAX_TYPES];    // spawn threshold, low 32 bits of floor(p * 2^32)
+    uint32_t delta_lo[SGW_MAX_TYPES];  // one-hot: 1 << 4*channel for channels 0..7, else 0
+    uint32_t delta_hi[SGW_MAX_TYPES];  // channels 8..15
+    double value[SGW_MAX_TYPES];
+    uint8_t spawn_choice[SGW_MAX_TYPES][SGW_MAX_CHOICES];
+    uint8_t spawn_count[SGW_MAX_TYPES];
+    uint8_t agent_type[SGW_MAX_AGENTS];
+    uint8_t dense_choice[SGW_MAX_CHOICES];
+    uint8_t layer_fill[8];
+    uint8_t layer_border[8];
+    uint8_t pad_[8];
+    double appearance[SGW_MAX_TYPES][SGW_MAX_CHANNELS];  // general (non one-hot) path only
+};
+constexpr int kTabFastBytes = offsetof(DevTables, appearance);
+static_assert(kTabFastBytes % 16 == 0, "LDS table block must keep 16-byte alignment");
+static_assert(sizeof(DevTables) % 16 == 0, "LDS table block must keep 16-byte alignment");
+
+struct Params {
+    int H, W, L, A, r, V, VV, C, T, nact, zA;
+    int cells;      // L*H*W bytes of one env's grid
+    int cells_pad;  // rounded up to 16
+    int env_lds;    // LDS bytes per env slice
+    int tab_bytes;  // LDS bytes of the table block
+    uint32_t default_type, fill_type;
+    uint32_t spawn_mask, thr_full_mask, pass_mask;
+    uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
+    uint32_t fill_delta_lo, fill_delta_hi;
+    uint32_t seed_lo, seed_hi;
+    uint32_t first_env;
+    int64_t E;
+    uint32_t epoch, turn, flags;
+    int a0, a1;
+    int do_move;  // 0: observe only
+    uint64_t dense_thr;
+    int dense_count;
+    uint8_t* grid;
+    uint8_t* pos;
+    uint8_t* actions;
+    float* obs;
+    float* rewards;
+    double* total;
+    const DevTables* tab;
+    int* status;
+};
+
+// ---------------------------------------------------------------- RNG
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ uint32_t word_of(const U4& v, int i) {
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// ---------------------------------------------------------------- group sync
+// WPE == 1: the group is one wavefront.  DS instructions of a wave execute in
+// issue order, so a compiler-level fence is all that is needed.
+template <int WPE>
+__device__ __forceinline__ void gsync() {
+    if constexpr (WPE == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- grid <-> LDS
+template <int G>
+__device__ __forceinline__ void load_grid(const Params& p, const uint8_t* __restrict__ src,
+                                          uint8_t* lds, int gtid) {
+    if ((p.cells & 15) == 0) {
+        const uint4* s = reinterpret_cast<const uint4*>(src);
+        uint4* d = reinterpret_cast<uint4*>(lds);
+        for (int i = gtid; i < (p.cells >> 4); i += G) d[i] = s[i];
+    } else if ((p.cells & 3) == 0) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d = reinterpret_cast<uint32_t*>(lds);
+        for (int i = gtid; i < (p.cells >> 2); i += G) d[i] = s[i];
+    } else {
+        for (int i = gtid; i < p.cells_pad; i += G) lds[i] = i < p.cells ? src[i] : (uint8_t)0xFF;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void store_grid(const Params& p, uint8_t* __restrict__ dst,
+                                           const uint8_t* lds, int gtid) {
+    if ((p.cells & 15) == 0) {
+        uint4* d = reinterpret_cast<uint4*>(dst);
+        const uint4* s = reinterpret_cast<const uint4*>(lds);
+        for (int i = gtid; i < (p.cells >> 4); i += G) d[i] = s[i];
+    } else if ((p.cells & 3) == 0) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(lds);
+        for (int i = gtid; i < (p.cells >> 2); i += G) d[i] = s[i];
+    } else {
+        for (int i = gtid; i < p.cells; i += G) dst[i] = lds[i];
+    }
+}
+
+// ---------------------------------------------------------------- sweep
+// Entity transitions (reference: environment.py:88-91).  RNG index of a cell ==
+// its byte offset in the [L][H][W] slice, so one LDS dword == one Philox block.
+template <int G>
+__device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uint8_t* lds_grid,
+                                      uint32_t env_id, int gtid) {
+    uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
+    const int ndw = (p.cells + 3) >> 2;
+    const uint32_t c3 = (p.epoch << 4) | SGW_STREAM_SPAWN;
+    for (int d = gtid; d < ndw; d += G) {
+        uint32_t v = g32[d];
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t t = (v >> (8 * b)) & 0xFFu;
+            const uint32_t is = (t < SGW_MAX_TYPES) ? ((p.spawn_mask >> t) & 1u) : 0u;
+            m |= is << b;
+        }
+        if (m == 0) continue;
+        const U4 w = philox4x32_10((uint32_t)d, p.turn, env_id, c3, p.seed_lo, p.seed_hi);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if ((m >> b) & 1u) {
+                const uint32_t t = (v >> (8 * b)) & 31u;
+                const bool hit = ((p.thr_full_mask >> t) & 1u) || (word_of(w, b) < tab->thr_lo[t]);
+                hits |= (hit ? 1u : 0u) << b;
+            }
+        }
+        if (hits == 0) continue;
+        const U4 k = philox4x32_10((uint32_t)d, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                                   p.seed_lo, p.seed_hi);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if ((hits >> b) & 1u) {
+                const uint32_t t = (v >> (8 * b)) & 31u;
+                const uint32_t n = tab->spawn_count[t];
+                const uint32_t pick = (uint32_t)(((uint64_t)word_of(k, b) * n) >> 32);
+                const uint32_t nt = tab->spawn_choice[t][pick];
+                v = (v & ~(0xFFu << (8 * b))) | (nt << (8 * b));
+            }
+        }
+        g32[d] = v;
+    }
+}
+
+// ---------------------------------------------------------------- step kernel
+// Per-env LDS slice: [grid cells_pad][pos 2*64][act 64][rew f32 x64]
+constexpr int kPosOff = 0;
+constexpr int kActOff = 2 * SGW_MAX_AGENTS;
+constexpr int kRewOff = kActOff + SGW_MAX_AGENTS;
+constexpr int kAgentLds = kRewOff + 4 * SGW_MAX_AGENTS;  // 448 bytes, multiple of 16
+
+template <int WPE, bool ONEHOT>
+__global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int G = WPE * kWave;     // threads per env group
+    constexpr int EPB = kBlock / G;    // envs per workgroup
+    const int tid = threadIdx.x;
+    const int sub = tid / G;
+    const int gtid = tid - sub * G;
+
+    // constant tables -> LDS (once per workgroup)
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(p.tab);
+        uint4* d = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < (p.tab_bytes >> 4); i += kBlock) d[i] = s[i];
+    }
+    __syncthreads();
+    const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
+    uint8_t* slice = smem + p.tab_bytes + sub * p.env_lds;
+    uint8_t* lg = slice;                              // grid
+    uint8_t* s_pos = slice + p.cells_pad + kPosOff;   // [A][2]
+    uint8_t* s_act = slice + p.cells_pad + kActOff;   // [A]
+    float* s_rew = reinterpret_cast<float*>(slice + p.cells_pad + kRewOff);
+
+    // window cell(s) this thread renders: fixed for the whole kernel
+    int wi[kMaxPass], wj[kMaxPass];
+#pragma unroll
+    for (int k = 0; k < kMaxPass; ++k) {
+        const int w = gtid + k * G;
+        wi[k] = w / p.V;
+        wj[k] = w - wi[k] * p.V;
+    }
+    const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
+    const bool dirty = (p.flags & SGW_STEP_SWEEP) || (p.do_move && p.a1 > p.a0);
+    const int zoff = p.zA * p.H * p.W;
+    const int HW = p.H * p.W;
+
+    for (int64_t env = (int64_t)blockIdx.x * EPB + sub; env < p.E; env += (int64_t)gridDim.x * EPB) {
+        const uint32_t env_id = p.first_env + (uint32_t)env;
+        uint8_t* ggrid = p.grid + env * p.cells;
+        load_grid<G>(p, ggrid, lg, gtid);
+        double tot = 0.0;
+        if (gtid == 0 && p.do_move) tot = p.total[env];
+        if (gtid < p.A) {
+            const uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
+            reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
+            if (p.do_move && gtid >= p.a0 && gtid < p.a1) {
+                uint32_t act;
+                if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
+                    const U4 w = philox4x32_10((uint32_t)gtid >> 2, p.turn, env_id,
+                                               (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+                    act = (uint32_t)(((uint64_t)word_of(w, gtid & 3) * (uint32_t)p.nact) >> 32);
+                    p.actions[env * p.A + gtid] = (uint8_t)act;
+                } else {
+                    act = p.actions[env * p.A + gtid];
+                }
+                s_act[gtid] = (uint8_t)act;
+            }
+        }
+        gsync<WPE>();
+        if (p.flags & SGW_STEP_SWEEP) {
+            sweep<G>(p, tab, lg, env_id, gtid);
+            gsync<WPE>();
+        }
+
+        int st_bits = 0;
+        for (int a = p.a0; a < p.a1; ++a) {
+            const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
+            // ---- pov: egocentric window (visual_field.py:9-101)
+            if (write_obs) {
+                float* obase = p.obs + ((env * p.A + a) * (int64_t)p.C) * p.VV;
+                auto render = [&](const int w, const int i, const int j) {
+                    const int gy = y - p.r + i, gx = x - p.r + j;
+                    const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                    const int off = gy * p.W + gx;
+                    float* o = obase + w;
+                    if constexpr (ONEHOT) {
+                        uint32_t lo = 0, hi = 0;
+                        if (inb) {
+                            for (int z = 0; z < p.L; ++z) {
+                                const uint32_t t = lg[z * HW + off] & 31u;
+                                lo += tab->delta_lo[t];
+                                if (p.C > 8) hi += tab->delta_hi[t];
+                            }
+                        } else {   // fill entity's appearance, once (visual_field.py:89-94)
+                            lo = p.fill_delta_lo;
+                            hi = p.fill_delta_hi;
+                        }
+                        const int c8 = p.C < 8 ? p.C : 8;
+                        for (int c = 0; c < c8; ++c) o[c * p.VV] = (float)((lo >> (4 * c)) & 15u);
+                        for (int c = 8; c < p.C; ++c) o[c * p.VV] = (float)((hi >> (4 * (c - 8))) & 15u);
+                    } else {
+                        for (int c = 0; c < p.C; ++c) {
+                            double acc;
+                            if (inb) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
+                                acc = tab->appearance[lg[off] & 31u][c];
+                                for (int z = 1; z < p.L; ++z) acc += tab->appearance[lg[z * HW + off] & 31u][c];
+                            } else {
+                                acc = tab->appearance[p.fill_type][c];
+                            }
+                            o[c * p.VV] = (float)acc;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int k = 0; k < kMaxPass; ++k) {
+                    const int w = gtid + k * G;
+                    if (w < p.VV) render(w, wi[k], wj[k]);
+                }
+                for (int w = gtid + kMaxPass * G; w < p.VV; w += G) {
+                    const int i = w / p.V;
+                    render(w, i, w - i * p.V);
+                }
+            }
+            if (!p.do_move) continue;
+            // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
+            const uint32_t act = s_act[a];
+            const bool act_ok = act < (uint32_t)p.nact;
+            const int dy = act_ok ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
+            const int dx = act_ok ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
+            const int ty = y + dy, tx = x + dx;
+            const bool inb = act_ok && (unsigned)ty < (unsigned)p.H && (unsigned)tx < (unsigned)p.W;
+            const int taddr = zoff + ty * p.W + tx;
+            const int oaddr = zoff + y * p.W + x;
+            const uint32_t t = inb ? lg[taddr] : 0xFFu;
+            const bool tok = t < (uint32_t)p.T;
+            const double val = (inb && tok) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
+            const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
+            if (gtid == 0) {
+                if (pass) {
+                    lg[taddr] = tab->agent_type[a];
+                    lg[oaddr] = (uint8_t)p.default_type;
+                    s_pos[2 * a] = (uint8_t)ty;
+                    s_pos[2 * a + 1] = (uint8_t)tx;
+                }
+                s_rew[a] = (float)val;
+                tot += val;   // world.total_reward += reward, float64, agent order (agent.py:172)
+                st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
+                           ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
+            }
+            gsync<WPE>();
+        }
+
+        if (dirty) store_grid<G>(p, ggrid, lg, gtid);
+        if (p.do_move) {
+            if (gtid >= p.a0 && gtid < p.a1) {
+                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
+                p.rewards[env * p.A + gtid] = s_rew[gtid];
+            }
+            if (gtid == 0) {
+                p.total[env] = tot;
+                if (st_bits) atomicOr(p.status, st_bits);
+            }
+        }
+        gsync<WPE>();   // slice is reused by the next env of this group
+    }
+}
+
+// ---------------------------------------------------------------- reset kernel
+// create_world + populate_environment (gridworld.py:47-65, treasurehunt/env.py:114-147).
+template <int WPE>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int G = WPE * kWave;
+    constexpr int EPB = kBlock / G;
+    const int tid = threadIdx.x;
+    const int sub = tid / G;
+    const int gtid = tid - sub * G;
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(p.tab);
+        uint4* d = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < (p.tab_bytes >> 4); i += kBlock) d[i] = s[i];
+    }
+    __syncthreads();
+    const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
+    uint8_t* slice = smem + p.tab_bytes + sub * p.env_lds;
+    uint8_t* lg = slice;
+    uint8_t* s_pos = slice + p.cells_pad + kPosOff;
+    const int HW = p.H * p.W;
+    const int zoff = p.zA * HW;
+
+    for (int64_t env = (int64_t)blockIdx.x * EPB + sub; env < p.E; env += (int64_t)gridDim.x * EPB) {
+        const uint32_t env_id = p.first_env + (uint32_t)env;
+        // layers: fill + border
+        for (int i = gtid; i < p.cells_pad; i += G) {
+            uint8_t v = 0xFF;
+            if (i < p.cells) {
+                const int z = i / HW;
+                const int rem = i - z * HW;
+                const int y = rem / p.W, x = rem - y * p.W;
+                v = tab->layer_fill[z];
+                const uint8_t b = tab->layer_border[z];
+                if (b != SGW_NO_BORDER && (y == 0 || y == p.H - 1 || x == 0 || x == p.W - 1)) v = b;
+            }
+            lg[i] = v;
+        }
+        gsync<WPE>();
+        // optional dense pre-seeding of the agent layer's interior
+        if (p.dense_count > 0 && p.dense_thr > 0) {
+            const int d0 = zoff >> 2, d1 = (zoff + HW + 3) >> 2;
+            for (int d = d0 + gtid; d < d1; d += G) {
+                const U4 w = philox4x32_10((uint32_t)d, 0u, env_id, (p.epoch << 4) | SGW_STREAM_DENSE, p.seed_lo, p.seed_hi);
+                uint32_t hits = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * d + b - zoff;
+                    if (i < 0 || i >= HW) continue;
+                    const int y = i / p.W, x = i - y * p.W;
+                    if (y == 0 || y == p.H - 1 || x == 0 || x == p.W - 1) continue;
+                    if ((uint64_t)word_of(w, b) < p.dense_thr) hits |= 1u << b;
+                }
+                if (hits == 0) continue;
+                const U4 k = philox4x32_10((uint32_t)d, 0u, env_id, (p.epoch << 4) | SGW_STREAM_DENSE_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((hits >> b) & 1u)
+                        lg[4 * d + b] = tab->dense_choice[(uint32_t)(((uint64_t)word_of(k, b) * (uint32_t)p.dense_count) >> 32)];
+            }
+            gsync<WPE>();
+        }
+        // agent placement: sequential sampling without replacement, done by the
+        // lanes of the first wave (lane a draws its own u32; lane 0 resolves)
+        uint32_t u = 0;
+        if (gtid < p.A) {
+            const U4 w = philox4x32_10((uint32_t)gtid >> 2, 0u, env_id, (p.epoch << 4) | SGW_STREAM_PLACE, p.seed_lo, p.seed_hi);
+            u = word_of(w, gtid & 3);
+        }
+        uint32_t* s_u = reinterpret_cast<uint32_t*>(slice + p.cells_pad + kRewOff);
+        if (gtid < p.A) s_u[gtid] = u;
+        gsync<WPE>();
+        if (gtid == 0) {
+            const int n = (p.H - 2) * (p.W - 2);
+            const int iw = p.W - 2;
+            // s_u[j], j < i, is reused as the ascending list of taken indices
+            for (int i = 0; i < p.A; ++i) {
+                int d = (int)(((uint64_t)s_u[i] * (uint32_t)(n - i)) >> 32);
+                for (int j = 0; j < i; ++j)
+                    if (d >= (int)s_u[j]) ++d;
+                int j = i;
+                while (j > 0 && (int)s_u[j - 1] > d) {
+                    s_u[j] = s_u[j - 1];
+                    --j;
+                }
+                s_u[j] = (uint32_t)d;
+                const int y = 1 + d / iw, x = 1 + d - (d / iw) * iw;
+                s_pos[2 * i] = (uint8_t)y;
+                s_pos[2 * i + 1] = (uint8_t)x;
+                lg[zoff + y * p.W + x] = tab->agent_type[i];
+            }
+            p.total[env] = 0.0;
+        }
+        gsync<WPE>();
+        store_grid<G>(p, p.grid + env * p.cells, lg, gtid);
+        if (gtid < p.A)
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
+        gsync<WPE>();
+    }
+}
+
+// ---------------------------------------------------------------- small kernels
+__global__ void random_actions_kernel(const Params p) {
+    const int64_t n = p.E * p.A;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t env = i / p.A;
+        const int a = (int)(i - env * p.A);
+        const U4 w = philox4x32_10((uint32_t)a >> 2, p.turn, p.first_env + (uint32_t)env,
+                                   (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+        p.actions[i] = (uint8_t)(((uint64_t)word_of(w, a & 3) * (uint32_t)p.nact) >> 32);
+    }
+}
+
+constexpr int kRedBlocks = 256;
+
+// stage 1: block b sums elements b*256+t, stride 65536, in a fixed order
+__global__ __launch_bounds__(kBlock) void reduce_stage1(const double* __restrict__ x, int64_t n, double* __restrict__ part) {
+    __shared__ double s[kBlock], s2[kBlock];
+    double a = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)kRedBlocks * kBlock) {
+        const double v = x[i];
+        a += v;
+        a2 += v * v;
+    }
+    s[threadIdx.x] = a;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            s[threadIdx.x] += s[threadIdx.x + k];
+            s2[threadIdx.x] += s2[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s[0];
+        part[kRedBlocks + blockIdx.x] = s2[0];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_stage2(const double* __restrict__ part, int64_t n, double* __restrict__ out) {
+    __shared__ double s[kBlock], s2[kBlock];
+    s[threadIdx.x] = part[threadIdx.x];
+    s2[threadIdx.x] = part[kRedBlocks + threadIdx.x];
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            s[threadIdx.x] += s[threadIdx.x + k];
+            s2[threadIdx.x] += s2[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s[0];
+        out[1] = s2[0];
+        out[2] = (double)n;
+        out[3] = 0.0;
+    }
+}
+static_assert(kRedBlocks == kBlock, "stage 2 assumes one partial per thread");
+
+// ---------------------------------------------------------------- host side
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(SGW_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kEventPool = 4096;
+
+}  // namespace
+
+struct sgw_engine {
+    sgw_config cfg;
+    Params base;          // everything except per-call fields
+    DevTables* d_tab = nullptr;
+    int* d_status = nullptr;
+    double* d_part = nullptr;
+    int wpe = 1;          // waves per env
+    bool onehot = true;
+    size_t lds_bytes = 0;
+    int grid_blocks = 1;
+    int reset_blocks = 1;
+    int num_cus = 256;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_used = 0;
+    double ms_acc = 0.0;
+    int64_t launches = 0;
+};
+
+namespace {
+
+uint64_t prob_threshold(double pr) {
+    const double t = std::floor(pr * 4294967296.0);
+    if (!(t > 0.0)) return 0;
+    if (t >= 4294967296.0) return 4294967296ull;
+    return (uint64_t)t;
+}
+
+int validate(const sgw_config* c) {
+    if (!c) return fail(SGW_EINVAL, "config is NULL");
+    if (c->height < 3 || c->width < 3 || c->height > SGW_MAX_DIM || c->width > SGW_MAX_DIM)
+        return fail(SGW_EINVAL, "height/width must be in [3, %d] (got %dx%d)", SGW_MAX_DIM, c->height, c->width);
+    if (c->layers < 1 || c->layers > SGW_MAX_LAYERS)
+        return fail(SGW_EINVAL, "layers must be in [1, %d] (got %d)", SGW_MAX_LAYERS, c->layers);
+    if (c->num_agents < 1 || c->num_agents > SGW_MAX_AGENTS)
+        return fail(SGW_EINVAL, "num_agents must be in [1, %d] (got %d)", SGW_MAX_AGENTS, c->num_agents);
+    if (c->num_agents > (c->height - 2) * (c->width - 2))
+        return fail(SGW_EINVAL, "more agents (%d) than interior cells", c->num_agents);
+    if (c->vision_radius < 0 || c->vision_radius > (std::min(c->height, c->width) - 1) / 2)
+        return fail(SGW_EINVAL, "vision_radius %d invalid: visual_field needs r <= (min(H,W)-1)//2 = %d",
+                    c->vision_radius, (std::min(c->height, c->width) - 1) / 2);
+    if (c->num_types < 1 || c->num_types > SGW_MAX_TYPES)
+        return fail(SGW_EINVAL, "num_types must be in [1, %d] (got %d)", SGW_MAX_TYPES, c->num_types);
+    if (c->num_channels < 1 || c->num_channels > SGW_MAX_CHANNELS)
+        return fail(SGW_EINVAL, "num_channels must be in [1, %d] (got %d)", SGW_MAX_CHANNELS, c->num_channels);
+    if (c->num_actions < 1 || c->num_actions > SGW_MAX_ACTIONS)
+        return fail(SGW_EINVAL, "num_actions must be in [1, %d] (got %d)", SGW_MAX_ACTIONS, c->num_actions);
+    for (int i = 0; i < c->num_actions; ++i)
+        if (c->action_dy[i] < -1 || c->action_dy[i] > 1 || c->action_dx[i] < -1 || c->action_dx[i] > 1)
+            return fail(SGW_EINVAL, "action %d: (dy, dx) must be in {-1,0,1}", i);
+    if (c->agent_layer < 0 || c->agent_layer >= c->layers) return fail(SGW_EINVAL, "agent_layer out of range");
+    if (c->default_type < 0 || c->default_type >= c->num_types) return fail(SGW_EINVAL, "default_type out of range");
+    if (c->fill_type < 0 || c->fill_type >= c->num_types) return fail(SGW_EINVAL, "fill_type out of range");
+    for (int a = 0; a < c->num_agents; ++a) {
+        if (c->agent_type[a] >= c->num_types) return fail(SGW_EINVAL, "agent_type[%d] out of range", a);
+        if (c->type_rule[c->agent_type[a]] != SGW_RULE_NONE)
+            return fail(SGW_EINVAL, "agent types are skipped by the sweep and must have SGW_RULE_NONE");
+    }
+    for (int t = 0; t < c->num_types; ++t) {
+        if (c->type_rule[t] == SGW_RULE_NONE) continue;
+        if (c->type_rule[t] != SGW_RULE_SPAWN)
+            return fail(SGW_EINVAL, "type %d: unsupported transition rule %d", t, (int)c->type_rule[t]);
+        if (c->spawn_count[t] < 1 || c->spawn_count[t] > SGW_MAX_CHOICES)
+            return fail(SGW_EINVAL, "type %d: spawn_count must be in [1, %d]", t, SGW_MAX_CHOICES);
+        for (int k = 0; k < c->spawn_count[t]; ++k)
+            if (c->spawn_choice[t][k] >= c->num_types) return fail(SGW_EINVAL, "type %d: spawn choice out of range", t);
+        if (!(c->spawn_prob[t] >= 0.0 && c->spawn_prob[t] <= 1.0))
+            return fail(SGW_EINVAL, "type %d: spawn_prob must be in [0, 1]", t);
+    }
+    for (int z = 0; z < c->layers; ++z) {
+        if (c->layer_fill_type[z] >= c->num_types) return fail(SGW_EINVAL, "layer_fill_type[%d] out of range", z);
+        if (c->layer_border_type[z] != SGW_NO_BORDER && c->layer_border_type[z] >= c->num_types)
+            return fail(SGW_EINVAL, "layer_border_type[%d] out of range", z);
+    }
+    if (c->dense_count > SGW_MAX_CHOICES) return fail(SGW_EINVAL, "dense_count too large");
+    for (int k = 0; k < c->dense_count; ++k)
+        if (c->dense_choice[k] >= c->num_types) return fail(SGW_EINVAL, "dense choice out of range");
+    if (!(c->dense_prob >= 0.0 && c->dense_prob <= 1.0)) return fail(SGW_EINVAL, "dense_prob must be in [0, 1]");
+    if (c->num_envs < 1) return fail(SGW_EINVAL, "num_envs must be >= 1");
+    if (c->first_env_id + (uint64_t)c->num_envs > 4294967296ull)
+        return fail(SGW_EINVAL, "global env ids must fit 32 bits");
+    return SGW_OK;
+}
+
+template <typename K>
+int occupancy_blocks(K kernel, size_t lds, int num_cus, int* out) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds));
+    if (per_cu < 1) per_cu = 1;
+    *out = per_cu * num_cus;
+    return SGW_OK;
+}
+
+using StepFn = void (*)(const Params);
+
+StepFn pick_step(int wpe, bool onehot) {
+    if (wpe == 1) return onehot ? step_kernel<1, true> : step_kernel<1, false>;
+    return onehot ? step_kernel<4, true> : step_kernel<4, false>;
+}
+StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
+
+int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int time_begin(sgw_engine* e, hipStream_t s) {
+    if (!e->timing) return SGW_OK;
+    if (e->ev_used == kEventPool) {
+        HIP_TRY(hipEventSynchronize(e->ev1[e->ev_used - 1]));
+        for (int i = 0; i < e->ev_used; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
+            e->ms_acc += ms;
+        }
+        e->ev_used = 0;
+    }
+    HIP_TRY(hipEventRecord(e->ev0[e->ev_used], s));
+    return SGW_OK;
+}
+
+int time_end(sgw_engine* e, hipStream_t s) {
+    if (!e->timing) return SGW_OK;
+    HIP_TRY(hipEventRecord(e->ev1[e->ev_used], s));
+    e->ev_used++;
+    e->launches++;
+    return SGW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sgw_last_error(void) { return g_err; }
+const char* sgw_version(void) { return "sgw 0.1 (gfx950)"; }
+
+int64_t sgw_obs_elems_per_env(const sgw_config* c) {
+    const int64_t V = 2 * c->vision_radius + 1;
+    return (int64_t)c->num_agents * c->num_channels * V * V;
+}
+int64_t sgw_grid_bytes_per_env(const sgw_config* c) { return (int64_t)c->layers * c->height * c->width; }
+int64_t sgw_algorithmic_bytes_per_env_step(const sgw_config* c) {
+    const int64_t V = 2 * c->vision_radius + 1;
+    // grid read+write, per agent obs f32 store + action + reward + pos load/store, total f64 rw
+    return 2 * sgw_grid_bytes_per_env(c) + (int64_t)c->num_agents * (c->num_channels * V * V * 4 + 1 + 4 + 4) + 16;
+}
+
+int sgw_create(const sgw_config* cfg, sgw_engine** out) {
+    if (!out) return fail(SGW_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate(cfg)) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+
+    sgw_engine* e = new (std::nothrow) sgw_engine();
+    if (!e) return fail(SGW_ENOMEM, "out of host memory");
+    e->cfg = *cfg;
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const sgw_config& c = e->cfg;
+
+    // ---- tables
+    DevTables h;
+    memset(&h, 0, sizeof(h));
+    bool onehot = true;
+    for (int t = 0; t < c.num_types; ++t) {
+        int ones = 0, ch = -1;
+        bool other = false;
+        for (int k = 0; k < c.num_channels; ++k) {
+            const double v = c.appearance[t][k];
+            h.appearance[t][k] = v;
+            if (v == 1.0) { ++ones; ch = k; }
+            else if (v != 0.0) other = true;
+        }
+        if (other || ones > 1) onehot = false;
+        if (ones == 1 && !other) {
+            if (ch < 8) h.delta_lo[t] = 1u << (4 * ch);
+            else h.delta_hi[t] = 1u << (4 * (ch - 8));
+        }
+        h.value[t] = c.type_value[t];
+        h.thr_lo[t] = (uint32_t)(prob_threshold(c.spawn_prob[t]) & 0xFFFFFFFFull);
+        h.spawn_count[t] = c.spawn_count[t];
+        memcpy(h.spawn_choice[t], c.spawn_choice[t], SGW_MAX_CHOICES);
+    }
+    memcpy(h.agent_type, c.agent_type, SGW_MAX_AGENTS);
+    memcpy(h.dense_choice, c.dense_choice, SGW_MAX_CHOICES);
+    memcpy(h.layer_fill, c.layer_fill_type, 8);
+    memcpy(h.layer_border, c.layer_border_type, 8);
+    e->onehot = onehot;
+
+    // ---- static launch parameters
+    Params& p = e->base;
+    memset(&p, 0, sizeof(p));
+    p.H = c.height; p.W = c.width; p.L = c.layers; p.A = c.num_agents; p.r = c.vision_radius;
+    p.V = 2 * c.vision_radius + 1; p.VV = p.V * p.V; p.C = c.num_channels; p.T = c.num_types;
+    p.nact = c.num_actions; p.zA = c.agent_layer;
+    p.cells = c.layers * c.height * c.width;
+    p.cells_pad = (p.cells + 15) & ~15;
+    p.env_lds = p.cells_pad + kAgentLds;
+    p.tab_bytes = onehot ? kTabFastBytes : (int)sizeof(DevTables);
+    p.default_type = (uint32_t)c.default_type;
+    p.fill_type = (uint32_t)c.fill_type;
+    for (int t = 0; t < c.num_types; ++t) {
+        if (c.type_rule[t] == SGW_RULE_SPAWN) {
+            p.spawn_mask |= 1u << t;
+            if (prob_threshold(c.spawn_prob[t]) >= 4294967296ull) p.thr_full_mask |= 1u << t;
+        }
+        if (c.type_passable[t]) p.pass_mask |= 1u << t;
+    }
+    for (int a = 0; a < c.num_actions; ++a) {
+        p.dy_pack |= (uint32_t)(c.action_dy[a] + 1) << (2 * a);
+        p.dx_pack |= (uint32_t)(c.action_dx[a] + 1) << (2 * a);
+    }
+    p.fill_delta_lo = h.delta_lo[c.fill_type];
+    p.fill_delta_hi = h.delta_hi[c.fill_type];
+    p.seed_lo = (uint32_t)c.seed;
+    p.seed_hi = (uint32_t)(c.seed >> 32);
+    p.first_env = (uint32_t)c.first_env_id;
+    p.E = c.num_envs;
+    p.dense_thr = prob_threshold(c.dense_prob);
+    p.dense_count = c.dense_count;
+
+    // ---- group geometry: one wave per env while a slice stays small, else a workgroup per env
+    e->wpe = (p.cells_pad <= 4096) ? 1 : 4;
+    const int epb = kBlock / (e->wpe * kWave);
+    e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
+    const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
+    const size_t lds_max = 160 * 1024;
+    if (e->lds_bytes > lds_max) {
+        delete e;
+        return fail(SGW_EINVAL, "world of %d bytes per env does not fit the %zu-byte LDS-resident path", p.cells, lds_max);
+    }
+
+    hipError_t err = hipMalloc(&e->d_tab, sizeof(DevTables));
+    if (err == hipSuccess) err = hipMemcpy(e->d_tab, &h, sizeof(DevTables), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc(&e->d_status, 4 * sizeof(int));
+    if (err == hipSuccess) err = hipMemset(e->d_status, 0, 4 * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&e->d_part, 2 * kRedBlocks * sizeof(double));
+    if (err != hipSuccess) {
+        sgw_destroy(e);
+        return fail(SGW_EHIP, "device allocation failed: %s", hipGetErrorString(err));
+    }
+    p.tab = e->d_tab;
+    p.status = e->d_status;
+
+    StepFn sk = pick_step(e->wpe, e->onehot);
+    StepFn rk = pick_reset(e->wpe);
+    if (e->lds_bytes > lds_cap || e->lds_bytes > 65536) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+        if (err != hipSuccess) {
+            sgw_destroy(e);
+            return fail(SGW_EHIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, hipGetErrorString(err));
+        }
+    }
+    int nb = 0;
+    if (int rc = occupancy_blocks(sk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
+    e->grid_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
+    if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
+    e->reset_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
+    *out = e;
+    return SGW_OK;
+}
+
+void sgw_destroy(sgw_engine* e) {
+    if (!e) return;
+    for (hipEvent_t ev : e->ev0) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev1) (void)hipEventDestroy(ev);
+    if (e->d_tab) (void)hipFree(e->d_tab);
+    if (e->d_status) (void)hipFree(e->d_status);
+    if (e->d_part) (void)hipFree(e->d_part);
+    delete e;
+}
+
+int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_reward, uint32_t epoch, void* stream) {
+    if (!e || !grid || !agent_pos || !total_reward) return fail(SGW_EINVAL, "sgw_reset: NULL argument");
+    const sgw_config& c = e->cfg;
+    const int b = c.layer_border_type[c.agent_layer];
+    if (b == SGW_NO_BORDER || c.type_passable[b])
+        return fail(SGW_EINVAL, "sgw_reset: the agent layer needs an impassable border type (the reference has no bounds check in move)");
+    if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+    Params p = e->base;
+    p.grid = grid; p.pos = agent_pos; p.total = total_reward; p.epoch = epoch;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pick_reset(e->wpe), dim3(e->reset_blocks), dim3(kBlock), e->lds_bytes, s, p);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
+    if (int rc = time_begin(e, s)) return rc;
+    hipLaunchKernelGGL(pick_step(e->wpe, e->onehot), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, p);
+    HIP_TRY(hipGetLastError());
+    return time_end(e, s);
+}
+
+int sgw_observe(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, float* obs, int32_t agent_begin,
+                int32_t agent_end, void* stream) {
+    if (!e || !grid || !agent_pos || !obs) return fail(SGW_EINVAL, "sgw_observe: NULL argument");
+    if (agent_begin < 0 || agent_end > e->cfg.num_agents || agent_begin > agent_end)
+        return fail(SGW_EINVAL, "sgw_observe: agent range [%d, %d) invalid", agent_begin, agent_end);
+    Params p = e->base;
+    p.grid = const_cast<uint8_t*>(grid); p.pos = const_cast<uint8_t*>(agent_pos); p.obs = obs;
+    p.a0 = agent_begin; p.a1 = agent_end; p.flags = 0; p.do_move = 0;
+    return launch_step(e, p, static_cast<hipStream_t>(stream));
+}
+
+int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs, float* rewards,
+             double* total_reward, uint32_t epoch, uint32_t turn, int32_t agent_begin, int32_t agent_end,
+             uint32_t flags, void* stream) {
+    if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward)
+        return fail(SGW_EINVAL, "sgw_step: NULL argument");
+    if (!obs && !(flags & SGW_STEP_NO_OBS)) return fail(SGW_EINVAL, "sgw_step: obs is NULL without SGW_STEP_NO_OBS");
+    if (agent_begin < 0 || agent_end > e->cfg.num_agents || agent_begin > agent_end)
+        return fail(SGW_EINVAL, "sgw_step: agent range [%d, %d) invalid", agent_begin, agent_end);
+    if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+    Params p = e->base;
+    p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
+    p.epoch = epoch; p.turn = turn; p.a0 = agent_begin; p.a1 = agent_end; p.flags = flags; p.do_move = 1;
+    return launch_step(e, p, static_cast<hipStream_t>(stream));
+}
+
+int sgw_random_actions(sgw_engine* e, uint8_t* actions, uint32_t epoch, uint32_t turn, void* stream) {
+    if (!e || !actions) return fail(SGW_EINVAL, "sgw_random_actions: NULL argument");
+    Params p = e->base;
+    p.actions = actions; p.epoch = epoch; p.turn = turn;
+    const int64_t n = p.E * p.A;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, kBlock), (int64_t)e->num_cus * 8);
+    hipLaunchKernelGGL(random_actions_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_reduce_metrics(sgw_engine* e, const double* total_reward, double* out, void* stream) {
+    if (!e || !total_reward || !out) return fail(SGW_EINVAL, "sgw_reduce_metrics: NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(reduce_stage1, dim3(kRedBlocks), dim3(kBlock), 0, s, total_reward, e->cfg.num_envs, e->d_part);
+    hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(kBlock), 0, s, e->d_part, e->cfg.num_envs, out);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_get_status(sgw_engine* e, int32_t* status_out, void* stream) {
+    if (!e || !status_out) return fail(SGW_EINVAL, "sgw_get_status: NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, e->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(int32_t), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *status_out = v;
+    return SGW_OK;
+}
+
+int sgw_set_timing(sgw_engine* e, int enable) {
+    if (!e) return fail(SGW_EINVAL, "sgw_set_timing: NULL engine");
+    if (enable && e->ev0.empty()) {
+        e->ev0.resize(kEventPool);
+        e->ev1.resize(kEventPool);
+        for (int i = 0; i < kEventPool; ++i) {
+            HIP_TRY(hipEventCreate(&e->ev0[i]));
+            HIP_TRY(hipEventCreate(&e->ev1[i]));
+        }
+    }
+    e->timing = enable != 0;
+    e->ev_used = 0;
+    e->ms_acc = 0.0;
+    e->launches = 0;
+    return SGW_OK;
+}
+
+int sgw_get_step_time_ms(sgw_engine* e, double* total_ms, int64_t* launches) {
+    if (!e || !total_ms || !launches) return fail(SGW_EINVAL, "sgw_get_step_time_ms: NULL argument");
+    if (e->ev_used > 0) {
+        HIP_TRY(hipEventSynchronize(e->ev1[e->ev_used - 1]));
+        for (int i = 0; i < e->ev_used; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
+            e->ms_acc += ms;
+        }
+        e->ev_used = 0;
+    }
+    *total_ms = e->ms_acc;
+    *launches = e->launches;
+    e->ms_acc = 0.0;
+    e->launches = 0;
+    return SGW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+"""GridEngine: owns the state tensors of E environments and drives the HIP kernels.
+
+PyTorch is plumbing here (device memory, streams); all step/observe/reset
+arithmetic runs in ``sorrel_amd/csrc/sgw.hip`` through the C ABI of
+``include/sgw.h``.  There is no CPU path: constructing an engine on a non-GPU
+device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _native as N
+from .spec import WorldSpec
+
+
+class GridEngine:
+    """State + kernels for ``num_envs`` independent worlds on one GPU.
+
+    Tensors (all on ``device``, per-env contiguous):
+      grid ``uint8 [E,L,H,W]`` · agent_pos ``uint8 [E,A,2]`` · actions ``uint8 [E,A]``
+      obs ``float32 [E,A,C,V,V]`` · rewards ``float32 [E,A]`` · total_reward ``float64 [E]``
+    """
+
+    def __init__(self, spec: WorldSpec, num_envs: int, device="cuda", first_env_id: int = 0,
+                 allocate_obs: bool = True):
+        self.spec = spec
+        self.num_envs = int(num_envs)
+        self.first_env_id = int(first_env_id)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.SgwError(
+                "GridEngine needs a HIP device (torch device 'cuda'); the step/observe path has no CPU fallback"
+            )
+        if not torch.cuda.is_available():
+            raise N.SgwError("no HIP device visible to PyTorch; the step/observe path has no CPU fallback")
+        self._lib = N.load()
+        self.config = spec.to_config(self.num_envs, self.first_env_id)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_create(C.byref(self.config), C.byref(self._h)))
+        E, A = self.num_envs, spec.num_agents
+        dev = self.device
+        self.grid = torch.zeros((E, spec.layers, spec.height, spec.width), dtype=torch.uint8, device=dev)
+        self.agent_pos = torch.zeros((E, A, 2), dtype=torch.uint8, device=dev)
+        self.actions = torch.zeros((E, A), dtype=torch.uint8, device=dev)
+        self.rewards = torch.zeros((E, A), dtype=torch.float32, device=dev)
+        self.total_reward = torch.zeros((E,), dtype=torch.float64, device=dev)
+        self.metrics = torch.zeros((4,), dtype=torch.float64, device=dev)
+        self.obs = (torch.zeros((E,) + spec.obs_shape, dtype=torch.float32, device=dev) if allocate_obs else None)
+        self.epoch = 0
+        self.turn = 0
+
+    # ------------------------------------------------------------------ util
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptr(t: Optional[torch.Tensor]):
+        return C.c_void_p(0 if t is None else t.data_ptr())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sgw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ ops
+    def reset(self, epoch: Optional[int] = None):
+        """create_world + populate_environment for every env (K3)."""
+        if epoch is not None:
+            self.epoch = int(epoch)
+        self.turn = 0
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_reset(self._h, self._ptr(self.grid), self._ptr(self.agent_pos),
+                                        self._ptr(self.total_reward), self.epoch, self._stream()))
+
+    def observe(self, agent_begin: int = 0, agent_end: Optional[int] = None, out: Optional[torch.Tensor] = None):
+        """Stateless egocentric observation of the agents (K1)."""
+        out = self.obs if out is None else out
+        if out is None:
+            raise ValueError("engine was built with allocate_obs=False; pass `out`")
+        agent_end = self.spec.num_agents if agent_end is None else agent_end
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_observe(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(out),
+                                          agent_begin, agent_end, self._stream()))
+        return out
+
+    def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,
+             write_obs: bool = True, agent_begin: int = 0, agent_end: Optional[int] = None,
+             turn: Optional[int] = None, advance_turn: bool = True, obs_out: Optional[torch.Tensor] = None):
+        """One ``Environment.take_turn`` for every env (K2).
+
+        ``actions``: uint8 ``[E, A]`` chosen by a policy; or ``random_actions=True``
+        to draw them on device from the counter RNG (they are stored to
+        ``self.actions``)."""
+        if advance_turn and turn is None:
+            self.turn += 1
+        t = self.turn if turn is None else int(turn)
+        if actions is not None:
+            if actions.dtype != torch.uint8 or actions.shape != self.actions.shape or not actions.is_contiguous():
+                self.actions.copy_(actions.to(torch.uint8).reshape(self.actions.shape))
+                actions = self.actions
+        else:
+            actions = self.actions
+            if not random_actions and agent_end != agent_begin:
+                pass  # caller wrote into self.actions
+        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
+        obs = self.obs if obs_out is None else obs_out
+        if not write_obs or obs is None:
+            flags |= N.STEP_NO_OBS
+            obs = None
+        agent_end = self.spec.num_agents if agent_end is None else agent_end
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_step(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(actions),
+                                       self._ptr(obs), self._ptr(self.rewards), self._ptr(self.total_reward),
+                                       self.epoch, t, agent_begin, agent_end, flags, self._stream()))
+        return obs, self.rewards
+
+    def random_actions(self, turn: Optional[int] = None):
+        t = self.turn + 1 if turn is None else int(turn)
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_random_actions(self._h, self._ptr(self.actions), self.epoch, t, self._stream()))
+        return self.actions
+
+    def reduce_metrics(self) -> torch.Tensor:
+        """Device tensor ``[sum(total_reward), sum(total_reward**2), E, 0]`` (K4)."""
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_reduce_metrics(self._h, self._ptr(self.total_reward), self._ptr(self.metrics),
+                                                 self._stream()))
+        return self.metrics
+
+    def status(self) -> int:
+        """Synchronising read-and-clear of the device status word."""
+        v = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_get_status(self._h, C.byref(v), self._stream()))
+        return int(v.value)
+
+    def raise_on_status(self):
+        s = self.status()
+        if s & N.STATUS_OOB_MOVE:
+            raise IndexError("an agent moved off the grid: the agent layer's border must be impassable "
+                             "(the reference has no bounds check in Gridworld.move)")
+        if s & N.STATUS_BAD_ACTION:
+            raise KeyError("action index outside the ActionSpec")
+        if s & N.STATUS_BAD_TYPE:
+            raise KeyError("grid holds an entity type id that was never registered")
+
+    # ------------------------------------------------------------------ timing
+    def set_timing(self, enable: bool):
+        N.check(self._lib.sgw_set_timing(self._h, 1 if enable else 0))
+
+    def step_time_ms(self):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        N.check(self._lib.sgw_get_step_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)

@@ -1,0 +1,121 @@
+"""Shared test plumbing: golden fixtures, spec conversions, the C oracle binding."""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import gridstep_oracle as O  # noqa: E402  (tests may use the oracle; the product may not)
+from sorrel_amd import _native as N  # noqa: E402
+from sorrel_amd.spec import WorldSpec  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    spec = oracle_spec_from_json(str(d["spec_json"]))
+    return d, spec
+
+
+def oracle_spec_from_json(text: str) -> O.Spec:
+    j = json.loads(text)
+    j["appearance"] = np.asarray(j["appearance"], dtype=np.float64)
+    return O.Spec(**j)
+
+
+def world_spec(spec: O.Spec) -> WorldSpec:
+    """oracle Spec -> product WorldSpec (same fields, independent classes)."""
+    return WorldSpec(
+        height=spec.height, width=spec.width, layers=spec.layers, num_agents=spec.num_agents,
+        vision_radius=spec.vision_radius, num_channels=spec.num_channels, agent_layer=spec.agent_layer,
+        default_type=spec.default_type, fill_type=spec.fill_type,
+        action_dy=list(spec.action_dy), action_dx=list(spec.action_dx), agent_type=list(spec.agent_type),
+        type_value=list(spec.type_value), type_passable=list(spec.type_passable), type_rule=list(spec.type_rule),
+        spawn_prob=list(spec.spawn_prob), spawn_choices=[list(c) for c in spec.spawn_choices],
+        appearance=np.asarray(spec.appearance, dtype=np.float64), seed=spec.seed,
+        layer_fill_type=list(spec.layer_fill_type), layer_border_type=list(spec.layer_border_type),
+        dense_prob=spec.dense_prob, dense_choices=list(spec.dense_choices),
+    )
+
+
+# ----------------------------------------------------------------------------- C oracle
+_olib = None
+
+
+def oracle_lib():
+    global _olib
+    if _olib is None:
+        import __graft_entry__ as g
+
+        path = g.build_oracle()
+        lib = C.CDLL(path)
+        lib.sgo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.sgo_rng_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.sgo_rng_u32.restype = C.c_uint32
+        vp = C.c_void_p
+        cfgp = C.POINTER(N.SgwConfig)
+        lib.sgo_reset.argtypes = [cfgp, vp, vp, vp, C.c_uint32, C.c_int]
+        lib.sgo_observe.argtypes = [cfgp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int]
+        lib.sgo_step.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                 C.c_uint32, C.c_int]
+        lib.sgo_random_actions.argtypes = [cfgp, vp, C.c_uint32, C.c_uint32]
+        lib.sgo_reduce_metrics.argtypes = [cfgp, vp, vp]
+        lib.sgo_threads.argtypes = [C.c_int]
+        _olib = lib
+    return _olib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class COracle:
+    """Batch state + the C restatement, with the engine's tensor layouts."""
+
+    def __init__(self, wspec: WorldSpec, num_envs: int, first_env_id: int = 0, threads: int = 0):
+        self.lib = oracle_lib()
+        self.spec = wspec
+        self.cfg = wspec.to_config(num_envs, first_env_id)
+        self.threads = threads
+        E, A = num_envs, wspec.num_agents
+        self.grid = np.zeros((E, wspec.layers, wspec.height, wspec.width), np.uint8)
+        self.pos = np.zeros((E, A, 2), np.uint8)
+        self.actions = np.zeros((E, A), np.uint8)
+        self.obs = np.zeros((E,) + wspec.obs_shape, np.float32)
+        self.rewards = np.zeros((E, A), np.float32)
+        self.total = np.zeros((E,), np.float64)
+
+    def reset(self, epoch=0):
+        self.lib.sgo_reset(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.total), epoch, self.threads)
+
+    def observe(self, a0=0, a1=None):
+        a1 = self.spec.num_agents if a1 is None else a1
+        self.lib.sgo_observe(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.obs), a0, a1, self.threads)
+        return self.obs
+
+    def step(self, epoch, turn, actions=None, random_actions=False, sweep=True, write_obs=True, a0=0, a1=None):
+        a1 = self.spec.num_agents if a1 is None else a1
+        if actions is not None:
+            self.actions[...] = actions
+        flags = (1 if sweep else 0) | (2 if random_actions else 0) | (0 if write_obs else 4)
+        return self.lib.sgo_step(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.actions),
+                                 _p(self.obs) if write_obs else None, _p(self.rewards), _p(self.total),
+                                 epoch, turn, a0, a1, flags, self.threads)
+
+    def metrics(self):
+        out = np.zeros(4, np.float64)
+        self.lib.sgo_reduce_metrics(C.byref(self.cfg), _p(self.total), _p(out))
+        return out

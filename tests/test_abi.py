@@ -1,0 +1,78 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/sgw.h declares, and the ctypes mirror of sgw_config has the C layout.
+No compute calls are made (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from tests import helpers as H
+from sorrel_amd import _native as N
+
+HEADER = os.path.join(H.ROOT, "include", "sgw.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_what_binding_expects():
+    assert set(declared_symbols()) == set(N.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = N.load()   # dlopen only (after torch, so one HIP runtime is mapped): no HIP call, works without a GPU
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"libsgw.so does not export {name}"
+
+
+def test_library_has_gfx950_code_object(built):
+    data = open(N.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    assert b"step_kernel" in data
+
+
+def test_config_struct_layout_matches_c(tmp_path):
+    src = tmp_path / "layout.c"
+    fields = [f[0] for f in N.SgwConfig._fields_]
+    body = "".join(f'printf("{f} %zu\\n", offsetof(sgw_config, {f}));\n' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sgw.h"\nint main(){\n'
+                   'printf("sizeof %zu\\n", sizeof(sgw_config));\n' + body + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(H.ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out["sizeof"]) == C.sizeof(N.SgwConfig)
+    for f in fields:
+        assert int(out[f]) == getattr(N.SgwConfig, f).offset, f
+
+
+def test_pure_host_helpers_agree_with_spec(built):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    lib = N.load()
+    for (h, w, a, r, want) in ((16, 16, 4, 2, 3476), (32, 32, 8, 3, 13592), (128, 128, 64, 5, 251984)):
+        spec = treasurehunt_spec(h, w, a, r)
+        cfg = spec.to_config(1)
+        # SURVEY.md 8(d) per-env-step algorithmic bytes for C2 / C3 / C5
+        assert lib.sgw_algorithmic_bytes_per_env_step(C.byref(cfg)) == want == spec.algorithmic_bytes_per_env_step()
+        assert lib.sgw_grid_bytes_per_env(C.byref(cfg)) == 2 * h * w
+        assert lib.sgw_obs_elems_per_env(C.byref(cfg)) == a * 6 * (2 * r + 1) ** 2
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+
+    from sorrel_amd.engine import GridEngine
+    from sorrel_amd.spec import treasurehunt_spec
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(N.SgwError):
+        GridEngine(treasurehunt_spec(16, 16, 4, 2), 8, device="cuda")
+    with pytest.raises(N.SgwError):
+        GridEngine(treasurehunt_spec(16, 16, 4, 2), 8, device="cpu")

@@ -1,0 +1,345 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the
+C ABI, against (1) the golden vectors produced by the reference itself, (2) the C oracle
+on the same seeded inputs at sizes it finishes in seconds, and (3) size-independent
+properties at BASELINE.json's full sizes.  Integer / byte / index work: bit-exact.
+Observations and rewards are float32 holding exactly representable values and are
+compared bit-exactly as well (np.array_equal)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+COUNTER_FIXTURES = [n for n in H.golden_names() if n != "stock_np_random"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no silent CPU fallback)")
+    return torch
+
+
+def make_engine(ws, E, first=0, **kw):
+    from sorrel_amd.engine import GridEngine
+
+    return GridEngine(ws, E, device="cuda:0", first_env_id=first, **kw)
+
+
+def assert_same(eng, co, what=("grid", "pos", "actions", "obs", "rewards", "total"), ctx=""):
+    import torch
+
+    torch.cuda.synchronize()
+    pairs = dict(grid=(eng.grid, co.grid), pos=(eng.agent_pos, co.pos), actions=(eng.actions, co.actions),
+                 obs=(eng.obs, co.obs), rewards=(eng.rewards, co.rewards), total=(eng.total_reward, co.total))
+    for k in what:
+        mine, ref = pairs[k]
+        mine = mine.cpu().numpy()
+        if not np.array_equal(mine, ref):
+            bad = np.argwhere(mine != ref)
+            raise AssertionError(f"{ctx}: {k} differs from the oracle at {bad[:5].tolist()} ({len(bad)} elements)")
+
+
+# ------------------------------------------------------------------ (1) golden vectors from the reference
+@pytest.mark.parametrize("name", COUNTER_FIXTURES)
+def test_hip_matches_reference_golden(torch_cuda, name):
+    torch = torch_cuda
+    d, spec = H.load_golden(name)
+    ws = H.world_spec(spec)
+    turns = d["obs"].shape[0]
+    epoch = int(d["epoch"]) if "epoch" in d else 0
+    for n, env_id in enumerate(int(e) for e in d["env_ids"]):
+        eng = make_engine(ws, 1, first=env_id)
+        eng.reset(epoch=epoch)
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.grid.cpu().numpy()[0], d["grid0"][n]), f"{name}: reset grid"
+        assert np.array_equal(eng.agent_pos.cpu().numpy()[0], d["pos0"][n]), f"{name}: reset positions"
+        for t in range(turns):
+            if "scripted" in d:
+                eng.step(torch.from_numpy(d["scripted"][t, n][None].astype(np.uint8)).cuda())
+            else:
+                eng.step(random_actions=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(eng.obs.cpu().numpy()[0], d["obs"][t, n]), f"{name}: obs turn {t}"
+            assert np.array_equal(eng.actions.cpu().numpy()[0], d["actions"][t, n]), f"{name}: actions turn {t}"
+            assert np.array_equal(eng.rewards.cpu().numpy()[0], d["rewards"][t, n]), f"{name}: rewards turn {t}"
+            assert eng.total_reward.cpu().numpy()[0] == d["total_reward"][t, n], f"{name}: total_reward turn {t}"
+            assert np.array_equal(eng.grid.cpu().numpy()[0], d["grid"][t, n]), f"{name}: grid turn {t}"
+            assert np.array_equal(eng.agent_pos.cpu().numpy()[0], d["pos"][t, n]), f"{name}: pos turn {t}"
+        assert eng.status() == 0
+
+
+def test_hip_from_injected_state_matches_golden(torch_cuda):
+    """State set from the fixture (not by sgw_reset), then stepped: add()/populate plumbing path."""
+    torch = torch_cuda
+    d, spec = H.load_golden("crowded_6x6")
+    ws = H.world_spec(spec)
+    ids = [int(e) for e in d["env_ids"]]
+    for n, env_id in enumerate(ids):
+        eng = make_engine(ws, 1, first=env_id)
+        eng.grid.copy_(torch.from_numpy(d["grid0"][n][None]))
+        eng.agent_pos.copy_(torch.from_numpy(d["pos0"][n][None]))
+        eng.total_reward.zero_()
+        for t in range(d["obs"].shape[0]):
+            eng.step(random_actions=True)
+            assert np.array_equal(eng.obs.cpu().numpy()[0], d["obs"][t, n])
+            assert np.array_equal(eng.grid.cpu().numpy()[0], d["grid"][t, n])
+
+
+# ------------------------------------------------------------------ (2) HIP vs C oracle, seeded, bigger
+def rollout_vs_oracle(ws, E, T, first=0, epoch=0, check_every=1):
+    eng = make_engine(ws, E, first=first)
+    co = H.COracle(ws, E, first_env_id=first)
+    eng.reset(epoch=epoch)
+    co.reset(epoch)
+    assert_same(eng, co, ("grid", "pos", "total"), ctx="reset")
+    for t in range(1, T + 1):
+        eng.step(random_actions=True)
+        st = co.step(epoch, t, random_actions=True)
+        assert st == 0
+        if t % check_every == 0 or t == T:
+            assert_same(eng, co, ctx=f"turn {t}")
+    assert eng.status() == 0
+    return eng, co
+
+
+def test_config2_full_batch_vs_oracle(torch_cuda):
+    """BASELINE config 2 at full size: 16x16, 4 agents, 5x5 window, 4096 envs."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rollout_vs_oracle(treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.005, seed=0), 4096, 12)
+
+
+def test_config3_shape_vs_oracle(torch_cuda):
+    """Headline shape 32x32, 8 agents, 7x7 window on 8192 envs (oracle finishes in seconds)."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rollout_vs_oracle(treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=1), 8192, 8, first=60000, check_every=2)
+
+
+def test_config5_shape_vs_oracle(torch_cuda):
+    """LDS-tile stress shape: 128x128, 64 agents, 11x11 window, dense entities (workgroup per env)."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rollout_vs_oracle(treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=2, dense_prob=0.25), 48, 4, first=16000)
+
+
+@pytest.mark.parametrize("shape", [(9, 13, 3, 4), (7, 7, 5, 3), (33, 21, 9, 2), (64, 64, 16, 4), (66, 70, 7, 6), (5, 5, 2, 2)])
+def test_ragged_shapes_vs_oracle(torch_cuda, shape):
+    """Grid byte counts that are not multiples of 16 / 4, odd sizes, maximum radius."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    h, w, a, r = shape
+    rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.08, seed=sum(shape), dense_prob=0.2), 37, 6, first=11, epoch=2)
+
+
+def test_high_spawn_prob_and_certain_spawn(torch_cuda):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rollout_vs_oracle(treasurehunt_spec(12, 12, 4, 2, spawn_prob=1.0, seed=5), 16, 3)
+    rollout_vs_oracle(treasurehunt_spec(12, 12, 4, 2, spawn_prob=0.0, seed=5), 16, 3)
+    rollout_vs_oracle(treasurehunt_spec(12, 12, 4, 2, spawn_prob=0.5, seed=5), 16, 5)
+
+
+def test_general_appearance_path_vs_oracle(torch_cuda):
+    """Non one-hot entity_map (override_entity_map): float64 layer sum on device."""
+    d, spec = H.load_golden("float_appearance_3layer")
+    ws = H.world_spec(spec)
+    rollout_vs_oracle(ws, 33, 8)
+
+
+def test_many_channels_hi_nibbles(torch_cuda):
+    """More than 8 one-hot channels exercises the second nibble word."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(14, 14, 3, 3, spawn_prob=0.1, seed=3)
+    ws.num_channels = 13
+    app = np.zeros((7, 13))
+    for t, ch in enumerate([0, 0, 12, 9, 3, 8, 11]):
+        if t >= 2:
+            app[t, ch] = 1.0
+    ws.appearance = app
+    rollout_vs_oracle(ws, 21, 6)
+
+
+def test_observe_kernel_vs_oracle(torch_cuda):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(20, 24, 6, 3, spawn_prob=0.1, seed=4, dense_prob=0.3)
+    eng, co = rollout_vs_oracle(ws, 100, 3)
+    eng.obs.fill_(-1.0)
+    co.obs.fill(-1.0)
+    eng.observe()
+    co.observe()
+    assert_same(eng, co, ("obs", "grid", "pos"), ctx="observe all")
+    eng.obs.fill_(-1.0)
+    co.obs.fill(-1.0)
+    eng.observe(2, 4)
+    co.observe(2, 4)
+    assert_same(eng, co, ("obs",), ctx="observe [2,4)")
+
+
+def test_policy_phase_stepping_equals_fused(torch_cuda):
+    """sweep once, then one sgw_step per agent (observe -> act), == one fused take_turn."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.05, seed=6)
+    E = 200
+    fused, phased = make_engine(ws, E), make_engine(ws, E)
+    fused.reset(0)
+    phased.reset(0)
+    for t in range(1, 8):
+        acts = fused.random_actions(turn=t).clone()
+        fused.step(acts)
+        phased.turn += 1
+        phased.step(acts, sweep=True, agent_begin=0, agent_end=0, turn=t)      # sweep only
+        rew = torch.zeros_like(phased.rewards)
+        for a in range(ws.num_agents):
+            phased.observe(a, a + 1)                                            # pov of agent a
+            phased.step(acts, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=t)
+            rew[:, a] = phased.rewards[:, a]
+        torch.cuda.synchronize()
+        assert torch.equal(fused.grid, phased.grid)
+        assert torch.equal(fused.obs, phased.obs)
+        assert torch.equal(fused.rewards, rew)
+        assert torch.equal(fused.total_reward, phased.total_reward)
+        assert torch.equal(fused.agent_pos, phased.agent_pos)
+
+
+def test_resharding_is_bit_exact(torch_cuda):
+    """Env results depend on the GLOBAL env id only: two half shards == one full batch."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.01, seed=7)
+    E = 512
+    full = make_engine(ws, E, first=1000)
+    lo, hi = make_engine(ws, E // 2, first=1000), make_engine(ws, E // 2, first=1000 + E // 2)
+    for e in (full, lo, hi):
+        e.reset(1)
+    for _ in range(5):
+        for e in (full, lo, hi):
+            e.step(random_actions=True)
+    torch.cuda.synchronize()
+    for name in ("grid", "agent_pos", "obs", "rewards", "total_reward", "actions"):
+        whole = getattr(full, name)
+        parts = torch.cat([getattr(lo, name), getattr(hi, name)], dim=0)
+        assert torch.equal(whole, parts), name
+
+
+def test_metric_reduction_vs_oracle(torch_cuda):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.05, seed=8)
+    eng, co = rollout_vs_oracle(ws, 3000, 10, check_every=10)
+    m = eng.reduce_metrics().cpu().numpy()
+    ref = co.metrics()
+    assert m[0] == ref[0] and m[1] == ref[1] and m[2] == 3000.0   # integer-valued sums: exact in any order
+    m2 = eng.reduce_metrics().cpu().numpy()
+    assert np.array_equal(m, m2)                                  # fixed order: bitwise reproducible
+
+
+def test_status_flags_bad_action_and_unwalled_border(torch_cuda):
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(8, 8, 2, 2, spawn_prob=0.0, seed=9)
+    eng = make_engine(ws, 4)
+    eng.reset(0)
+    eng.step(torch.full((4, 2), 9, dtype=torch.uint8, device="cuda"))
+    assert eng.status() & N.STATUS_BAD_ACTION
+    # knock a hole in the wall above agent 0 of env 0 and walk it off the grid
+    eng.reset(0)
+    y, x = [int(v) for v in eng.agent_pos[0, 0].cpu()]
+    eng.grid[0, 1, :, x] = 1
+    for _ in range(8):
+        eng.step(torch.zeros((4, 2), dtype=torch.uint8, device="cuda"))   # "up"
+    with pytest.raises(IndexError):
+        eng.raise_on_status()
+
+
+def test_create_rejects_invalid_configs(torch_cuda):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    with pytest.raises(ValueError):
+        make_engine(treasurehunt_spec(10, 10, 2, 5), 4)          # r > (min-1)//2
+    with pytest.raises(ValueError):
+        make_engine(treasurehunt_spec(4, 4, 5, 1), 4)            # more agents than interior cells
+    ws = treasurehunt_spec(10, 10, 2, 2)
+    ws.type_rule[3] = 7
+    with pytest.raises(ValueError):
+        make_engine(ws, 4)                                       # unsupported transition rule
+
+
+# ------------------------------------------------------------------ (3) full BASELINE sizes: properties
+def check_properties(torch, eng, ws, T):
+    """Size-independent invariants of take_turn."""
+    E, A = eng.num_envs, ws.num_agents
+    agent_t, zA = ws.agent_type[0], ws.agent_layer
+    cum = torch.zeros(E, dtype=torch.float64, device="cuda")
+    for t in range(T):
+        eng.step(random_actions=True)
+        cum += eng.rewards.double().sum(dim=1)
+    torch.cuda.synchronize()
+    # total_reward is the running sum of the per-agent rewards (integers here: exact)
+    assert torch.equal(cum, eng.total_reward)
+    # exactly A agent cells per env, at the recorded positions, on the agent layer
+    g = eng.grid
+    assert torch.equal((g == agent_t).sum(dim=(1, 2, 3)), torch.full((E,), A, device="cuda"))
+    pos = eng.agent_pos.long()
+    e_idx = torch.arange(E, device="cuda")[:, None].expand(E, A)
+    assert bool((g[e_idx, zA, pos[..., 0], pos[..., 1]] == agent_t).all())
+    # walls and the inert layer never change
+    assert bool((g[:, zA, 0, :] == 2).all() and (g[:, zA, -1, :] == 2).all()
+                and (g[:, zA, :, 0] == 2).all() and (g[:, zA, :, -1] == 2).all())
+    assert bool((g[:, 0] == 0).all())
+    # observations: every value is a small count; channel 0 (EmptyEntity) is all-zero;
+    # stateless re-observation of the final state shows each agent at its window centre
+    assert bool((eng.obs[:, :, 0] == 0).all())
+    assert float(eng.obs.max()) <= ws.layers
+    eng.observe()
+    r = ws.vision_radius
+    assert bool((eng.obs[:, :, 5, r, r] == 1.0).all())
+    assert eng.status() == 0
+
+
+def test_config3_full_size_properties(torch_cuda):
+    """BASELINE headline: 32x32, 8 agents, 7x7 window, 65 536 envs."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=0)
+    eng = make_engine(ws, 65536)
+    eng.reset(0)
+    check_properties(torch, eng, ws, 20)
+    # determinism: an identical second run gives identical tensors
+    eng2 = make_engine(ws, 65536, allocate_obs=False)
+    eng2.reset(0)
+    for _ in range(20):
+        eng2.step(random_actions=True, write_obs=False)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grid, eng2.grid) and torch.equal(eng.total_reward, eng2.total_reward)
+    # a strided sample of envs against the oracle, env by env (global ids)
+    for env_id in (0, 1, 777, 32768, 65535):
+        co = H.COracle(ws, 1, first_env_id=env_id, threads=1)
+        co.reset(0)
+        for t in range(1, 21):
+            co.step(0, t, random_actions=True)
+        assert np.array_equal(eng.grid[env_id].cpu().numpy(), co.grid[0])
+        assert eng.total_reward[env_id].item() == co.total[0]
+
+
+def test_config5_per_gpu_size_properties(torch_cuda):
+    """Config 5 per-GPU share: 128x128, 64 agents, 11x11 window, dense, 2048 envs."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=0, dense_prob=0.25)
+    eng = make_engine(ws, 2048)
+    eng.reset(0)
+    check_properties(torch, eng, ws, 3)

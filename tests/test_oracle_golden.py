@@ -1,0 +1,143 @@
+"""CPU tests: the oracle (Python and C restatements) against the golden vectors that
+were produced by running the reference's own step loop (oracle/make_golden.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from oracle import gridstep_oracle as O
+from oracle import numpy_order
+
+COUNTER_FIXTURES = [n for n in H.golden_names() if n != "stock_np_random"]
+KEYS = ("grid0", "pos0", "obs", "actions", "rewards", "total_reward", "grid", "pos")
+
+
+def test_fixture_inventory():
+    names = H.golden_names()
+    for must in ("c1_treasurehunt_10x10", "c2_treasurehunt_16x16", "c3_treasurehunt_32x32", "crowded_6x6",
+                 "ragged_9x13_rmax", "c5_small_dense", "scripted_noop", "basic_doublewall", "basic_1layer",
+                 "float_appearance_3layer", "stock_np_random"):
+        assert must in names
+
+
+# Random123 known-answer vectors for Philox4x32-10
+KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", KAT)
+def test_philox_kat_python(ctr, key, want):
+    got = tuple(int(v) for v in O.philox4x32_10(*ctr, *key))
+    assert got == want
+
+
+@pytest.mark.parametrize("ctr,key,want", KAT)
+def test_philox_kat_c(ctr, key, want):
+    lib = H.oracle_lib()
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    out = (C.c_uint32 * 4)()
+    lib.sgo_philox4x32_10(c, k, out)
+    assert tuple(out) == want
+
+
+def test_rng_u32_c_matches_python():
+    lib = H.oracle_lib()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        seed = int(rng.integers(0, 2**63))
+        env, epoch, turn = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**28)), int(rng.integers(0, 2**32))
+        stream, idx = int(rng.integers(0, 6)), int(rng.integers(0, 2**20))
+        assert lib.sgo_rng_u32(seed, env, epoch, turn, stream, idx) == int(O.rng_u32(seed, env, epoch, turn, stream, idx))
+
+
+@pytest.mark.parametrize("name", COUNTER_FIXTURES)
+def test_python_oracle_matches_reference(name):
+    d, spec = H.load_golden(name)
+    turns = d["obs"].shape[0]
+    epoch = int(d["epoch"]) if "epoch" in d else 0
+    scripted = d["scripted"] if "scripted" in d else None
+    mine = O.rollout(spec, [int(e) for e in d["env_ids"]], turns, epoch=epoch, actions=scripted)
+    for k in KEYS:
+        assert np.array_equal(mine[k], d[k]), f"{name}: {k} differs from the reference"
+    assert not d["dones"].any()
+
+
+@pytest.mark.parametrize("name", COUNTER_FIXTURES)
+def test_c_oracle_matches_reference(name):
+    d, spec = H.load_golden(name)
+    ws = H.world_spec(spec)
+    turns = d["obs"].shape[0]
+    epoch = int(d["epoch"]) if "epoch" in d else 0
+    for n, env_id in enumerate(int(e) for e in d["env_ids"]):
+        co = H.COracle(ws, 1, first_env_id=env_id, threads=1)
+        co.reset(epoch)
+        assert np.array_equal(co.grid[0], d["grid0"][n]), f"{name}: reset grid"
+        assert np.array_equal(co.pos[0], d["pos0"][n]), f"{name}: reset pos"
+        for t in range(turns):
+            if "scripted" in d:
+                st = co.step(epoch, t + 1, actions=d["scripted"][t, n][None])
+            else:
+                st = co.step(epoch, t + 1, random_actions=True)
+            assert st == 0
+            assert np.array_equal(co.obs[0], d["obs"][t, n]), f"{name}: obs turn {t}"
+            assert np.array_equal(co.actions[0], d["actions"][t, n]), f"{name}: actions turn {t}"
+            assert np.array_equal(co.rewards[0], d["rewards"][t, n]), f"{name}: rewards turn {t}"
+            assert co.total[0] == d["total_reward"][t, n], f"{name}: total_reward turn {t}"
+            assert np.array_equal(co.grid[0], d["grid"][t, n]), f"{name}: grid turn {t}"
+            assert np.array_equal(co.pos[0], d["pos"][t, n]), f"{name}: pos turn {t}"
+
+
+def test_numpy_order_mode_matches_stock_reference():
+    """Unmodified Treasurehunt + RandomModel on the global np.random stream (BASELINE config 1 plumbing)."""
+    d, spec = H.load_golden("stock_np_random")
+    mine = numpy_order.rollout_numpy_order(spec, d["obs"].shape[0], np_seed=int(d["np_seed"]))
+    for k in KEYS:
+        assert np.array_equal(mine[k], d[k]), f"stock_np_random: {k} differs from the reference"
+
+
+def test_visual_field_restatement_equals_closed_form():
+    rng = np.random.default_rng(1)
+    spec = O.treasurehunt_spec(11, 14, 3, 5, spawn_prob=0.3, seed=2)
+    st = O.reset_env(spec, 0)
+    for t in range(1, 6):
+        O.step_env(spec, st, 0, 0, t)
+    for _ in range(40):
+        y, x = int(rng.integers(0, 11)), int(rng.integers(0, 14))
+        assert np.array_equal(O.visual_field(spec, st.grid, y, x), O.visual_field_closed_form(spec, st.grid, y, x))
+
+
+def test_sweep_order_is_unobservable():
+    spec = O.treasurehunt_spec(12, 12, 3, 2, spawn_prob=0.2, seed=3)
+    a, b = O.reset_env(spec, 5), O.reset_env(spec, 5)
+    for t in range(1, 10):
+        O.step_env(spec, a, 5, 0, t, fast_sweep=False)
+        O.step_env(spec, b, 5, 0, t, fast_sweep=True)
+        assert np.array_equal(a.grid, b.grid) and a.total_reward == b.total_reward
+
+
+def test_c_oracle_batch_equals_python_oracle_c2_shape():
+    """A few hundred envs of the config-2 shape: C batch port == Python restatement."""
+    spec = O.treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.02, seed=9)
+    ws = H.world_spec(spec)
+    E, T = 24, 6
+    co = H.COracle(ws, E, first_env_id=100, threads=2)
+    co.reset(0)
+    py = O.rollout(spec, list(range(100, 100 + E)), T)
+    assert np.array_equal(co.grid, py["grid0"])
+    for t in range(T):
+        co.step(0, t + 1, random_actions=True)
+        assert np.array_equal(co.obs, py["obs"][t])
+        assert np.array_equal(co.grid, py["grid"][t])
+        assert np.array_equal(co.total, py["total_reward"][t])
+
+
+def test_spec_validation_rejects_degenerate_radius():
+    spec = O.treasurehunt_spec(10, 10, 2, 5)
+    with pytest.raises(ValueError):
+        spec.validate()

@@ -104,14 +104,10 @@ class GridEngine:
         if advance_turn and turn is None:
             self.turn += 1
         t = self.turn if turn is None else int(turn)
-        if actions is not None:
-            if actions.dtype != torch.uint8 or actions.shape != self.actions.shape or not actions.is_contiguous():
-                self.actions.copy_(actions.to(torch.uint8).reshape(self.actions.shape))
-                actions = self.actions
-        else:
-            actions = self.actions
-            if not random_actions and agent_end != agent_begin:
-                pass  # caller wrote into self.actions
+        if actions is not None and actions is not self.actions:
+            # the step always consumes self.actions (so it also records what was taken)
+            self.actions.copy_(actions.to(device=self.device, dtype=torch.uint8).reshape(self.actions.shape))
+        actions = self.actions
         flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
         obs = self.obs if obs_out is None else obs_out
         if not write_obs or obs is None:

@@ -39,8 +39,7 @@ constexpr int kMaxPass = 2;  // window cells per thread held in registers
 // memory, copied into LDS at the start of every workgroup.
 struct DevTables {
     uint32_t thr_lo[SGW_MAX_TYPES];    // spawn threshold, low 32 bits of floor(p * 2^32)
-    uint32_t delta_lo[SGW_MAX_TYPES];  // one-hot: 1 << 4*channel for channels 0..7, else 0
-    uint32_t delta_hi[SGW_MAX_TYPES];  // channels 8..15
+    uint32_t delta[4][SGW_MAX_TYPES];  // one-hot: word c/4 holds 1 << 8*(c%4) for the type's channel c, else 0
     double value[SGW_MAX_TYPES];
     uint8_t spawn_choice[SGW_MAX_TYPES][SGW_MAX_CHOICES];
     uint8_t spawn_count[SGW_MAX_TYPES];
@@ -64,7 +63,13 @@ struct Params {
     uint32_t default_type, fill_type;
     uint32_t spawn_mask, thr_full_mask, pass_mask;
     uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
-    uint32_t fill_delta_lo, fill_delta_hi;
+    uint32_t fill_delta[4];
+    // single-spawner fast path (exactly one type carries SGW_RULE_SPAWN)
+    uint32_t spawn_pat;      // type id replicated in 4 bytes
+    uint32_t spawn_thr;      // low 32 bits of floor(p * 2^32)
+    uint32_t spawn_full;     // p >= 1
+    uint32_t spawn_n;        // number of choices
+    uint32_t choice_lo, choice_hi;  // the <= 8 choice type ids, one per byte
     uint32_t seed_lo, seed_hi;
     uint32_t first_env;
     int64_t E;
@@ -104,6 +109,13 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
         k1 += 0xBB67AE85u;
     }
     return U4{c0, c1, c2, c3};
+}
+
+// Keeps the compiler from hoisting the env-invariant first Philox round of every
+// (lane, block) pair out of the persistent env loop (that costs ~2 VGPRs per block).
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 __device__ __forceinline__ uint32_t word_of(const U4& v, int i) {
@@ -285,20 +297,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                     const int off = gy * p.W + gx;
                     float* o = obase + w;
                     if constexpr (ONEHOT) {
-                        uint32_t lo = 0, hi = 0;
+                        uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+                        const int nw = (p.C + 3) >> 2;
                         if (inb) {
                             for (int z = 0; z < p.L; ++z) {
                                 const uint32_t t = lg[z * HW + off] & 31u;
-                                lo += tab->delta_lo[t];
-                                if (p.C > 8) hi += tab->delta_hi[t];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    if (q < nw) cnt[q] += tab->delta[q][t];
                             }
                         } else {   // fill entity's appearance, once (visual_field.py:89-94)
-                            lo = p.fill_delta_lo;
-                            hi = p.fill_delta_hi;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cnt[q] = p.fill_delta[q];
                         }
-                        const int c8 = p.C < 8 ? p.C : 8;
-                        for (int c = 0; c < c8; ++c) o[c * p.VV] = (float)((lo >> (4 * c)) & 15u);
-                        for (int c = 8; c < p.C; ++c) o[c * p.VV] = (float)((hi >> (4 * (c - 8))) & 15u);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int c = 4 * q + b;
+                                if (c < p.C) o[c * p.VV] = (float)((cnt[q] >> (8 * b)) & 0xFFu);
+                            }
+                        }
                     } else {
                         for (int c = 0; c < p.C; ++c) {
                             double acc;
@@ -363,6 +382,246 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             }
         }
         gsync<WPE>();   // slice is reused by the next env of this group
+    }
+}
+
+// ---------------------------------------------------------------- fast step kernel
+// Wave-per-env specialisation for worlds whose byte count is a multiple of 16 and
+// <= 4 KiB with at most one spawning type (all BASELINE configs up to 32x32x2):
+//   * the grid is loaded straight into registers (16 B per lane per unit), the
+//     sweep runs on registers (byte-parallel spawner match, one Philox block per
+//     dword, the rare kind draw deferred to a short divergent loop), then the
+//     grid goes to LDS once with ds_write_b128;
+//   * agent state lives in registers (lane a = agent a) and is broadcast with
+//     v_readlane, so the move logic is scalar and never touches LDS tables;
+//   * window geometry (L, C, r) is compile-time, so the gather/emit is branch-free
+//     and the channel loop is unrolled into v_cvt_f32_ubyteN + global_store_dword.
+constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
+
+__device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
+    // 0x80 in every byte of v that equals the corresponding byte of pat (exact, no carries between bytes)
+    const uint32_t x = v ^ pat;
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
+__device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id) {
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t dv = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
+        const uint32_t m = match_bytes(dv, p.spawn_pat);
+        if (m) {
+            const U4 w = philox4x32_10(opaque(unit * 4 + k), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+            const bool f = p.spawn_full != 0;
+            uint32_t hb = 0;
+            hb |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
+            hb |= ((m & 0x8000u) && (f || w.y < p.spawn_thr)) ? 2u : 0u;
+            hb |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
+            hb |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
+            hits |= hb << (4 * k);
+        }
+    }
+    return hits;
+}
+
+// Rare second draw: what spawns in each hit cell; written straight into the LDS grid.
+__device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, uint8_t* lg, const Params& p,
+                                            const uint32_t env_id) {
+    while (hits) {
+        const uint32_t cell = (uint32_t)__ffs(hits) - 1u;
+        hits &= hits - 1u;
+        const uint32_t off = unit * 16u + cell;   // byte offset == RNG index
+        const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
+        lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+    }
+}
+
+template <bool ONEHOT, int TL, int TC, int TR>
+__global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sub = tid >> 6;
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(p.tab);
+        uint4* d = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < (p.tab_bytes >> 4); i += kBlock) d[i] = s[i];
+    }
+    __syncthreads();
+    const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
+    uint8_t* lg = smem + p.tab_bytes + sub * p.env_lds;
+    uint4* lg16 = reinterpret_cast<uint4*>(lg);
+
+    const int L = TL ? TL : p.L;
+    const int C = TC ? TC : p.C;
+    const int r = TR ? TR : p.r;
+    const int V = 2 * r + 1, VV = V * V;
+    const int W = p.W, H = p.H, HW = H * W;
+    const int nunits = p.cells >> 4;
+    const int zoff = p.zA * HW;
+    constexpr int NW = TC ? (TC + 3) / 4 : 4;   // counter words
+
+    // per-lane window geometry (fixed for the whole kernel): up to two cells per lane
+    int wdi[2], wdj[2], woff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int w = lane + 64 * k;
+        const int i = w / V, j = w - i * V;
+        wdi[k] = i - r;
+        wdj[k] = j - r;
+        woff[k] = wdi[k] * W + wdj[k];
+    }
+    // register-resident tables: lane t holds value[t]; lane a holds agent a's type
+    const double vtab = tab->value[lane & 31];
+    const uint32_t vt_lo = (uint32_t)__double_as_longlong(vtab), vt_hi = (uint32_t)(__double_as_longlong(vtab) >> 32);
+    const uint32_t atype = tab->agent_type[lane];
+    const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
+    const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
+    const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
+    const bool mine = lane >= p.a0 && lane < p.a1;   // this lane's agent is stepped in this call
+
+    for (int64_t env = (int64_t)blockIdx.x * 4 + sub; env < p.E; env += (int64_t)gridDim.x * 4) {
+        const uint32_t env_id = p.first_env + (uint32_t)env;
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.cells);
+        uint4 u[kMaxUnits];
+#pragma unroll
+        for (int k = 0; k < kMaxUnits; ++k)
+            if (lane + 64 * k < nunits) u[k] = src[lane + 64 * k];
+        uint32_t py = 0, px = 0, act = 0;
+        float rew = 0.f;
+        if (lane < p.A) {
+            const uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + lane];
+            py = yx & 0xFFu;
+            px = yx >> 8;
+            if (p.do_move && mine) {
+                if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
+                    const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                                               p.seed_lo, p.seed_hi);
+                    act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
+                    p.actions[env * p.A + lane] = (uint8_t)act;
+                } else {
+                    act = p.actions[env * p.A + lane];
+                }
+            }
+        }
+        double tot = p.do_move ? p.total[env] : 0.0;
+
+        // grid -> LDS; the Bernoulli half of the sweep runs on the registers meanwhile
+        uint32_t hits[kMaxUnits];
+#pragma unroll
+        for (int k = 0; k < kMaxUnits; ++k) {
+            hits[k] = 0;
+            if (lane + 64 * k < nunits) {
+                lg16[lane + 64 * k] = u[k];
+                if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id);
+            }
+        }
+        gsync<1>();
+        if (do_sweep) {
+#pragma unroll
+            for (int k = 0; k < kMaxUnits; ++k)
+                if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id);
+            gsync<1>();
+        }
+
+        int st_bits = 0;
+        for (int a = p.a0; a < p.a1; ++a) {
+            const int y = __builtin_amdgcn_readlane((int)py, a);
+            const int x = __builtin_amdgcn_readlane((int)px, a);
+            const int cbase = y * W + x;
+            if (write_obs) {
+                float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (64 * k >= VV) break;
+                    const int w = lane + 64 * k;
+                    if (w < VV) {
+                        const bool inb = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
+                        const int off = inb ? cbase + woff[k] : 0;   // clamped: the read is always in range
+                        float* o = obase + w;
+                        if constexpr (ONEHOT) {
+                            uint32_t cnt[NW];
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) cnt[q] = 0;
+                            for (int z = 0; z < L; ++z) {
+                                const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) cnt[q] += tab->delta[q][t];
+                            }
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < C) o[c * VV] = (float)((cnt[q] >> (8 * b)) & 0xFFu);
+                                }
+                            }
+                        } else {
+                            for (int c = 0; c < C; ++c) {
+                                double acc = tab->appearance[lg[off] & 31u][c];   // left-to-right float64 layer sum
+                                for (int z = 1; z < L; ++z) acc += tab->appearance[lg[z * HW + off] & 31u][c];
+                                o[c * VV] = (float)(inb ? acc : tab->appearance[p.fill_type][c]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!p.do_move) continue;
+            // ---- scalar move resolution (agent.py:187-225, gridworld.py:95-122)
+            const uint32_t sact = (uint32_t)__builtin_amdgcn_readlane((int)act, a);
+            const bool act_ok = sact < (uint32_t)p.nact;
+            const int dy = act_ok ? (int)((p.dy_pack >> (2 * sact)) & 3u) - 1 : 0;
+            const int dx = act_ok ? (int)((p.dx_pack >> (2 * sact)) & 3u) - 1 : 0;
+            const int ty = y + dy, tx = x + dx;
+            const bool inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+            const int taddr = inb ? zoff + ty * W + tx : zoff + cbase;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[taddr]);
+            const bool tok = inb && t < (uint32_t)p.T;
+            const uint32_t tl = t & 31u;
+            const uint32_t v_lo = (uint32_t)__builtin_amdgcn_readlane((int)vt_lo, (int)tl);
+            const uint32_t v_hi = (uint32_t)__builtin_amdgcn_readlane((int)vt_hi, (int)tl);
+            const double val = tok ? __longlong_as_double(((long long)v_hi << 32) | v_lo) : 0.0;   // reward BEFORE the move
+            const bool pass = tok && ((p.pass_mask >> tl) & 1u);
+            // cross-lane reads stay in wave-uniform control flow (a register reloaded under a
+            // partial exec mask would hand v_readlane stale lanes)
+            const uint32_t my_type = (uint32_t)__builtin_amdgcn_readlane((int)atype, a);
+            if (pass) {
+                if (lane == 0) {
+                    lg[taddr] = (uint8_t)my_type;
+                    lg[zoff + cbase] = (uint8_t)p.default_type;
+                }
+                py = lane == a ? (uint32_t)ty : py;
+                px = lane == a ? (uint32_t)tx : px;
+            }
+            rew = lane == a ? (float)val : rew;
+            tot += val;   // float64, agent order (agent.py:172)
+            st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
+                       ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
+            gsync<1>();
+        }
+
+        if (dirty) {
+            uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.cells);
+#pragma unroll
+            for (int k = 0; k < kMaxUnits; ++k)
+                if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
+        }
+        if (p.do_move) {
+            if (lane < p.A && mine) {
+                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)(py | (px << 8));
+                p.rewards[env * p.A + lane] = rew;
+            }
+            if (lane == 0) {
+                p.total[env] = tot;
+                if (st_bits) atomicOr(p.status, st_bits);
+            }
+        }
+        gsync<1>();
     }
 }
 
@@ -556,7 +815,12 @@ struct sgw_engine {
     double* d_part = nullptr;
     int wpe = 1;          // waves per env
     bool onehot = true;
-    size_t lds_bytes = 0;
+    bool fast = false;    // step_fast specialisation applies
+    void (*step_fn)(const Params) = nullptr;
+    void (*reset_fn)(const Params) = nullptr;
+    size_t lds_bytes = 0;       // reset / generic step
+    size_t step_lds_bytes = 0;  // step kernel actually launched
+    int step_env_lds = 0;
     int grid_blocks = 1;
     int reset_blocks = 1;
     int num_cus = 256;
@@ -650,6 +914,13 @@ StepFn pick_step(int wpe, bool onehot) {
 }
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
+StepFn pick_fast(bool onehot, int L, int C, int r) {
+    if (!onehot) return step_fast<false, 0, 0, 0>;
+    if (L == 2 && C == 6 && r == 3) return step_fast<true, 2, 6, 3>;   // BASELINE configs 3/4 (headline)
+    if (L == 2 && C == 6 && r == 2) return step_fast<true, 2, 6, 2>;   // BASELINE config 2
+    return step_fast<true, 0, 0, 0>;
+}
+
 int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int time_begin(sgw_engine* e, hipStream_t s) {
@@ -722,10 +993,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             else if (v != 0.0) other = true;
         }
         if (other || ones > 1) onehot = false;
-        if (ones == 1 && !other) {
-            if (ch < 8) h.delta_lo[t] = 1u << (4 * ch);
-            else h.delta_hi[t] = 1u << (4 * (ch - 8));
-        }
+        if (ones == 1 && !other) h.delta[ch >> 2][t] = 1u << (8 * (ch & 3));
         h.value[t] = c.type_value[t];
         h.thr_lo[t] = (uint32_t)(prob_threshold(c.spawn_prob[t]) & 0xFFFFFFFFull);
         h.spawn_count[t] = c.spawn_count[t];
@@ -760,8 +1028,23 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         p.dy_pack |= (uint32_t)(c.action_dy[a] + 1) << (2 * a);
         p.dx_pack |= (uint32_t)(c.action_dx[a] + 1) << (2 * a);
     }
-    p.fill_delta_lo = h.delta_lo[c.fill_type];
-    p.fill_delta_hi = h.delta_hi[c.fill_type];
+    for (int q = 0; q < 4; ++q) p.fill_delta[q] = h.delta[q][c.fill_type];
+    int nspawn = 0;
+    p.spawn_pat = 0xFFFFFFFFu;   // matches no valid type id
+    for (int t = 0; t < c.num_types; ++t) {
+        if (c.type_rule[t] != SGW_RULE_SPAWN) continue;
+        ++nspawn;
+        p.spawn_pat = 0x01010101u * (uint32_t)t;
+        const uint64_t thr = prob_threshold(c.spawn_prob[t]);
+        p.spawn_thr = (uint32_t)(thr & 0xFFFFFFFFull);
+        p.spawn_full = thr >= 4294967296ull ? 1u : 0u;
+        p.spawn_n = c.spawn_count[t];
+        p.choice_lo = p.choice_hi = 0;
+        for (int k = 0; k < c.spawn_count[t]; ++k) {
+            if (k < 4) p.choice_lo |= (uint32_t)c.spawn_choice[t][k] << (8 * k);
+            else p.choice_hi |= (uint32_t)c.spawn_choice[t][k] << (8 * (k - 4));
+        }
+    }
     p.seed_lo = (uint32_t)c.seed;
     p.seed_hi = (uint32_t)(c.seed >> 32);
     p.first_env = (uint32_t)c.first_env_id;
@@ -773,6 +1056,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->wpe = (p.cells_pad <= 4096) ? 1 : 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
+    e->fast = e->wpe == 1 && (p.cells & 15) == 0 && (p.cells >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128;
+    e->step_env_lds = e->fast ? p.cells_pad : p.env_lds;
+    e->step_lds_bytes = (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
     const size_t lds_max = 160 * 1024;
     if (e->lds_bytes > lds_max) {
@@ -792,8 +1078,10 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = pick_step(e->wpe, e->onehot);
+    StepFn sk = e->fast ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius) : pick_step(e->wpe, e->onehot);
     StepFn rk = pick_reset(e->wpe);
+    e->step_fn = sk;
+    e->reset_fn = rk;
     if (e->lds_bytes > lds_cap || e->lds_bytes > 65536) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err == hipSuccess)
@@ -804,7 +1092,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         }
     }
     int nb = 0;
-    if (int rc = occupancy_blocks(sk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
+    if (int rc = occupancy_blocks(sk, e->step_lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     e->grid_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     e->reset_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
@@ -832,14 +1120,16 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.total = total_reward; p.epoch = epoch;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(pick_reset(e->wpe), dim3(e->reset_blocks), dim3(kBlock), e->lds_bytes, s, p);
+    hipLaunchKernelGGL(e->reset_fn, dim3(e->reset_blocks), dim3(kBlock), e->lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
 }
 
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (int rc = time_begin(e, s)) return rc;
-    hipLaunchKernelGGL(pick_step(e->wpe, e->onehot), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, p);
+    p.env_lds = e->step_env_lds;
+    if (p.spawn_mask == 0) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
+    hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(kBlock), e->step_lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
 }

@@ -39,7 +39,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         acc = defaultdict(list)
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if "step_kernel" in row.get("Kernel_Name", ""):
+                if "step_" in row.get("Kernel_Name", ""):
                     acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             print("  %-24s n=%d avg=%.6g" % (k, len(v), sum(v) / len(v)))

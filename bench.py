@@ -94,6 +94,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip observation stores (NOT a valid bench line)")
+    ap.add_argument("--diag-alias-obs", action="store_true", help="diagnostic: all envs store obs to one small region (NOT valid)")
+    ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
     args = ap.parse_args()
 
     import torch
@@ -130,14 +132,17 @@ def main() -> int:
         torch.cuda.synchronize(dev)
 
     write_obs = not args.no_obs
+    sweep = not args.no_sweep
+    if args.diag_alias_obs:
+        eng._diag_flags = 0x100
     for _ in range(args.warmup):
-        eng.step(random_actions=True, write_obs=write_obs)
+        eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                   # on the stream sgw_step launches on
     for _ in range(args.steps):
-        eng.step(random_actions=True, write_obs=write_obs)
+        eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
@@ -170,7 +175,7 @@ def main() -> int:
                 "envs_per_gpu": E, "global_envs": total_envs, "agents": A, "grid": [H, W, spec.layers],
                 "window": spec.window, "channels": spec.num_channels, "spawn_prob": p_spawn, "dense_prob": p_dense,
                 "sharding": f"env-batch x{world}, no data-path collective; one 32-byte all-reduce at end of rollout",
-                "obs_written": write_obs,
+                "obs_written": write_obs, "sweep": sweep,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

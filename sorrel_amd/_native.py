@@ -47,7 +47,7 @@ class SgwConfig(C.Structure):
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsgw.so")
+LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")   # SGW_LIB: diagnostic builds (tools/)
 
 # every symbol include/sgw.h declares
 EXPORTS = (

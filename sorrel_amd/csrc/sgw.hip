@@ -93,13 +93,14 @@ struct U4 {
     uint32_t x, y, z, w;
 };
 
+// Philox-4x32-10 (Salmon et al., SC'11); key = (k0, k1) wave-uniform.
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;   // gfx950 has no v_xor3_b32
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
@@ -388,14 +389,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
 // ---------------------------------------------------------------- fast step kernel
 // Wave-per-env specialisation for worlds whose byte count is a multiple of 16 and
 // <= 4 KiB with at most one spawning type (all BASELINE configs up to 32x32x2):
-//   * the grid is loaded straight into registers (16 B per lane per unit), the
-//     sweep runs on registers (byte-parallel spawner match, one Philox block per
-//     dword, the rare kind draw deferred to a short divergent loop), then the
-//     grid goes to LDS once with ds_write_b128;
-//   * agent state lives in registers (lane a = agent a) and is broadcast with
-//     v_readlane, so the move logic is scalar and never touches LDS tables;
-//   * window geometry (L, C, r) is compile-time, so the gather/emit is branch-free
-//     and the channel loop is unrolled into v_cvt_f32_ubyteN + global_store_dword.
+//   * the grid is loaded straight into registers (16 B per lane per unit) one env
+//     AHEAD of its use, so HBM latency hides under the previous env's work;
+//   * the Bernoulli half of the sweep runs on those registers (byte-parallel
+//     spawner match, one Philox block per dword); the rare "what spawns" draw is
+//     deferred to a short divergent loop that patches single bytes in LDS;
+//   * everything about an agent's move that does not depend on the other agents
+//     (action -> target cell, bounds, status) is computed for all agents at once,
+//     lane a = agent a; the strictly sequential part is a handful of scalar ops:
+//     read the target type from LDS, test passability, patch two bytes;
+//   * window geometry (L, C, r, and for the BASELINE shapes H, W) is compile-time,
+//     so gather/emit is branch-free: v_cvt_f32_ubyteN + global_store_dword.
 constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
 
 __device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
@@ -439,7 +443,7 @@ __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, 
     }
 }
 
-template <bool ONEHOT, int TL, int TC, int TR>
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW>
 __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -459,8 +463,11 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     const int C = TC ? TC : p.C;
     const int r = TR ? TR : p.r;
     const int V = 2 * r + 1, VV = V * V;
-    const int W = p.W, H = p.H, HW = H * W;
-    const int nunits = p.cells >> 4;
+    const int H = TH ? TH : p.H, W = TW ? TW : p.W, HW = H * W;
+    constexpr bool kStatic = TL && TH && TW;
+    const int cells = kStatic ? TL * TH * TW : p.cells;
+    const int nunits = cells >> 4;
+    constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane
     const int zoff = p.zA * HW;
     constexpr int NW = TC ? (TC + 3) / 4 : 4;   // counter words
 
@@ -474,45 +481,56 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         wdj[k] = j - r;
         woff[k] = wdi[k] * W + wdj[k];
     }
-    // register-resident tables: lane t holds value[t]; lane a holds agent a's type
+    // register-resident tables: lane t holds value[t] (f64 bits + its f32 rounding); lane a holds agent a's type
     const double vtab = tab->value[lane & 31];
     const uint32_t vt_lo = (uint32_t)__double_as_longlong(vtab), vt_hi = (uint32_t)(__double_as_longlong(vtab) >> 32);
+    const uint32_t vt_f32 = __float_as_uint((float)vtab);
     const uint32_t atype = tab->agent_type[lane];
     const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
     const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
     const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
-    const bool mine = lane >= p.a0 && lane < p.a1;   // this lane's agent is stepped in this call
+    const bool mine = lane >= p.a0 && lane < p.a1 && lane < p.A;   // this lane's agent is stepped in this call
+    const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
+    const int64_t stride = (int64_t)gridDim.x * 4;
 
-    for (int64_t env = (int64_t)blockIdx.x * 4 + sub; env < p.E; env += (int64_t)gridDim.x * 4) {
-        const uint32_t env_id = p.first_env + (uint32_t)env;
-        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.cells);
-        uint4 u[kMaxUnits];
+    // ---- prologue: loads of the first env
+    int64_t env = (int64_t)blockIdx.x * 4 + sub;
+    uint4 nxt[NU];
+    uint32_t nyx = 0, nact = 0;
+    if (env < p.E) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * cells);
 #pragma unroll
-        for (int k = 0; k < kMaxUnits; ++k)
-            if (lane + 64 * k < nunits) u[k] = src[lane + 64 * k];
-        uint32_t py = 0, px = 0, act = 0;
-        float rew = 0.f;
-        if (lane < p.A) {
-            const uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + lane];
-            py = yx & 0xFFu;
-            px = yx >> 8;
-            if (p.do_move && mine) {
-                if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
-                    const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
-                                               p.seed_lo, p.seed_hi);
-                    act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
-                    p.actions[env * p.A + lane] = (uint8_t)act;
-                } else {
-                    act = p.actions[env * p.A + lane];
-                }
+        for (int k = 0; k < NU; ++k)
+            if (lane + 64 * k < nunits) nxt[k] = src[lane + 64 * k];
+        if (lane < p.A) nyx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + lane];
+        if (mine && p.do_move && !rnd) nact = p.actions[env * p.A + lane];
+    }
+
+    for (; env < p.E; env += stride) {
+        const uint32_t env_id = p.first_env + (uint32_t)env;
+        uint4 u[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) u[k] = nxt[k];
+        const uint32_t yx = nyx;
+        uint32_t act = nact;
+        // ---- prefetch the next env of this wave (its latency hides under this env's work)
+        {
+            const int64_t en = env + stride;
+            if (en < p.E) {
+                const uint4* src = reinterpret_cast<const uint4*>(p.grid + en * cells);
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) nxt[k] = src[lane + 64 * k];
+                if (lane < p.A) nyx = reinterpret_cast<const uint16_t*>(p.pos)[en * p.A + lane];
+                if (mine && p.do_move && !rnd) nact = p.actions[en * p.A + lane];
             }
         }
         double tot = p.do_move ? p.total[env] : 0.0;
 
-        // grid -> LDS; the Bernoulli half of the sweep runs on the registers meanwhile
-        uint32_t hits[kMaxUnits];
+        // ---- grid -> LDS; the Bernoulli half of the sweep runs on the registers
+        uint32_t hits[NU];
 #pragma unroll
-        for (int k = 0; k < kMaxUnits; ++k) {
+        for (int k = 0; k < NU; ++k) {
             hits[k] = 0;
             if (lane + 64 * k < nunits) {
                 lg16[lane + 64 * k] = u[k];
@@ -522,18 +540,45 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         gsync<1>();
         if (do_sweep) {
 #pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k)
+            for (int k = 0; k < NU; ++k)
                 if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id);
             gsync<1>();
         }
 
-        int st_bits = 0;
+        // ---- everything about agent `lane`'s move that does not depend on the other agents
+        const uint32_t py = yx & 0xFFu, px = yx >> 8;
+        uint32_t taddr_v = 0xFFFFFFFFu;          // target cell (LDS byte offset) or "invalid"
+        uint32_t npos = yx;                      // position if the move succeeds
+        int st_lane = 0;
+        if (p.do_move && mine) {
+            if (rnd) {
+                const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                                           p.seed_lo, p.seed_hi);
+                act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
+                p.actions[env * p.A + lane] = (uint8_t)act;
+            }
+            const bool act_ok = act < (uint32_t)p.nact;
+            const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
+            const int dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+            const int ty = (int)py + dy, tx = (int)px + dx;
+            const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+            if (act_ok && inb) {
+                taddr_v = (uint32_t)(zoff + ty * W + tx);
+                npos = (uint32_t)ty | ((uint32_t)tx << 8);
+            }
+            st_lane = !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
+        }
+        const uint32_t oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;   // own cell
+        uint32_t rew_bits = 0, moved = 0;
+
+        // ---- agents, strictly in list order
         for (int a = p.a0; a < p.a1; ++a) {
-            const int y = __builtin_amdgcn_readlane((int)py, a);
-            const int x = __builtin_amdgcn_readlane((int)px, a);
-            const int cbase = y * W + x;
+            const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
             if (write_obs) {
-                float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
+                const int y = __builtin_amdgcn_readlane((int)py, a);
+                const int x = __builtin_amdgcn_readlane((int)px, a);
+                const int cbase = s_o - zoff;
+                float* obase = p.obs + (((p.flags & 0x100u) ? (int64_t)sub : env * p.A + a) * (int64_t)C) * VV;   // 0x100: diagnostic aliasing (tools/)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (64 * k >= VV) break;
@@ -546,10 +591,18 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                             uint32_t cnt[NW];
 #pragma unroll
                             for (int q = 0; q < NW; ++q) cnt[q] = 0;
-                            for (int z = 0; z < L; ++z) {
+#pragma unroll
+                            for (int z = 0; z < (TL ? TL : 1); ++z) {
                                 const uint32_t t = lg[z * HW + off] & 31u;
 #pragma unroll
                                 for (int q = 0; q < NW; ++q) cnt[q] += tab->delta[q][t];
+                            }
+                            if constexpr (TL == 0) {
+                                for (int z = 1; z < L; ++z) {
+                                    const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                    for (int q = 0; q < NW; ++q) cnt[q] += tab->delta[q][t];
+                                }
                             }
 #pragma unroll
                             for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
@@ -572,54 +625,41 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 }
             }
             if (!p.do_move) continue;
-            // ---- scalar move resolution (agent.py:187-225, gridworld.py:95-122)
-            const uint32_t sact = (uint32_t)__builtin_amdgcn_readlane((int)act, a);
-            const bool act_ok = sact < (uint32_t)p.nact;
-            const int dy = act_ok ? (int)((p.dy_pack >> (2 * sact)) & 3u) - 1 : 0;
-            const int dx = act_ok ? (int)((p.dx_pack >> (2 * sact)) & 3u) - 1 : 0;
-            const int ty = y + dy, tx = x + dx;
-            const bool inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
-            const int taddr = inb ? zoff + ty * W + tx : zoff + cbase;
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[taddr]);
-            const bool tok = inb && t < (uint32_t)p.T;
+            // ---- the sequential part (agent.py:219-221, gridworld.py:110-122): scalar
+            const uint32_t s_t = (uint32_t)__builtin_amdgcn_readlane((int)taddr_v, a);
+            const uint32_t my_type = (uint32_t)__builtin_amdgcn_readlane((int)atype, a);
+            const bool valid = s_t != 0xFFFFFFFFu;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[valid ? s_t : (uint32_t)s_o]);
+            const bool tok = valid && t < (uint32_t)p.T;
             const uint32_t tl = t & 31u;
             const uint32_t v_lo = (uint32_t)__builtin_amdgcn_readlane((int)vt_lo, (int)tl);
             const uint32_t v_hi = (uint32_t)__builtin_amdgcn_readlane((int)vt_hi, (int)tl);
-            const double val = tok ? __longlong_as_double(((long long)v_hi << 32) | v_lo) : 0.0;   // reward BEFORE the move
+            const uint32_t v_f = (uint32_t)__builtin_amdgcn_readlane((int)vt_f32, (int)tl);
             const bool pass = tok && ((p.pass_mask >> tl) & 1u);
-            // cross-lane reads stay in wave-uniform control flow (a register reloaded under a
-            // partial exec mask would hand v_readlane stale lanes)
-            const uint32_t my_type = (uint32_t)__builtin_amdgcn_readlane((int)atype, a);
-            if (pass) {
-                if (lane == 0) {
-                    lg[taddr] = (uint8_t)my_type;
-                    lg[zoff + cbase] = (uint8_t)p.default_type;
-                }
-                py = lane == a ? (uint32_t)ty : py;
-                px = lane == a ? (uint32_t)tx : px;
+            if (pass && lane == 0) {
+                lg[s_t] = (uint8_t)my_type;
+                lg[s_o] = (uint8_t)p.default_type;
             }
-            rew = lane == a ? (float)val : rew;
-            tot += val;   // float64, agent order (agent.py:172)
-            st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
-                       ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
+            if (tok) tot += __longlong_as_double(((long long)v_hi << 32) | v_lo);   // reward BEFORE the move; float64, agent order
+            rew_bits = lane == a ? (tok ? v_f : 0u) : rew_bits;
+            moved = lane == a ? (pass ? 1u : 0u) : moved;
+            if (valid && !tok) st_lane |= SGW_STATUS_BAD_TYPE;
             gsync<1>();
         }
 
         if (dirty) {
-            uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.cells);
+            uint4* dst = reinterpret_cast<uint4*>(p.grid + env * cells);
 #pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k)
+            for (int k = 0; k < NU; ++k)
                 if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
         }
         if (p.do_move) {
-            if (lane < p.A && mine) {
-                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)(py | (px << 8));
-                p.rewards[env * p.A + lane] = rew;
+            if (mine) {
+                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)(moved ? npos : yx);
+                p.rewards[env * p.A + lane] = __uint_as_float(rew_bits);
+                if (st_lane) atomicOr(p.status, st_lane);
             }
-            if (lane == 0) {
-                p.total[env] = tot;
-                if (st_bits) atomicOr(p.status, st_bits);
-            }
+            if (lane == 0) p.total[env] = tot;
         }
         gsync<1>();
     }
@@ -914,11 +954,12 @@ StepFn pick_step(int wpe, bool onehot) {
 }
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
-StepFn pick_fast(bool onehot, int L, int C, int r) {
-    if (!onehot) return step_fast<false, 0, 0, 0>;
-    if (L == 2 && C == 6 && r == 3) return step_fast<true, 2, 6, 3>;   // BASELINE configs 3/4 (headline)
-    if (L == 2 && C == 6 && r == 2) return step_fast<true, 2, 6, 2>;   // BASELINE config 2
-    return step_fast<true, 0, 0, 0>;
+StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W) {
+    if (!onehot) return step_fast<false, 0, 0, 0, 0, 0>;
+    if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) return step_fast<true, 2, 6, 3, 32, 32>;   // BASELINE configs 3/4 (headline)
+    if (L == 2 && C == 6 && r == 2 && H == 16 && W == 16) return step_fast<true, 2, 6, 2, 16, 16>;   // BASELINE config 2
+    if (L == 2 && C == 6) return step_fast<true, 2, 6, 0, 0, 0>;   // treasurehunt-shaped, any size
+    return step_fast<true, 0, 0, 0, 0, 0>;
 }
 
 int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -1078,7 +1119,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = e->fast ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius) : pick_step(e->wpe, e->onehot);
+    StepFn sk = e->fast ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width) : pick_step(e->wpe, e->onehot);
     StepFn rk = pick_reset(e->wpe);
     e->step_fn = sk;
     e->reset_fn = rk;

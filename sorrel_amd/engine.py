@@ -52,6 +52,7 @@ class GridEngine:
         self.obs = (torch.zeros((E,) + spec.obs_shape, dtype=torch.float32, device=dev) if allocate_obs else None)
         self.epoch = 0
         self.turn = 0
+        self._diag_flags = 0   # diagnostics only (tools/): never set by the product path
 
     # ------------------------------------------------------------------ util
     def _stream(self):
@@ -108,7 +109,7 @@ class GridEngine:
             # the step always consumes self.actions (so it also records what was taken)
             self.actions.copy_(actions.to(device=self.device, dtype=torch.uint8).reshape(self.actions.shape))
         actions = self.actions
-        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
+        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0) | self._diag_flags
         obs = self.obs if obs_out is None else obs_out
         if not write_obs or obs is None:
             flags |= N.STEP_NO_OBS

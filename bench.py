@@ -94,7 +94,6 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip observation stores (NOT a valid bench line)")
-    ap.add_argument("--diag-alias-obs", action="store_true", help="diagnostic: all envs store obs to one small region (NOT valid)")
     ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
     args = ap.parse_args()
 
@@ -133,8 +132,6 @@ def main() -> int:
 
     write_obs = not args.no_obs
     sweep = not args.no_sweep
-    if args.diag_alias_obs:
-        eng._diag_flags = 0x100
     for _ in range(args.warmup):
         eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
     barrier()

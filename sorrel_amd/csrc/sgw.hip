@@ -94,6 +94,13 @@ struct U4 {
     uint32_t x, y, z, w;
 };
 
+// a ^ b ^ k in one VALU op (gfx950: v_bitop3_b32 with truth table 0x96; there is no v_xor3_b32 on gfx9).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t k) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+
 // Philox-4x32-10 (Salmon et al., SC'11); key = (k0, k1) wave-uniform.
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
@@ -101,8 +108,8 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;   // gfx950 has no v_xor3_b32
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int sub = tid >> 6;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps all env-indexed address math scalar
     const int64_t env = (int64_t)blockIdx.x * 4 + sub;
     if (env >= p.E) return;   // whole wave exits together
 
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 const int y = __builtin_amdgcn_readlane((int)py, a);
                 const int x = __builtin_amdgcn_readlane((int)px, a);
                 const int cbase = s_o - zoff;
-                float* obase = p.obs + (((p.flags & 0x100u) ? (int64_t)sub : env * p.A + a) * (int64_t)C) * VV;   // 0x100: diagnostic aliasing (tools/)
+                float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (64 * k >= VV) break;

@@ -161,6 +161,16 @@ def main() -> int:
         if not write_obs:
             alg_bytes -= E * A * spec.num_channels * spec.window ** 2 * 4
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected by
+        # tools/profile_gpu.sh on this same command and committed under profiles/; null when no matching pass exists
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")) as fh:
+                tj = json.load(fh)
+            if tj.get("envs") == E and write_obs and sweep:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -176,8 +186,8 @@ def main() -> int:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "step_fast<...> (sgw_step)" if spec.grid_bytes_per_env() <= 4096 else "step_kernel<4,...> (sgw_step)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },
             "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status},

@@ -1,0 +1,114 @@
+"""``Agent`` / ``MovingAgent`` with the interface of ``sorrel/agents/agent.py:14-225``.
+
+One ``Agent`` object stands for one agent *slot* in every env of the batch: its
+``pov`` returns ``[E, ...]`` observations, ``get_action`` returns ``[E]`` actions and
+``act`` returns ``[E]`` rewards.  ``transition`` keeps the reference's order
+(pov -> get_action -> act -> is_done -> memory), which is what makes
+"agent i+1 observes agent i's move" hold for policy-driven agents."""
+from __future__ import annotations
+
+from abc import abstractmethod
+
+import torch
+
+from sorrel_amd.entities.entity import Entity
+
+
+class Agent(Entity):
+    """Abstract agent.  ``has_transitions`` defaults to True as in the reference; the
+    entity sweep skips agents (``sorrel/environment.py:90``)."""
+
+    def __init__(self, observation_spec, action_spec, model, location=None):
+        self.observation_spec = observation_spec
+        self.action_spec = action_spec
+        self.model = model
+        self._location = location
+        super().__init__()            # (the reference also resets _location to None here)
+        self.has_transitions = True
+        self.slot = None              # index in Environment.agents, set by the Environment
+        self._world = None
+
+    # -- abstract hooks (sorrel/agents/agent.py:57-111)
+    @abstractmethod
+    def reset(self) -> None: ...
+
+    @abstractmethod
+    def pov(self, world): ...
+
+    @abstractmethod
+    def get_action(self, state): ...
+
+    @abstractmethod
+    def act(self, world, action): ...
+
+    @abstractmethod
+    def is_done(self, world) -> bool: ...
+
+    def type_key(self):
+        # an agent's transition is its own step, never a sweep rule
+        return (type(self).__module__, type(self).__qualname__, self.kind, float(self.value), bool(self.passable),
+                False, None)
+
+    @property
+    def locations(self) -> torch.Tensor:
+        """``[E, 3]`` (y, x, z) of this agent in every env."""
+        w = self._world
+        yx = w.agent_pos[:, self.slot].long()
+        z = torch.full((yx.shape[0], 1), w.agent_layer, dtype=torch.long, device=yx.device)
+        return torch.cat([yx, z], dim=1)
+
+    @property
+    def location(self) -> tuple:
+        """Location in env 0 (the reference's single world); see ``locations`` for the batch."""
+        if self._world is not None and self._world.agent_pos is not None and self.slot is not None \
+                and self._world.agent_layer is not None:
+            y, x = (int(v) for v in self._world.agent_pos[0, self.slot])
+            return (y, x, self._world.agent_layer)
+        if self._location is None:
+            raise AttributeError(f"{self.kind} location is None.")
+        return self._location
+
+    @location.setter
+    def location(self, value):
+        self._location = value
+
+    def add_memory(self, state, action, reward, done) -> None:
+        mem = getattr(self.model, "memory", None)
+        if mem is not None:
+            mem.add(state, action, reward, done)
+
+    def model_take_action(self, state):
+        return self.model.take_action(state)
+
+    def transition(self, world) -> None:
+        """pov -> get_action -> act -> is_done -> memory (``agent.py:155-173``).
+        ``world.total_reward += reward`` happens inside the step kernel, in agent order."""
+        state = self.pov(world)
+        action = self.get_action(state)
+        reward = self.act(world, action)
+        done = self.is_done(world)
+        self.add_memory(state, action, reward, done)
+
+
+class MovingAgent(Agent):
+    """Agent that moves up / down / left / right (``agent.py:176-225``)."""
+
+    direction = 2
+
+    def movement(self, action):
+        """New location for an action: an int gives the env-0 tuple (reference call shape),
+        a tensor ``[E]`` gives ``[E, 3]``.  Any other action name stays in place."""
+        names = self.action_spec.actions
+        delta = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
+        if isinstance(action, int):
+            dy, dx = delta.get(names[action], (0, 0))
+            y, x, z = self.location
+            return (y + dy, x + dx, z)
+        table = torch.tensor([delta.get(names[i], (0, 0)) + (0,) for i in range(self.action_spec.n_actions)],
+                             device=action.device)
+        return self.locations + table[action.long()]
+
+    def act(self, world, action):
+        """reward = value of the target BEFORE the move, then ``world.move`` -- one
+        ``sgw_step`` phase for this agent slot; returns rewards ``[E]``."""
+        return world._environment._act(self, action)

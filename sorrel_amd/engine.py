@@ -25,7 +25,7 @@ class GridEngine:
     """
 
     def __init__(self, spec: WorldSpec, num_envs: int, device="cuda", first_env_id: int = 0,
-                 allocate_obs: bool = True):
+                 allocate_obs: bool = True, tensors: Optional[dict] = None):
         self.spec = spec
         self.num_envs = int(num_envs)
         self.first_env_id = int(first_env_id)
@@ -43,16 +43,27 @@ class GridEngine:
             N.check(self._lib.sgw_create(C.byref(self.config), C.byref(self._h)))
         E, A = self.num_envs, spec.num_agents
         dev = self.device
-        self.grid = torch.zeros((E, spec.layers, spec.height, spec.width), dtype=torch.uint8, device=dev)
-        self.agent_pos = torch.zeros((E, A, 2), dtype=torch.uint8, device=dev)
-        self.actions = torch.zeros((E, A), dtype=torch.uint8, device=dev)
-        self.rewards = torch.zeros((E, A), dtype=torch.float32, device=dev)
-        self.total_reward = torch.zeros((E,), dtype=torch.float64, device=dev)
+        tensors = tensors or {}
+
+        def adopt(name, shape, dtype):
+            t = tensors.get(name)
+            if t is None:
+                return torch.zeros(shape, dtype=dtype, device=dev)
+            if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+                raise ValueError(f"tensor {name!r} must be contiguous {dtype} {tuple(shape)} on {dev}")
+            return t
+
+        # state tensors may be adopted from the caller (the batched Gridworld owns them)
+        self.grid = adopt("grid", (E, spec.layers, spec.height, spec.width), torch.uint8)
+        self.agent_pos = adopt("agent_pos", (E, A, 2), torch.uint8)
+        self.actions = adopt("actions", (E, A), torch.uint8)
+        self.rewards = adopt("rewards", (E, A), torch.float32)
+        self.total_reward = adopt("total_reward", (E,), torch.float64)
         self.metrics = torch.zeros((4,), dtype=torch.float64, device=dev)
         self.obs = (torch.zeros((E,) + spec.obs_shape, dtype=torch.float32, device=dev) if allocate_obs else None)
         self.epoch = 0
         self.turn = 0
-        self._diag_flags = 0   # diagnostics only (tools/): never set by the product path
+        self._scratch_obs = None
 
     # ------------------------------------------------------------------ util
     def _stream(self):
@@ -83,16 +94,24 @@ class GridEngine:
             N.check(self._lib.sgw_reset(self._h, self._ptr(self.grid), self._ptr(self.agent_pos),
                                         self._ptr(self.total_reward), self.epoch, self._stream()))
 
-    def observe(self, agent_begin: int = 0, agent_end: Optional[int] = None, out: Optional[torch.Tensor] = None):
-        """Stateless egocentric observation of the agents (K1)."""
+    def observe(self, agent_begin: int = 0, agent_end: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                pos: Optional[torch.Tensor] = None):
+        """Stateless egocentric observation of the agents (K1).  ``pos`` (uint8 ``[E, A, 2]``)
+        observes from other cells than the agents' own."""
         out = self.obs if out is None else out
         if out is None:
             raise ValueError("engine was built with allocate_obs=False; pass `out`")
+        pos = self.agent_pos if pos is None else pos
         agent_end = self.spec.num_agents if agent_end is None else agent_end
         with torch.cuda.device(self.device):
-            N.check(self._lib.sgw_observe(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(out),
+            N.check(self._lib.sgw_observe(self._h, self._ptr(self.grid), self._ptr(pos), self._ptr(out),
                                           agent_begin, agent_end, self._stream()))
         return out
+
+    def scratch_obs(self) -> torch.Tensor:
+        if self._scratch_obs is None:
+            self._scratch_obs = torch.zeros((self.num_envs,) + self.spec.obs_shape, dtype=torch.float32, device=self.device)
+        return self._scratch_obs
 
     def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,
              write_obs: bool = True, agent_begin: int = 0, agent_end: Optional[int] = None,
@@ -109,7 +128,7 @@ class GridEngine:
             # the step always consumes self.actions (so it also records what was taken)
             self.actions.copy_(actions.to(device=self.device, dtype=torch.uint8).reshape(self.actions.shape))
         actions = self.actions
-        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0) | self._diag_flags
+        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
         obs = self.obs if obs_out is None else obs_out
         if not write_obs or obs is None:
             flags |= N.STEP_NO_OBS

@@ -1,0 +1,326 @@
+"""``Environment`` with the interface of ``sorrel/environment.py:18-93``: the batch driver.
+
+Subclass it exactly like the reference: implement ``setup_agents`` (assign
+``self.agents``) and ``populate_environment``.  ``take_turn`` advances ALL
+``world.num_envs`` worlds:
+
+* fused (one kernel launch): every agent's model is a ``RandomModel`` (actions drawn
+  on device) or an ``actions [E, A]`` tensor is passed;
+* phased (1 + 2A launches): policy-driven agents -- the entity sweep, then for each
+  agent in list order ``agent.transition(world)`` = observe -> policy -> act, so
+  agent i+1 observes agent i's move exactly as in the reference.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from sorrel_amd.agents.agent import Agent
+from sorrel_amd.entities.entity import Entity
+from sorrel_amd.spec import NO_BORDER, RULE_NONE, RULE_SPAWN, WorldSpec, action_deltas
+
+try:  # omegaconf is optional (absent in the build image)
+    from omegaconf import DictConfig, OmegaConf  # type: ignore
+except Exception:  # pragma: no cover
+    DictConfig = None
+    OmegaConf = None
+
+
+class AttrDict(dict):
+    """dict with attribute access: stands in for ``omegaconf.DictConfig`` when it is absent."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = AttrDict(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _normalise_config(config):
+    if DictConfig is not None and isinstance(config, DictConfig):
+        return config
+    if isinstance(config, dict):
+        return OmegaConf.create(config) if OmegaConf is not None else AttrDict(config)
+    if isinstance(config, (list, tuple)):       # dotlist
+        root: dict = {}
+        for item in config:
+            k, v = item.split("=", 1)
+            cur = root
+            parts = k.split(".")
+            for p in parts[:-1]:
+                cur = cur.setdefault(p, {})
+            cur[parts[-1]] = v
+        return OmegaConf.create(root) if OmegaConf is not None else AttrDict(root)
+    return config
+
+
+class _FillEntity(Entity):
+    """Stand-in type for ``fill_entity_kind`` when no placed entity has that kind."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+
+
+class Environment:
+    world = None
+    config = None
+    agents: List[Agent]
+    stop_if_done: bool
+
+    def __init__(self, world, config, stop_if_done: bool = False) -> None:
+        self.config = _normalise_config(config)
+        self.world = world
+        world._environment = self
+        self.turn = 0
+        self.epoch = 0
+        self._engine = None
+        self._engine_version = -1
+        self._device_populated = False
+        self.world.create_world()
+        self.stop_if_done = stop_if_done
+        self.setup_agents()
+        self._attach_agents()
+        self.populate_environment()
+
+    @abstractmethod
+    def setup_agents(self) -> None:
+        """Create the agents and assign them to ``self.agents``."""
+
+    @abstractmethod
+    def populate_environment(self) -> None:
+        """Populate the (already default-filled) world: either host-side ``world.add`` calls
+        (applied to every env) or ``world.set_layout(...)`` + ``self.spawn_agents()`` for the
+        on-device reset kernel."""
+
+    # ------------------------------------------------------------------ batch plumbing
+    @property
+    def num_envs(self) -> int:
+        return self.world.num_envs
+
+    def _attach_agents(self):
+        w = self.world
+        if len(self.agents) == 0:
+            raise ValueError("setup_agents() must create at least one agent")
+        w.agent_slots = list(self.agents)
+        w.agent_pos = torch.zeros((w.num_envs, len(self.agents), 2), dtype=torch.uint8, device=w.device)
+        for slot, agent in enumerate(self.agents):
+            agent.slot, agent._world = slot, w
+
+    def spawn_agents(self) -> None:
+        """Place the agents on distinct random interior cells of their layer in every env
+        (``examples/treasurehunt/env.py:138-147``) -- runs the reset kernel (K3) together
+        with the layout declared by ``world.set_layout``."""
+        if self.world.layout is None:
+            raise ValueError("spawn_agents() needs world.set_layout(...) first")
+        if self.world.agent_layer is None:
+            self.world.agent_layer = self.world.layers - 1
+        self._device_populated = True
+        eng = self._ensure_engine()
+        eng.reset(epoch=self.epoch)
+
+    def compile_spec(self) -> WorldSpec:
+        """Entities, agents, observation spec and action spec -> the engine's tables."""
+        w, agents = self.world, self.agents
+        ospec, aspec = agents[0].observation_spec, agents[0].action_spec
+        for a in agents[1:]:
+            o = a.observation_spec
+            if o.vision_radius != ospec.vision_radius or o.fill_entity_kind != ospec.fill_entity_kind or \
+                    list(o.entity_map) != list(ospec.entity_map) or \
+                    any(not np.array_equal(o.entity_map[k], ospec.entity_map[k]) for k in o.entity_map) or \
+                    a.action_spec.names != aspec.names:
+                raise ValueError("all agents of one batched Environment must share observation and action specs")
+        if ospec.full_view:
+            raise ValueError("full_view observation specs are not part of the fused step; use observe() on demand")
+        agent_types = [w.registry.register(a) for a in agents]
+        # resolve spawn rules (may register the spawned types); iterate to a fixed point
+        spawn = {}
+        n_seen = -1
+        while n_seen != len(w.registry):
+            n_seen = len(w.registry)
+            for t, proto in enumerate(list(w.registry.prototypes)):
+                if isinstance(proto, Agent) or not proto.has_transitions or t in spawn:
+                    continue
+                if proto.transition_rule is None:
+                    raise ValueError(
+                        f"{type(proto).__name__} has has_transitions=True but no declarative transition_rule; "
+                        "arbitrary Python transition() bodies cannot run on the device")
+                spawn[t] = w.spawn_rule_of(proto)
+        fill_kind = ospec.fill_entity_kind
+        fill_type = next((t for t, p in enumerate(w.registry.prototypes) if p.kind == fill_kind), None)
+        if fill_type is None:
+            fill_type = w.registry.register(_FillEntity(fill_kind))
+        protos = w.registry.prototypes
+        T, C = len(protos), ospec.num_channels
+        app = np.zeros((T, C), dtype=np.float64)
+        for t, p in enumerate(protos):
+            if p.kind not in ospec.entity_map:
+                raise KeyError(p.kind)     # the reference raises KeyError in visual_field for an unmapped kind
+            app[t] = np.asarray(ospec.entity_map[p.kind], dtype=np.float64)
+        dy, dx = action_deltas(aspec.names)
+        if w.agent_layer is None:
+            w.agent_layer = w.layers - 1
+        lay = w.layout or dict(fill=[w.default_type] * w.layers, border=[NO_BORDER] * w.layers, dense_prob=0.0, dense=[])
+        return WorldSpec(
+            height=w.height, width=w.width, layers=w.layers, num_agents=len(agents),
+            vision_radius=ospec.vision_radius, num_channels=C, agent_layer=w.agent_layer,
+            default_type=w.default_type, fill_type=fill_type, action_dy=dy, action_dx=dx,
+            agent_type=agent_types,
+            type_value=[p.value for p in protos], type_passable=[1 if p.passable else 0 for p in protos],
+            type_rule=[RULE_SPAWN if t in spawn else RULE_NONE for t in range(T)],
+            spawn_prob=[spawn[t][0] if t in spawn else 0.0 for t in range(T)],
+            spawn_choices=[spawn[t][1] if t in spawn else [] for t in range(T)],
+            appearance=app, seed=w.seed, layer_fill_type=lay["fill"], layer_border_type=lay["border"],
+            dense_prob=lay["dense_prob"], dense_choices=lay["dense"],
+            type_names=[type(p).__name__ for p in protos],
+        )
+
+    def _ensure_engine(self):
+        from sorrel_amd.engine import GridEngine
+
+        w = self.world
+        if self._engine is not None and self._engine_version == w.registry.version:
+            return self._engine
+        spec = self.compile_spec()
+        if self._engine is not None:
+            self._engine.close()
+        first = getattr(w, "first_env_id", 0)
+        self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first,
+                                  tensors=dict(grid=w.grid, agent_pos=w.agent_pos, total_reward=w.total_reward))
+        self._engine_version = w.registry.version
+        self._validate_border()
+        return self._engine
+
+    def _validate_border(self):
+        """Engine precondition: the reference has no bounds check in ``move`` --
+        the agent layer's border must be impassable."""
+        w = self.world
+        if self._device_populated:
+            return
+        passable = torch.tensor([1 if p.passable else 0 for p in w.registry.prototypes], dtype=torch.uint8, device=w.device)
+        g = w.grid[:, w.agent_layer].long()
+        border = torch.cat([g[:, 0, :], g[:, -1, :], g[:, :, 0], g[:, :, -1]], dim=1)
+        if bool(passable[border].any()):
+            raise ValueError("the border of the agent layer must be impassable in every env "
+                             "(Gridworld.move has no bounds check)")
+
+    # ------------------------------------------------------------------ reference API
+    def reset(self) -> None:
+        """``turn = 0``, fresh world, re-populate, reset agents (``environment.py:72-79``)."""
+        self.turn = 0
+        self.epoch += 1
+        self.world.is_done = False
+        self.world.create_world()
+        self.populate_environment()
+        for agent in self.agents:
+            agent.reset()
+
+    def take_turn(self, actions: Optional[torch.Tensor] = None) -> None:
+        """One full step of every env: entity transitions, then each agent in list order
+        (``environment.py:81-93``)."""
+        eng = self._ensure_engine()
+        self.turn += 1
+        eng.epoch, eng.turn = self.epoch, self.turn
+        if actions is not None:
+            eng.step(actions, turn=self.turn)
+        elif all(getattr(a.model, "device_random", False) for a in self.agents):
+            eng.step(random_actions=True, turn=self.turn)
+        else:
+            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)   # entity sweep only
+            for agent in self.agents:
+                agent.transition(self.world)
+
+    # ------------------------------------------------------------------ kernels behind the agent hooks
+    def _observe(self, who):
+        """[E, C, V, V] float32 of an agent slot (Agent / int), or from a (y, x, z) cell."""
+        eng = self._ensure_engine()
+        if isinstance(who, Agent):
+            who = who.slot
+        if isinstance(who, int):
+            eng.observe(who, who + 1)
+            return eng.obs[:, who]
+        y, x, z = (int(v) for v in who)
+        if z != self.world.agent_layer:
+            pass  # the window is layer-summed: only (y, x) matters
+        pos = torch.zeros_like(eng.agent_pos)
+        pos[:, 0, 0], pos[:, 0, 1] = y, x
+        eng.observe(0, 1, pos=pos, out=eng.scratch_obs())
+        return eng.scratch_obs()[:, 0]
+
+    def _full_view(self, ospec):
+        """Whole-map appearance summed over layers, ``[E, C, H, W]`` (``visual_field.py:41-55``)."""
+        w = self.world
+        spec = self.compile_spec()
+        app = torch.tensor(spec.appearance, dtype=torch.float64, device=w.device)        # [T, C]
+        return app[w.grid.long()].sum(dim=1).permute(0, 3, 1, 2).contiguous()
+
+    def _act(self, agent: Agent, action) -> torch.Tensor:
+        eng = self._ensure_engine()
+        a = agent.slot
+        if not torch.is_tensor(action):
+            action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
+        eng.actions[:, a] = action.to(torch.uint8)
+        eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn)
+        return eng.rewards[:, a]
+
+    # ------------------------------------------------------------------ step outputs (batched additions)
+    @property
+    def obs(self):
+        return self._ensure_engine().obs
+
+    @property
+    def rewards(self):
+        return self._ensure_engine().rewards
+
+    @property
+    def actions(self):
+        return self._ensure_engine().actions
+
+    @property
+    def dones(self):
+        """All-zero inside an epoch: ``world.is_done`` only flips after the turn loop
+        (``environment.py:171``)."""
+        return torch.zeros_like(self._ensure_engine().rewards)
+
+    @property
+    def total_reward(self):
+        return self.world.total_reward
+
+    # ------------------------------------------------------------------ thin epoch loop (environment.py:108-211)
+    def run_experiment(self, epochs: Optional[int] = None, max_turns: Optional[int] = None, logger=None,
+                       all_reduce: bool = True):
+        """reset -> ``max_turns`` x take_turn -> per-epoch metrics (sum / mean of
+        ``total_reward`` over ALL envs of ALL ranks: the one RCCL all-reduce)."""
+        from sorrel_amd import distributed as D
+
+        exp = self.config.experiment
+        epochs = int(exp.epochs) if epochs is None else epochs
+        max_turns = int(exp.max_turns) if max_turns is None else max_turns
+        history = []
+        for epoch in range(epochs + 1):
+            self.reset()
+            for agent in self.agents:
+                agent.model.start_epoch_action(epoch=epoch)
+            while self.turn < max_turns:
+                self.take_turn()
+                if self.world.is_done and self.stop_if_done:
+                    break
+            self.world.is_done = True
+            m = D.rollout_metrics(self._ensure_engine(), all_reduce=all_reduce)
+            history.append(m)
+            for agent in self.agents:
+                agent.model.end_epoch_action(epoch=epoch)
+            if logger is not None:
+                logger.record_turn(epoch, 0.0, m["mean_total_reward"], getattr(self.agents[0].model, "epsilon", 0.0))
+        return history

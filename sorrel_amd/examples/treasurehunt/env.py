@@ -1,0 +1,51 @@
+"""``TreasurehuntEnv`` (``sorrel/examples/treasurehunt/env.py:25-147``) on the batched engine."""
+from sorrel_amd.action.action_spec import ActionSpec
+from sorrel_amd.environment import Environment
+from sorrel_amd.examples.treasurehunt.agents import TreasurehuntAgent
+from sorrel_amd.examples.treasurehunt.entities import Bone, EmptyEntity, Food, Gem, Sand, Wall
+from sorrel_amd.models import RandomModel
+from sorrel_amd.observation.observation_spec import OneHotObservationSpec
+
+ENTITY_LIST = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+
+
+class TreasurehuntEnv(Environment):
+    """config keys: ``world.{height,width,gem_value,food_value,bone_value,spawn_prob}``,
+    ``model.agent_vision_radius``, optional ``model.num_agents`` (default 2),
+    optional ``world.dense_prob`` (pre-seed items at reset)."""
+
+    def __init__(self, world, config, model_factory=None):
+        self._model_factory = model_factory
+        super().__init__(world, config)
+
+    def setup_agents(self):
+        n = int(self.config.model.get("num_agents", 2))
+        agents = []
+        for _ in range(n):
+            ospec = OneHotObservationSpec(ENTITY_LIST, full_view=False,
+                                          vision_radius=int(self.config.model.agent_vision_radius))
+            size = 1
+            for d in ospec.input_size:
+                size *= d
+            ospec.override_input_size((size,))
+            aspec = ActionSpec(["up", "down", "left", "right"])
+            if self._model_factory is not None:
+                model = self._model_factory(ospec.input_size, aspec.n_actions)
+            else:
+                model = RandomModel(ospec.input_size, aspec.n_actions)
+            agents.append(TreasurehuntAgent(ospec, aspec, model))
+        self.agents = agents
+
+    def populate_environment(self):
+        """Sand below, walls around the top layer, spawning EmptyEntity inside, agents on
+        distinct random interior cells (``env.py:114-147``) -- declared once, executed by the
+        reset kernel for every env."""
+        v = self.world.values
+        dense = float(self.config.world.get("dense_prob", 0.0))
+        self.world.set_layout(
+            layer_fill=[Sand(), EmptyEntity()],
+            layer_border=[None, Wall()],
+            dense_prob=dense,
+            dense_choices=[Gem(v["gem"]), Food(v["food"]), Bone(v["bone"])] if dense > 0 else [],
+        )
+        self.spawn_agents()

@@ -1,0 +1,61 @@
+"""The model call shape the step path needs (``sorrel/models/base_model.py:10-111``).
+
+Policy learning is out of scope of this engine; what the hot path needs from a model
+is ``take_action(state) -> actions`` (batched: one action per env) and a ``memory``
+to append transitions to."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from sorrel_amd.buffers import Buffer
+
+
+class BaseModel:
+    def __init__(self, input_size, action_space: int, memory_size: int = 0, epsilon: float = 0.0, num_envs: int = 1,
+                 device=None):
+        self.input_size = input_size
+        self.action_space = action_space
+        obs = tuple(input_size) if isinstance(input_size, Sequence) else (input_size,)
+        self.memory = Buffer(capacity=memory_size, obs_shape=obs, num_envs=num_envs, device=device) if memory_size else None
+        self.epsilon = epsilon
+
+    def take_action(self, state) -> torch.Tensor:
+        """``state``: float32 ``[E, ...]``; returns integer actions ``[E]``."""
+        raise NotImplementedError
+
+    def train_step(self):
+        return 0.0
+
+    def reset(self):
+        pass
+
+    def set_epsilon(self, new_epsilon: float) -> None:
+        self.epsilon = new_epsilon
+
+    def epsilon_decay(self, decay_rate: float) -> None:
+        self.epsilon *= 1 - decay_rate
+
+    def start_epoch_action(self, **kwargs):
+        pass
+
+    def end_epoch_action(self, **kwargs):
+        pass
+
+    @property
+    def model_name(self):
+        return self.__class__.__name__
+
+
+class RandomModel(BaseModel):
+    """Uniform random actions (``base_model.py:107-111``: ``np.random.randint(0, action_space)``).
+
+    In the batched engine these are drawn ON DEVICE from the counter RNG
+    (``SGW_STREAM_ACTION`` keyed by seed, global env id, epoch, turn, agent slot), which
+    is what lets ``Environment.take_turn`` run as one fused kernel."""
+
+    device_random = True
+
+    def take_action(self, state):
+        raise RuntimeError("RandomModel actions are drawn inside the step kernel (random_actions=True)")

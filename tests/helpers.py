@@ -119,3 +119,18 @@ class COracle:
         out = np.zeros(4, np.float64)
         self.lib.sgo_reduce_metrics(C.byref(self.cfg), _p(self.total), _p(out))
         return out
+
+
+def oracle_spec(ws: WorldSpec) -> O.Spec:
+    """product WorldSpec -> oracle Spec (the inverse of world_spec)."""
+    return O.Spec(
+        height=ws.height, width=ws.width, layers=ws.layers, num_agents=ws.num_agents,
+        vision_radius=ws.vision_radius, num_types=ws.num_types, num_channels=ws.num_channels,
+        agent_layer=ws.agent_layer, default_type=ws.default_type, fill_type=ws.fill_type,
+        action_dy=list(ws.action_dy), action_dx=list(ws.action_dx), agent_type=list(ws.agent_type),
+        type_value=list(ws.type_value), type_passable=list(ws.type_passable), type_rule=list(ws.type_rule),
+        spawn_prob=list(ws.spawn_prob), spawn_choices=[list(c) for c in ws.spawn_choices],
+        appearance=np.asarray(ws.appearance, dtype=np.float64), seed=ws.seed,
+        layer_fill_type=list(ws.layer_fill_type), layer_border_type=list(ws.layer_border_type),
+        dense_prob=ws.dense_prob, dense_choices=list(ws.dense_choices),
+    )

@@ -1,0 +1,153 @@
+"""GPU tests through the Sorrel-shaped API (Environment / Gridworld / Agent / ObservationSpec):
+the classes compile to engine tables, take_turn runs the HIP kernels, results equal the oracle."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from oracle import gridstep_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no silent CPU fallback)")
+    return torch
+
+
+def make_env(h, w, a, r, E, p=0.02, seed=5, model_factory=None, dense=0.0):
+    from sorrel_amd.examples.treasurehunt.entities import EmptyEntity
+    from sorrel_amd.examples.treasurehunt.env import TreasurehuntEnv
+    from sorrel_amd.examples.treasurehunt.main import make_config
+    from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
+
+    cfg = make_config(h, w, a, r, spawn_prob=p)
+    if dense:
+        cfg["world"]["dense_prob"] = dense
+    world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=seed)
+    return TreasurehuntEnv(world, cfg, model_factory=model_factory)
+
+
+def test_treasurehunt_env_fused_random_vs_oracle(torch_cuda):
+    torch = torch_cuda
+    E, T = 48, 10
+    env = make_env(16, 16, 4, 2, E, dense=0.2)
+    ospec = H.oracle_spec(env.compile_spec())
+    states = [O.reset_env(ospec, e, epoch=0) for e in range(E)]
+    torch.cuda.synchronize()
+    assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+    for t in range(1, T + 1):
+        env.take_turn()
+        assert env.turn == t
+        torch.cuda.synchronize()
+        obs, rew = env.obs.cpu().numpy(), env.rewards.cpu().numpy()
+        for e in range(E):
+            o, a, r = O.step_env(ospec, states[e], e, 0, t)
+            assert np.array_equal(obs[e], o) and np.array_equal(rew[e], r)
+            assert np.array_equal(env.actions[e].cpu().numpy(), a)
+        assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+        assert np.array_equal(env.world.total_reward.cpu().numpy(), np.array([s.total_reward for s in states]))
+    assert not env.dones.any()
+    # reference-style accessors on the batched world
+    a0 = env.agents[0]
+    assert a0.location == (int(states[0].pos[0, 0]), int(states[0].pos[0, 1]), 1)
+    assert env.world.observe(a0.location).kind == "TreasurehuntAgent"
+    assert env.world.map[0, 0, 1].kind == "Wall" and env.world.map[0, 0, 0].kind == "EmptyEntity"
+
+
+def test_reset_starts_a_new_epoch(torch_cuda):
+    torch = torch_cuda
+    env = make_env(12, 12, 3, 2, 16)
+    ospec = H.oracle_spec(env.compile_spec())
+    for _ in range(3):
+        env.take_turn()
+    env.reset()
+    assert env.turn == 0 and env.epoch == 1
+    torch.cuda.synchronize()
+    states = [O.reset_env(ospec, e, epoch=1) for e in range(16)]
+    assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+    assert float(env.world.total_reward.abs().sum()) == 0.0
+    env.take_turn()
+    torch.cuda.synchronize()
+    for e in range(16):
+        O.step_env(ospec, states[e], e, 1, 1)
+    assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+
+
+def policy_np(obs, a):
+    """Deterministic toy policy of the flattened observation (and the agent slot)."""
+    return int((int(obs.sum()) * 7 + int(obs[1].sum()) * 3 + int(obs[5].sum()) + a) % 4)
+
+
+def test_policy_driven_agents_take_the_phased_path(torch_cuda):
+    """Agents with a real model: sweep, then per agent observe -> policy -> act, in list order."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+
+    class ToyPolicy(BaseModel):
+        slot_counter = [0]
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=8, num_envs=24, device="cuda:0")
+            self.slot = ToyPolicy.slot_counter[0]
+            ToyPolicy.slot_counter[0] += 1
+
+        def take_action(self, state):
+            s = state.reshape(state.shape[0], 6, -1)
+            return ((s.sum(dim=(1, 2)).long() * 7 + s[:, 1].sum(dim=1).long() * 3 + s[:, 5].sum(dim=1).long() + self.slot) % 4)
+
+    ToyPolicy.slot_counter[0] = 0
+    E, T = 24, 8
+    env = make_env(14, 14, 3, 2, E, p=0.05, model_factory=ToyPolicy)
+    ospec = H.oracle_spec(env.compile_spec())
+    states = [O.reset_env(ospec, e, epoch=0) for e in range(E)]
+    for t in range(1, T + 1):
+        env.take_turn()
+        torch.cuda.synchronize()
+        for e in range(E):
+            o, a, r = O.step_env_policy(ospec, states[e], e, 0, t, policy_np)
+            assert np.array_equal(env.actions[e].cpu().numpy(), a), (t, e)
+            assert np.array_equal(env.rewards[e].cpu().numpy(), r)
+        assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+        assert np.array_equal(env.world.total_reward.cpu().numpy(), np.array([s.total_reward for s in states]))
+    # the replay memory received what the reference would store: obs f32, action i64, reward f32, done 0
+    mem = env.agents[1].model.memory
+    assert mem.size == T and mem.states.dtype == torch.float32 and mem.actions.dtype == torch.int64
+    assert float(mem.dones.sum()) == 0.0
+
+
+def test_observe_from_arbitrary_cell_and_full_view(torch_cuda):
+    torch = torch_cuda
+    from sorrel_amd.observation.observation_spec import OneHotObservationSpec
+    from sorrel_amd.examples.treasurehunt.env import ENTITY_LIST
+
+    env = make_env(12, 12, 2, 2, 6, dense=0.3)
+    ospec = H.oracle_spec(env.compile_spec())
+    states = [O.reset_env(ospec, e, epoch=0) for e in range(6)]
+    spec = env.agents[0].observation_spec
+    got = spec.observe(env.world, (0, 11, 1)).cpu().numpy()          # a corner: mostly out of bounds
+    for e in range(6):
+        assert np.array_equal(got[e], O.visual_field(ospec, states[e].grid, 0, 11).astype(np.float32))
+    full = OneHotObservationSpec(ENTITY_LIST, full_view=True, env_dims=(12, 12))
+    fv = full.observe(env.world).cpu().numpy()
+    app = ospec.appearance
+    for e in range(6):
+        want = app[states[e].grid].sum(axis=0).transpose(2, 0, 1)
+        assert np.array_equal(fv[e], want)
+
+
+def test_run_experiment_thin_loop(torch_cuda):
+    env = make_env(10, 10, 2, 2, 32)
+    hist = env.run_experiment(epochs=1, max_turns=5, all_reduce=False)
+    assert len(hist) == 2 and hist[0]["envs"] == 32.0
+    ospec = H.oracle_spec(env.compile_spec())
+    tot = 0.0
+    for e in range(32):
+        st = O.reset_env(ospec, e, epoch=2)       # ctor = epoch 0, first reset() = 1, second = 2
+        for t in range(1, 6):
+            O.step_env(ospec, st, e, 2, t)
+        tot += st.total_reward
+    assert hist[1]["sum_total_reward"] == tot

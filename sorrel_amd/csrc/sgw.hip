@@ -672,6 +672,305 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     }
 }
 
+// ---------------------------------------------------------------- big step kernel
+// Workgroup-per-env kernel for worlds above 4 KiB (BASELINE config 5: 128x128x2 = 32 KiB
+// of LDS per env, 64 agents, 11x11 windows).  Same ingredients as step_fast (register
+// sweep, per-agent move inputs computed in parallel, scalar sequential part), plus:
+// the A sequential agent phases are PIPELINED over the four waves.  Agent a is owned by
+// wave (a - a0) & 3; an owner waits for the LDS turn word to reach a, gathers its window
+// from LDS, resolves the move, passes the turn on, and only then converts and streams
+// its observation out -- so the chain between consecutive agents is gather + move
+// (a few hundred cycles) and the store traffic of up to three agents overlaps it.
+constexpr int kBigThreads = 256;
+constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
+
+template <bool ONEHOT, int TL, int TC, int TR>
+__global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t env = blockIdx.x;
+    const uint32_t env_id = p.first_env + (uint32_t)env;
+
+    const int L = TL ? TL : p.L;
+    const int C = TC ? TC : p.C;
+    const int r = TR ? TR : p.r;
+    const int V = 2 * r + 1, VV = V * V;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int cells = p.cells;
+    const int nunits = cells >> 4;
+    const int zoff = p.zA * HW;
+    constexpr int NW = TC ? (TC + 3) / 4 : 4;
+    constexpr int NP = TR ? ((2 * TR + 1) * (2 * TR + 1) + 63) / 64 : 2;   // window passes per wave held in registers
+
+    // LDS: [tables][agent arrays][grid]
+    uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // target cell or 0xFFFFFFFF
+    uint32_t* s_oa = s_ta + 64;                                             // own cell
+    uint32_t* s_np = s_oa + 64;                                             // position if the move succeeds
+    uint32_t* s_rm = s_np + 64;                                             // reward f32 bits
+    double* s_val = reinterpret_cast<double*>(s_rm + 64);                   // reward f64 (for total, in agent order)
+    volatile int* s_turn = reinterpret_cast<volatile int*>(s_val + 64);
+    uint32_t* s_moved = reinterpret_cast<uint32_t*>(const_cast<int*>(s_turn) + 1);   // bit mask, 2 words
+    double* s_vtab = reinterpret_cast<double*>(const_cast<int*>(s_turn) + 4);         // value[32] (keeps global loads out of the chain)
+    uint8_t* s_atype = reinterpret_cast<uint8_t*>(s_vtab + 32);                       // agent_type[64]
+    uint8_t* lg = smem + p.tab_bytes + kBigAgentLds;
+    uint4* lg16 = reinterpret_cast<uint4*>(lg);
+    const DevTables* gtab = p.tab;
+
+    const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
+    const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
+    const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
+    const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
+
+    // ---- tables -> LDS
+    if constexpr (ONEHOT) {
+        uint32_t* wd = reinterpret_cast<uint32_t*>(smem);
+        if (tid < 4 * SGW_MAX_TYPES) wd[tid] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid];
+    } else {
+        double* wa = reinterpret_cast<double*>(smem);
+        for (int i = tid; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBigThreads) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
+    }
+    if (tid < 32) s_vtab[tid] = gtab->value[tid];
+    if (tid >= 64 && tid < 128) s_atype[tid - 64] = gtab->agent_type[tid - 64];
+    const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(smem);
+    const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(smem);
+
+    // ---- grid -> LDS, sweep on the registers, 4 units per thread per round
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * cells);
+        for (int base = 0; base < nunits; base += 4 * kBigThreads) {
+            uint4 u[4];
+            uint32_t hits[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * kBigThreads + tid;
+                if (idx < nunits) u[k] = src[idx];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * kBigThreads + tid;
+                hits[k] = 0;
+                if (idx < nunits) {
+                    lg16[idx] = u[k];
+                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)idx, p, env_id);
+                }
+            }
+            if (do_sweep) {
+                // this thread wrote these units itself (DS ops of a wave are ordered), so the rare
+                // kind draws can patch LDS right away; one combined loop keeps the trip count low
+                uint32_t any = hits[0] | hits[1] | hits[2] | hits[3];
+                while (__builtin_amdgcn_readfirstlane(__any(any != 0))) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (hits[k]) {
+                            const uint32_t cell = (uint32_t)__ffs(hits[k]) - 1u;
+                            hits[k] &= hits[k] - 1u;
+                            const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
+                            const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                                                       p.seed_lo, p.seed_hi);
+                            const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
+                            lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+                            break;
+                        }
+                    }
+                    any = hits[0] | hits[1] | hits[2] | hits[3];
+                }
+            }
+        }
+    }
+
+    // ---- per-agent move inputs, all agents at once (thread a = agent a)
+    uint32_t yx = 0;
+    int st_lane = 0;
+    const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
+    if (tid < 64) {
+        uint32_t ta = 0xFFFFFFFFu, npos = 0, oa = 0;
+        if (tid < p.A) {
+            yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
+            const uint32_t py = yx & 0xFFu, px = yx >> 8;
+            oa = (uint32_t)zoff + py * (uint32_t)W + px;
+            npos = yx;
+            if (p.do_move && mine) {
+                uint32_t act;
+                if (rnd) {
+                    const U4 w = philox4x32_10(opaque((uint32_t)tid >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                                               p.seed_lo, p.seed_hi);
+                    act = __umulhi(word_of(w, tid & 3), (uint32_t)p.nact);
+                    p.actions[env * p.A + tid] = (uint8_t)act;
+                } else {
+                    act = p.actions[env * p.A + tid];
+                }
+                const bool act_ok = act < (uint32_t)p.nact;
+                const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
+                const int dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+                const int ty = (int)py + dy, tx = (int)px + dx;
+                const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+                if (act_ok && inb) {
+                    ta = (uint32_t)(zoff + ty * W + tx);
+                    npos = (uint32_t)ty | ((uint32_t)tx << 8);
+                }
+                st_lane = !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
+            }
+        }
+        s_ta[tid] = ta;
+        (void)oa;
+        s_oa[tid] = yx;                    // packed (y, x); the own-cell offset is recomputed from it
+        s_np[tid] = npos;
+        s_rm[tid] = 0;
+        s_val[tid] = 0.0;
+        if (tid == 0) {
+            *s_turn = p.a0;
+            s_moved[0] = 0;
+            s_moved[1] = 0;
+        }
+    }
+    __syncthreads();
+
+    // per-lane window geometry: NP cells per lane
+    int wdi[NP], wdj[NP], woff[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int w = lane + 64 * k;
+        const int i = w / V, j = w - i * V;
+        wdi[k] = i - r;
+        wdj[k] = j - r;
+        woff[k] = wdi[k] * W + wdj[k];
+    }
+
+    // ---- agents, strictly in list order, pipelined over the waves
+    // Chain between consecutive agents = turn word seen -> ONE LDS round trip (window bytes +
+    // target byte) -> scalar decision -> two byte writes -> turn word passed on.  Everything
+    // static (own cell, target cell) is fetched before the turn arrives; table lookups,
+    // conversion and the stores happen after the hand-off.
+    int st_wave = 0;
+    for (int a = p.a0 + wv; a < p.a1; a += 4) {
+        // (y, x) of agent a as of the start of the turn (only agent a itself moves agent a) and its target
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
+        const uint32_t s_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ta[a]);
+        const uint32_t my_type = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_atype[a]);
+        const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
+        const int cbase = y * W + x;
+        const uint32_t s_o = (uint32_t)zoff + (uint32_t)cbase;
+        const bool valid = s_t != 0xFFFFFFFFu;
+        int offk[NP];
+        bool inbk[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int w = lane + 64 * k;
+            inbk[k] = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
+            offk[k] = (inbk[k] && w < VV) ? cbase + woff[k] : 0;
+        }
+        if (p.do_move) {
+            while (*s_turn != a) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // one batch of LDS byte reads: the window (L layers, packed 4 per word) and the move target
+        uint32_t tb[NP][2];
+        if (write_obs) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                uint32_t lo = 0, hi = 0;
+                if constexpr (TL != 0) {
+#pragma unroll
+                    for (int z = 0; z < TL; ++z) {
+                        const uint32_t t = lg[z * HW + offk[k]];
+                        if (z < 4) lo |= (t & 31u) << (8 * z);
+                        else hi |= (t & 31u) << (8 * (z - 4));
+                    }
+                } else {
+                    for (int z = 0; z < L; ++z) {
+                        const uint32_t t = lg[z * HW + offk[k]];
+                        if (z < 4) lo |= (t & 31u) << (8 * z);
+                        else hi |= (t & 31u) << (8 * (z - 4));
+                    }
+                }
+                tb[k][0] = lo;
+                tb[k][1] = hi;
+            }
+        }
+        if (p.do_move) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[valid ? s_t : s_o]);
+            const bool tok = valid && t < (uint32_t)p.T;
+            const uint32_t tl = t & 31u;
+            const bool pass = tok && ((p.pass_mask >> tl) & 1u);
+            if (lane == 0) {
+                if (pass) {
+                    lg[s_t] = (uint8_t)my_type;
+                    lg[s_o] = (uint8_t)p.default_type;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                *s_turn = a + 1;                                   // hand the turn on first ...
+                if (pass) atomicOr(&s_moved[a >> 5], 1u << (a & 31));
+                const double val = tok ? s_vtab[tl] : 0.0;         // ... bookkeeping after (reward BEFORE the move)
+                s_val[a] = val;
+                s_rm[a] = __float_as_uint((float)val);
+            }
+            if (valid && !tok) st_wave |= SGW_STATUS_BAD_TYPE;
+        }
+        if (write_obs) {
+            float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int w = lane + 64 * k;
+                if (w < VV) {
+                    float* o = obase + w;
+                    if constexpr (ONEHOT) {
+                        uint32_t cnt[NW];
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) cnt[q] = 0;
+                        for (int z = 0; z < L; ++z) {
+                            const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) cnt[q] += wdelta[q * 32 + t];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) {
+                            const uint32_t cq = inbk[k] ? cnt[q] : p.fill_delta[q];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int c = 4 * q + b;
+                                if (c < C) OBS_STORE(o + c * VV, (float)((cq >> (8 * b)) & 0xFFu));
+                            }
+                        }
+                    } else {
+                        for (int c = 0; c < C; ++c) {
+                            double acc = wapp[tb[k][0] & 31u][c];   // left-to-right float64 layer sum
+                            for (int z = 1; z < L; ++z) {
+                                const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
+                                acc += wapp[t][c];
+                            }
+                            OBS_STORE(o + c * VV, (float)(inbk[k] ? acc : wapp[p.fill_type][c]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // windows wider than NP*64 cells (not a BASELINE shape): handled by the generic kernel (host dispatch)
+    __syncthreads();
+
+    // ---- write-back
+    if (dirty) {
+        uint4* dst = reinterpret_cast<uint4*>(p.grid + env * cells);
+        for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[idx];
+    }
+    if (p.do_move) {
+        if (tid < 64 && mine) {
+            const bool mv = (s_moved[tid >> 5] >> (tid & 31)) & 1u;
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)(mv ? s_np[tid] : yx);
+            p.rewards[env * p.A + tid] = __uint_as_float(s_rm[tid]);
+            if (st_lane) atomicOr(p.status, st_lane);
+        }
+        if (tid == 0) {
+            double tot = p.total[env];
+            for (int a = p.a0; a < p.a1; ++a) tot += s_val[a];   // float64, agent order (agent.py:172)
+            p.total[env] = tot;
+        }
+        if (lane == 0 && st_wave) atomicOr(p.status, st_wave);
+    }
+}
+
 // ---------------------------------------------------------------- reset kernel
 // create_world + populate_environment (gridworld.py:47-65, treasurehunt/env.py:114-147).
 template <int WPE>
@@ -863,6 +1162,7 @@ struct sgw_engine {
     int wpe = 1;          // waves per env
     bool onehot = true;
     bool fast = false;    // step_fast specialisation applies
+    bool big = false;     // step_big (workgroup per env, pipelined agents) applies
     void (*step_fn)(const Params) = nullptr;
     void (*reset_fn)(const Params) = nullptr;
     size_t lds_bytes = 0;       // reset / generic step
@@ -961,6 +1261,12 @@ StepFn pick_step(int wpe, bool onehot) {
     return onehot ? step_kernel<4, true> : step_kernel<4, false>;
 }
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
+
+StepFn pick_big(bool onehot, int L, int C, int r) {
+    if (!onehot) return step_big<false, 0, 0, 0>;
+    if (L == 2 && C == 6 && r == 5) return step_big<true, 2, 6, 5>;   // BASELINE config 5
+    return step_big<true, 0, 0, 0>;
+}
 
 StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W) {
     if (!onehot) return step_fast<false, 0, 0, 0, 0, 0>;
@@ -1108,8 +1414,10 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->fast = e->wpe == 1 && (p.cells & 15) == 0 && (p.cells >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
+    e->big = e->wpe == 4 && (p.cells & 15) == 0 && nspawn <= 1 && p.VV <= 128;
     e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
+    if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
     const size_t lds_max = 160 * 1024;
     if (e->lds_bytes > lds_max) {
@@ -1129,12 +1437,14 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = e->fast ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width) : pick_step(e->wpe, e->onehot);
+    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width)
+                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius)
+                         : pick_step(e->wpe, e->onehot);
     StepFn rk = pick_reset(e->wpe);
     e->step_fn = sk;
     e->reset_fn = rk;
-    if (e->lds_bytes > lds_cap || e->lds_bytes > 65536) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+    if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err != hipSuccess) {
@@ -1145,7 +1455,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     int nb = 0;
     if (int rc = occupancy_blocks(sk, e->step_lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     // generic kernel: persistent grid; fast kernel: one env per wave, the dispatcher balances
-    e->grid_blocks = e->fast ? (int)ceil_div(p.E, epb) : (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
+    e->grid_blocks = (e->fast || e->big) ? (int)ceil_div(p.E, epb) : (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     e->reset_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
     *out = e;
@@ -1180,7 +1490,7 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (int rc = time_begin(e, s)) return rc;
     p.env_lds = e->step_env_lds;
-    if (e->fast) p.tab_bytes = e->fast_tab_bytes;
+    if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     if (p.spawn_mask == 0) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(kBlock), e->step_lds_bytes, s, p);
     HIP_TRY(hipGetLastError());

@@ -94,6 +94,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip observation stores (NOT a valid bench line)")
+    ap.add_argument("--diag-agents", type=int, default=-1, help="diagnostic: step only the first N agents (NOT valid)")
     ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
     args = ap.parse_args()
 
@@ -132,6 +133,9 @@ def main() -> int:
 
     write_obs = not args.no_obs
     sweep = not args.no_sweep
+    if args.diag_agents >= 0:
+        _orig_step = eng.step
+        eng.step = lambda *a, **k: _orig_step(*a, agent_end=args.diag_agents, **k)
     for _ in range(args.warmup):
         eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
     barrier()

@@ -675,17 +675,29 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
 // ---------------------------------------------------------------- big step kernel
 // Workgroup-per-env kernel for worlds above 4 KiB (BASELINE config 5: 128x128x2 = 32 KiB
 // of LDS per env, 64 agents, 11x11 windows).  Same ingredients as step_fast (register
-// sweep, per-agent move inputs computed in parallel, scalar sequential part), plus:
-// the A sequential agent phases are PIPELINED over the four waves.  Agent a is owned by
-// wave (a - a0) & 3; an owner waits for the LDS turn word to reach a, gathers its window
-// from LDS, resolves the move, passes the turn on, and only then converts and streams
-// its observation out -- so the chain between consecutive agents is gather + move
-// (a few hundred cycles) and the store traffic of up to three agents overlaps it.
-constexpr int kBigThreads = 256;
+// sweep, per-agent move inputs computed in parallel, scalar sequential part), plus a
+// JOURNAL so that the A sequential agent phases do not serialise the observation work:
+//   phase M  wave 0 resolves all moves in registers: the targets of all agents are read from LDS at
+//            once, and a short scalar loop corrects each for earlier movers with two ballots (no LDS
+//            access, no cross-wave hand-off); it records what each agent found and whether it moved;
+//   phase R  all waves render the observations in parallel from the FINAL grid; agent a must see the
+//            grid after the moves of agents < a only, so the moves of agents >= a that touch its
+//            window (found with one ballot) are undone in registers, latest first.
+// History (config 5, 2048 envs, us per launch): generic kernel 274; turn word passed from wave to
+// wave 131 -> 113 (three dependent LDS round trips per agent); LDS move chain + journal 124;
+// the same with renderers racing the mover (progress words, dynamic queue) 108; moves resolved in
+// registers + barrier 118-122.  The last is kept: it has no cross-wave race to reason about.
+// Requires impassable agent types (a passable agent could be "entered" twice in one turn, which the
+// two-batch patch cannot order); the host dispatch checks it.
+#ifndef SGW_BIG_THREADS
+#define SGW_BIG_THREADS 256
+#endif
+constexpr int kBigThreads = SGW_BIG_THREADS;
+constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
 
 template <bool ONEHOT, int TL, int TC, int TR>
-__global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
+__global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_big(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -705,14 +717,12 @@ __global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
     constexpr int NP = TR ? ((2 * TR + 1) * (2 * TR + 1) + 63) / 64 : 2;   // window passes per wave held in registers
 
     // LDS: [tables][agent arrays][grid]
-    uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // target cell or 0xFFFFFFFF
-    uint32_t* s_oa = s_ta + 64;                                             // own cell
-    uint32_t* s_np = s_oa + 64;                                             // position if the move succeeds
+    uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // journal entry of each agent (phase M -> R)
+    uint32_t* s_oa = s_ta + 64;                                             // packed (y, x) at the start of the turn
+    uint32_t* s_np = s_oa + 64;                                             // packed (y, x) if the move succeeds
     uint32_t* s_rm = s_np + 64;                                             // reward f32 bits
     double* s_val = reinterpret_cast<double*>(s_rm + 64);                   // reward f64 (for total, in agent order)
-    volatile int* s_turn = reinterpret_cast<volatile int*>(s_val + 64);
-    uint32_t* s_moved = reinterpret_cast<uint32_t*>(const_cast<int*>(s_turn) + 1);   // bit mask, 2 words
-    double* s_vtab = reinterpret_cast<double*>(const_cast<int*>(s_turn) + 4);         // value[32] (keeps global loads out of the chain)
+    double* s_vtab = s_val + 64 + 2;                                         // value[32] (keeps global loads out of the chain)
     uint8_t* s_atype = reinterpret_cast<uint8_t*>(s_vtab + 32);                       // agent_type[64]
     uint8_t* lg = smem + p.tab_bytes + kBigAgentLds;
     uint4* lg16 = reinterpret_cast<uint4*>(lg);
@@ -780,17 +790,17 @@ __global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
         }
     }
 
-    // ---- per-agent move inputs, all agents at once (thread a = agent a)
+    // ---- per-agent move inputs, all agents at once (wave 0: lane a = agent a)
     uint32_t yx = 0;
     int st_lane = 0;
     const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
-    if (tid < 64) {
-        uint32_t ta = 0xFFFFFFFFu, npos = 0, oa = 0;
+    uint32_t ta_v = 0xFFFFFFFFu, npos_v = 0, oaddr_v = 0, jr = 0;
+    if (wv == 0) {
         if (tid < p.A) {
             yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
             const uint32_t py = yx & 0xFFu, px = yx >> 8;
-            oa = (uint32_t)zoff + py * (uint32_t)W + px;
-            npos = yx;
+            oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;
+            npos_v = yx;
             if (p.do_move && mine) {
                 uint32_t act;
                 if (rnd) {
@@ -807,80 +817,100 @@ __global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
                 const int ty = (int)py + dy, tx = (int)px + dx;
                 const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
                 if (act_ok && inb) {
-                    ta = (uint32_t)(zoff + ty * W + tx);
-                    npos = (uint32_t)ty | ((uint32_t)tx << 8);
+                    ta_v = (uint32_t)(zoff + ty * W + tx);
+                    npos_v = (uint32_t)ty | ((uint32_t)tx << 8);
                 }
                 st_lane = !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
             }
         }
-        s_ta[tid] = ta;
-        (void)oa;
-        s_oa[tid] = yx;                    // packed (y, x); the own-cell offset is recomputed from it
-        s_np[tid] = npos;
-        s_rm[tid] = 0;
-        s_val[tid] = 0.0;
-        if (tid == 0) {
-            *s_turn = p.a0;
-            s_moved[0] = 0;
-            s_moved[1] = 0;
+        s_oa[tid] = yx;          // packed (y, x) at the start of the turn
+        s_np[tid] = npos_v;      // packed (y, x) if the move succeeds
+        s_ta[tid] = 0;           // journal: empty
+    }
+    __syncthreads();             // grid (+ sweep patches) and tables visible to every wave
+
+    // ---- phase M: the strictly sequential part, by wave 0 alone, entirely in registers.
+    // All targets are read from the pre-move grid in ONE LDS round trip (lane a = agent a).  What
+    // agent a finds on its target when its turn comes differs from that only if an earlier mover
+    // left from or entered that very cell; the scalar loop below finds the latest such mover with
+    // two ballots (no LDS access inside the loop).  The grid is patched afterwards in two ordered
+    // batches: every mover's old cell <- default, then every mover's new cell <- its type (a cell
+    // can be left and then entered in one turn, never the other way round: an agent moves once).
+    if (wv == 0 && p.do_move) {
+        const uint32_t atype_v = s_atype[lane];
+        const bool validv = ta_v != 0xFFFFFFFFu;
+        const uint32_t t0_v = lg[validv ? ta_v : oaddr_v];
+        uint32_t passed_v = 0;
+        for (int a = p.a0; a < p.a1; ++a) {
+            const uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)ta_v, a);
+            const bool valid = X != 0xFFFFFFFFu;
+            uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t0_v, a);
+            const unsigned long long m_dst = __ballot(passed_v && ta_v == X);
+            const unsigned long long m_src = __ballot(passed_v && oaddr_v == X);
+            const unsigned long long m_any = m_dst | m_src;
+            if (m_any) {
+                const int last = 63 - __builtin_clzll(m_any);
+                const uint32_t at_last = (uint32_t)__builtin_amdgcn_readlane((int)atype_v, last);
+                t = ((m_dst >> last) & 1ull) ? at_last : p.default_type;
+            }
+            const bool tok = valid && t < (uint32_t)p.T;
+            const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
+            const uint32_t entry = (t & 0xFFu) | (tok ? 0x100u : 0u) | (pass ? 0x200u : 0u) | ((valid && !tok) ? 0x400u : 0u);
+            jr = lane == a ? entry : jr;
+            passed_v = lane == a ? (pass ? 1u : 0u) : passed_v;
         }
+        if (passed_v) lg[oaddr_v] = (uint8_t)p.default_type;
+        gsync<1>();
+        if (passed_v) lg[ta_v] = (uint8_t)atype_v;
+        const double val = (jr & 0x100u) ? s_vtab[jr & 31u] : 0.0;     // reward = value of the target BEFORE the move
+        s_val[lane] = val;
+        s_rm[lane] = __float_as_uint((float)val);
+        s_ta[lane] = jr;                                                // journal for the render phase
+        if (jr & 0x400u) st_lane |= SGW_STATUS_BAD_TYPE;
     }
     __syncthreads();
 
-    // per-lane window geometry: NP cells per lane
-    int wdi[NP], wdj[NP], woff[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int w = lane + 64 * k;
-        const int i = w / V, j = w - i * V;
-        wdi[k] = i - r;
-        wdj[k] = j - r;
-        woff[k] = wdi[k] * W + wdj[k];
-    }
-
-    // ---- agents, strictly in list order, pipelined over the waves
-    // Chain between consecutive agents = turn word seen -> ONE LDS round trip (window bytes +
-    // target byte) -> scalar decision -> two byte writes -> turn word passed on.  Everything
-    // static (own cell, target cell) is fetched before the turn arrives; table lookups,
-    // conversion and the stores happen after the hand-off.
-    int st_wave = 0;
-    for (int a = p.a0 + wv; a < p.a1; a += 4) {
-        // (y, x) of agent a as of the start of the turn (only agent a itself moves agent a) and its target
-        const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
-        const uint32_t s_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ta[a]);
-        const uint32_t my_type = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_atype[a]);
-        const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
-        const int cbase = y * W + x;
-        const uint32_t s_o = (uint32_t)zoff + (uint32_t)cbase;
-        const bool valid = s_t != 0xFFFFFFFFu;
-        int offk[NP];
-        bool inbk[NP];
+    // ---- phase R: observations, all waves in parallel (agent a -> wave (a - a0) mod waves).
+    // LDS now holds the grid AFTER all moves of this call; agent a must see it after the moves of
+    // agents < a only, so the moves of agents b >= a that touch a's window (one ballot) are undone
+    // in registers, latest first; an undo restores the two cells the move changed.
+    if (write_obs) {
+        // per-lane window geometry: NP cells per lane
+        int wdi[NP], wdj[NP], woff[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int w = lane + 64 * k;
-            inbk[k] = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
-            offk[k] = (inbk[k] && w < VV) ? cbase + woff[k] : 0;
+            const int i = w / V, j = w - i * V;
+            wdi[k] = i - r;
+            wdj[k] = j - r;
+            woff[k] = wdi[k] * W + wdj[k];
         }
-        if (p.do_move) {
-            while (*s_turn != a) {}
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        // one batch of LDS byte reads: the window (L layers, packed 4 per word) and the move target
-        uint32_t tb[NP][2];
-        if (write_obs) {
+        // lane b: journal of agent b (where it was, where it went, what it found there)
+        const uint32_t jb = s_ta[lane], srcb = s_oa[lane], dstb = s_np[lane], atb = s_atype[lane];
+        const bool movedb = p.do_move && (jb & 0x200u) && lane >= p.a0 && lane < p.a1;
+        const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
+        for (int a = p.a0 + wv; a < p.a1; a += kBigWaves) {
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
+            const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
+            const int cbase = y * W + x;
+            uint32_t tb[NP][2];
+            bool inbk[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
+                const int w = lane + 64 * k;
+                inbk[k] = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
+                const int off = (inbk[k] && w < VV) ? cbase + woff[k] : 0;
                 uint32_t lo = 0, hi = 0;
                 if constexpr (TL != 0) {
 #pragma unroll
                     for (int z = 0; z < TL; ++z) {
-                        const uint32_t t = lg[z * HW + offk[k]];
+                        const uint32_t t = lg[z * HW + off];
                         if (z < 4) lo |= (t & 31u) << (8 * z);
                         else hi |= (t & 31u) << (8 * (z - 4));
                     }
                 } else {
                     for (int z = 0; z < L; ++z) {
-                        const uint32_t t = lg[z * HW + offk[k]];
+                        const uint32_t t = lg[z * HW + off];
                         if (z < 4) lo |= (t & 31u) << (8 * z);
                         else hi |= (t & 31u) << (8 * (z - 4));
                     }
@@ -888,27 +918,30 @@ __global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
                 tb[k][0] = lo;
                 tb[k][1] = hi;
             }
-        }
-        if (p.do_move) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[valid ? s_t : s_o]);
-            const bool tok = valid && t < (uint32_t)p.T;
-            const uint32_t tl = t & 31u;
-            const bool pass = tok && ((p.pass_mask >> tl) & 1u);
-            if (lane == 0) {
-                if (pass) {
-                    lg[s_t] = (uint8_t)my_type;
-                    lg[s_o] = (uint8_t)p.default_type;
+            // which later moves touch this window?  (lane b tests move b)
+            const int sy = (int)(srcb & 0xFFu), sx = (int)((srcb >> 8) & 0xFFu);
+            const int ey = (int)(dstb & 0xFFu), ex = (int)((dstb >> 8) & 0xFFu);
+            const bool near_src = (unsigned)(sy - y + r) <= (unsigned)(2 * r) && (unsigned)(sx - x + r) <= (unsigned)(2 * r);
+            const bool near_dst = (unsigned)(ey - y + r) <= (unsigned)(2 * r) && (unsigned)(ex - x + r) <= (unsigned)(2 * r);
+            unsigned long long undo = __ballot(movedb && lane >= a && (near_src || near_dst));
+            while (undo) {
+                const int b = 63 - __builtin_clzll(undo);            // latest move first
+                undo &= ~(1ull << b);
+                const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)srcb, b);
+                const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)dstb, b);
+                const uint32_t oldt = (uint32_t)__builtin_amdgcn_readlane((int)jb, b) & 31u;    // what the target held
+                const uint32_t agt = (uint32_t)__builtin_amdgcn_readlane((int)atb, b) & 31u;    // the mover itself
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const uint32_t key = (uint32_t)((y + wdi[k]) & 0xFF) | ((uint32_t)((x + wdj[k]) & 0xFF) << 8);
+                    const bool at_dst = inbk[k] && key == dst, at_src = inbk[k] && key == src;
+                    if (at_dst || at_src) {
+                        const uint32_t nv = at_src ? agt : oldt;     // src restored last (matters only if src == dst)
+                        if (zw == 0) tb[k][0] = (tb[k][0] & ~(0xFFu << zsh)) | (nv << zsh);
+                        else tb[k][1] = (tb[k][1] & ~(0xFFu << zsh)) | (nv << zsh);
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                *s_turn = a + 1;                                   // hand the turn on first ...
-                if (pass) atomicOr(&s_moved[a >> 5], 1u << (a & 31));
-                const double val = tok ? s_vtab[tl] : 0.0;         // ... bookkeeping after (reward BEFORE the move)
-                s_val[a] = val;
-                s_rm[a] = __float_as_uint((float)val);
             }
-            if (valid && !tok) st_wave |= SGW_STATUS_BAD_TYPE;
-        }
-        if (write_obs) {
             float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
@@ -956,9 +989,8 @@ __global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
         for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[idx];
     }
     if (p.do_move) {
-        if (tid < 64 && mine) {
-            const bool mv = (s_moved[tid >> 5] >> (tid & 31)) & 1u;
-            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)(mv ? s_np[tid] : yx);
+        if (wv == 0 && mine) {
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)((jr & 0x200u) ? npos_v : yx);
             p.rewards[env * p.A + tid] = __uint_as_float(s_rm[tid]);
             if (st_lane) atomicOr(p.status, st_lane);
         }
@@ -967,7 +999,6 @@ __global__ __launch_bounds__(kBigThreads, 3) void step_big(const Params p) {
             for (int a = p.a0; a < p.a1; ++a) tot += s_val[a];   // float64, agent order (agent.py:172)
             p.total[env] = tot;
         }
-        if (lane == 0 && st_wave) atomicOr(p.status, st_wave);
     }
 }
 
@@ -1414,7 +1445,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->fast = e->wpe == 1 && (p.cells & 15) == 0 && (p.cells >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
-    e->big = e->wpe == 4 && (p.cells & 15) == 0 && nspawn <= 1 && p.VV <= 128;
+    bool agents_impassable = true;
+    for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
+    e->big = e->wpe == 4 && (p.cells & 15) == 0 && nspawn <= 1 && p.VV <= 128 && agents_impassable;
     e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
@@ -1492,7 +1525,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     p.env_lds = e->step_env_lds;
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     if (p.spawn_mask == 0) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(kBlock), e->step_lds_bytes, s, p);
+    hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), e->step_lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
 }

@@ -127,6 +127,16 @@ def test_config5_shape_vs_oracle(torch_cuda):
     rollout_vs_oracle(treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=2, dense_prob=0.25), 48, 4, first=16000)
 
 
+def test_big_kernel_crowded_vs_oracle(torch_cuda):
+    """Workgroup-per-env kernel under heavy contention: 64 agents on a 46x46 interior with 11x11
+    windows, dense items -- many moves touch many windows (journal undo), many agents compete for
+    cells and follow each other into vacated cells (register move resolution)."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rollout_vs_oracle(treasurehunt_spec(48, 48, 64, 5, spawn_prob=0.1, seed=12, dense_prob=0.3), 40, 12, first=7)
+    rollout_vs_oracle(treasurehunt_spec(80, 64, 64, 2, spawn_prob=0.02, seed=13), 24, 6, first=3)     # 10 KiB env, one window pass
+
+
 @pytest.mark.parametrize("shape", [(9, 13, 3, 4), (7, 7, 5, 3), (33, 21, 9, 2), (64, 64, 16, 4), (66, 70, 7, 6), (5, 5, 2, 2)])
 def test_ragged_shapes_vs_oracle(torch_cuda, shape):
     """Grid byte counts that are not multiples of 16 / 4, odd sizes, maximum radius."""

@@ -114,11 +114,18 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no HIP device; the hot path has no CPU fallback", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SGW_BENCH_REHEARSAL=1 (1-GPU box only): every rank shares cuda:0 and the collectives run over gloo,
+    # to rehearse the N>1 control path where a second GPU is not available.  Never set by the driver.
+    rehearsal = os.environ.get("SGW_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     H, W, A, r, E_cfg, p_spawn, p_dense = CONFIGS[args.config]
     E = args.envs or E_cfg
@@ -128,7 +135,10 @@ def main() -> int:
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if rehearsal:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev_index])
         torch.cuda.synchronize(dev)
 
     write_obs = not args.no_obs
@@ -153,6 +163,8 @@ def main() -> int:
     metrics = eng.reduce_metrics().clone()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
+        if rehearsal:     # gloo reduces host tensors
+            metrics, tmax = metrics.cpu(), tmax.cpu()
         dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -200,7 +212,7 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     return 0
 

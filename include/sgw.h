@@ -72,6 +72,10 @@ extern "C" {
 
 #define SGW_NO_BORDER 255
 
+/* observation post-processing (sgw_config.obs_post) */
+#define SGW_OBS_POST_NONE 0            /* OneHotObservationSpec: the layer sum itself */
+#define SGW_OBS_POST_CLIP255_DIV255 1  /* RGBObservationSpec: np.clip(obs, 0, 255) / 255 (observation_spec.py:483) */
+
 /* counter-RNG stream ids: u32 = Philox4x32-10(ctr = {index>>2, turn, env, epoch<<4|stream},
  * key = {seed lo, seed hi})[index & 3] */
 #define SGW_STREAM_SPAWN 0
@@ -105,7 +109,7 @@ typedef struct sgw_config {
     int32_t agent_layer;   /* layer (z) every agent lives on */
     int32_t default_type;  /* Gridworld.default_entity: refills vacated cells */
     int32_t fill_type;     /* ObservationSpec.fill_entity_kind: out-of-bounds appearance */
-    int32_t reserved0;
+    int32_t obs_post;      /* SGW_OBS_POST_*: applied to the float64 layer sum before the float32 cast */
     int8_t action_dy[SGW_MAX_ACTIONS]; /* in {-1,0,1}; (0,0) for non-move action names */
     int8_t action_dx[SGW_MAX_ACTIONS];
     uint8_t agent_type[SGW_MAX_AGENTS];

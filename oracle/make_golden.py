@@ -113,11 +113,11 @@ def build_plugins(R):
 # harness environments (user-side subclasses of the reference Environment)
 # --------------------------------------------------------------------------- #
 def make_treasurehunt_env(R, spec: O.Spec, turns: int, actions_names=("up", "down", "left", "right"),
-                          entity_map_override=None):
+                          entity_map_override=None, rgb=False):
     CounterEmpty, CounterModel, _ = build_plugins(R)
     Environment = R["environment"].Environment
     th, tha, thw = R["th_entities"], R["th_agents"], R["th_world"]
-    OneHot = R["observation_spec"].OneHotObservationSpec
+    OneHot = R["observation_spec"].RGBObservationSpec if rgb else R["observation_spec"].OneHotObservationSpec
     ActionSpec = R["action_spec"].ActionSpec
     entity_list = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
 
@@ -191,7 +191,7 @@ def type_ids_treasurehunt(R, world, CounterEmpty) -> np.ndarray:
 
 
 def run_reference_treasurehunt(R, spec: O.Spec, env_ids, turns, scripted=None, epoch=0,
-                               actions_names=("up", "down", "left", "right"), entity_map_override=None):
+                               actions_names=("up", "down", "left", "right"), entity_map_override=None, rgb=False):
     E, A, C, V = len(env_ids), spec.num_agents, spec.num_channels, spec.window
     out = dict(
         grid0=np.zeros((E, spec.layers, spec.height, spec.width), np.uint8),
@@ -207,7 +207,7 @@ def run_reference_treasurehunt(R, spec: O.Spec, env_ids, turns, scripted=None, e
     for n, env_id in enumerate(env_ids):
         Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec = spec.seed, int(env_id), epoch, 0, spec
         Ctx.scripted = None if scripted is None else scripted[:, n]
-        env, CounterEmpty = make_treasurehunt_env(R, spec, turns, actions_names, entity_map_override)
+        env, CounterEmpty = make_treasurehunt_env(R, spec, turns, actions_names, entity_map_override, rgb=rgb)
         out["grid0"][n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
         out["pos0"][n] = [a.location[:2] for a in env.agents]
         for t in range(turns):
@@ -518,6 +518,19 @@ def main() -> int:
     ref = run_reference_basic(R, spec, [4], 12, moves, entity_map_override=emap)
     check_against_oracle(spec, [4], 12, ref)
     save("float_appearance_3layer", spec, [4], ref)
+
+    print("rgb_treasurehunt: RGBObservationSpec (uint8 colours summed over layers, clip(0,255)/255)")
+    spec = O.treasurehunt_spec(12, 11, 3, 3, spawn_prob=0.05, seed=21, dense_prob=0.2)
+    rgb_map = R["observation_spec"].RGBObservationSpec(
+        ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"], full_view=False, vision_radius=3).entity_map
+    kinds = ["EmptyEntity", "EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+    spec.appearance = np.stack([rgb_map[k].astype(np.float64) for k in kinds])
+    spec.num_channels, spec.obs_post = 3, 1
+    ids = [0, 9]
+    ref = run_reference_treasurehunt(R, spec, ids, 15, rgb=True)
+    check_against_oracle(spec, ids, 15, ref)
+    assert 0.0 < ref["obs"].max() <= 1.0
+    save("rgb_treasurehunt", spec, ids, ref)
 
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)

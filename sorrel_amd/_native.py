@@ -12,6 +12,7 @@ MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_D
 RULE_NONE, RULE_SPAWN = 0, 1
 NO_BORDER = 255
 STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS = 1, 2, 4
+OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE = 1, 2, 4
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
@@ -24,7 +25,7 @@ class SgwConfig(C.Structure):
         ("num_agents", C.c_int32), ("vision_radius", C.c_int32),
         ("num_types", C.c_int32), ("num_channels", C.c_int32), ("num_actions", C.c_int32),
         ("agent_layer", C.c_int32), ("default_type", C.c_int32), ("fill_type", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("obs_post", C.c_int32),
         ("action_dy", C.c_int8 * MAX_ACTIONS), ("action_dx", C.c_int8 * MAX_ACTIONS),
         ("agent_type", C.c_uint8 * MAX_AGENTS),
         ("type_value", C.c_double * MAX_TYPES),

@@ -77,6 +77,7 @@ struct Params {
     uint32_t epoch, turn, flags;
     int a0, a1;
     int do_move;  // 0: observe only
+    int obs_post; // SGW_OBS_POST_*
     uint64_t dense_thr;
     int dense_count;
     uint8_t* grid;
@@ -129,6 +130,12 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
 
 __device__ __forceinline__ uint32_t word_of(const U4& v, int i) {
     return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// RGBObservationSpec: np.clip(obs, 0, 255) / 255 on the float64 layer sum (observation_spec.py:483)
+__device__ __forceinline__ float obs_finish(double acc, int post) {
+    if (post == SGW_OBS_POST_CLIP255_DIV255) acc = fmin(fmax(acc, 0.0), 255.0) / 255.0;
+    return (float)acc;
 }
 
 // ---------------------------------------------------------------- group sync
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                             } else {
                                 acc = tab->appearance[p.fill_type][c];
                             }
-                            o[c * p.VV] = (float)acc;
+                            o[c * p.VV] = obs_finish(acc, p.obs_post);
                         }
                     }
                 };
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                             for (int c = 0; c < C; ++c) {
                                 double acc = wapp[lg[off] & 31u][c];   // left-to-right float64 layer sum
                                 for (int z = 1; z < L; ++z) acc += wapp[lg[z * HW + off] & 31u][c];
-                                OBS_STORE(o + c * VV, (float)(inb ? acc : wapp[p.fill_type][c]));
+                                OBS_STORE(o + c * VV, obs_finish(inb ? acc : wapp[p.fill_type][c], p.obs_post));
                             }
                         }
                     }
@@ -973,7 +980,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
                                 const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
                                 acc += wapp[t][c];
                             }
-                            OBS_STORE(o + c * VV, (float)(inbk[k] ? acc : wapp[p.fill_type][c]));
+                            OBS_STORE(o + c * VV, obs_finish(inbk[k] ? acc : wapp[p.fill_type][c], p.obs_post));
                         }
                     }
                 }
@@ -1270,6 +1277,8 @@ int validate(const sgw_config* c) {
     for (int k = 0; k < c->dense_count; ++k)
         if (c->dense_choice[k] >= c->num_types) return fail(SGW_EINVAL, "dense choice out of range");
     if (!(c->dense_prob >= 0.0 && c->dense_prob <= 1.0)) return fail(SGW_EINVAL, "dense_prob must be in [0, 1]");
+    if (c->obs_post != SGW_OBS_POST_NONE && c->obs_post != SGW_OBS_POST_CLIP255_DIV255)
+        return fail(SGW_EINVAL, "unknown obs_post %d", c->obs_post);
     if (c->num_envs < 1) return fail(SGW_EINVAL, "num_envs must be >= 1");
     if (c->first_env_id + (uint64_t)c->num_envs > 4294967296ull)
         return fail(SGW_EINVAL, "global env ids must fit 32 bits");
@@ -1389,6 +1398,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     memcpy(h.dense_choice, c.dense_choice, SGW_MAX_CHOICES);
     memcpy(h.layer_fill, c.layer_fill_type, 8);
     memcpy(h.layer_border, c.layer_border_type, 8);
+    if (c.obs_post != SGW_OBS_POST_NONE) onehot = false;   // post-processing lives on the general float64 path
     e->onehot = onehot;
 
     // ---- static launch parameters
@@ -1437,6 +1447,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.E = c.num_envs;
     p.dense_thr = prob_threshold(c.dense_prob);
     p.dense_count = c.dense_count;
+    p.obs_post = c.obs_post;
 
     // ---- group geometry: one wave per env while a slice stays small, else a workgroup per env
     e->wpe = (p.cells_pad <= 4096) ? 1 : 4;

@@ -136,7 +136,8 @@ class Environment:
         ospec, aspec = agents[0].observation_spec, agents[0].action_spec
         for a in agents[1:]:
             o = a.observation_spec
-            if o.vision_radius != ospec.vision_radius or o.fill_entity_kind != ospec.fill_entity_kind or \
+            if type(o) is not type(ospec) or o.vision_radius != ospec.vision_radius or \
+                    o.fill_entity_kind != ospec.fill_entity_kind or \
                     list(o.entity_map) != list(ospec.entity_map) or \
                     any(not np.array_equal(o.entity_map[k], ospec.entity_map[k]) for k in o.entity_map) or \
                     a.action_spec.names != aspec.names:
@@ -183,7 +184,7 @@ class Environment:
             spawn_choices=[spawn[t][1] if t in spawn else [] for t in range(T)],
             appearance=app, seed=w.seed, layer_fill_type=lay["fill"], layer_border_type=lay["border"],
             dense_prob=lay["dense_prob"], dense_choices=lay["dense"],
-            type_names=[type(p).__name__ for p in protos],
+            type_names=[type(p).__name__ for p in protos], obs_post=int(getattr(ospec, "obs_post", 0)),
         )
 
     def _ensure_engine(self):
@@ -263,7 +264,10 @@ class Environment:
         w = self.world
         spec = self.compile_spec()
         app = torch.tensor(spec.appearance, dtype=torch.float64, device=w.device)        # [T, C]
-        return app[w.grid.long()].sum(dim=1).permute(0, 3, 1, 2).contiguous()
+        out = app[w.grid.long()].sum(dim=1).permute(0, 3, 1, 2).contiguous()
+        if getattr(ospec, "obs_post", 0) == 1:
+            out = out.clamp(0, 255) / 255
+        return out
 
     def _act(self, agent: Agent, action) -> torch.Tensor:
         eng = self._ensure_engine()

@@ -4,7 +4,7 @@ from sorrel_amd.environment import Environment
 from sorrel_amd.examples.treasurehunt.agents import TreasurehuntAgent
 from sorrel_amd.examples.treasurehunt.entities import Bone, EmptyEntity, Food, Gem, Sand, Wall
 from sorrel_amd.models import RandomModel
-from sorrel_amd.observation.observation_spec import OneHotObservationSpec
+from sorrel_amd.observation.observation_spec import OneHotObservationSpec, RGBObservationSpec
 
 ENTITY_LIST = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
 
@@ -22,8 +22,11 @@ class TreasurehuntEnv(Environment):
         n = int(self.config.model.get("num_agents", 2))
         agents = []
         for _ in range(n):
-            ospec = OneHotObservationSpec(ENTITY_LIST, full_view=False,
-                                          vision_radius=int(self.config.model.agent_vision_radius))
+            kind = self.config.model.get("observation_spec", "onehot")     # options: "onehot", "rgb" (main.py:24)
+            if kind not in ("onehot", "rgb"):
+                raise ValueError(f"Unknown observation spec type: {kind}")
+            ospec = (OneHotObservationSpec if kind == "onehot" else RGBObservationSpec)(
+                ENTITY_LIST, full_view=False, vision_radius=int(self.config.model.agent_vision_radius))
             size = 1
             for d in ospec.input_size:
                 size *= d

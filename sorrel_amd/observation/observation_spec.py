@@ -7,6 +7,7 @@ appearance table (``entity_map``) the engine is compiled from.
 """
 from __future__ import annotations
 
+import colorsys
 from abc import abstractmethod
 from typing import Dict, Optional, Sequence
 
@@ -58,6 +59,20 @@ class ObservationSpec:
     def num_channels(self) -> int:
         return len(next(iter(self.entity_map.values())))
 
+    #: post-processing of the layer sum the engine applies (0 = none); see include/sgw.h SGW_OBS_POST_*
+    obs_post = 0
+
+    def _engine_observe(self, world, location):
+        if not self.full_view and location is None:
+            raise TypeError(
+                "location not provided when full_view is false. Please provide the location of the observer.")
+        env = getattr(world, "_environment", None)
+        if env is None:
+            raise RuntimeError("the world is not attached to an Environment (the engine is compiled there)")
+        if self.full_view:
+            return env._full_view(self)
+        return env._observe(location)
+
 
 class OneHotObservationSpec(ObservationSpec):
     """One-hot egocentric observations (``observation_spec.py:116-205``)."""
@@ -85,12 +100,38 @@ class OneHotObservationSpec(ObservationSpec):
         ``(y, x, z)`` tuple observes from that cell in every env.  With ``full_view`` the
         whole map is returned ``[E, C, H, W]`` (appearance summed over layers,
         ``visual_field.py:41-55``)."""
-        if not self.full_view and location is None:
-            raise TypeError(
-                "location not provided when full_view is false. Please provide the location of the observer.")
-        env = getattr(world, "_environment", None)
-        if env is None:
-            raise RuntimeError("the world is not attached to an Environment (the engine is compiled there)")
+        return self._engine_observe(world, location)
+
+
+class RGBObservationSpec(ObservationSpec):
+    """RGB image observations (``observation_spec.py:386-483``): the same window gather with an
+    RGB appearance per kind (summed over layers), then ``np.clip(obs, 0, 255) / 255`` -- done by
+    the kernels' float64 path (``SGW_OBS_POST_CLIP255_DIV255``)."""
+
+    obs_post = 1
+
+    def __init__(self, entity_list, full_view: bool, vision_radius: Optional[int] = None,
+                 env_dims: Optional[Sequence[int]] = None, fill_entity_kind: str = "Wall"):
+        super().__init__(entity_list, full_view, vision_radius, env_dims, fill_entity_kind)
         if self.full_view:
-            return env._full_view(self)
-        return env._observe(location)
+            self.input_size = (3, *env_dims)
+        else:
+            v = 2 * self.vision_radius + 1
+            self.input_size = (3, v, v)
+
+    def generate_map(self, entity_list):
+        """``"EmptyEntity"`` -> black; the other kinds get evenly spaced hues at full saturation
+        and value, as uint8 triples (``observation_spec.py:425-450``)."""
+        others = [e for e in entity_list if e != "EmptyEntity"]
+        out, k = {}, 0
+        for kind in entity_list:
+            if kind == "EmptyEntity":
+                out[kind] = np.zeros(3, dtype=np.uint8)
+            else:
+                rgb = colorsys.hsv_to_rgb(k / max(1, len(others)), 1.0, 1.0)
+                out[kind] = np.array([int(c * 255) for c in rgb], dtype=np.uint8)
+                k += 1
+        return out
+
+    def observe(self, world, location=None):
+        return self._engine_observe(world, location)

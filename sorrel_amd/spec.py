@@ -58,6 +58,7 @@ class WorldSpec:
     dense_prob: float = 0.0
     dense_choices: List[int] = field(default_factory=list)
     type_names: List[str] = field(default_factory=list)   # debugging only
+    obs_post: int = 0   # N.OBS_POST_*: 1 = RGBObservationSpec's clip(0, 255) / 255
 
     @property
     def num_types(self) -> int:
@@ -101,6 +102,7 @@ class WorldSpec:
         c.num_agents, c.vision_radius = self.num_agents, self.vision_radius
         c.num_types, c.num_channels, c.num_actions = T, self.num_channels, self.num_actions
         c.agent_layer, c.default_type, c.fill_type = self.agent_layer, self.default_type, self.fill_type
+        c.obs_post = int(self.obs_post)
         for i in range(self.num_actions):
             c.action_dy[i], c.action_dx[i] = int(self.action_dy[i]), int(self.action_dx[i])
         for a in range(self.num_agents):

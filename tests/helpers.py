@@ -47,7 +47,7 @@ def world_spec(spec: O.Spec) -> WorldSpec:
         spawn_prob=list(spec.spawn_prob), spawn_choices=[list(c) for c in spec.spawn_choices],
         appearance=np.asarray(spec.appearance, dtype=np.float64), seed=spec.seed,
         layer_fill_type=list(spec.layer_fill_type), layer_border_type=list(spec.layer_border_type),
-        dense_prob=spec.dense_prob, dense_choices=list(spec.dense_choices),
+        dense_prob=spec.dense_prob, dense_choices=list(spec.dense_choices), obs_post=getattr(spec, "obs_post", 0),
     )
 
 
@@ -132,5 +132,5 @@ def oracle_spec(ws: WorldSpec) -> O.Spec:
         spawn_prob=list(ws.spawn_prob), spawn_choices=[list(c) for c in ws.spawn_choices],
         appearance=np.asarray(ws.appearance, dtype=np.float64), seed=ws.seed,
         layer_fill_type=list(ws.layer_fill_type), layer_border_type=list(ws.layer_border_type),
-        dense_prob=ws.dense_prob, dense_choices=list(ws.dense_choices),
+        dense_prob=ws.dense_prob, dense_choices=list(ws.dense_choices), obs_post=ws.obs_post,
     )

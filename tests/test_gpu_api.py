@@ -139,6 +139,29 @@ def test_observe_from_arbitrary_cell_and_full_view(torch_cuda):
         assert np.array_equal(fv[e], want)
 
 
+def test_rgb_observation_spec_through_the_api(torch_cuda):
+    """config model.observation_spec = "rgb" (examples/treasurehunt/main.py:24): clip(sum, 0, 255) / 255."""
+    torch = torch_cuda
+    from sorrel_amd.examples.treasurehunt.entities import EmptyEntity
+    from sorrel_amd.examples.treasurehunt.env import TreasurehuntEnv
+    from sorrel_amd.examples.treasurehunt.main import make_config
+    from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
+
+    cfg = make_config(12, 12, 3, 2, spawn_prob=0.05)
+    cfg["model"]["observation_spec"] = "rgb"
+    env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=10, device="cuda:0", seed=2), cfg)
+    ospec = H.oracle_spec(env.compile_spec())
+    assert ospec.obs_post == 1 and ospec.num_channels == 3
+    states = [O.reset_env(ospec, e, epoch=0) for e in range(10)]
+    for t in range(1, 7):
+        env.take_turn()
+        torch.cuda.synchronize()
+        for e in range(10):
+            o, a, r = O.step_env(ospec, states[e], e, 0, t)
+            assert np.array_equal(env.obs[e].cpu().numpy(), o)
+    assert 0.0 < float(env.obs.max()) <= 1.0
+
+
 def test_run_experiment_thin_loop(torch_cuda):
     env = make_env(10, 10, 2, 2, 32)
     hist = env.run_experiment(epochs=1, max_turns=5, all_reduce=False)

@@ -17,7 +17,7 @@ def test_fixture_inventory():
     names = H.golden_names()
     for must in ("c1_treasurehunt_10x10", "c2_treasurehunt_16x16", "c3_treasurehunt_32x32", "crowded_6x6",
                  "ragged_9x13_rmax", "c5_small_dense", "scripted_noop", "basic_doublewall", "basic_1layer",
-                 "float_appearance_3layer", "stock_np_random"):
+                 "float_appearance_3layer", "rgb_treasurehunt", "stock_np_random"):
         assert must in names
 
 

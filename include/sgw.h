@@ -84,6 +84,12 @@ extern "C" {
 #define SGW_STREAM_PLACE 3
 #define SGW_STREAM_DENSE 4
 #define SGW_STREAM_DENSE_KIND 5
+#define SGW_STREAM_TAG_INIT 6
+
+/* what Agent.act does (sgw_config.agent_rule) */
+#define SGW_AGENT_RULE_MOVE 0 /* MovingAgent.act: reward = value of the target, then move (sorrel/agents/agent.py:215-225) */
+#define SGW_AGENT_RULE_TAG 1  /* TagAgent.act: move, tag the first adjacent NotIt agent, reward for not being it
+                               * (sorrel/examples/tag/agents.py:76-106); needs sgw_bind_agent_state */
 
 /* sgw_step flags */
 #define SGW_STEP_SWEEP 1u           /* run the entity-transition sweep first */
@@ -128,10 +134,14 @@ typedef struct sgw_config {
     double dense_prob;
     uint8_t dense_count;
     uint8_t dense_choice[SGW_MAX_CHOICES];
-    uint8_t reserved1[7];
+    uint8_t agent_rule;     /* SGW_AGENT_RULE_*: what Agent.act does */
+    uint8_t tag_it_type;    /* SGW_AGENT_RULE_TAG: type of an agent that is "it" (kind "It") */
+    uint8_t tag_notit_type; /*                     ... that is not (kind "NotIt") */
+    uint8_t reserved1[4];
     uint64_t seed;
     uint64_t first_env_id; /* global id of local env 0 (multi-GPU sharding) */
     int64_t num_envs;      /* E on this device */
+    double tag_reward;     /* SGW_AGENT_RULE_TAG: TagAgent.reward_per_turn */
 } sgw_config;
 
 typedef struct sgw_engine sgw_engine;
@@ -159,6 +169,15 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
 /* out (device, 4 doubles) = { sum(total_reward), sum(total_reward^2), E, 0 },
  * summed in a fixed order (bitwise reproducible). */
 int sgw_reduce_metrics(sgw_engine* eng, const double* total_reward, double* out, void* stream);
+
+/* Per-env agent state: the CURRENT entity type of every agent, uint8 [E][A] (Tag: It / NotIt; it
+ * survives resets, as TagAgent.it does).  Once bound, sgw_reset places the agents with these types
+ * and sgw_step keeps them up to date; `state_at_pov` (uint8 [E][A], may be NULL) receives each
+ * agent's type at the moment it observed (what TagAgent.pov appends to its observation).
+ * sgw_init_agent_state fills `agent_state` with the configured agent types and, for
+ * SGW_AGENT_RULE_TAG, draws the initial "it" agent of every env (sorrel/examples/tag/env.py:66-69). */
+int sgw_bind_agent_state(sgw_engine* eng, uint8_t* agent_state, uint8_t* state_at_pov);
+int sgw_init_agent_state(sgw_engine* eng, uint8_t* agent_state, void* stream);
 
 /* Fill `actions` from STREAM_ACTION without stepping (what a RandomModel would choose). */
 int sgw_random_actions(sgw_engine* eng, uint8_t* actions, uint32_t epoch, uint32_t turn, void* stream);

@@ -355,6 +355,112 @@ def run_reference_basic(R, spec: O.Spec, env_ids, turns, actions_names, entity_m
 
 
 # --------------------------------------------------------------------------- #
+# Tag: the first agent <-> agent interaction (sorrel/examples/tag)
+# --------------------------------------------------------------------------- #
+def tag_spec(height, width, num_agents, vision_radius, seed, reward_per_turn=10) -> O.Spec:
+    """Types: 0 EmptyEntity (basic, passable, inert), 1 Wall, 2 TagAgent that is it (kind "It"),
+    3 TagAgent that is not (kind "NotIt").  entity_list of examples/tag/env.py:40."""
+    app = np.zeros((4, 4))
+    app[1, 1] = app[2, 2] = app[3, 3] = 1.0
+    return O.Spec(
+        height=height, width=width, layers=1, num_agents=num_agents, vision_radius=vision_radius,
+        num_types=4, num_channels=4, agent_layer=0, default_type=0, fill_type=1,
+        action_dy=[-1, 1, 0, 0], action_dx=[0, 0, -1, 1], agent_type=[3] * num_agents,
+        type_value=[0, -1, 0, 0], type_passable=[1, 0, 0, 0], type_rule=[0] * 4, spawn_prob=[0.0] * 4,
+        spawn_choices=[[]] * 4, appearance=app, seed=seed, layer_fill_type=[0], layer_border_type=[1],
+        agent_rule=O.AGENT_RULE_TAG, tag_it_type=2, tag_notit_type=3, tag_reward=reward_per_turn,
+    )
+
+
+def run_reference_tag(R, spec: O.Spec, env_ids, turns, epoch=0):
+    """The reference's own TagAgent (pov with the it flag, act with move + tagging) and step loop."""
+    _, CounterModel, _ = build_plugins(R)
+    import sorrel.examples.tag.agents as tag_agents
+
+    Environment = R["environment"].Environment
+    Gridworld = R["worlds"].Gridworld
+    ent = R["entities"]
+    OneHot = R["observation_spec"].OneHotObservationSpec
+    ActionSpec = R["action_spec"].ActionSpec
+    TagAgent = tag_agents.TagAgent
+    entity_list = ["EmptyEntity", "Wall", "It", "NotIt"]
+
+    class TagHarness(Environment):
+        def setup_agents(self):
+            agents = []
+            for slot in range(spec.num_agents):
+                ospec = OneHot(entity_list, full_view=False, vision_radius=spec.vision_radius)
+                n = int(np.prod(ospec.input_size)) + 1          # + the it flag (tag/env.py:47-48)
+                ospec.override_input_size((n,))
+                aspec = ActionSpec(["up", "down", "left", "right"])
+                model = CounterModel(ospec.input_size, aspec.n_actions, memory_size=turns + 1, slot=slot)
+                agents.append(TagAgent(ospec, aspec, model, reward_per_turn=spec.tag_reward))
+            state0 = O.init_agent_state(spec, Ctx.env)          # stands in for np.random.choice (env.py:66-69)
+            for a, agent in enumerate(agents):
+                if state0[a] == spec.tag_it_type:
+                    agent.it = True
+            self.agents = agents
+
+        def populate_environment(self):
+            H, W = self.world.height, self.world.width
+            for index in np.ndindex(self.world.map.shape):
+                y, x, z = index
+                if y in [0, H - 1] or x in [0, W - 1]:
+                    self.world.add(index, ent.Wall())
+            pos = O.place_agents(spec, Ctx.env, Ctx.epoch)
+            for (y, x), agent in zip(pos, self.agents):
+                self.world.add((int(y), int(x), 0), agent)
+
+    def type_ids(world):
+        H, W, Ls = world.map.shape
+        g = np.zeros((Ls, H, W), dtype=np.uint8)
+        for (y, x, z), e in np.ndenumerate(world.map):
+            if isinstance(e, TagAgent):
+                assert e.kind == ("It" if e.it else "NotIt")
+                t = 2 if e.it else 3
+            elif type(e) is ent.EmptyEntity:
+                t = 0
+            elif type(e) is ent.Wall:
+                t = 1
+            else:
+                raise RuntimeError(f"unmapped entity {e!r}")
+            g[z, y, x] = t
+        return g
+
+    E, A, C, V = len(env_ids), spec.num_agents, spec.num_channels, spec.window
+    n = C * V * V
+    out = dict(
+        grid0=np.zeros((E, 1, spec.height, spec.width), np.uint8), pos0=np.zeros((E, A, 2), np.uint8),
+        obs=np.zeros((turns, E, A, C, V, V), np.float32), actions=np.zeros((turns, E, A), np.uint8),
+        rewards=np.zeros((turns, E, A), np.float32), dones=np.zeros((turns, E, A), np.float32),
+        total_reward=np.zeros((turns, E), np.float64),
+        grid=np.zeros((turns, E, 1, spec.height, spec.width), np.uint8), pos=np.zeros((turns, E, A, 2), np.uint8),
+        state_at_pov=np.zeros((turns, E, A), np.uint8), agent_state=np.zeros((turns, E, A), np.uint8),
+    )
+    cfg = {"experiment": {"epochs": 1, "max_turns": turns, "record_period": 1}}
+    for k, env_id in enumerate(env_ids):
+        Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec, Ctx.scripted = spec.seed, int(env_id), epoch, 0, spec, None
+        env = TagHarness(Gridworld(spec.height, spec.width, 1, ent.EmptyEntity()), cfg)
+        out["grid0"][k] = type_ids(env.world)
+        out["pos0"][k] = [a.location[:2] for a in env.agents]
+        for t in range(turns):
+            Ctx.turn = env.turn + 1
+            env.take_turn()
+            for a, agent in enumerate(env.agents):
+                mem = agent.model.memory
+                out["obs"][t, k, a] = mem.states[t][:n].reshape(C, V, V)
+                out["state_at_pov"][t, k, a] = 2 if mem.states[t][n] == 1.0 else 3      # the flag pov() appended
+                out["actions"][t, k, a] = mem.actions[t]
+                out["rewards"][t, k, a] = mem.rewards[t]
+                out["dones"][t, k, a] = mem.dones[t]
+                out["pos"][t, k, a] = agent.location[:2]
+                out["agent_state"][t, k, a] = 2 if agent.it else 3
+            out["total_reward"][t, k] = env.world.total_reward
+            out["grid"][t, k] = type_ids(env.world)
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # stock Treasurehunt with the reference's own global np.random stream
 # --------------------------------------------------------------------------- #
 def run_reference_stock(R, height, width, num_agents, radius, spawn_prob, turns, np_seed):
@@ -429,7 +535,10 @@ def save(name, spec, env_ids, ref, extra=None):
 
 def check_against_oracle(spec, env_ids, turns, ref, scripted=None, epoch=0):
     mine = O.rollout(spec, env_ids, turns, epoch=epoch, actions=scripted)
-    for k in ("grid0", "pos0", "obs", "actions", "rewards", "total_reward", "grid", "pos"):
+    keys = ["grid0", "pos0", "obs", "actions", "rewards", "total_reward", "grid", "pos"]
+    if "state_at_pov" in ref:
+        keys += ["state_at_pov", "agent_state"]
+    for k in keys:
         if not np.array_equal(mine[k], ref[k]):
             bad = np.argwhere(mine[k] != ref[k])[0]
             raise AssertionError(f"restatement differs from the reference in {k} at {bad}")
@@ -531,6 +640,21 @@ def main() -> int:
     check_against_oracle(spec, ids, 15, ref)
     assert 0.0 < ref["obs"].max() <= 1.0
     save("rgb_treasurehunt", spec, ids, ref)
+
+    print("tag_9x9: examples/tag TagAgent (move, tag an adjacent NotIt agent, reward for not being it)")
+    spec = tag_spec(9, 9, 5, 2, seed=31)
+    ids = [0, 4, 11]
+    ref = run_reference_tag(R, spec, ids, 40)
+    check_against_oracle(spec, ids, 40, ref)
+    assert (ref["agent_state"][1:] != ref["agent_state"][:-1]).any(), "nobody was ever tagged"
+    save("tag_9x9", spec, ids, ref)
+
+    print("tag_crowded_6x7: 8 taggers on a 4x5 interior")
+    spec = tag_spec(6, 7, 8, 2, seed=32, reward_per_turn=2.5)
+    ids = [1, 2]
+    ref = run_reference_tag(R, spec, ids, 30)
+    check_against_oracle(spec, ids, 30, ref)
+    save("tag_crowded_6x7", spec, ids, ref)
 
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)

@@ -13,6 +13,7 @@ RULE_NONE, RULE_SPAWN = 0, 1
 NO_BORDER = 255
 STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS = 1, 2, 4
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
+AGENT_RULE_MOVE, AGENT_RULE_TAG = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE = 1, 2, 4
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
@@ -40,10 +41,12 @@ class SgwConfig(C.Structure):
         ("dense_prob", C.c_double),
         ("dense_count", C.c_uint8),
         ("dense_choice", C.c_uint8 * MAX_CHOICES),
-        ("reserved1", C.c_uint8 * 7),
+        ("agent_rule", C.c_uint8), ("tag_it_type", C.c_uint8), ("tag_notit_type", C.c_uint8),
+        ("reserved1", C.c_uint8 * 4),
         ("seed", C.c_uint64),
         ("first_env_id", C.c_uint64),
         ("num_envs", C.c_int64),
+        ("tag_reward", C.c_double),
     ]
 
 
@@ -53,7 +56,7 @@ LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")
 # every symbol include/sgw.h declares
 EXPORTS = (
     "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_reduce_metrics",
-    "sgw_random_actions", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
+    "sgw_random_actions", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms",
     "sgw_last_error", "sgw_version",
 )
@@ -110,6 +113,10 @@ def load():
     lib.sgw_reduce_metrics.restype = C.c_int
     lib.sgw_random_actions.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]
     lib.sgw_random_actions.restype = C.c_int
+    lib.sgw_bind_agent_state.argtypes = [vp, u8p, u8p]
+    lib.sgw_bind_agent_state.restype = C.c_int
+    lib.sgw_init_agent_state.argtypes = [vp, u8p, vp]
+    lib.sgw_init_agent_state.restype = C.c_int
     lib.sgw_get_status.argtypes = [vp, C.POINTER(C.c_int32), vp]
     lib.sgw_get_status.restype = C.c_int
     for name in ("sgw_obs_elems_per_env", "sgw_grid_bytes_per_env", "sgw_algorithmic_bytes_per_env_step"):

@@ -78,6 +78,11 @@ struct Params {
     int a0, a1;
     int do_move;  // 0: observe only
     int obs_post; // SGW_OBS_POST_*
+    int agent_rule;            // SGW_AGENT_RULE_*
+    uint32_t tag_it, tag_notit;
+    double tag_reward;
+    uint8_t* agent_state;      // optional [E][A]: current type of every agent
+    uint8_t* state_at_pov;     // optional [E][A]: type at observation time
     uint64_t dense_thr;
     int dense_count;
     uint8_t* grid;
@@ -235,7 +240,9 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
 constexpr int kPosOff = 0;
 constexpr int kActOff = 2 * SGW_MAX_AGENTS;
 constexpr int kRewOff = kActOff + SGW_MAX_AGENTS;
-constexpr int kAgentLds = kRewOff + 4 * SGW_MAX_AGENTS;  // 448 bytes, multiple of 16
+constexpr int kTypeOff = kRewOff + 4 * SGW_MAX_AGENTS;   // current type of each agent
+constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it observed
+constexpr int kAgentLds = kPovOff + SGW_MAX_AGENTS;     // 576 bytes, multiple of 16
 
 template <int WPE, bool ONEHOT>
 __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
@@ -259,6 +266,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
     uint8_t* s_pos = slice + p.cells_pad + kPosOff;   // [A][2]
     uint8_t* s_act = slice + p.cells_pad + kActOff;   // [A]
     float* s_rew = reinterpret_cast<float*>(slice + p.cells_pad + kRewOff);
+    uint8_t* s_type = slice + p.cells_pad + kTypeOff;   // [A] current entity type of each agent
+    uint8_t* s_pov = slice + p.cells_pad + kPovOff;     // [A] its type when it observed
 
     // window cell(s) this thread renders: fixed for the whole kernel
     int wi[kMaxPass], wj[kMaxPass];
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
         if (gtid < p.A) {
             const uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
             reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
+            s_type[gtid] = p.agent_state ? p.agent_state[env * p.A + gtid] : tab->agent_type[gtid];
             if (p.do_move && gtid >= p.a0 && gtid < p.a1) {
                 uint32_t act;
                 if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             if (!p.do_move) continue;
             // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
             const uint32_t act = s_act[a];
+            const uint32_t my_type = s_type[a];
             const bool act_ok = act < (uint32_t)p.nact;
             const int dy = act_ok ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
             const int dx = act_ok ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
@@ -369,19 +380,52 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             const int oaddr = zoff + y * p.W + x;
             const uint32_t t = inb ? lg[taddr] : 0xFFu;
             const bool tok = t < (uint32_t)p.T;
-            const double val = (inb && tok) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
+            double val = (inb && tok && p.agent_rule == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
             const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
+            const int cy = pass ? ty : y, cx = pass ? tx : x;   // where the agent stands after the move
+            gsync<WPE>();   // every thread has read s_type / the target before thread 0 rewrites them
             if (gtid == 0) {
+                s_pov[a] = (uint8_t)my_type;
                 if (pass) {
-                    lg[taddr] = tab->agent_type[a];
+                    lg[taddr] = (uint8_t)my_type;
                     lg[oaddr] = (uint8_t)p.default_type;
                     s_pos[2 * a] = (uint8_t)ty;
                     s_pos[2 * a + 1] = (uint8_t)tx;
                 }
-                s_rew[a] = (float)val;
-                tot += val;   // world.total_reward += reward, float64, agent order (agent.py:172)
                 st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
                            ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
+            }
+            if (p.agent_rule == SGW_AGENT_RULE_TAG) {
+                // TagAgent.act (sorrel/examples/tag/agents.py:84-106): look at the four neighbours in
+                // Location.adjacent order (up, right, down, left; off-map skipped); an agent that is
+                // "it" hands the flag to the FIRST neighbour that is a NotIt agent.  Every thread
+                // evaluates the same LDS bytes, so `mine_now` stays uniform.
+                gsync<WPE>();
+                uint32_t mine_now = my_type;
+                const int own = zoff + cy * p.W + cx;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
+                    const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                    const bool ain = (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
+                    const uint32_t nt = ain ? lg[zoff + ay * p.W + ax] : 0xFFu;
+                    if (mine_now == p.tag_it && nt == p.tag_notit) {
+                        mine_now = p.tag_notit;
+                        if (gtid == 0) {
+                            lg[own] = (uint8_t)p.tag_notit;
+                            lg[zoff + ay * p.W + ax] = (uint8_t)p.tag_it;
+                            s_type[a] = (uint8_t)p.tag_notit;
+                        }
+                        // the neighbour's slot: the agent standing on (ay, ax)
+                        if (gtid < p.A && gtid != a && s_pos[2 * gtid] == ay && s_pos[2 * gtid + 1] == ax)
+                            s_type[gtid] = (uint8_t)p.tag_it;
+                    }
+                }
+                val = mine_now != p.tag_it ? p.tag_reward : 0.0;
+            }
+            if (gtid == 0) {
+                s_rew[a] = (float)val;
+                tot += val;   // world.total_reward += reward, float64, agent order (agent.py:172)
             }
             gsync<WPE>();
         }
@@ -391,7 +435,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             if (gtid >= p.a0 && gtid < p.a1) {
                 reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
                 p.rewards[env * p.A + gtid] = s_rew[gtid];
+                if (p.state_at_pov) p.state_at_pov[env * p.A + gtid] = s_pov[gtid];
             }
+            if (gtid < p.A && p.agent_state) p.agent_state[env * p.A + gtid] = s_type[gtid];   // a tag can flip any agent
             if (gtid == 0) {
                 p.total[env] = tot;
                 if (st_bits) atomicOr(p.status, st_bits);
@@ -1098,7 +1144,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Params p) {
                 const int y = 1 + d / iw, x = 1 + d - (d / iw) * iw;
                 s_pos[2 * i] = (uint8_t)y;
                 s_pos[2 * i + 1] = (uint8_t)x;
-                lg[zoff + y * p.W + x] = tab->agent_type[i];
+                lg[zoff + y * p.W + x] = p.agent_state ? p.agent_state[env * p.A + i] : tab->agent_type[i];
             }
             p.total[env] = 0.0;
         }
@@ -1119,6 +1165,20 @@ __global__ void random_actions_kernel(const Params p) {
         const U4 w = philox4x32_10((uint32_t)a >> 2, p.turn, p.first_env + (uint32_t)env,
                                    (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
         p.actions[i] = (uint8_t)(((uint64_t)word_of(w, a & 3) * (uint32_t)p.nact) >> 32);
+    }
+}
+
+// sgw_init_agent_state: configured types; Tag draws the initial "it" agent of every env
+__global__ void init_agent_state_kernel(const Params p) {
+    for (int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; env < p.E; env += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t* st = p.agent_state + env * p.A;
+        if (p.agent_rule == SGW_AGENT_RULE_TAG) {
+            const U4 w = philox4x32_10(0u, 0u, p.first_env + (uint32_t)env, SGW_STREAM_TAG_INIT, p.seed_lo, p.seed_hi);
+            const uint32_t it = __umulhi(w.x, (uint32_t)p.A);
+            for (int a = 0; a < p.A; ++a) st[a] = (uint8_t)((uint32_t)a == it ? p.tag_it : p.tag_notit);
+        } else {
+            for (int a = 0; a < p.A; ++a) st[a] = p.tab->agent_type[a];
+        }
     }
 }
 
@@ -1197,6 +1257,8 @@ struct sgw_engine {
     DevTables* d_tab = nullptr;
     int* d_status = nullptr;
     double* d_part = nullptr;
+    uint8_t* agent_state = nullptr;    // caller-owned, bound with sgw_bind_agent_state
+    uint8_t* state_at_pov = nullptr;
     int wpe = 1;          // waves per env
     bool onehot = true;
     bool fast = false;    // step_fast specialisation applies
@@ -1277,6 +1339,14 @@ int validate(const sgw_config* c) {
     for (int k = 0; k < c->dense_count; ++k)
         if (c->dense_choice[k] >= c->num_types) return fail(SGW_EINVAL, "dense choice out of range");
     if (!(c->dense_prob >= 0.0 && c->dense_prob <= 1.0)) return fail(SGW_EINVAL, "dense_prob must be in [0, 1]");
+    if (c->agent_rule != SGW_AGENT_RULE_MOVE && c->agent_rule != SGW_AGENT_RULE_TAG)
+        return fail(SGW_EINVAL, "unknown agent_rule %d", (int)c->agent_rule);
+    if (c->agent_rule == SGW_AGENT_RULE_TAG) {
+        if (c->tag_it_type >= c->num_types || c->tag_notit_type >= c->num_types || c->tag_it_type == c->tag_notit_type)
+            return fail(SGW_EINVAL, "tag_it_type / tag_notit_type must be two distinct registered types");
+        if (c->type_passable[c->tag_it_type] || c->type_passable[c->tag_notit_type])
+            return fail(SGW_EINVAL, "tag agent types must be impassable");
+    }
     if (c->obs_post != SGW_OBS_POST_NONE && c->obs_post != SGW_OBS_POST_CLIP255_DIV255)
         return fail(SGW_EINVAL, "unknown obs_post %d", c->obs_post);
     if (c->num_envs < 1) return fail(SGW_EINVAL, "num_envs must be >= 1");
@@ -1448,17 +1518,22 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.dense_thr = prob_threshold(c.dense_prob);
     p.dense_count = c.dense_count;
     p.obs_post = c.obs_post;
+    p.agent_rule = c.agent_rule;
+    p.tag_it = c.tag_it_type;
+    p.tag_notit = c.tag_notit_type;
+    p.tag_reward = c.tag_reward;
 
     // ---- group geometry: one wave per env while a slice stays small, else a workgroup per env
     e->wpe = (p.cells_pad <= 4096) ? 1 : 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
-    e->fast = e->wpe == 1 && (p.cells & 15) == 0 && (p.cells >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128;
+    const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // the specialised kernels implement MovingAgent.act only
+    e->fast = e->wpe == 1 && (p.cells & 15) == 0 && (p.cells >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && plain_move;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
-    e->big = e->wpe == 4 && (p.cells & 15) == 0 && nspawn <= 1 && p.VV <= 128 && agents_impassable;
+    e->big = e->wpe == 4 && (p.cells & 15) == 0 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move;
     e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
@@ -1525,6 +1600,7 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
     if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.total = total_reward; p.epoch = epoch;
+    p.agent_state = e->agent_state;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(e->reset_fn, dim3(e->reset_blocks), dim3(kBlock), e->lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
@@ -1533,6 +1609,10 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
 
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (int rc = time_begin(e, s)) return rc;
+    p.agent_state = e->agent_state;
+    p.state_at_pov = e->state_at_pov;
+    if (p.agent_rule == SGW_AGENT_RULE_TAG && p.do_move && !p.agent_state)
+        return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
     p.env_lds = e->step_env_lds;
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     if (p.spawn_mask == 0) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
@@ -1565,6 +1645,24 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
     p.epoch = epoch; p.turn = turn; p.a0 = agent_begin; p.a1 = agent_end; p.flags = flags; p.do_move = 1;
     return launch_step(e, p, static_cast<hipStream_t>(stream));
+}
+
+int sgw_bind_agent_state(sgw_engine* e, uint8_t* agent_state, uint8_t* state_at_pov) {
+    if (!e) return fail(SGW_EINVAL, "sgw_bind_agent_state: NULL engine");
+    if (!agent_state && state_at_pov) return fail(SGW_EINVAL, "sgw_bind_agent_state: state_at_pov without agent_state");
+    e->agent_state = agent_state;
+    e->state_at_pov = state_at_pov;
+    return SGW_OK;
+}
+
+int sgw_init_agent_state(sgw_engine* e, uint8_t* agent_state, void* stream) {
+    if (!e || !agent_state) return fail(SGW_EINVAL, "sgw_init_agent_state: NULL argument");
+    Params p = e->base;
+    p.agent_state = agent_state;
+    const int blocks = (int)std::min<int64_t>(ceil_div(p.E, kBlock), (int64_t)e->num_cus * 8);
+    hipLaunchKernelGGL(init_agent_state_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
 }
 
 int sgw_random_actions(sgw_engine* e, uint8_t* actions, uint32_t epoch, uint32_t turn, void* stream) {

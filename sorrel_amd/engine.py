@@ -64,6 +64,15 @@ class GridEngine:
         self.epoch = 0
         self.turn = 0
         self._scratch_obs = None
+        # per-env agent state (current entity type of each agent): needed by interaction rules (Tag)
+        self.agent_state = self.state_at_pov = None
+        if spec.agent_rule != N.AGENT_RULE_MOVE:
+            self.agent_state = adopt("agent_state", (E, A), torch.uint8)
+            self.state_at_pov = torch.zeros((E, A), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(self.device):
+                N.check(self._lib.sgw_bind_agent_state(self._h, self._ptr(self.agent_state), self._ptr(self.state_at_pov)))
+                if "agent_state" not in tensors:
+                    N.check(self._lib.sgw_init_agent_state(self._h, self._ptr(self.agent_state), self._stream()))
 
     # ------------------------------------------------------------------ util
     def _stream(self):

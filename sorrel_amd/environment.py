@@ -144,7 +144,19 @@ class Environment:
                 raise ValueError("all agents of one batched Environment must share observation and action specs")
         if ospec.full_view:
             raise ValueError("full_view observation specs are not part of the fused step; use observe() on demand")
-        agent_types = [w.registry.register(a) for a in agents]
+        rule = getattr(agents[0], "interaction_rule", None)
+        tag = dict(agent_rule=0, tag_it_type=0, tag_notit_type=0, tag_reward=0.0)
+        if rule is None:
+            agent_types = [w.registry.register(a) for a in agents]
+        else:
+            from sorrel_amd.agents.rules import TagRule
+
+            if not isinstance(rule, TagRule):
+                raise ValueError(f"unsupported agent interaction rule {rule!r}")
+            it_t = w.registry.register(agents[0].as_kind(rule.it_kind))
+            notit_t = w.registry.register(agents[0].as_kind(rule.notit_kind))
+            agent_types = [notit_t] * len(agents)
+            tag = dict(agent_rule=1, tag_it_type=it_t, tag_notit_type=notit_t, tag_reward=float(rule.reward_per_turn))
         # resolve spawn rules (may register the spawned types); iterate to a fixed point
         spawn = {}
         n_seen = -1
@@ -184,7 +196,7 @@ class Environment:
             spawn_choices=[spawn[t][1] if t in spawn else [] for t in range(T)],
             appearance=app, seed=w.seed, layer_fill_type=lay["fill"], layer_border_type=lay["border"],
             dense_prob=lay["dense_prob"], dense_choices=lay["dense"],
-            type_names=[type(p).__name__ for p in protos], obs_post=int(getattr(ospec, "obs_post", 0)),
+            type_names=[type(p).__name__ for p in protos], obs_post=int(getattr(ospec, "obs_post", 0)), **tag,
         )
 
     def _ensure_engine(self):
@@ -197,8 +209,11 @@ class Environment:
         if self._engine is not None:
             self._engine.close()
         first = getattr(w, "first_env_id", 0)
-        self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first,
-                                  tensors=dict(grid=w.grid, agent_pos=w.agent_pos, total_reward=w.total_reward))
+        tensors = dict(grid=w.grid, agent_pos=w.agent_pos, total_reward=w.total_reward)
+        if getattr(w, "agent_state", None) is not None:
+            tensors["agent_state"] = w.agent_state          # survives engine rebuilds (and resets)
+        self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first, tensors=tensors)
+        w.agent_state = self._engine.agent_state
         self._engine_version = w.registry.version
         self._validate_border()
         return self._engine

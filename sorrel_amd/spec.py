@@ -59,6 +59,10 @@ class WorldSpec:
     dense_choices: List[int] = field(default_factory=list)
     type_names: List[str] = field(default_factory=list)   # debugging only
     obs_post: int = 0   # N.OBS_POST_*: 1 = RGBObservationSpec's clip(0, 255) / 255
+    agent_rule: int = 0          # N.AGENT_RULE_*
+    tag_it_type: int = 0
+    tag_notit_type: int = 0
+    tag_reward: float = 0.0
 
     @property
     def num_types(self) -> int:
@@ -103,6 +107,8 @@ class WorldSpec:
         c.num_types, c.num_channels, c.num_actions = T, self.num_channels, self.num_actions
         c.agent_layer, c.default_type, c.fill_type = self.agent_layer, self.default_type, self.fill_type
         c.obs_post = int(self.obs_post)
+        c.agent_rule, c.tag_it_type, c.tag_notit_type = int(self.agent_rule), int(self.tag_it_type), int(self.tag_notit_type)
+        c.tag_reward = float(self.tag_reward)
         for i in range(self.num_actions):
             c.action_dy[i], c.action_dx[i] = int(self.action_dy[i]), int(self.action_dx[i])
         for a in range(self.num_agents):

@@ -81,6 +81,7 @@ class Gridworld(World):
         self.agent_slots: List = []
         self.agent_pos: Optional[torch.Tensor] = None
         self.agent_layer: Optional[int] = None
+        self.agent_state: Optional[torch.Tensor] = None   # [E, A] current type of each agent (interaction rules)
         # declarative reset layout (set_layout) -- None = host-built template
         self.layout = None
         self.create_world()

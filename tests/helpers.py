@@ -48,6 +48,8 @@ def world_spec(spec: O.Spec) -> WorldSpec:
         appearance=np.asarray(spec.appearance, dtype=np.float64), seed=spec.seed,
         layer_fill_type=list(spec.layer_fill_type), layer_border_type=list(spec.layer_border_type),
         dense_prob=spec.dense_prob, dense_choices=list(spec.dense_choices), obs_post=getattr(spec, "obs_post", 0),
+        agent_rule=getattr(spec, "agent_rule", 0), tag_it_type=getattr(spec, "tag_it_type", 0),
+        tag_notit_type=getattr(spec, "tag_notit_type", 0), tag_reward=getattr(spec, "tag_reward", 0.0),
     )
 
 
@@ -67,10 +69,11 @@ def oracle_lib():
         lib.sgo_rng_u32.restype = C.c_uint32
         vp = C.c_void_p
         cfgp = C.POINTER(N.SgwConfig)
-        lib.sgo_reset.argtypes = [cfgp, vp, vp, vp, C.c_uint32, C.c_int]
+        lib.sgo_reset.argtypes = [cfgp, vp, vp, vp, C.c_uint32, C.c_int, vp]
         lib.sgo_observe.argtypes = [cfgp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int]
         lib.sgo_step.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
-                                 C.c_uint32, C.c_int]
+                                 C.c_uint32, C.c_int, vp, vp]
+        lib.sgo_init_agent_state.argtypes = [cfgp, vp]
         lib.sgo_random_actions.argtypes = [cfgp, vp, C.c_uint32, C.c_uint32]
         lib.sgo_reduce_metrics.argtypes = [cfgp, vp, vp]
         lib.sgo_threads.argtypes = [C.c_int]
@@ -97,9 +100,13 @@ class COracle:
         self.obs = np.zeros((E,) + wspec.obs_shape, np.float32)
         self.rewards = np.zeros((E, A), np.float32)
         self.total = np.zeros((E,), np.float64)
+        self.agent_state = np.zeros((E, A), np.uint8)
+        self.state_at_pov = np.zeros((E, A), np.uint8)
+        self.lib.sgo_init_agent_state(C.byref(self.cfg), _p(self.agent_state))
 
     def reset(self, epoch=0):
-        self.lib.sgo_reset(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.total), epoch, self.threads)
+        self.lib.sgo_reset(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.total), epoch, self.threads,
+                           _p(self.agent_state))
 
     def observe(self, a0=0, a1=None):
         a1 = self.spec.num_agents if a1 is None else a1
@@ -113,7 +120,7 @@ class COracle:
         flags = (1 if sweep else 0) | (2 if random_actions else 0) | (0 if write_obs else 4)
         return self.lib.sgo_step(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.actions),
                                  _p(self.obs) if write_obs else None, _p(self.rewards), _p(self.total),
-                                 epoch, turn, a0, a1, flags, self.threads)
+                                 epoch, turn, a0, a1, flags, self.threads, _p(self.agent_state), _p(self.state_at_pov))
 
     def metrics(self):
         out = np.zeros(4, np.float64)
@@ -133,4 +140,5 @@ def oracle_spec(ws: WorldSpec) -> O.Spec:
         appearance=np.asarray(ws.appearance, dtype=np.float64), seed=ws.seed,
         layer_fill_type=list(ws.layer_fill_type), layer_border_type=list(ws.layer_border_type),
         dense_prob=ws.dense_prob, dense_choices=list(ws.dense_choices), obs_post=ws.obs_post,
+        agent_rule=ws.agent_rule, tag_it_type=ws.tag_it_type, tag_notit_type=ws.tag_notit_type, tag_reward=ws.tag_reward,
     )

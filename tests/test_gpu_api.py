@@ -162,6 +162,33 @@ def test_rgb_observation_spec_through_the_api(torch_cuda):
     assert 0.0 < float(env.obs.max()) <= 1.0
 
 
+def test_tag_env_through_the_api(torch_cuda):
+    """examples/tag through the class API: fused random turns and the phased policy path."""
+    torch = torch_cuda
+    from sorrel_amd.entities import EmptyEntity
+    from sorrel_amd.examples.tag.env import TagEnv
+    from sorrel_amd.worlds import Gridworld
+
+    cfg = {"agent": {"num_agents": 5, "vision_radius": 2, "reward_per_turn": 10}, "experiment": {"epochs": 1, "max_turns": 5}}
+    E = 20
+    env = TagEnv(Gridworld(9, 9, 1, EmptyEntity(), num_envs=E, device="cuda:0", seed=31), cfg)
+    ospec = H.oracle_spec(env.compile_spec())
+    assert ospec.agent_rule == O.AGENT_RULE_TAG
+    states = [O.reset_env(ospec, e, epoch=0) for e in range(E)]
+    for t in range(1, 16):
+        env.take_turn()
+        torch.cuda.synchronize()
+        for e in range(E):
+            o, a, r = O.step_env(ospec, states[e], e, 0, t)
+            assert np.array_equal(env.obs[e].cpu().numpy(), o) and np.array_equal(env.rewards[e].cpu().numpy(), r)
+        assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+        assert np.array_equal(env.world.agent_state.cpu().numpy(), np.stack([s.agent_state for s in states]))
+    its = torch.stack([a.its for a in env.agents], dim=1)
+    assert bool((its.sum(dim=1) == 1).all())
+    pov = env.agents[2].pov(env.world)
+    assert pov.shape == (E, 4 * 25 + 1) and torch.equal(pov[:, -1].bool(), env.agents[2].its)
+
+
 def test_run_experiment_thin_loop(torch_cuda):
     env = make_env(10, 10, 2, 2, 32)
     hist = env.run_experiment(epochs=1, max_turns=5, all_reduce=False)

@@ -69,6 +69,9 @@ def test_hip_matches_reference_golden(torch_cuda, name):
             assert eng.total_reward.cpu().numpy()[0] == d["total_reward"][t, n], f"{name}: total_reward turn {t}"
             assert np.array_equal(eng.grid.cpu().numpy()[0], d["grid"][t, n]), f"{name}: grid turn {t}"
             assert np.array_equal(eng.agent_pos.cpu().numpy()[0], d["pos"][t, n]), f"{name}: pos turn {t}"
+            if "agent_state" in d:      # interaction rules (Tag): who is "it" now / was when observing
+                assert np.array_equal(eng.agent_state.cpu().numpy()[0], d["agent_state"][t, n]), f"{name}: agent_state turn {t}"
+                assert np.array_equal(eng.state_at_pov.cpu().numpy()[0], d["state_at_pov"][t, n]), f"{name}: state_at_pov turn {t}"
         assert eng.status() == 0
 
 
@@ -125,6 +128,31 @@ def test_config5_shape_vs_oracle(torch_cuda):
     from sorrel_amd.spec import treasurehunt_spec
 
     rollout_vs_oracle(treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=2, dense_prob=0.25), 48, 4, first=16000)
+
+
+def test_tag_rule_batch_vs_oracle(torch_cuda):
+    """Tag (agent <-> agent interaction) on a few hundred envs, incl. a reset in the middle: the
+    "it" flag survives resets (agents are not re-created), positions do not."""
+    import torch
+    d, spec = H.load_golden("tag_9x9")
+    ws = H.world_spec(spec)
+    E = 300
+    eng = make_engine(ws, E, first=50)
+    co = H.COracle(ws, E, first_env_id=50)
+    assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)          # same initial "it" draw
+    assert ((co.agent_state == ws.tag_it_type).sum(axis=1) == 1).all()
+    for epoch in (0, 1):
+        eng.reset(epoch=epoch)
+        co.reset(epoch)
+        assert_same(eng, co, ("grid", "pos"), ctx=f"reset {epoch}")
+        for t in range(1, 21):
+            eng.step(random_actions=True)
+            co.step(epoch, t, random_actions=True)
+            assert_same(eng, co, ctx=f"epoch {epoch} turn {t}")
+            torch.cuda.synchronize()
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
+            assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov)
+        assert ((co.agent_state == ws.tag_it_type).sum(axis=1) == 1).all()       # exactly one "it" per env, always
 
 
 def test_big_kernel_crowded_vs_oracle(torch_cuda):

@@ -174,6 +174,42 @@ def test_ragged_shapes_vs_oracle(torch_cuda, shape):
     rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.08, seed=sum(shape), dense_prob=0.2), 37, 6, first=11, epoch=2)
 
 
+def _random_world(rng):
+    """A random but valid world: shape, layers, agents, radius, spawn/dense rates, values, actions."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    big = rng.random() < 0.25
+    h = int(rng.integers(48, 90)) if big else int(rng.integers(5, 41))
+    w = int(rng.integers(48, 90)) if big else int(rng.integers(5, 41))
+    if rng.random() < 0.5:          # make the byte count a multiple of 16 half of the time (specialised kernels)
+        w = max(8, (w // 8) * 8)
+        h = max(6, (h // 2) * 2)
+    rmax = (min(h, w) - 1) // 2
+    r = int(rng.integers(0, min(rmax, 5) + 1))
+    a = int(rng.integers(1, min(64, (h - 2) * (w - 2)) + 1))
+    a = min(a, 64 if big else 24)
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=float(rng.choice([0.0, 0.003, 0.05, 0.4])), seed=int(rng.integers(0, 2**40)),
+                           gem_value=int(rng.integers(1, 20)), food_value=float(rng.choice([5, 0.5, 2.25])),
+                           bone_value=-int(rng.integers(1, 20)), dense_prob=float(rng.choice([0.0, 0.1, 0.5])))
+    if rng.random() < 0.3:          # a fifth, non-move action name: the agent stays and is paid its own value
+        ws.action_dy, ws.action_dx = ws.action_dy + [0], ws.action_dx + [0]
+    if rng.random() < 0.3:          # a third, inert layer on top
+        ws.layers = 3
+        ws.layer_fill_type = ws.layer_fill_type + [0]
+        ws.layer_border_type = ws.layer_border_type + [255]
+    return ws
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_random_worlds_vs_oracle(torch_cuda, case):
+    """Soak: random shapes / agent counts / radii / rates through whichever kernel the dispatcher
+    picks (step_fast, step_big, generic), a few dozen envs, every tensor compared every turn."""
+    rng = np.random.default_rng(1000 + case)
+    ws = _random_world(rng)
+    rollout_vs_oracle(ws, int(rng.integers(3, 40)), int(rng.integers(2, 7)), first=int(rng.integers(0, 2**31)),
+                      epoch=int(rng.integers(0, 50)))
+
+
 def test_high_spawn_prob_and_certain_spawn(torch_cuda):
     from sorrel_amd.spec import treasurehunt_spec
 

@@ -42,7 +42,7 @@
  *   - there is no CPU fallback: without a HIP device every launch fails.
  *
  * Tensor layouts (C order, per-env contiguous)
- *   grid          uint8  [E][L][H][W]   entity TYPE id per cell
+ *   grid          uint8  [E][L][H][W]   entity TYPE id per cell (env e starts at e * grid_env_stride)
  *   agent_pos     uint8  [E][A][2]      (y, x) of each agent on `agent_layer`
  *   actions       uint8  [E][A]         action index per agent
  *   obs           float  [E][A][C][V][V], V = 2*vision_radius+1
@@ -142,6 +142,8 @@ typedef struct sgw_config {
     uint64_t first_env_id; /* global id of local env 0 (multi-GPU sharding) */
     int64_t num_envs;      /* E on this device */
     double tag_reward;     /* SGW_AGENT_RULE_TAG: TagAgent.reward_per_turn */
+    int64_t grid_env_stride; /* bytes between consecutive envs in `grid`; 0 = dense (L*H*W).  A stride that is a
+                              * multiple of 16 lets worlds of any byte count use the 16-byte load/store kernels */
 } sgw_config;
 
 typedef struct sgw_engine sgw_engine;

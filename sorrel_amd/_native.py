@@ -47,6 +47,7 @@ class SgwConfig(C.Structure):
         ("first_env_id", C.c_uint64),
         ("num_envs", C.c_int64),
         ("tag_reward", C.c_double),
+        ("grid_env_stride", C.c_int64),
     ]
 
 

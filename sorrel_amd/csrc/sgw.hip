@@ -58,6 +58,7 @@ static_assert(sizeof(DevTables) % 16 == 0, "LDS table block must keep 16-byte al
 struct Params {
     int H, W, L, A, r, V, VV, C, T, nact, zA;
     int cells;      // L*H*W bytes of one env's grid
+    int64_t env_stride;  // bytes between envs in HBM (>= cells; multiple of 16 on the vector paths)
     int cells_pad;  // rounded up to 16
     int env_lds;    // LDS bytes per env slice
     int tab_bytes;  // LDS bytes of the table block
@@ -160,11 +161,11 @@ __device__ __forceinline__ void gsync() {
 template <int G>
 __device__ __forceinline__ void load_grid(const Params& p, const uint8_t* __restrict__ src,
                                           uint8_t* lds, int gtid) {
-    if ((p.cells & 15) == 0) {
+    if ((p.cells & 15) == 0 && (p.env_stride & 15) == 0) {
         const uint4* s = reinterpret_cast<const uint4*>(src);
         uint4* d = reinterpret_cast<uint4*>(lds);
         for (int i = gtid; i < (p.cells >> 4); i += G) d[i] = s[i];
-    } else if ((p.cells & 3) == 0) {
+    } else if ((p.cells & 3) == 0 && (p.env_stride & 3) == 0) {
         const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
         uint32_t* d = reinterpret_cast<uint32_t*>(lds);
         for (int i = gtid; i < (p.cells >> 2); i += G) d[i] = s[i];
@@ -176,11 +177,11 @@ __device__ __forceinline__ void load_grid(const Params& p, const uint8_t* __rest
 template <int G>
 __device__ __forceinline__ void store_grid(const Params& p, uint8_t* __restrict__ dst,
                                            const uint8_t* lds, int gtid) {
-    if ((p.cells & 15) == 0) {
+    if ((p.cells & 15) == 0 && (p.env_stride & 15) == 0) {
         uint4* d = reinterpret_cast<uint4*>(dst);
         const uint4* s = reinterpret_cast<const uint4*>(lds);
         for (int i = gtid; i < (p.cells >> 4); i += G) d[i] = s[i];
-    } else if ((p.cells & 3) == 0) {
+    } else if ((p.cells & 3) == 0 && (p.env_stride & 3) == 0) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst);
         const uint32_t* s = reinterpret_cast<const uint32_t*>(lds);
         for (int i = gtid; i < (p.cells >> 2); i += G) d[i] = s[i];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
 
     for (int64_t env = (int64_t)blockIdx.x * EPB + sub; env < p.E; env += (int64_t)gridDim.x * EPB) {
         const uint32_t env_id = p.first_env + (uint32_t)env;
-        uint8_t* ggrid = p.grid + env * p.cells;
+        uint8_t* ggrid = p.grid + env * p.env_stride;
         load_grid<G>(p, ggrid, lg, gtid);
         double tot = 0.0;
         if (gtid == 0 && p.do_move) tot = p.total[env];
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     const int H = TH ? TH : p.H, W = TW ? TW : p.W, HW = H * W;
     constexpr bool kStatic = TL && TH && TW;
     const int cells = kStatic ? TL * TH * TW : p.cells;
-    const int nunits = cells >> 4;
+    const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane
     const int zoff = p.zA * HW;
     constexpr int NW = TC ? (TC + 3) / 4 : 4;   // counter words
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // ---- issue every global load of this env first
     uint4 u[NU];
     {
-        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * cells);
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
 #pragma unroll
         for (int k = 0; k < NU; ++k)
             if (lane + 64 * k < nunits) u[k] = src[lane + 64 * k];
@@ -590,6 +591,23 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
 
         // ---- grid -> LDS; the Bernoulli half of the sweep runs on the registers
         uint32_t hits[NU];
+        if constexpr (!kStatic) {
+            if (cells & 15) {   // ragged world: bytes past the last cell are not cells (no type, no RNG index)
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k == nunits - 1) {
+                        const int tail = cells & 15;
+                        uint32_t d[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int keep = tail - 4 * q;   // valid bytes in this dword
+                            if (keep <= 0) d[q] = 0xFFFFFFFFu;
+                            else if (keep < 4) d[q] |= 0xFFFFFFFFu << (8 * keep);
+                        }
+                        u[k] = make_uint4(d[0], d[1], d[2], d[3]);
+                    }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
             hits[k] = 0;
@@ -709,7 +727,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         }
 
         if (dirty) {
-            uint4* dst = reinterpret_cast<uint4*>(p.grid + env * cells);
+            uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll
             for (int k = 0; k < NU; ++k)
                 if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
@@ -764,7 +782,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     const int V = 2 * r + 1, VV = V * V;
     const int H = p.H, W = p.W, HW = H * W;
     const int cells = p.cells;
-    const int nunits = cells >> 4;
+    const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     const int zoff = p.zA * HW;
     constexpr int NW = TC ? (TC + 3) / 4 : 4;
     constexpr int NP = TR ? ((2 * TR + 1) * (2 * TR + 1) + 63) / 64 : 2;   // window passes per wave held in registers
@@ -801,7 +819,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
 
     // ---- grid -> LDS, sweep on the registers, 4 units per thread per round
     {
-        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * cells);
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
         for (int base = 0; base < nunits; base += 4 * kBigThreads) {
             uint4 u[4];
             uint32_t hits[4];
@@ -809,6 +827,17 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
             for (int k = 0; k < 4; ++k) {
                 const int idx = base + k * kBigThreads + tid;
                 if (idx < nunits) u[k] = src[idx];
+                if ((cells & 15) && idx == nunits - 1) {   // ragged world: mask the bytes past the last cell
+                    const int tail = cells & 15;
+                    uint32_t d[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int keep = tail - 4 * q;
+                        if (keep <= 0) d[q] = 0xFFFFFFFFu;
+                        else if (keep < 4) d[q] |= 0xFFFFFFFFu << (8 * keep);
+                    }
+                    u[k] = make_uint4(d[0], d[1], d[2], d[3]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1038,7 +1067,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
 
     // ---- write-back
     if (dirty) {
-        uint4* dst = reinterpret_cast<uint4*>(p.grid + env * cells);
+        uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
         for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[idx];
     }
     if (p.do_move) {
@@ -1149,7 +1178,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Params p) {
             p.total[env] = 0.0;
         }
         gsync<WPE>();
-        store_grid<G>(p, p.grid + env * p.cells, lg, gtid);
+        store_grid<G>(p, p.grid + env * p.env_stride, lg, gtid);
         if (gtid < p.A)
             reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
         gsync<WPE>();
@@ -1349,6 +1378,8 @@ int validate(const sgw_config* c) {
     }
     if (c->obs_post != SGW_OBS_POST_NONE && c->obs_post != SGW_OBS_POST_CLIP255_DIV255)
         return fail(SGW_EINVAL, "unknown obs_post %d", c->obs_post);
+    if (c->grid_env_stride != 0 && c->grid_env_stride < (int64_t)c->layers * c->height * c->width)
+        return fail(SGW_EINVAL, "grid_env_stride is smaller than one env");
     if (c->num_envs < 1) return fail(SGW_EINVAL, "num_envs must be >= 1");
     if (c->first_env_id + (uint64_t)c->num_envs > 4294967296ull)
         return fail(SGW_EINVAL, "global env ids must fit 32 bits");
@@ -1479,6 +1510,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.nact = c.num_actions; p.zA = c.agent_layer;
     p.cells = c.layers * c.height * c.width;
     p.cells_pad = (p.cells + 15) & ~15;
+    p.env_stride = c.grid_env_stride > 0 ? c.grid_env_stride : p.cells;
     p.env_lds = p.cells_pad + kAgentLds;
     p.tab_bytes = onehot ? kTabFastBytes : (int)sizeof(DevTables);
     p.default_type = (uint32_t)c.default_type;
@@ -1528,12 +1560,13 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // the specialised kernels implement MovingAgent.act only
-    e->fast = e->wpe == 1 && (p.cells & 15) == 0 && (p.cells >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && plain_move;
+    const bool vec16 = (p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad;   // 16-byte loads/stores per env are legal
+    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && plain_move;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
-    e->big = e->wpe == 4 && (p.cells & 15) == 0 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move;
+    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move;
     e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _native as N
-from .spec import WorldSpec
+from .spec import WorldSpec, alloc_grid
 
 
 class GridEngine:
@@ -37,13 +37,29 @@ class GridEngine:
         if not torch.cuda.is_available():
             raise N.SgwError("no HIP device visible to PyTorch; the step/observe path has no CPU fallback")
         self._lib = N.load()
-        self.config = spec.to_config(self.num_envs, self.first_env_id)
-        self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            N.check(self._lib.sgw_create(C.byref(self.config), C.byref(self._h)))
         E, A = self.num_envs, spec.num_agents
         dev = self.device
         tensors = tensors or {}
+        # the grid may be a view with a padded env stride (spec.alloc_grid); inner dims must be dense
+        g = tensors.get("grid")
+        if g is None:
+            g = alloc_grid(E, spec.layers, spec.height, spec.width, dev)
+        hw = spec.height * spec.width
+        if tuple(g.shape) != (E, spec.layers, spec.height, spec.width) or g.dtype != torch.uint8 or g.device != dev \
+                or (E > 0 and tuple(g.stride()[1:]) != (hw, spec.width, 1)) or (E > 1 and g.stride(0) < spec.layers * hw):
+            raise ValueError("grid must be uint8 [E, L, H, W] on the engine's device with dense (L, H, W) strides")
+        self.grid = g
+        self.config = spec.to_config(self.num_envs, self.first_env_id)
+        cells = spec.layers * hw
+        if E > 1:
+            self.config.grid_env_stride = int(g.stride(0))
+        else:   # one env: any stride is right; claim the padded one if the allocation really has the pad bytes
+            pad = (cells + 15) // 16 * 16
+            avail = g.untyped_storage().nbytes() - g.storage_offset()
+            self.config.grid_env_stride = pad if avail >= pad else 0
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_create(C.byref(self.config), C.byref(self._h)))
 
         def adopt(name, shape, dtype):
             t = tensors.get(name)
@@ -54,7 +70,6 @@ class GridEngine:
             return t
 
         # state tensors may be adopted from the caller (the batched Gridworld owns them)
-        self.grid = adopt("grid", (E, spec.layers, spec.height, spec.width), torch.uint8)
         self.agent_pos = adopt("agent_pos", (E, A, 2), torch.uint8)
         self.actions = adopt("actions", (E, A), torch.uint8)
         self.rewards = adopt("rewards", (E, A), torch.float32)

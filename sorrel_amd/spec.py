@@ -24,6 +24,18 @@ NO_BORDER = N.NO_BORDER
 _MOVES = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
 
 
+def alloc_grid(num_envs: int, layers: int, height: int, width: int, device):
+    """``uint8 [E, L, H, W]`` view whose env stride is padded to a multiple of 16 bytes, so that
+    worlds of any byte count (e.g. the tutorial's 21x21x2 = 882 B) can use the 16-byte load/store
+    kernels.  Index it like a dense tensor; ``.cpu().numpy()`` gives a dense copy."""
+    import torch
+
+    cells = layers * height * width
+    stride = (cells + 15) // 16 * 16
+    storage = torch.zeros((num_envs, stride), dtype=torch.uint8, device=device)
+    return storage[:, :cells].view(num_envs, layers, height, width)
+
+
 def action_deltas(action_names: Sequence[str]):
     """MovingAgent.movement (``sorrel/agents/agent.py:187-213``): only the four
     names move; any other action name leaves the agent where it is."""

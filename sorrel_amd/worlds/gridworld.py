@@ -22,6 +22,7 @@ import torch
 from sorrel_amd.entities.entity import Entity
 from sorrel_amd.entities.rules import SpawnRule
 from sorrel_amd.location import Location
+from sorrel_amd.spec import alloc_grid
 
 
 class World:
@@ -74,8 +75,7 @@ class Gridworld(World):
         self.seed = int(seed)
         self.registry = TypeRegistry()
         self.default_type = self.registry.register(default_entity)
-        self.grid = torch.zeros((self.num_envs, self.layers, self.height, self.width), dtype=torch.uint8,
-                                device=self.device)
+        self.grid = alloc_grid(self.num_envs, self.layers, self.height, self.width, self.device)
         self.total_reward = torch.zeros((self.num_envs,), dtype=torch.float64, device=self.device)
         # agent bookkeeping (filled by Environment / add())
         self.agent_slots: List = []

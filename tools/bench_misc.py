@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Diagnostic throughput of the shapes that run on the generic / Tag paths (run on the GPU box)."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+from sorrel_amd.engine import GridEngine
+from sorrel_amd.spec import WorldSpec, treasurehunt_spec, action_deltas
+
+def tag_spec(h, w, a, r):
+    app = np.zeros((4, 4)); app[1, 1] = app[2, 2] = app[3, 3] = 1.0
+    dy, dx = action_deltas(["up", "down", "left", "right"])
+    return WorldSpec(height=h, width=w, layers=1, num_agents=a, vision_radius=r, num_channels=4, agent_layer=0,
+                     default_type=0, fill_type=1, action_dy=dy, action_dx=dx, agent_type=[3] * a,
+                     type_value=[0, -1, 0, 0], type_passable=[1, 0, 0, 0], type_rule=[0] * 4, spawn_prob=[0.0] * 4,
+                     spawn_choices=[[]] * 4, appearance=app, seed=1, layer_fill_type=[0], layer_border_type=[1],
+                     agent_rule=1, tag_it_type=2, tag_notit_type=3, tag_reward=10.0)
+
+def run(name, spec, E, K=100):
+    eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
+    for _ in range(5): eng.step(random_actions=True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(K): eng.step(random_actions=True)
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) / K * 1000
+    byt = spec.algorithmic_bytes_per_env_step() * E
+    print(f"{name:34s} E={E:7d} {us:8.1f} us/step  {E*spec.num_agents/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)")
+
+run("tag 11x11x1 A5 r4 (example default)", tag_spec(11, 11, 5, 4), 65536)
+run("tag 32x32x1 A8 r3", tag_spec(32, 32, 8, 3), 65536)
+run("treasurehunt 10x10x2 A2 r2 (ragged)", treasurehunt_spec(10, 10, 2, 2), 65536)
+run("treasurehunt 21x21x2 A2 r2 (default)", treasurehunt_spec(21, 21, 2, 2), 65536)
+run("treasurehunt 32x32x2 A8 r3 (fast)", treasurehunt_spec(32, 32, 8, 3), 65536)

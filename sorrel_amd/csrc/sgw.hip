@@ -511,7 +511,7 @@ __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, 
     }
 }
 
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW>
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
@@ -555,7 +555,9 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     if (mine && p.do_move && !rnd) act = p.actions[env * p.A + lane];
     // register-resident tables: lane t holds value[t] (f64 bits + its f32 rounding); lane a holds agent a's type
     const double vtab = gtab->value[lane & 31];
-    const uint32_t atype = gtab->agent_type[lane];
+    uint32_t atype = gtab->agent_type[lane];   // lane a: CURRENT entity type of agent a
+    if (p.agent_state && lane < p.A) atype = p.agent_state[env * p.A + lane];
+    uint32_t pov_type = atype;                 // ... and its type when it observed (TagAgent.pov)
     if constexpr (ONEHOT) {
         // the one-hot counter words this wave looks up, [NW][32] u32
         uint32_t* wd = reinterpret_cast<uint32_t*>(wl);
@@ -719,9 +721,50 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 lg[s_t] = (uint8_t)my_type;
                 lg[s_o] = (uint8_t)p.default_type;
             }
-            if (tok) tot += __longlong_as_double(((long long)v_hi << 32) | v_lo);   // reward BEFORE the move; float64, agent order
-            rew_bits = lane == a ? (tok ? v_f : 0u) : rew_bits;
             moved = lane == a ? (pass ? 1u : 0u) : moved;
+            if constexpr (!TAG) {
+                if (tok) tot += __longlong_as_double(((long long)v_hi << 32) | v_lo);   // reward BEFORE the move; float64, agent order
+                rew_bits = lane == a ? (tok ? v_f : 0u) : rew_bits;
+            } else {
+                // ---- TagAgent.act (sorrel/examples/tag/agents.py:84-106), scalar: the four neighbours of the
+                // cell the agent now stands on, in Location.adjacent order (up, right, down, left; off-map
+                // skipped); an agent that is "it" hands the flag to the first NotIt neighbour.
+                gsync<1>();
+                pov_type = lane == a ? my_type : pov_type;
+                const uint32_t np_a = (uint32_t)__builtin_amdgcn_readlane((int)npos, a);
+                const int cy = pass ? (int)(np_a & 0xFFu) : (int)(((uint32_t)s_o - (uint32_t)zoff) / (uint32_t)W);
+                const int cx = pass ? (int)((np_a >> 8) & 0xFFu) : (int)(((uint32_t)s_o - (uint32_t)zoff) % (uint32_t)W);
+                const int own = zoff + cy * W + cx;
+                uint32_t nt[4];
+                bool ain[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0), ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                    ain[d] = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                    nt[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[ain[d] ? zoff + ay * W + ax : own]);
+                }
+                int dstar = -1;
+#pragma unroll
+                for (int d = 3; d >= 0; --d)
+                    if (ain[d] && nt[d] == p.tag_notit) dstar = d;
+                uint32_t mine_now = my_type;
+                if (my_type == p.tag_it && dstar >= 0) {
+                    const int ay = cy + (dstar == 0 ? -1 : dstar == 2 ? 1 : 0), ax = cx + (dstar == 1 ? 1 : dstar == 3 ? -1 : 0);
+                    if (lane == 0) {
+                        lg[own] = (uint8_t)p.tag_notit;
+                        lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
+                    }
+                    // who stands there: lane b's current position is its start position or, if it moved, its target
+                    const uint32_t curpos = moved ? npos : yx;
+                    const uint32_t key = (uint32_t)ay | ((uint32_t)ax << 8);
+                    atype = (lane < p.A && lane != a && curpos == key) ? p.tag_it : atype;
+                    atype = lane == a ? p.tag_notit : atype;
+                    mine_now = p.tag_notit;
+                }
+                const double val = mine_now != p.tag_it ? p.tag_reward : 0.0;
+                tot += val;
+                rew_bits = lane == a ? __float_as_uint((float)val) : rew_bits;
+            }
             if (valid && !tok) st_lane |= SGW_STATUS_BAD_TYPE;
             gsync<1>();
         }
@@ -736,8 +779,10 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             if (mine) {
                 reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)(moved ? npos : yx);
                 p.rewards[env * p.A + lane] = __uint_as_float(rew_bits);
+                if (p.state_at_pov) p.state_at_pov[env * p.A + lane] = (uint8_t)pov_type;
                 if (st_lane) atomicOr(p.status, st_lane);
             }
+            if (TAG && p.agent_state && lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)atype;   // a tag can flip any agent
             if (lane == 0) p.total[env] = tot;
         }
     }
@@ -1409,7 +1454,8 @@ StepFn pick_big(bool onehot, int L, int C, int r) {
     return step_big<true, 0, 0, 0>;
 }
 
-StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W) {
+StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag) {
+    if (tag) return onehot ? step_fast<true, 0, 0, 0, 0, 0, true> : step_fast<false, 0, 0, 0, 0, 0, true>;
     if (!onehot) return step_fast<false, 0, 0, 0, 0, 0>;
     if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) return step_fast<true, 2, 6, 3, 32, 32>;   // BASELINE configs 3/4 (headline)
     if (L == 2 && C == 6 && r == 2 && H == 16 && W == 16) return step_fast<true, 2, 6, 2, 16, 16>;   // BASELINE config 2
@@ -1561,12 +1607,17 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // the specialised kernels implement MovingAgent.act only
     const bool vec16 = (p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad;   // 16-byte loads/stores per env are legal
-    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && plain_move;
+    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128;   // MovingAgent.act and TagAgent.act
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
     e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move;
+    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
+    e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
+    if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
+        if (f[0] == '1') e->fast = e->big = false;
+    }
     e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
@@ -1589,7 +1640,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width)
+    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius)
                          : pick_step(e->wpe, e->onehot);
     StepFn rk = pick_reset(e->wpe);

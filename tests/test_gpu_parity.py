@@ -155,6 +155,32 @@ def test_tag_rule_batch_vs_oracle(torch_cuda):
         assert ((co.agent_state == ws.tag_it_type).sum(axis=1) == 1).all()       # exactly one "it" per env, always
 
 
+@pytest.mark.parametrize("name", ["c2_treasurehunt_16x16", "crowded_6x6", "tag_9x9", "tag_crowded_6x7", "rgb_treasurehunt",
+                                  "c5_small_dense", "basic_doublewall"])
+def test_generic_kernel_matches_reference_golden(torch_cuda, name, monkeypatch):
+    """The fallback kernel (any shape, every rule) on fixtures the specialised kernels would take."""
+    monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    test_hip_matches_reference_golden(torch_cuda, name)
+
+
+def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    rollout_vs_oracle(treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.01, seed=3), 1000, 5)                       # wave per env
+    rollout_vs_oracle(treasurehunt_spec(96, 80, 40, 4, spawn_prob=0.05, seed=4, dense_prob=0.2), 30, 4)        # workgroup per env
+    d, spec = H.load_golden("tag_9x9")
+    ws = H.world_spec(spec)
+    eng, co = make_engine(ws, 200, first=9), H.COracle(ws, 200, first_env_id=9)
+    eng.reset(0)
+    co.reset(0)
+    for t in range(1, 15):
+        eng.step(random_actions=True)
+        co.step(0, t, random_actions=True)
+        assert_same(eng, co, ctx=f"generic tag turn {t}")
+        assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
+
+
 def test_big_kernel_crowded_vs_oracle(torch_cuda):
     """Workgroup-per-env kernel under heavy contention: 64 agents on a 46x46 interior with 11x11
     windows, dense items -- many moves touch many windows (journal undo), many agents compete for

@@ -665,9 +665,49 @@ def main() -> int:
         assert np.array_equal(mine[k], ref[k]), f"numpy-order restatement differs in {k}"
     save("stock_np_random", spec, [0], ref, extra={"np_seed": np.array(0)})
 
+    print("buffer_ring: reference replay Buffer semantics")
+    make_buffer_fixture()
     print(f"done in {time.time() - t0:.1f}s")
     return 0
 
+
+
+def make_buffer_fixture():
+    """Replay ring semantics of the reference Buffer (sorrel/buffers.py:11-154): index arithmetic,
+    n_frames stacking in current_state(), add_empty(), and sample() for given draws."""
+    ref_loader.install()
+    from sorrel.buffers import Buffer
+
+    cap, nf, obs = 7, 3, 5
+    rng = np.random.default_rng(3)
+    buf = Buffer(capacity=cap, obs_shape=(obs,), n_frames=nf)
+    T = 20
+    states = rng.standard_normal((T, obs)).astype(np.float32)
+    actions = rng.integers(0, 4, T)
+    rewards = rng.standard_normal(T).astype(np.float32)
+    dones = (rng.random(T) < 0.2).astype(np.float32)
+    rec = dict(idx=[], size=[], cur=[])
+    for t in range(T):
+        buf.add(states[t], int(actions[t]), float(rewards[t]), bool(dones[t]))
+        if t == 11:
+            buf.add_empty()
+        rec["idx"].append(buf.idx)
+        rec["size"].append(buf.size)
+        cur = buf.current_state()
+        pad = np.full((nf - 1, obs), np.nan, np.float32)
+        pad[: cur.shape[0]] = cur
+        rec["cur"].append(pad)
+    np.random.seed(5)
+    s, a, r, ns, d, valid = buf.sample(3)
+    np.random.seed(5)
+    draws = np.random.choice(max(1, buf.size - nf - 1), 3, replace=False)
+    out = dict(states=states, actions=actions, rewards=rewards, dones=dones, idx=np.array(rec["idx"]), size=np.array(rec["size"]),
+               cur=np.stack(rec["cur"]), final_states=buf.states.copy(), final_actions=buf.actions.copy(),
+               sample_draws=draws, s=s, a=a, r=r, ns=ns, d=d, valid=valid,
+               params=np.array([cap, nf, obs, T]))
+    path = os.path.join(GOLDEN_DIR, "buffer_ring.npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path)} bytes)")
 
 if __name__ == "__main__":
     sys.exit(main())

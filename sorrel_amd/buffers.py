@@ -56,13 +56,13 @@ class Buffer:
         sel = [(self.idx - k + j) % self.capacity for j in range(k)]
         return self.states[sel]
 
-    def sample(self, batch_size: int):
+    def sample(self, batch_size: int, starts=None, envs=None):
         """Uniform sample of (turn, env) pairs with ``n_frames`` stacking:
-        states, actions, rewards, next_states, dones, valid (``sorrel/buffers.py:98-124``)."""
+        states, actions, rewards, next_states, dones, valid (``sorrel/buffers.py:98-124``).
+        ``starts`` / ``envs`` override the random draws (first frame index and env of each sample)."""
         hi = max(1, self.size - self.n_frames - 1)
-        g = torch.Generator(device="cpu")
-        t0 = torch.randint(0, hi, (batch_size,), generator=g)
-        e = torch.randint(0, self.num_envs, (batch_size,), generator=g).to(self.device)
+        t0 = torch.randint(0, hi, (batch_size,)) if starts is None else torch.as_tensor(starts, dtype=torch.long)
+        e = (torch.randint(0, self.num_envs, (batch_size,)) if envs is None else torch.as_tensor(envs, dtype=torch.long)).to(self.device)
         idx = (t0[:, None] + torch.arange(self.n_frames)[None, :]).to(self.device)        # [B, n_frames]
         ee = e[:, None].expand_as(idx)
         states = self.states[idx, ee].reshape(batch_size, -1)

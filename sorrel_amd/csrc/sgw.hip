@@ -896,22 +896,24 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
             if (do_sweep) {
                 // this thread wrote these units itself (DS ops of a wave are ordered), so the rare
                 // kind draws can patch LDS right away; one combined loop keeps the trip count low
-                uint32_t any = hits[0] | hits[1] | hits[2] | hits[3];
-                while (__builtin_amdgcn_readfirstlane(__any(any != 0))) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (hits[k]) {
-                            const uint32_t cell = (uint32_t)__ffs(hits[k]) - 1u;
-                            hits[k] &= hits[k] - 1u;
-                            const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
-                            const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
-                                                       p.seed_lo, p.seed_hi);
-                            const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
-                            lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
-                            break;
-                        }
+                uint32_t h0 = hits[0], h1 = hits[1], h2 = hits[2], h3 = hits[3];   // named: keeps them in registers
+                while (__builtin_amdgcn_readfirstlane(__any((h0 | h1 | h2 | h3) != 0))) {
+                    // this lane's next hit cell: lowest set bit of the first non-empty unit
+                    const int k = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+                    const uint32_t hk = h0 ? h0 : h1 ? h1 : h2 ? h2 : h3;
+                    if (hk) {
+                        const uint32_t cell = (uint32_t)__ffs(hk) - 1u;
+                        const uint32_t cleared = hk & (hk - 1u);
+                        h0 = k == 0 ? cleared : h0;
+                        h1 = k == 1 ? cleared : h1;
+                        h2 = k == 2 ? cleared : h2;
+                        h3 = k == 3 ? cleared : h3;
+                        const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
+                        const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                                                   p.seed_lo, p.seed_hi);
+                        const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
+                        lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
                     }
-                    any = hits[0] | hits[1] | hits[2] | hits[3];
                 }
             }
         }

@@ -227,3 +227,28 @@ def test_border_precondition_is_checked():
     env = OpenEnv(Gridworld(5, 5, 1, EmptyEntity(), num_envs=2, device="cpu"), {"experiment": {"epochs": 1}})
     with pytest.raises(ValueError, match="border"):
         env._validate_border()
+
+
+def test_replay_buffer_matches_reference_ring_semantics():
+    """The device replay ring (num_envs = 1) against a trace of the reference Buffer: index arithmetic,
+    n_frames stacking of current_state(), add_empty(), and sample() for the same draws."""
+    from sorrel_amd.buffers import Buffer
+
+    d = np.load(H.GOLDEN_DIR + "/buffer_ring.npz")
+    cap, nf, obs, T = (int(v) for v in d["params"])
+    buf = Buffer(capacity=cap, obs_shape=(obs,), n_frames=nf, num_envs=1, device="cpu")
+    for t in range(T):
+        buf.add(torch.from_numpy(d["states"][t][None]), torch.tensor([int(d["actions"][t])]),
+                torch.tensor([float(d["rewards"][t])]), float(d["dones"][t]))
+        if t == 11:
+            buf.add_empty()
+        assert (buf.idx, buf.size) == (int(d["idx"][t]), int(d["size"][t]))
+        cur = buf.current_state()[:, 0].numpy()
+        want = d["cur"][t]
+        want = want[~np.isnan(want).any(axis=1)]
+        assert cur.shape == want.shape and np.array_equal(cur, want), t
+    assert np.array_equal(buf.states[:, 0].numpy(), d["final_states"])
+    assert np.array_equal(buf.actions[:, 0].numpy(), d["final_actions"])
+    s, a, r, ns, dn, valid = buf.sample(3, starts=d["sample_draws"], envs=[0, 0, 0])
+    for mine, ref in ((s, d["s"]), (a, d["a"]), (r, d["r"]), (ns, d["ns"]), (dn, d["d"]), (valid, d["valid"])):
+        assert np.array_equal(mine.numpy(), ref)

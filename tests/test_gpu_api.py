@@ -189,6 +189,64 @@ def test_tag_env_through_the_api(torch_cuda):
     assert pov.shape == (E, 4 * 25 + 1) and torch.equal(pov[:, -1].bool(), env.agents[2].its)
 
 
+def test_host_built_template_world(torch_cuda):
+    """populate_environment with plain world.add(...) calls (the reference's imperative style): the same
+    template in every env, basic entities, a user-defined MovingAgent subclass, explicit actions."""
+    torch = torch_cuda
+    from sorrel_amd.action.action_spec import ActionSpec
+    from sorrel_amd.agents import MovingAgent
+    from sorrel_amd.entities import EmptyEntity, Gem, Wall
+    from sorrel_amd.environment import Environment
+    from sorrel_amd.models import RandomModel
+    from sorrel_amd.observation.observation_spec import OneHotObservationSpec
+    from sorrel_amd.worlds import Gridworld
+
+    class Walker(MovingAgent):
+        def reset(self): ...
+        def pov(self, world): return self.observation_spec.observe(world, self)
+        def get_action(self, state): return self.model.take_action(state)
+        def is_done(self, world): return world.is_done
+
+    class BasicEnv(Environment):
+        def setup_agents(self):
+            self.agents = []
+            for _ in range(3):
+                o = OneHotObservationSpec(["EmptyEntity", "Wall", "Gem", "Walker"], full_view=False, vision_radius=2)
+                self.agents.append(Walker(o, ActionSpec(["up", "down", "left", "right", "wait"]), RandomModel((100,), 5)))
+
+        def populate_environment(self):
+            H, W = self.world.height, self.world.width
+            for y in range(H):
+                for x in range(W):
+                    if y in (0, H - 1) or x in (0, W - 1):
+                        self.world.add((y, x, 0), Wall())
+            for (y, x, v) in ((2, 2, 3.5), (2, 5, -2), (4, 4, 7), (5, 2, 1)):
+                self.world.add((y, x, 0), Gem(v))
+            for agent, loc in zip(self.agents, ((1, 1, 0), (3, 4, 0), (6, 6, 0))):
+                self.world.add(loc, agent)
+
+    E = 12
+    env = BasicEnv(Gridworld(8, 9, 1, EmptyEntity(), num_envs=E, device="cuda:0", seed=1), {"experiment": {"epochs": 1}})
+    spec = env.compile_spec()
+    ospec = H.oracle_spec(spec)
+    g0 = env.world.grid.cpu().numpy()
+    assert (g0 == g0[0]).all()                                        # one template, every env
+    states = [O.EnvState(grid=g0[e].copy(), pos=env.world.agent_pos[e].cpu().numpy().astype(np.int64), total_reward=0.0)
+              for e in range(E)]
+    rng = np.random.default_rng(0)
+    for t in range(1, 13):
+        acts = rng.integers(0, 5, size=(E, 3))
+        env.take_turn(torch.from_numpy(acts.astype(np.uint8)).cuda())
+        torch.cuda.synchronize()
+        for e in range(E):
+            o, a, r = O.step_env(ospec, states[e], e, 0, t, actions=acts[e])
+            assert np.array_equal(env.obs[e].cpu().numpy(), o) and np.array_equal(env.rewards[e].cpu().numpy(), r)
+        assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+        assert np.array_equal(env.world.total_reward.cpu().numpy(), np.array([s.total_reward for s in states]))
+    env._ensure_engine().raise_on_status()
+    assert env.agents[0].location == (int(states[0].pos[0, 0]), int(states[0].pos[0, 1]), 0)
+
+
 def test_run_experiment_thin_loop(torch_cuda):
     env = make_env(10, 10, 2, 2, 32)
     hist = env.run_experiment(epochs=1, max_turns=5, all_reduce=False)

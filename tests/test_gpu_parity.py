@@ -181,6 +181,14 @@ def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
         assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
 
 
+def test_largest_worlds_vs_oracle(torch_cuda):
+    """More than 64 KiB of LDS per env (needs the raised dynamic-LDS limit), up to the 256x256 coordinate limit."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rollout_vs_oracle(treasurehunt_spec(200, 200, 48, 5, spawn_prob=0.01, seed=15, dense_prob=0.1), 6, 3, first=2)     # 80 KB
+    rollout_vs_oracle(treasurehunt_spec(256, 256, 64, 5, spawn_prob=0.01, seed=16, dense_prob=0.05), 4, 2, first=1)    # 128 KiB
+
+
 def test_big_kernel_crowded_vs_oracle(torch_cuda):
     """Workgroup-per-env kernel under heavy contention: 64 agents on a 46x46 interior with 11x11
     windows, dense items -- many moves touch many windows (journal undo), many agents compete for

@@ -95,6 +95,8 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip observation stores (NOT a valid bench line)")
     ap.add_argument("--diag-agents", type=int, default=-1, help="diagnostic: step only the first N agents (NOT valid)")
+    ap.add_argument("--obs-dtype", default="f32", choices=["f32", "u8"],
+                    help="u8 = compact one-hot counts (an extra, reported separately; the contract format is f32)")
     ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
     args = ap.parse_args()
 
@@ -130,7 +132,8 @@ def main() -> int:
     H, W, A, r, E_cfg, p_spawn, p_dense = CONFIGS[args.config]
     E = args.envs or E_cfg
     spec = treasurehunt_spec(H, W, A, r, spawn_prob=p_spawn, seed=0, dense_prob=p_dense)
-    eng = GridEngine(spec, E, device=dev, first_env_id=rank * E)   # global env ids: re-sharding is bit-exact
+    obs_dtype = torch.float32 if args.obs_dtype == "f32" else torch.uint8
+    eng = GridEngine(spec, E, device=dev, first_env_id=rank * E, obs_dtype=obs_dtype)   # global env ids: re-sharding is bit-exact
     eng.reset(epoch=0)
 
     def barrier():
@@ -176,6 +179,8 @@ def main() -> int:
         alg_bytes = spec.algorithmic_bytes_per_env_step() * E          # per launch (one rank's kernel)
         if not write_obs:
             alg_bytes -= E * A * spec.num_channels * spec.window ** 2 * 4
+        elif args.obs_dtype == "u8":
+            alg_bytes -= E * A * spec.num_channels * spec.window ** 2 * 3      # C*V*V*1 instead of *4
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected by
         # tools/profile_gpu.sh on this same command and committed under profiles/; null when no matching pass exists
@@ -183,18 +188,19 @@ def main() -> int:
         try:
             with open(os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")) as fh:
                 tj = json.load(fh)
-            if tj.get("envs") == E and write_obs and sweep:
+            if tj.get("envs") == E and write_obs and sweep and args.obs_dtype == "f32":
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
+            "metric": "agent-steps/sec" if args.obs_dtype == "f32" else "agent-steps/sec (compact uint8 observations; NOT the contract metric)",
+            "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: {H}x{W} grid x {spec.layers} layers, {A} agents, {spec.window}x{spec.window} window, "
-                            f"{E} envs/GPU x {world} GPU = {total_envs} envs, treasurehunt rules, random actions, f32 one-hot obs",
+                            f"{E} envs/GPU x {world} GPU = {total_envs} envs, treasurehunt rules, random actions, {args.obs_dtype} one-hot obs",
                 "envs_per_gpu": E, "global_envs": total_envs, "agents": A, "grid": [H, W, spec.layers],
                 "window": spec.window, "channels": spec.num_channels, "spawn_prob": p_spawn, "dense_prob": p_dense,
                 "sharding": f"env-batch x{world}, no data-path collective; one 32-byte all-reduce at end of rollout",

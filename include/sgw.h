@@ -181,6 +181,14 @@ int sgw_reduce_metrics(sgw_engine* eng, const double* total_reward, double* out,
 int sgw_bind_agent_state(sgw_engine* eng, uint8_t* agent_state, uint8_t* state_at_pov);
 int sgw_init_agent_state(sgw_engine* eng, uint8_t* agent_state, void* stream);
 
+/* Observation element type written by sgw_step / sgw_observe.  SGW_OBS_F32 (default) is the contract
+ * format (the reference's replay buffer stores float32, sorrel/buffers.py:31).  SGW_OBS_U8 is a
+ * compact extra for one-hot specs: the same [E][A][C][V][V] layout with uint8 counts (exactly the
+ * float values, 4x fewer bytes); it is rejected for non one-hot appearance tables. */
+#define SGW_OBS_F32 0
+#define SGW_OBS_U8 1
+int sgw_set_obs_format(sgw_engine* eng, int format);
+
 /* Fill `actions` from STREAM_ACTION without stepping (what a RandomModel would choose). */
 int sgw_random_actions(sgw_engine* eng, uint8_t* actions, uint32_t epoch, uint32_t turn, void* stream);
 

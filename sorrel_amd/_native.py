@@ -14,6 +14,7 @@ NO_BORDER = 255
 STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS = 1, 2, 4
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 AGENT_RULE_MOVE, AGENT_RULE_TAG = 0, 1
+OBS_F32, OBS_U8 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE = 1, 2, 4
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
@@ -57,7 +58,7 @@ LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")
 # every symbol include/sgw.h declares
 EXPORTS = (
     "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_reduce_metrics",
-    "sgw_random_actions", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
+    "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms",
     "sgw_last_error", "sgw_version",
 )
@@ -114,6 +115,8 @@ def load():
     lib.sgw_reduce_metrics.restype = C.c_int
     lib.sgw_random_actions.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]
     lib.sgw_random_actions.restype = C.c_int
+    lib.sgw_set_obs_format.argtypes = [vp, C.c_int]
+    lib.sgw_set_obs_format.restype = C.c_int
     lib.sgw_bind_agent_state.argtypes = [vp, u8p, u8p]
     lib.sgw_bind_agent_state.restype = C.c_int
     lib.sgw_init_agent_state.argtypes = [vp, u8p, vp]

@@ -79,6 +79,7 @@ struct Params {
     int a0, a1;
     int do_move;  // 0: observe only
     int obs_post; // SGW_OBS_POST_*
+    int obs_u8;   // SGW_OBS_U8: observations are uint8 counts (one-hot specs only)
     int agent_rule;            // SGW_AGENT_RULE_*
     uint32_t tag_it, tag_notit;
     double tag_reward;
@@ -342,7 +343,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
                                 const int c = 4 * q + b;
-                                if (c < p.C) o[c * p.VV] = (float)((cnt[q] >> (8 * b)) & 0xFFu);
+                                if (c < p.C) {
+                                    const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                                    if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * p.VV] = (uint8_t)v;
+                                    else o[c * p.VV] = (float)v;
+                                }
                             }
                         }
                     } else {
@@ -687,12 +692,24 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                             }
 #pragma unroll
                             for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
+                            if (!p.obs_u8) {
 #pragma unroll
-                            for (int q = 0; q < NW; ++q) {
+                                for (int q = 0; q < NW; ++q) {
 #pragma unroll
-                                for (int b = 0; b < 4; ++b) {
-                                    const int c = 4 * q + b;
-                                    if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
+                                    }
+                                }
+                            } else {   // compact format: the same counts as bytes
+                                uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
+                                    }
                                 }
                             }
                         } else {
@@ -1087,12 +1104,25 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
                             for (int q = 0; q < NW; ++q) cnt[q] += wdelta[q * 32 + t];
                         }
 #pragma unroll
-                        for (int q = 0; q < NW; ++q) {
-                            const uint32_t cq = inbk[k] ? cnt[q] : p.fill_delta[q];
+                        for (int q = 0; q < NW; ++q) cnt[q] = inbk[k] ? cnt[q] : p.fill_delta[q];
+                        if (!p.obs_u8) {
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int c = 4 * q + b;
-                                if (c < C) OBS_STORE(o + c * VV, (float)((cq >> (8 * b)) & 0xFFu));
+                            for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
+                                }
+                            }
+                        } else {   // compact format: the same counts as bytes
+                            uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
+                                }
                             }
                         }
                     } else {
@@ -1333,6 +1363,7 @@ struct sgw_engine {
     DevTables* d_tab = nullptr;
     int* d_status = nullptr;
     double* d_part = nullptr;
+    int obs_format = SGW_OBS_F32;
     uint8_t* agent_state = nullptr;    // caller-owned, bound with sgw_bind_agent_state
     uint8_t* state_at_pov = nullptr;
     int wpe = 1;          // waves per env
@@ -1697,6 +1728,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (int rc = time_begin(e, s)) return rc;
     p.agent_state = e->agent_state;
     p.state_at_pov = e->state_at_pov;
+    p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
     if (p.agent_rule == SGW_AGENT_RULE_TAG && p.do_move && !p.agent_state)
         return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
     p.env_lds = e->step_env_lds;
@@ -1731,6 +1763,15 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
     p.epoch = epoch; p.turn = turn; p.a0 = agent_begin; p.a1 = agent_end; p.flags = flags; p.do_move = 1;
     return launch_step(e, p, static_cast<hipStream_t>(stream));
+}
+
+int sgw_set_obs_format(sgw_engine* e, int format) {
+    if (!e) return fail(SGW_EINVAL, "sgw_set_obs_format: NULL engine");
+    if (format != SGW_OBS_F32 && format != SGW_OBS_U8) return fail(SGW_EINVAL, "unknown observation format %d", format);
+    if (format == SGW_OBS_U8 && !e->onehot)
+        return fail(SGW_EINVAL, "SGW_OBS_U8 needs a one-hot appearance table (counts are exact small integers)");
+    e->obs_format = format;
+    return SGW_OK;
 }
 
 int sgw_bind_agent_state(sgw_engine* e, uint8_t* agent_state, uint8_t* state_at_pov) {

@@ -25,7 +25,7 @@ class GridEngine:
     """
 
     def __init__(self, spec: WorldSpec, num_envs: int, device="cuda", first_env_id: int = 0,
-                 allocate_obs: bool = True, tensors: Optional[dict] = None):
+                 allocate_obs: bool = True, tensors: Optional[dict] = None, obs_dtype=torch.float32):
         self.spec = spec
         self.num_envs = int(num_envs)
         self.first_env_id = int(first_env_id)
@@ -75,7 +75,14 @@ class GridEngine:
         self.rewards = adopt("rewards", (E, A), torch.float32)
         self.total_reward = adopt("total_reward", (E,), torch.float64)
         self.metrics = torch.zeros((4,), dtype=torch.float64, device=dev)
-        self.obs = (torch.zeros((E,) + spec.obs_shape, dtype=torch.float32, device=dev) if allocate_obs else None)
+        # float32 is the contract format (what the reference's replay buffer stores); uint8 is a compact
+        # extra for one-hot specs (same layout, same values, 4x fewer bytes)
+        if obs_dtype not in (torch.float32, torch.uint8):
+            raise ValueError("obs_dtype must be torch.float32 or torch.uint8")
+        self.obs_dtype = obs_dtype
+        if obs_dtype == torch.uint8:
+            N.check(self._lib.sgw_set_obs_format(self._h, N.OBS_U8))
+        self.obs = (torch.zeros((E,) + spec.obs_shape, dtype=obs_dtype, device=dev) if allocate_obs else None)
         self.epoch = 0
         self.turn = 0
         self._scratch_obs = None
@@ -134,7 +141,7 @@ class GridEngine:
 
     def scratch_obs(self) -> torch.Tensor:
         if self._scratch_obs is None:
-            self._scratch_obs = torch.zeros((self.num_envs,) + self.spec.obs_shape, dtype=torch.float32, device=self.device)
+            self._scratch_obs = torch.zeros((self.num_envs,) + self.spec.obs_shape, dtype=self.obs_dtype, device=self.device)
         return self._scratch_obs
 
     def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,

@@ -181,6 +181,37 @@ def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
         assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 8, 3, 300), (21, 21, 2, 2, 100), (128, 128, 64, 5, 6)])
+def test_compact_uint8_observations(torch_cuda, shape, monkeypatch):
+    """SGW_OBS_U8: same layout, the float32 counts as bytes (fast, big and generic kernels)."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    h, w, a, r, E = shape
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=77, dense_prob=0.2)
+    for force_generic in ("0", "1"):
+        monkeypatch.setenv("SGW_FORCE_GENERIC", force_generic)
+        f32, u8 = make_engine(ws, E), make_engine(ws, E, obs_dtype=torch.uint8)
+        f32.reset(0)
+        u8.reset(0)
+        for _ in range(4):
+            f32.step(random_actions=True)
+            u8.step(random_actions=True)
+            assert u8.obs.dtype == torch.uint8 and torch.equal(u8.obs.float(), f32.obs)
+            assert torch.equal(u8.grid, f32.grid) and torch.equal(u8.rewards, f32.rewards)
+        u8.obs.zero_()
+        u8.observe()
+        f32.observe()
+        assert torch.equal(u8.obs.float(), f32.obs)
+
+
+def test_compact_uint8_needs_a_one_hot_table(torch_cuda):
+    torch = torch_cuda
+    d, spec = H.load_golden("float_appearance_3layer")
+    with pytest.raises(ValueError):
+        make_engine(H.world_spec(spec), 4, obs_dtype=torch.uint8)
+
+
 def test_largest_worlds_vs_oracle(torch_cuda):
     """More than 64 KiB of LDS per env (needs the raised dynamic-LDS limit), up to the 256x256 coordinate limit."""
     from sorrel_amd.spec import treasurehunt_spec

@@ -67,7 +67,7 @@ def cpu_baseline(spec, seconds_target: float = 12.0):
     def run(t0, n):
         for t in range(t0, t0 + n):
             lib.sgo_step(C.byref(cfg), p(grid), p(pos), p(act), p(obs), p(rew), p(tot), C.c_uint32(0), C.c_uint32(t),
-                         C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(0), C.c_void_p(0), C.c_void_p(0))
+                         C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
 
     run(1, 2)                                   # warm-up + page-in
     t = time.perf_counter()

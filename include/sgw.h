@@ -69,10 +69,19 @@ extern "C" {
 /* entity transition rules (Entity.transition plugins the device can run) */
 #define SGW_RULE_NONE 0
 #define SGW_RULE_SPAWN 1   /* w.p. p replace own cell by one of n types, uniformly */
+#define SGW_RULE_BECOME_IF 2 /* become rule_become if the cell of layer rule_layer in the same column holds a type in
+                             * rule_mask; rule_layer < 0 = always (timers).  Cleanup: Pollution, Apple, beams
+                             * (sorrel/examples/cleanup/entities.py:57-66,94-105, agents.py:190-205).  Columns are
+                             * swept in ndenumerate order: a lower layer has already transitioned, a higher has not. */
 
 #define SGW_NO_BORDER 255
 
 /* observation post-processing (sgw_config.obs_post) */
+/* action kinds (sgw_config.action_kind), SGW_AGENT_RULE_CLEANUP */
+#define SGW_ACTION_MOVE 0
+#define SGW_ACTION_CLEAN 1
+#define SGW_ACTION_ZAP 2
+
 #define SGW_OBS_POST_NONE 0            /* OneHotObservationSpec: the layer sum itself */
 #define SGW_OBS_POST_CLIP255_DIV255 1  /* RGBObservationSpec: np.clip(obs, 0, 255) / 255 (observation_spec.py:483) */
 
@@ -88,6 +97,9 @@ extern "C" {
 
 /* what Agent.act does (sgw_config.agent_rule) */
 #define SGW_AGENT_RULE_MOVE 0 /* MovingAgent.act: reward = value of the target, then move (sorrel/agents/agent.py:215-225) */
+#define SGW_AGENT_RULE_CLEANUP 2 /* CleanupAgent.act: move (turning the agent) or fire a clean / zap beam; reward summed over
+                                  * all layers of the target cell (sorrel/examples/cleanup/agents.py:93-177);
+                                  * needs sgw_bind_agent_dir */
 #define SGW_AGENT_RULE_TAG 1  /* TagAgent.act: move, tag the first adjacent NotIt agent, reward for not being it
                                * (sorrel/examples/tag/agents.py:76-106); needs sgw_bind_agent_state */
 
@@ -142,6 +154,18 @@ typedef struct sgw_config {
     uint64_t first_env_id; /* global id of local env 0 (multi-GPU sharding) */
     int64_t num_envs;      /* E on this device */
     double tag_reward;     /* SGW_AGENT_RULE_TAG: TagAgent.reward_per_turn */
+    /* SGW_RULE_BECOME_IF parameters, per type */
+    int8_t rule_layer[SGW_MAX_TYPES];
+    uint8_t rule_become[SGW_MAX_TYPES];
+    uint32_t rule_mask[SGW_MAX_TYPES];
+    /* SGW_AGENT_RULE_CLEANUP parameters */
+    uint8_t action_kind[SGW_MAX_ACTIONS];
+    int32_t beam_radius;
+    uint8_t clean_beam_type; /* type of a freshly fired beam (its timer = a chain of SGW_RULE_BECOME_IF types) */
+    uint8_t zap_beam_type;
+    uint8_t reserved2[2];
+    uint32_t beam_block_mask;    /* bit t: no beam is placed on a beam-layer cell holding type t (walls) */
+    int32_t reward_total_factor; /* how many times act's reward enters total_reward (0 = 1; Cleanup = 2) */
     int64_t grid_env_stride; /* bytes between consecutive envs in `grid`; 0 = dense (L*H*W).  A stride that is a
                               * multiple of 16 lets worlds of any byte count use the 16-byte load/store kernels */
 } sgw_config;
@@ -180,6 +204,9 @@ int sgw_reduce_metrics(sgw_engine* eng, const double* total_reward, double* out,
  * SGW_AGENT_RULE_TAG, draws the initial "it" agent of every env (sorrel/examples/tag/env.py:66-69). */
 int sgw_bind_agent_state(sgw_engine* eng, uint8_t* agent_state, uint8_t* state_at_pov);
 int sgw_init_agent_state(sgw_engine* eng, uint8_t* agent_state, void* stream);
+/* Facing of every agent, uint8 [E][A]: 0 up, 1 right, 2 down, 3 left (MovingAgent.direction; CleanupAgent
+ * starts at 2).  Caller-initialised; sgw_step updates it on move actions and reads it to aim beams. */
+int sgw_bind_agent_dir(sgw_engine* eng, uint8_t* agent_dir);
 
 /* Observation element type written by sgw_step / sgw_observe.  SGW_OBS_F32 (default) is the contract
  * format (the reference's replay buffer stores float32, sorrel/buffers.py:31).  SGW_OBS_U8 is a

@@ -461,6 +461,185 @@ def run_reference_tag(R, spec: O.Spec, env_ids, turns, epoch=0):
 
 
 # --------------------------------------------------------------------------- #
+# Cleanup: cross-layer conditional transitions, timers, beams (sorrel/examples/cleanup)
+# --------------------------------------------------------------------------- #
+CLEANUP_KINDS = ["EmptyEntity", "Wall", "River", "Pollution", "AppleTree", "Apple", "CleanBeam", "ZapBeam", "CleanupAgent"]
+
+
+def cleanup_spec(height, width, num_agents, vision_radius, seed, beam_radius=3, pollution_p=0.009, apple_p=0.002) -> O.Spec:
+    """Types: 0 EmptyEntity, 1 Sand (kind EmptyEntity), 2 Wall, 3 River, 4 Pollution, 5 AppleTree, 6 Apple,
+    7/8 CleanBeam fresh/aged, 9/10 ZapBeam fresh/aged, 11 CleanupAgent.  Layers: 0 objects, 1 agents, 2 beams."""
+    chan = [0, 0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8]
+    app = np.zeros((12, 9))
+    for t, c in enumerate(chan):
+        if c != 0:
+            app[t, c] = 1.0
+    beams = (1 << 7) | (1 << 8)
+    names = ["up", "down", "left", "right", "clean", "zap"]
+    return O.Spec(
+        height=height, width=width, layers=3, num_agents=num_agents, vision_radius=vision_radius,
+        num_types=12, num_channels=9, agent_layer=1, default_type=0, fill_type=2,
+        action_dy=[-1, 1, 0, 0, 0, 0], action_dx=[0, 0, -1, 1, 0, 0], agent_type=[11] * num_agents,
+        type_value=[0, 0, 0, 0, 0, 0, 1, 0, 0, -1, -1, 0], type_passable=[1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        type_rule=[0, 0, 0, O.RULE_SPAWN, O.RULE_BECOME_IF, O.RULE_SPAWN, O.RULE_BECOME_IF,
+                   O.RULE_BECOME_IF, O.RULE_BECOME_IF, O.RULE_BECOME_IF, O.RULE_BECOME_IF, 0],
+        spawn_prob=[0, 0, 0, pollution_p, 0, apple_p, 0, 0, 0, 0, 0, 0],
+        spawn_choices=[[], [], [], [4], [], [6], [], [], [], [], [], []],
+        rule_layer=[0, 0, 0, 0, 2, 0, 1, -1, -1, -1, -1, 0],
+        rule_mask=[0, 0, 0, 0, beams, 0, 1 << 11, 0, 0, 0, 0, 0],
+        rule_become=[0, 0, 0, 0, 3, 0, 5, 8, 0, 10, 0, 0],
+        appearance=app, seed=seed, layer_fill_type=[0, 0, 0], layer_border_type=[2, 2, 2],
+        agent_rule=O.AGENT_RULE_CLEANUP, action_kind=[0, 0, 0, 0, O.ACTION_CLEAN, O.ACTION_ZAP], beam_radius=beam_radius,
+        clean_beam_type=7, zap_beam_type=9, beam_block_mask=1 << 2, reward_total_factor=2,
+    )
+
+
+def run_reference_cleanup(R, spec: O.Spec, env_ids, turns, initial_apples=6, epoch=0):
+    """The reference's own CleanupAgent / CleanupObservation / Pollution / Apple / Beam classes and step loop.
+    Plugins: River / AppleTree draw from the counter RNG; populate_environment places apples and agents with it."""
+    _, CounterModel, _ = build_plugins(R)
+    import sorrel.examples.cleanup.agents as ca
+    import sorrel.examples.cleanup.entities as ce
+    import sorrel.examples.cleanup.world as cw
+
+    Environment = R["environment"].Environment
+    ActionSpec = R["action_spec"].ActionSpec
+    OrigRiver, OrigTree = ce.River, ce.AppleTree
+
+    class CounterRiver(OrigRiver):
+        def __init__(self):
+            super().__init__()
+            self.kind = "River"
+
+        def transition(self, world):
+            y, x, z = self.location
+            idx = int(O.cell_index(spec, y, x, z))
+            if int(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, O.STREAM_SPAWN, idx)) < O.prob_threshold(world.pollution_spawn_chance):
+                world.add(self.location, ce.Pollution())
+
+    class CounterTree(OrigTree):
+        def __init__(self):
+            super().__init__()
+            self.kind = "AppleTree"
+
+        def transition(self, world):
+            if not world.pollution > world.pollution_threshold:
+                y, x, z = self.location
+                idx = int(O.cell_index(spec, y, x, z))
+                if int(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, O.STREAM_SPAWN, idx)) < O.prob_threshold(world.apple_spawn_chance):
+                    world.add(self.location, ce.Apple())
+
+    # Pollution.transition / Apple.transition create `River()` / `AppleTree()` through their module globals
+    ce.River, ce.AppleTree = CounterRiver, CounterTree
+
+    class Harness(Environment):
+        def setup_agents(self):
+            self.agents = []
+            for slot in range(spec.num_agents):
+                ospec = ca.CleanupObservation(entity_list=CLEANUP_KINDS, vision_radius=spec.vision_radius)
+                aspec = ActionSpec(["up", "down", "left", "right", "clean", "zap"])
+                flat = (int(np.prod(ospec.input_size)),)        # replay rows are flat vectors (input_size is (1, n))
+                model = CounterModel(flat, aspec.n_actions, memory_size=turns + 1, slot=slot)
+                self.agents.append(ca.CleanupAgent(observation_spec=ospec, action_spec=aspec, model=model))
+
+        def populate_environment(self):
+            # the layout rules of examples/cleanup/env.py:84-117 (mode DEFAULT), random picks from the counter RNG
+            w = self.world
+            spawn_points, apple_points = [], []
+            for index in np.ndindex(w.map.shape):
+                H, W, L = index
+                if H in [0, w.height - 1] or W in [0, w.width - 1]:
+                    w.add(index, ce.Wall())
+                elif L == 0:
+                    if (0 < H < (w.height // 3)) or (H < ((w.height // 3) * 2 - 1) and W in [w.width // 3, 1 + w.width // 3]):
+                        w.add(index, CounterRiver())
+                    elif (w.height - 1 - (w.height // 3)) < H < (w.height - 1):
+                        w.add(index, CounterTree())
+                        apple_points.append(index)
+                    else:
+                        w.add(index, ce.Sand())
+                        spawn_points.append((index[0], index[1], w.agent_layer))
+
+            def pick(n_from, k, stream):
+                u = O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, stream, np.arange(k))
+                taken, out = [], []
+                for i in range(k):
+                    d = int((int(u[i]) * (n_from - i)) >> 32)
+                    for t in taken:
+                        if d >= t:
+                            d += 1
+                    taken.append(d)
+                    taken.sort()
+                    out.append(d)
+                return out
+
+            for i in pick(len(apple_points), w.initial_apples, O.STREAM_DENSE):
+                w.add(tuple(apple_points[i]), ce.Apple())
+            for i, agent in zip(pick(len(spawn_points), len(self.agents), O.STREAM_PLACE), self.agents):
+                w.add(tuple(spawn_points[i]), agent)
+
+    cfg = ref_loader.DictConfig({
+        "experiment": {"epochs": 1, "max_turns": turns, "record_period": 1},
+        "env": {"height": spec.height, "width": spec.width, "layers": 3, "full_mdp": False, "pollution_threshold": 0.5,
+                "initial_apples": initial_apples, "apple_spawn_chance": spec.spawn_prob[5],
+                "pollution_spawn_chance": spec.spawn_prob[3], "mode": "DEFAULT"},
+        "agent": {"agent": {"num": spec.num_agents, "beam_radius": spec.beam_radius,
+                            "obs": {"channels": 8, "vision": spec.vision_radius, "n_frames": 1, "embeddings": 3}}},
+    })
+
+    def type_ids(world):
+        H, W, Ls = world.map.shape
+        g = np.zeros((Ls, H, W), dtype=np.uint8)
+        for (y, x, z), e in np.ndenumerate(world.map):
+            name = type(e).__name__
+            if isinstance(e, ca.CleanupAgent):
+                t = 11
+            elif isinstance(e, ca.CleanBeam):
+                t = 7 + (1 if e.turn_counter >= 1 else 0)
+            elif isinstance(e, ca.ZapBeam):
+                t = 9 + (1 if e.turn_counter >= 1 else 0)
+            else:
+                t = {"EmptyEntity": 0, "Sand": 1, "Wall": 2, "CounterRiver": 3, "Pollution": 4, "CounterTree": 5, "Apple": 6}[name]
+            g[z, y, x] = t
+        return g
+
+    E, A, C, V = len(env_ids), spec.num_agents, spec.num_channels, spec.window
+    n = C * V * V
+    out = dict(
+        grid0=np.zeros((E, 3, spec.height, spec.width), np.uint8), pos0=np.zeros((E, A, 2), np.uint8),
+        obs=np.zeros((turns, E, A, C, V, V), np.float32), pos_code=np.zeros((turns, E, A, 12), np.float32),
+        actions=np.zeros((turns, E, A), np.uint8), rewards=np.zeros((turns, E, A), np.float32),
+        dones=np.zeros((turns, E, A), np.float32), total_reward=np.zeros((turns, E), np.float64),
+        grid=np.zeros((turns, E, 3, spec.height, spec.width), np.uint8), pos=np.zeros((turns, E, A, 2), np.uint8),
+        agent_dir=np.zeros((turns, E, A), np.uint8),
+    )
+    try:
+        for k, env_id in enumerate(env_ids):
+            Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec, Ctx.scripted = spec.seed, int(env_id), epoch, 0, spec, None
+            env = Harness(cw.CleanupWorld(cfg, ce.EmptyEntity()), cfg)
+            out["grid0"][k] = type_ids(env.world)
+            out["pos0"][k] = [a.location[:2] for a in env.agents]
+            for t in range(turns):
+                Ctx.turn = env.turn + 1
+                env.take_turn()
+                for a, agent in enumerate(env.agents):
+                    mem = agent.model.memory
+                    st = np.asarray(mem.states[t]).reshape(-1)
+                    out["obs"][t, k, a] = st[:n].reshape(C, V, V)
+                    out["pos_code"][t, k, a] = st[n:]
+                    out["actions"][t, k, a] = mem.actions[t]
+                    out["rewards"][t, k, a] = mem.rewards[t]
+                    out["dones"][t, k, a] = mem.dones[t]
+                    out["pos"][t, k, a] = agent.location[:2]
+                    out["agent_dir"][t, k, a] = agent.direction
+                out["total_reward"][t, k] = env.world.total_reward
+                out["grid"][t, k] = type_ids(env.world)
+    finally:
+        ce.River, ce.AppleTree = OrigRiver, OrigTree
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # stock Treasurehunt with the reference's own global np.random stream
 # --------------------------------------------------------------------------- #
 def run_reference_stock(R, height, width, num_agents, radius, spawn_prob, turns, np_seed):
@@ -533,11 +712,14 @@ def save(name, spec, env_ids, ref, extra=None):
     print(f"  wrote {path} ({os.path.getsize(path)} bytes)")
 
 
-def check_against_oracle(spec, env_ids, turns, ref, scripted=None, epoch=0):
-    mine = O.rollout(spec, env_ids, turns, epoch=epoch, actions=scripted)
+def check_against_oracle(spec, env_ids, turns, ref, scripted=None, epoch=0, injected=False):
+    mine = O.rollout(spec, env_ids, turns, epoch=epoch, actions=scripted,
+                     initial=(ref["grid0"], ref["pos0"]) if injected else None)
     keys = ["grid0", "pos0", "obs", "actions", "rewards", "total_reward", "grid", "pos"]
     if "state_at_pov" in ref:
         keys += ["state_at_pov", "agent_state"]
+    if "agent_dir" in ref:
+        keys += ["agent_dir"]
     for k in keys:
         if not np.array_equal(mine[k], ref[k]):
             bad = np.argwhere(mine[k] != ref[k])[0]
@@ -655,6 +837,14 @@ def main() -> int:
     ref = run_reference_tag(R, spec, ids, 30)
     check_against_oracle(spec, ids, 30, ref)
     save("tag_crowded_6x7", spec, ids, ref)
+
+    print("cleanup_15x16: examples/cleanup (rivers/pollution/apples, conditional transitions, beam timers, beams)")
+    spec = cleanup_spec(15, 16, 4, 3, seed=41, beam_radius=3, pollution_p=0.06, apple_p=0.03)
+    ids = [0, 7]
+    ref = run_reference_cleanup(R, spec, ids, 40, initial_apples=6)
+    check_against_oracle(spec, ids, 40, ref, injected=True)
+    assert (ref["grid"] == 7).any() and (ref["grid"] == 9).any() and (ref["grid"] == 4).any(), "beams / pollution never appeared"
+    save("cleanup_15x16", spec, ids, ref)
 
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)

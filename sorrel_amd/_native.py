@@ -9,11 +9,12 @@ import ctypes as C
 import os
 
 MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
-RULE_NONE, RULE_SPAWN = 0, 1
+RULE_NONE, RULE_SPAWN, RULE_BECOME_IF = 0, 1, 2
 NO_BORDER = 255
 STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS = 1, 2, 4
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
-AGENT_RULE_MOVE, AGENT_RULE_TAG = 0, 1
+AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
+ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2
 OBS_F32, OBS_U8 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE = 1, 2, 4
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
@@ -48,6 +49,10 @@ class SgwConfig(C.Structure):
         ("first_env_id", C.c_uint64),
         ("num_envs", C.c_int64),
         ("tag_reward", C.c_double),
+        ("rule_layer", C.c_int8 * MAX_TYPES), ("rule_become", C.c_uint8 * MAX_TYPES), ("rule_mask", C.c_uint32 * MAX_TYPES),
+        ("action_kind", C.c_uint8 * MAX_ACTIONS), ("beam_radius", C.c_int32),
+        ("clean_beam_type", C.c_uint8), ("zap_beam_type", C.c_uint8), ("reserved2", C.c_uint8 * 2),
+        ("beam_block_mask", C.c_uint32), ("reward_total_factor", C.c_int32),
         ("grid_env_stride", C.c_int64),
     ]
 
@@ -58,7 +63,7 @@ LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")
 # every symbol include/sgw.h declares
 EXPORTS = (
     "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_reduce_metrics",
-    "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
+    "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms",
     "sgw_last_error", "sgw_version",
 )
@@ -119,6 +124,8 @@ def load():
     lib.sgw_set_obs_format.restype = C.c_int
     lib.sgw_bind_agent_state.argtypes = [vp, u8p, u8p]
     lib.sgw_bind_agent_state.restype = C.c_int
+    lib.sgw_bind_agent_dir.argtypes = [vp, u8p]
+    lib.sgw_bind_agent_dir.restype = C.c_int
     lib.sgw_init_agent_state.argtypes = [vp, u8p, vp]
     lib.sgw_init_agent_state.restype = C.c_int
     lib.sgw_get_status.argtypes = [vp, C.POINTER(C.c_int32), vp]

@@ -49,6 +49,11 @@ struct DevTables {
     uint8_t layer_fill[8];
     uint8_t layer_border[8];
     uint8_t pad_[8];
+    uint8_t rule[SGW_MAX_TYPES];          // SGW_RULE_* per type
+    int8_t rule_layer[SGW_MAX_TYPES];     // SGW_RULE_BECOME_IF: layer to test (< 0: always)
+    uint8_t rule_become[SGW_MAX_TYPES];
+    uint8_t pad2_[SGW_MAX_TYPES];
+    uint32_t rule_mask[SGW_MAX_TYPES];
     double appearance[SGW_MAX_TYPES][SGW_MAX_CHANNELS];  // general (non one-hot) path only
 };
 constexpr int kTabFastBytes = offsetof(DevTables, appearance);
@@ -84,6 +89,12 @@ struct Params {
     uint32_t tag_it, tag_notit;
     double tag_reward;
     uint8_t* agent_state;      // optional [E][A]: current type of every agent
+    uint8_t* agent_dir;        // optional [E][A]: facing (SGW_AGENT_RULE_CLEANUP)
+    int has_become;            // some type carries SGW_RULE_BECOME_IF: ordered, layer-by-layer sweep
+    uint32_t kind_pack;        // 2 bits per action: SGW_ACTION_*
+    int beam_radius;
+    uint32_t clean_beam, zap_beam, beam_block_mask;
+    int total_factor;
     uint8_t* state_at_pov;     // optional [E][A]: type at observation time
     uint64_t dense_thr;
     int dense_count;
@@ -237,6 +248,35 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
     }
 }
 
+// Ordered sweep for rule sets with cross-layer conditions (SGW_RULE_BECOME_IF, e.g. Cleanup): the
+// reference visits cells in (y, x, z) order over a LIVE view, so within a column a lower layer has
+// already transitioned when a higher one is visited and a higher one has not when a lower one is.
+// Columns never read each other, so: one pass per layer, all cells of the layer in parallel.
+template <int WPE, int G>
+__device__ __forceinline__ void sweep_ordered(const Params& p, const DevTables* tab, uint8_t* lg, uint32_t env_id, int gtid) {
+    const int HW = p.H * p.W;
+    for (int z = 0; z < p.L; ++z) {
+        for (int cidx = gtid; cidx < HW; cidx += G) {
+            const int off = z * HW + cidx;
+            const uint32_t t = lg[off];
+            if (t >= SGW_MAX_TYPES) continue;
+            const uint32_t rule = tab->rule[t];
+            if (rule == SGW_RULE_BECOME_IF) {
+                const int zl = tab->rule_layer[t];
+                const bool fire = zl < 0 || ((tab->rule_mask[t] >> (lg[zl * HW + cidx] & 31u)) & 1u);
+                if (fire) lg[off] = tab->rule_become[t];
+            } else if (rule == SGW_RULE_SPAWN) {
+                const U4 w = philox4x32_10((uint32_t)off >> 2, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                if (((p.thr_full_mask >> t) & 1u) || word_of(w, off & 3) < tab->thr_lo[t]) {
+                    const U4 k = philox4x32_10((uint32_t)off >> 2, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+                    lg[off] = tab->spawn_choice[t][__umulhi(word_of(k, off & 3), (uint32_t)tab->spawn_count[t])];
+                }
+            }
+        }
+        gsync<WPE>();
+    }
+}
+
 // ---------------------------------------------------------------- step kernel
 // Per-env LDS slice: [grid cells_pad][pos 2*64][act 64][rew f32 x64]
 constexpr int kPosOff = 0;
@@ -244,7 +284,8 @@ constexpr int kActOff = 2 * SGW_MAX_AGENTS;
 constexpr int kRewOff = kActOff + SGW_MAX_AGENTS;
 constexpr int kTypeOff = kRewOff + 4 * SGW_MAX_AGENTS;   // current type of each agent
 constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it observed
-constexpr int kAgentLds = kPovOff + SGW_MAX_AGENTS;     // 576 bytes, multiple of 16
+constexpr int kDirOff = kPovOff + SGW_MAX_AGENTS;       // its facing (Cleanup)
+constexpr int kAgentLds = kDirOff + SGW_MAX_AGENTS;     // 640 bytes, multiple of 16
 
 template <int WPE, bool ONEHOT>
 __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
@@ -270,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
     float* s_rew = reinterpret_cast<float*>(slice + p.cells_pad + kRewOff);
     uint8_t* s_type = slice + p.cells_pad + kTypeOff;   // [A] current entity type of each agent
     uint8_t* s_pov = slice + p.cells_pad + kPovOff;     // [A] its type when it observed
+    uint8_t* s_dir = slice + p.cells_pad + kDirOff;     // [A] its facing
 
     // window cell(s) this thread renders: fixed for the whole kernel
     int wi[kMaxPass], wj[kMaxPass];
@@ -294,6 +336,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             const uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
             reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
             s_type[gtid] = p.agent_state ? p.agent_state[env * p.A + gtid] : tab->agent_type[gtid];
+            s_dir[gtid] = p.agent_dir ? p.agent_dir[env * p.A + gtid] : (uint8_t)2;
             if (p.do_move && gtid >= p.a0 && gtid < p.a1) {
                 uint32_t act;
                 if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
@@ -309,8 +352,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
         }
         gsync<WPE>();
         if (p.flags & SGW_STEP_SWEEP) {
-            sweep<G>(p, tab, lg, env_id, gtid);
-            gsync<WPE>();
+            if (p.has_become) {
+                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid);
+            } else {
+                sweep<G>(p, tab, lg, env_id, gtid);
+                gsync<WPE>();
+            }
         }
 
         int st_bits = 0;
@@ -374,6 +421,63 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                 }
             }
             if (!p.do_move) continue;
+            if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {
+                // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
+                // same LDS bytes, so all control flow here is uniform; single threads do the writes.
+                const uint32_t act = s_act[a];
+                const uint32_t my_type = s_type[a];
+                const bool act_ok = act < (uint32_t)p.nact;
+                const uint32_t kind = act_ok ? (p.kind_pack >> (2 * act)) & 3u : 0u;
+                const int dy = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
+                const int dx = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
+                const int ny = y + dy, nx = x + dx;
+                const uint32_t facing = s_dir[a] & 3u;
+                gsync<WPE>();
+                if (act_ok && kind != SGW_ACTION_MOVE && p.zA + 1 < p.L && gtid < 3 * p.beam_radius) {
+                    // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
+                    const int arm = gtid / p.beam_radius, i = gtid - arm * p.beam_radius;
+                    const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
+                    const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
+                    const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                    const int by = y + side * ry + step * fy, bx = x + side * rx + step * fx;
+                    if ((unsigned)by < (unsigned)p.H && (unsigned)bx < (unsigned)p.W) {
+                        const int boff = (p.zA + 1) * HW + by * p.W + bx;
+                        if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
+                            lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
+                    }
+                }
+                gsync<WPE>();
+                const bool inb = act_ok && (unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W;
+                double val = 0.0;
+                uint32_t t = 0xFFu;
+                if (inb) {
+                    for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * p.W + nx] & 31u];   // all layers, BEFORE the move
+                    t = lg[zoff + ny * p.W + nx];
+                }
+                const bool pass = inb && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                gsync<WPE>();
+                if (gtid == 0) {
+                    s_pov[a] = (uint8_t)my_type;
+                    if (act_ok && kind == SGW_ACTION_MOVE) {            // movement() turns the agent even if the move fails
+                        if (dy == -1 && dx == 0) s_dir[a] = 0;
+                        else if (dy == 1 && dx == 0) s_dir[a] = 2;
+                        else if (dy == 0 && dx == -1) s_dir[a] = 3;
+                        else if (dy == 0 && dx == 1) s_dir[a] = 1;
+                    }
+                    if (pass) {
+                        lg[zoff + ny * p.W + nx] = (uint8_t)my_type;
+                        lg[zoff + y * p.W + x] = (uint8_t)p.default_type;
+                        s_pos[2 * a] = (uint8_t)ny;
+                        s_pos[2 * a + 1] = (uint8_t)nx;
+                    }
+                    s_rew[a] = (float)val;
+                    tot += val * (double)(p.total_factor - 1);       // the extra add inside act() (agents.py:172) ...
+                    tot += val;                                      // ... and Agent.transition's own (agent.py:172)
+                    st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0);
+                }
+                gsync<WPE>();
+                continue;
+            }
             // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
             const uint32_t act = s_act[a];
             const uint32_t my_type = s_type[a];
@@ -444,6 +548,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                 if (p.state_at_pov) p.state_at_pov[env * p.A + gtid] = s_pov[gtid];
             }
             if (gtid < p.A && p.agent_state) p.agent_state[env * p.A + gtid] = s_type[gtid];   // a tag can flip any agent
+            if (gtid < p.A && p.agent_dir) p.agent_dir[env * p.A + gtid] = s_dir[gtid];
             if (gtid == 0) {
                 p.total[env] = tot;
                 if (st_bits) atomicOr(p.status, st_bits);
@@ -1366,6 +1471,7 @@ struct sgw_engine {
     int obs_format = SGW_OBS_F32;
     uint8_t* agent_state = nullptr;    // caller-owned, bound with sgw_bind_agent_state
     uint8_t* state_at_pov = nullptr;
+    uint8_t* agent_dir = nullptr;      // caller-owned, bound with sgw_bind_agent_dir
     int wpe = 1;          // waves per env
     bool onehot = true;
     bool fast = false;    // step_fast specialisation applies
@@ -1428,6 +1534,11 @@ int validate(const sgw_config* c) {
     }
     for (int t = 0; t < c->num_types; ++t) {
         if (c->type_rule[t] == SGW_RULE_NONE) continue;
+        if (c->type_rule[t] == SGW_RULE_BECOME_IF) {
+            if (c->rule_layer[t] >= c->layers) return fail(SGW_EINVAL, "type %d: rule_layer out of range", t);
+            if (c->rule_become[t] >= c->num_types) return fail(SGW_EINVAL, "type %d: rule_become out of range", t);
+            continue;
+        }
         if (c->type_rule[t] != SGW_RULE_SPAWN)
             return fail(SGW_EINVAL, "type %d: unsupported transition rule %d", t, (int)c->type_rule[t]);
         if (c->spawn_count[t] < 1 || c->spawn_count[t] > SGW_MAX_CHOICES)
@@ -1446,8 +1557,15 @@ int validate(const sgw_config* c) {
     for (int k = 0; k < c->dense_count; ++k)
         if (c->dense_choice[k] >= c->num_types) return fail(SGW_EINVAL, "dense choice out of range");
     if (!(c->dense_prob >= 0.0 && c->dense_prob <= 1.0)) return fail(SGW_EINVAL, "dense_prob must be in [0, 1]");
-    if (c->agent_rule != SGW_AGENT_RULE_MOVE && c->agent_rule != SGW_AGENT_RULE_TAG)
+    if (c->agent_rule != SGW_AGENT_RULE_MOVE && c->agent_rule != SGW_AGENT_RULE_TAG && c->agent_rule != SGW_AGENT_RULE_CLEANUP)
         return fail(SGW_EINVAL, "unknown agent_rule %d", (int)c->agent_rule);
+    if (c->agent_rule == SGW_AGENT_RULE_CLEANUP) {
+        if (c->beam_radius < 0 || 3 * c->beam_radius > 64) return fail(SGW_EINVAL, "beam_radius must be in [0, 21]");
+        if (c->clean_beam_type >= c->num_types || c->zap_beam_type >= c->num_types)
+            return fail(SGW_EINVAL, "beam types out of range");
+        for (int i = 0; i < c->num_actions; ++i)
+            if (c->action_kind[i] > SGW_ACTION_ZAP) return fail(SGW_EINVAL, "action %d: unknown action kind", i);
+    }
     if (c->agent_rule == SGW_AGENT_RULE_TAG) {
         if (c->tag_it_type >= c->num_types || c->tag_notit_type >= c->num_types || c->tag_it_type == c->tag_notit_type)
             return fail(SGW_EINVAL, "tag_it_type / tag_notit_type must be two distinct registered types");
@@ -1574,6 +1692,12 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         h.spawn_count[t] = c.spawn_count[t];
         memcpy(h.spawn_choice[t], c.spawn_choice[t], SGW_MAX_CHOICES);
     }
+    for (int t = 0; t < c.num_types; ++t) {
+        h.rule[t] = c.type_rule[t];
+        h.rule_layer[t] = c.rule_layer[t];
+        h.rule_become[t] = c.rule_become[t];
+        h.rule_mask[t] = c.rule_mask[t];
+    }
     memcpy(h.agent_type, c.agent_type, SGW_MAX_AGENTS);
     memcpy(h.dense_choice, c.dense_choice, SGW_MAX_CHOICES);
     memcpy(h.layer_fill, c.layer_fill_type, 8);
@@ -1633,19 +1757,30 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tag_it = c.tag_it_type;
     p.tag_notit = c.tag_notit_type;
     p.tag_reward = c.tag_reward;
+    p.has_become = 0;
+    for (int t = 0; t < c.num_types; ++t)
+        if (c.type_rule[t] == SGW_RULE_BECOME_IF) p.has_become = 1;
+    p.kind_pack = 0;
+    for (int a = 0; a < c.num_actions; ++a) p.kind_pack |= (uint32_t)(c.action_kind[a] & 3u) << (2 * a);
+    p.beam_radius = c.beam_radius;
+    p.clean_beam = c.clean_beam_type;
+    p.zap_beam = c.zap_beam_type;
+    p.beam_block_mask = c.beam_block_mask;
+    p.total_factor = c.reward_total_factor > 0 ? c.reward_total_factor : 1;
 
     // ---- group geometry: one wave per env while a slice stays small, else a workgroup per env
     e->wpe = (p.cells_pad <= 4096) ? 1 : 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
-    const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // the specialised kernels implement MovingAgent.act only
+    const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // step_big implements MovingAgent.act only
+    const bool simple_rules = !p.has_become && c.agent_rule != SGW_AGENT_RULE_CLEANUP;   // else: generic kernel
     const bool vec16 = (p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad;   // 16-byte loads/stores per env are legal
-    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128;   // MovingAgent.act and TagAgent.act
+    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
-    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move;
+    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move && simple_rules;
     e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
@@ -1728,6 +1863,9 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (int rc = time_begin(e, s)) return rc;
     p.agent_state = e->agent_state;
     p.state_at_pov = e->state_at_pov;
+    p.agent_dir = e->agent_dir;
+    if (p.agent_rule == SGW_AGENT_RULE_CLEANUP && p.do_move && !p.agent_dir)
+        return fail(SGW_EINVAL, "SGW_AGENT_RULE_CLEANUP needs sgw_bind_agent_dir");
     p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
     if (p.agent_rule == SGW_AGENT_RULE_TAG && p.do_move && !p.agent_state)
         return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
@@ -1779,6 +1917,12 @@ int sgw_bind_agent_state(sgw_engine* e, uint8_t* agent_state, uint8_t* state_at_
     if (!agent_state && state_at_pov) return fail(SGW_EINVAL, "sgw_bind_agent_state: state_at_pov without agent_state");
     e->agent_state = agent_state;
     e->state_at_pov = state_at_pov;
+    return SGW_OK;
+}
+
+int sgw_bind_agent_dir(sgw_engine* e, uint8_t* agent_dir) {
+    if (!e) return fail(SGW_EINVAL, "sgw_bind_agent_dir: NULL engine");
+    e->agent_dir = agent_dir;
     return SGW_OK;
 }
 

@@ -88,13 +88,23 @@ class GridEngine:
         self._scratch_obs = None
         # per-env agent state (current entity type of each agent): needed by interaction rules (Tag)
         self.agent_state = self.state_at_pov = None
-        if spec.agent_rule != N.AGENT_RULE_MOVE:
+        if spec.agent_rule == N.AGENT_RULE_TAG:
             self.agent_state = adopt("agent_state", (E, A), torch.uint8)
             self.state_at_pov = torch.zeros((E, A), dtype=torch.uint8, device=dev)
             with torch.cuda.device(self.device):
                 N.check(self._lib.sgw_bind_agent_state(self._h, self._ptr(self.agent_state), self._ptr(self.state_at_pov)))
                 if "agent_state" not in tensors:
                     N.check(self._lib.sgw_init_agent_state(self._h, self._ptr(self.agent_state), self._stream()))
+        # per-env facing of each agent, 0 up / 1 right / 2 down / 3 left (Cleanup's beams)
+        self.agent_dir = None
+        if spec.agent_rule == N.AGENT_RULE_CLEANUP:
+            self.agent_dir = tensors.get("agent_dir")
+            if self.agent_dir is None:
+                self.agent_dir = torch.full((E, A), 2, dtype=torch.uint8, device=dev)   # CleanupAgent.__init__: facing down (agents.py:74); like Tag's flag it survives resets
+            elif tuple(self.agent_dir.shape) != (E, A) or self.agent_dir.dtype != torch.uint8 or self.agent_dir.device != dev \
+                    or not self.agent_dir.is_contiguous():
+                raise ValueError("agent_dir must be contiguous uint8 [E, A] on the engine's device")
+            N.check(self._lib.sgw_bind_agent_dir(self._h, self._ptr(self.agent_dir)))
 
     # ------------------------------------------------------------------ util
     def _stream(self):

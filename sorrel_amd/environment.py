@@ -20,7 +20,9 @@ import torch
 
 from sorrel_amd.agents.agent import Agent
 from sorrel_amd.entities.entity import Entity
-from sorrel_amd.spec import NO_BORDER, RULE_NONE, RULE_SPAWN, WorldSpec, action_deltas
+from sorrel_amd.agents.rules import CleanupRule, TagRule
+from sorrel_amd.entities.rules import AgeRule, BecomeIfRule
+from sorrel_amd.spec import NO_BORDER, RULE_BECOME_IF, RULE_NONE, RULE_SPAWN, WorldSpec, action_deltas
 
 try:  # omegaconf is optional (absent in the build image)
     from omegaconf import DictConfig, OmegaConf  # type: ignore
@@ -145,31 +147,45 @@ class Environment:
         if ospec.full_view:
             raise ValueError("full_view observation specs are not part of the fused step; use observe() on demand")
         rule = getattr(agents[0], "interaction_rule", None)
-        tag = dict(agent_rule=0, tag_it_type=0, tag_notit_type=0, tag_reward=0.0)
+        extra = dict(agent_rule=0)
         if rule is None:
             agent_types = [w.registry.register(a) for a in agents]
-        else:
-            from sorrel_amd.agents.rules import TagRule
-
-            if not isinstance(rule, TagRule):
-                raise ValueError(f"unsupported agent interaction rule {rule!r}")
+        elif isinstance(rule, TagRule):
             it_t = w.registry.register(agents[0].as_kind(rule.it_kind))
             notit_t = w.registry.register(agents[0].as_kind(rule.notit_kind))
             agent_types = [notit_t] * len(agents)
-            tag = dict(agent_rule=1, tag_it_type=it_t, tag_notit_type=notit_t, tag_reward=float(rule.reward_per_turn))
-        # resolve spawn rules (may register the spawned types); iterate to a fixed point
-        spawn = {}
+            extra = dict(agent_rule=1, tag_it_type=it_t, tag_notit_type=notit_t, tag_reward=float(rule.reward_per_turn))
+        elif isinstance(rule, CleanupRule):
+            agent_types = [w.registry.register(a) for a in agents]
+            clean, zap = rule.beams()
+            kinds = {rule.clean_action: 1, rule.zap_action: 2}          # SGW_ACTION_CLEAN / SGW_ACTION_ZAP
+            extra = dict(agent_rule=2, action_kind=[kinds.get(n, 0) for n in aspec.names], beam_radius=rule.beam_radius,
+                         clean_beam_type=w.registry.register(clean), zap_beam_type=w.registry.register(zap),
+                         reward_total_factor=2 if rule.count_total_twice else 1)
+        else:
+            raise ValueError(f"unsupported agent interaction rule {rule!r}")
+        # resolve transition rules (may register the types they produce); iterate to a fixed point
+        spawn, become = {}, {}
         n_seen = -1
         while n_seen != len(w.registry):
             n_seen = len(w.registry)
             for t, proto in enumerate(list(w.registry.prototypes)):
-                if isinstance(proto, Agent) or not proto.has_transitions or t in spawn:
+                if isinstance(proto, Agent) or not proto.has_transitions or t in spawn or t in become:
                     continue
-                if proto.transition_rule is None:
+                trule = proto.transition_rule
+                if trule is None:
                     raise ValueError(
                         f"{type(proto).__name__} has has_transitions=True but no declarative transition_rule; "
                         "arbitrary Python transition() bodies cannot run on the device")
-                spawn[t] = w.spawn_rule_of(proto)
+                if isinstance(trule, BecomeIfRule):
+                    ent, layer, kinds_ = trule.resolve(w)
+                    become[t] = (w.registry.register(ent), layer, kinds_)
+                elif isinstance(trule, AgeRule):
+                    for ent, r in trule.chain(proto, w):
+                        nxt, layer, kinds_ = r.resolve(w)
+                        become[w.registry.register(ent)] = (w.registry.register(nxt), layer, kinds_)
+                else:
+                    spawn[t] = w.spawn_rule_of(proto)
         fill_kind = ospec.fill_entity_kind
         fill_type = next((t for t, p in enumerate(w.registry.prototypes) if p.kind == fill_kind), None)
         if fill_type is None:
@@ -184,6 +200,14 @@ class Environment:
         dy, dx = action_deltas(aspec.names)
         if w.agent_layer is None:
             w.agent_layer = w.layers - 1
+        if extra["agent_rule"] == 2:
+            extra["beam_block_mask"] = sum(1 << t for t, p in enumerate(protos) if type(p).__name__ in rule.blocked)
+            if w.agent_layer + 1 >= w.layers:
+                raise ValueError("CleanupRule needs a beam layer above the agent layer")
+
+        def kind_mask(kinds_):
+            return sum(1 << t for t, p in enumerate(protos) if p.kind in kinds_)
+
         lay = w.layout or dict(fill=[w.default_type] * w.layers, border=[NO_BORDER] * w.layers, dense_prob=0.0, dense=[])
         return WorldSpec(
             height=w.height, width=w.width, layers=w.layers, num_agents=len(agents),
@@ -191,12 +215,15 @@ class Environment:
             default_type=w.default_type, fill_type=fill_type, action_dy=dy, action_dx=dx,
             agent_type=agent_types,
             type_value=[p.value for p in protos], type_passable=[1 if p.passable else 0 for p in protos],
-            type_rule=[RULE_SPAWN if t in spawn else RULE_NONE for t in range(T)],
+            type_rule=[RULE_SPAWN if t in spawn else RULE_BECOME_IF if t in become else RULE_NONE for t in range(T)],
+            rule_layer=[become[t][1] if t in become else 0 for t in range(T)],
+            rule_mask=[kind_mask(become[t][2]) if t in become else 0 for t in range(T)],
+            rule_become=[become[t][0] if t in become else 0 for t in range(T)],
             spawn_prob=[spawn[t][0] if t in spawn else 0.0 for t in range(T)],
             spawn_choices=[spawn[t][1] if t in spawn else [] for t in range(T)],
             appearance=app, seed=w.seed, layer_fill_type=lay["fill"], layer_border_type=lay["border"],
             dense_prob=lay["dense_prob"], dense_choices=lay["dense"],
-            type_names=[type(p).__name__ for p in protos], obs_post=int(getattr(ospec, "obs_post", 0)), **tag,
+            type_names=[type(p).__name__ for p in protos], obs_post=int(getattr(ospec, "obs_post", 0)), **extra,
         )
 
     def _ensure_engine(self):
@@ -212,8 +239,11 @@ class Environment:
         tensors = dict(grid=w.grid, agent_pos=w.agent_pos, total_reward=w.total_reward)
         if getattr(w, "agent_state", None) is not None:
             tensors["agent_state"] = w.agent_state          # survives engine rebuilds (and resets)
+        if getattr(w, "agent_dir", None) is not None:
+            tensors["agent_dir"] = w.agent_dir
         self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first, tensors=tensors)
         w.agent_state = self._engine.agent_state
+        w.agent_dir = self._engine.agent_dir
         self._engine_version = w.registry.version
         self._validate_border()
         return self._engine

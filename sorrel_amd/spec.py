@@ -19,6 +19,7 @@ from . import _native as N
 
 RULE_NONE = N.RULE_NONE
 RULE_SPAWN = N.RULE_SPAWN
+RULE_BECOME_IF = N.RULE_BECOME_IF
 NO_BORDER = N.NO_BORDER
 
 _MOVES = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
@@ -75,6 +76,15 @@ class WorldSpec:
     tag_it_type: int = 0
     tag_notit_type: int = 0
     tag_reward: float = 0.0
+    rule_layer: List[int] = field(default_factory=list)      # RULE_BECOME_IF, per type
+    rule_mask: List[int] = field(default_factory=list)
+    rule_become: List[int] = field(default_factory=list)
+    action_kind: List[int] = field(default_factory=list)     # AGENT_RULE_CLEANUP
+    beam_radius: int = 0
+    clean_beam_type: int = 0
+    zap_beam_type: int = 0
+    beam_block_mask: int = 0
+    reward_total_factor: int = 1
 
     @property
     def num_types(self) -> int:
@@ -121,6 +131,14 @@ class WorldSpec:
         c.obs_post = int(self.obs_post)
         c.agent_rule, c.tag_it_type, c.tag_notit_type = int(self.agent_rule), int(self.tag_it_type), int(self.tag_notit_type)
         c.tag_reward = float(self.tag_reward)
+        for t in range(T):
+            c.rule_layer[t] = int(self.rule_layer[t]) if t < len(self.rule_layer) else 0
+            c.rule_mask[t] = int(self.rule_mask[t]) & 0xFFFFFFFF if t < len(self.rule_mask) else 0
+            c.rule_become[t] = int(self.rule_become[t]) if t < len(self.rule_become) else 0
+        for i in range(self.num_actions):
+            c.action_kind[i] = int(self.action_kind[i]) if i < len(self.action_kind) else 0
+        c.beam_radius, c.clean_beam_type, c.zap_beam_type = int(self.beam_radius), int(self.clean_beam_type), int(self.zap_beam_type)
+        c.beam_block_mask, c.reward_total_factor = int(self.beam_block_mask) & 0xFFFFFFFF, int(self.reward_total_factor)
         for i in range(self.num_actions):
             c.action_dy[i], c.action_dx[i] = int(self.action_dy[i]), int(self.action_dx[i])
         for a in range(self.num_agents):

@@ -82,6 +82,7 @@ class Gridworld(World):
         self.agent_pos: Optional[torch.Tensor] = None
         self.agent_layer: Optional[int] = None
         self.agent_state: Optional[torch.Tensor] = None   # [E, A] current type of each agent (interaction rules)
+        self.agent_dir: Optional[torch.Tensor] = None     # [E, A] facing of each agent (Cleanup)
         # declarative reset layout (set_layout) -- None = host-built template
         self.layout = None
         self.create_world()
@@ -210,6 +211,32 @@ class Gridworld(World):
             dense_prob=float(dense_prob),
             dense=[self.registry.register(e) for e in dense_choices],
         )
+
+    def set_template(self, entities: np.ndarray) -> None:
+        """Copy one host-built map -- an object array ``(H, W, L)`` of entities, the reference's
+        ``world.map`` layout -- into every env with a single upload (instead of one ``add`` per cell)."""
+        if entities.shape != (self.height, self.width, self.layers):
+            raise IndexError(f"template shape {entities.shape} != world shape {(self.height, self.width, self.layers)}")
+        ids = np.empty((self.layers, self.height, self.width), dtype=np.uint8)
+        for (y, x, z), e in np.ndenumerate(entities):
+            ids[z, y, x] = self.default_type if e is None else self.registry.register(e)
+        self.grid.copy_(torch.from_numpy(ids).to(self.device).expand_as(self.grid))
+
+    def scatter_random(self, cells: Sequence, count: int, entity: Entity, generator: torch.Generator) -> torch.Tensor:
+        """In every env put ``entity`` on ``count`` of the candidate ``cells`` [(y, x, z)], drawn without
+        replacement per env (the batched ``np.random.choice(len(points), size=count, replace=False)``
+        of the reference's populate code).  Returns the chosen cell indices ``[E, count]``."""
+        if count > len(cells):
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        pts = torch.tensor([tuple(int(v) for v in c) for c in cells], dtype=torch.long).reshape(-1, 3)
+        keys = torch.rand((self.num_envs, len(cells)), generator=generator)
+        pick = keys.argsort(dim=1)[:, :count]                                   # [E, count]
+        tid = self.registry.register(entity)
+        e_idx = torch.arange(self.num_envs)[:, None].expand_as(pick)
+        sel = pts[pick]                                                          # [E, count, 3]
+        dev = self.device
+        self.grid[e_idx.to(dev), sel[..., 2].to(dev), sel[..., 0].to(dev), sel[..., 1].to(dev)] = tid
+        return pick
 
     def spawn_rule_of(self, proto: Entity):
         """(prob, [type ids]) of a prototype's SpawnRule, resolving callables against this world."""

@@ -21,6 +21,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 NON_WORLD_FIXTURES = {"buffer_ring"}   # fixtures that are not step-loop traces
+INJECTED_FIXTURES = {"cleanup_15x16"}  # worlds populated by host code: runs start from the stored grid0 / pos0
 
 
 def golden_names():
@@ -54,6 +55,11 @@ def world_spec(spec: O.Spec) -> WorldSpec:
         dense_prob=spec.dense_prob, dense_choices=list(spec.dense_choices), obs_post=getattr(spec, "obs_post", 0),
         agent_rule=getattr(spec, "agent_rule", 0), tag_it_type=getattr(spec, "tag_it_type", 0),
         tag_notit_type=getattr(spec, "tag_notit_type", 0), tag_reward=getattr(spec, "tag_reward", 0.0),
+        rule_layer=list(getattr(spec, "rule_layer", [])), rule_mask=list(getattr(spec, "rule_mask", [])),
+        rule_become=list(getattr(spec, "rule_become", [])), action_kind=list(getattr(spec, "action_kind", [])),
+        beam_radius=getattr(spec, "beam_radius", 0), clean_beam_type=getattr(spec, "clean_beam_type", 0),
+        zap_beam_type=getattr(spec, "zap_beam_type", 0), beam_block_mask=getattr(spec, "beam_block_mask", 0),
+        reward_total_factor=getattr(spec, "reward_total_factor", 1),
     )
 
 
@@ -76,7 +82,7 @@ def oracle_lib():
         lib.sgo_reset.argtypes = [cfgp, vp, vp, vp, C.c_uint32, C.c_int, vp]
         lib.sgo_observe.argtypes = [cfgp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int]
         lib.sgo_step.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
-                                 C.c_uint32, C.c_int, vp, vp]
+                                 C.c_uint32, C.c_int, vp, vp, vp]
         lib.sgo_init_agent_state.argtypes = [cfgp, vp]
         lib.sgo_random_actions.argtypes = [cfgp, vp, C.c_uint32, C.c_uint32]
         lib.sgo_reduce_metrics.argtypes = [cfgp, vp, vp]
@@ -106,6 +112,7 @@ class COracle:
         self.total = np.zeros((E,), np.float64)
         self.agent_state = np.zeros((E, A), np.uint8)
         self.state_at_pov = np.zeros((E, A), np.uint8)
+        self.agent_dir = np.full((E, A), 2, np.uint8)       # CleanupAgent starts facing down
         self.lib.sgo_init_agent_state(C.byref(self.cfg), _p(self.agent_state))
 
     def reset(self, epoch=0):
@@ -124,7 +131,8 @@ class COracle:
         flags = (1 if sweep else 0) | (2 if random_actions else 0) | (0 if write_obs else 4)
         return self.lib.sgo_step(C.byref(self.cfg), _p(self.grid), _p(self.pos), _p(self.actions),
                                  _p(self.obs) if write_obs else None, _p(self.rewards), _p(self.total),
-                                 epoch, turn, a0, a1, flags, self.threads, _p(self.agent_state), _p(self.state_at_pov))
+                                 epoch, turn, a0, a1, flags, self.threads, _p(self.agent_state), _p(self.state_at_pov),
+                                 _p(self.agent_dir))
 
     def metrics(self):
         out = np.zeros(4, np.float64)
@@ -145,4 +153,7 @@ def oracle_spec(ws: WorldSpec) -> O.Spec:
         layer_fill_type=list(ws.layer_fill_type), layer_border_type=list(ws.layer_border_type),
         dense_prob=ws.dense_prob, dense_choices=list(ws.dense_choices), obs_post=ws.obs_post,
         agent_rule=ws.agent_rule, tag_it_type=ws.tag_it_type, tag_notit_type=ws.tag_notit_type, tag_reward=ws.tag_reward,
+        rule_layer=list(ws.rule_layer), rule_mask=list(ws.rule_mask), rule_become=list(ws.rule_become),
+        action_kind=list(ws.action_kind), beam_radius=ws.beam_radius, clean_beam_type=ws.clean_beam_type,
+        zap_beam_type=ws.zap_beam_type, beam_block_mask=ws.beam_block_mask, reward_total_factor=ws.reward_total_factor,
     )

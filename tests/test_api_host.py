@@ -252,3 +252,100 @@ def test_replay_buffer_matches_reference_ring_semantics():
     s, a, r, ns, dn, valid = buf.sample(3, starts=d["sample_draws"], envs=[0, 0, 0])
     for mine, ref in ((s, d["s"]), (a, d["a"]), (r, d["r"]), (ns, d["ns"]), (dn, d["d"]), (valid, d["valid"])):
         assert np.array_equal(mine.numpy(), ref)
+
+
+# ------------------------------------------------------------------ Cleanup: classes -> tables, pinned by the reference fixture
+CLEANUP_CFG = {
+    "experiment": {"epochs": 1, "max_turns": 40},
+    "env": {"height": 15, "width": 16, "layers": 3, "pollution_threshold": 0.5, "initial_apples": 6,
+            "apple_spawn_chance": 0.03, "pollution_spawn_chance": 0.06, "mode": "DEFAULT"},
+    "agent": {"agent": {"num": 4, "beam_radius": 3, "obs": {"vision": 3, "embeddings": 3}}},
+}
+
+
+def make_cleanup_env(E=3, seed=41, device="cpu", model_factory=None):
+    from sorrel_amd.examples.cleanup.entities import EmptyEntity as CEmpty
+    from sorrel_amd.examples.cleanup.env import CleanupEnv
+    from sorrel_amd.examples.cleanup.world import CleanupWorld
+
+    return CleanupEnv(CleanupWorld(CLEANUP_CFG, CEmpty(), num_envs=E, device=device, seed=seed), CLEANUP_CFG,
+                      model_factory=model_factory)
+
+
+def cleanup_type_map(ws):
+    """fixture type id (oracle/make_golden.py cleanup_spec) -> id in the class-compiled spec."""
+    first, second = {}, {}
+    for t, n in enumerate(ws.type_names):
+        (second if n in first else first)[n] = t
+    order = ["EmptyEntity", "Sand", "Wall", "River", "Pollution", "AppleTree", "Apple"]
+    return np.array([first[n] for n in order] + [first["CleanBeam"], second["CleanBeam"], first["ZapBeam"], second["ZapBeam"],
+                                                  first["CleanupAgent"]], dtype=np.uint8)
+
+
+def test_cleanup_classes_compile_to_the_reference_behaviour():
+    """The Cleanup example's entity / agent classes, compiled to tables and run by the C oracle from
+    the fixture's start state, reproduce what the REFERENCE produced (tests/golden/cleanup_15x16.npz):
+    pins BecomeIfRule / AgeRule / CleanupRule compilation without a GPU."""
+    d, _ = H.load_golden("cleanup_15x16")
+    env = make_cleanup_env(E=1)
+    ws = env.compile_spec()
+    assert ws.agent_rule == 2 and ws.reward_total_factor == 2 and ws.action_kind == [0, 0, 0, 0, 1, 2]
+    assert ws.type_rule.count(RULE_SPAWN) == 2 and ws.type_rule.count(2) == 6
+    tmap = cleanup_type_map(ws)
+    assert sorted(tmap.tolist()) == list(range(12))
+    # the host-built template equals the reference's populate_environment map (apples / agents aside)
+    tmpl = env.world.grid[0].numpy().copy()
+    g0 = tmap[d["grid0"][0]]
+    static = (g0 != tmap[6]) & (g0 != tmap[11]) & (tmpl != tmap[6]) & (tmpl != tmap[11])
+    assert np.array_equal(tmpl[static], g0[static])
+    assert int((tmpl == tmap[6]).sum()) == 6 and int((tmpl[1] == tmap[11]).sum()) == 4
+    for n, env_id in enumerate(int(e) for e in d["env_ids"]):
+        co = H.COracle(ws, 1, first_env_id=env_id)
+        co.grid[0], co.pos[0], co.total[0] = tmap[d["grid0"][n]], d["pos0"][n], 0.0
+        for t in range(d["obs"].shape[0]):
+            assert co.step(0, t + 1, random_actions=True) == 0
+            assert np.array_equal(co.obs[0], d["obs"][t, n]), f"obs turn {t}"
+            assert np.array_equal(co.actions[0], d["actions"][t, n])
+            assert np.array_equal(co.rewards[0], d["rewards"][t, n])
+            assert co.total[0] == d["total_reward"][t, n]
+            assert np.array_equal(co.grid[0], tmap[d["grid"][t, n]]), f"grid turn {t}"
+            assert np.array_equal(co.pos[0], d["pos"][t, n]) and np.array_equal(co.agent_dir[0], d["agent_dir"][t, n])
+
+
+def test_cleanup_observation_positional_code_matches_reference_fixture():
+    """CleanupObservation = flattened visual field ++ positional code; the code rows the reference
+    stored (float32) equal the host-built table gathered at the agents' cells."""
+    from sorrel_amd.observation import embedding
+
+    d, _ = H.load_golden("cleanup_15x16")
+    env = make_cleanup_env(E=2)
+    tab = embedding.positional_embedding_table(env.world, (3, 3)).numpy()
+    assert tab.shape == (15, 16, 12)
+    pos_at_pov = np.concatenate([d["pos0"][None], d["pos"][:-1]], axis=0)      # agent a observes before it moves
+    for t in range(d["obs"].shape[0]):
+        for n in range(d["obs"].shape[1]):
+            for a in range(4):
+                y, x = pos_at_pov[t, n, a]    # its own position only changes in its own act, after its pov
+                assert np.array_equal(tab[y, x], d["pos_code"][t, n, a]), (t, n, a)
+    spec = env.agents[0].observation_spec
+    assert spec.input_size == (1, 9 * 49 + 12)
+    with pytest.raises(ValueError):
+        spec.observe(env.world, None)
+
+
+def test_cleanup_populate_draws_per_env_without_replacement():
+    env = make_cleanup_env(E=64)
+    ws = env.compile_spec()
+    tmap = cleanup_type_map(ws)
+    g = env.world.grid.numpy()
+    assert ((g[:, 0] == tmap[6]).reshape(64, -1).sum(1) == 6).all()            # 6 apples in every env
+    assert ((g[:, 1] == tmap[11]).reshape(64, -1).sum(1) == 4).all()           # 4 agents on distinct cells
+    pos = env.world.agent_pos.numpy()
+    for e in range(64):
+        for a in range(4):
+            assert g[e, 1, pos[e, a, 0], pos[e, a, 1]] == tmap[11]
+            assert g[e, 0, pos[e, a, 0], pos[e, a, 1]] == tmap[1]              # agents start on sand
+    assert len({pos[e].tobytes() for e in range(64)}) > 32                      # placements differ across envs
+    before = g.copy()
+    env.reset()                                                                 # new epoch -> new draw, same template
+    assert not np.array_equal(env.world.grid.numpy(), before)

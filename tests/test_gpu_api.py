@@ -189,6 +189,65 @@ def test_tag_env_through_the_api(torch_cuda):
     assert pov.shape == (E, 4 * 25 + 1) and torch.equal(pov[:, -1].bool(), env.agents[2].its)
 
 
+def test_cleanup_env_through_the_api(torch_cuda):
+    """examples/cleanup through the class API: fused random turns, then the phased policy path
+    (entity sweep, then per agent observe -> policy -> act), both against the C oracle."""
+    torch = torch_cuda
+    from tests.test_api_host import make_cleanup_env
+
+    class BeamHappyPolicy:
+        """Deterministic function of the observation; favours the beam actions."""
+        memory = None
+        device_random = False
+
+        def __init__(self, input_size, n_actions):
+            self.n = n_actions
+            self.seen = []
+
+        def reset(self): pass
+        def start_epoch_action(self, **kw): pass
+        def end_epoch_action(self, **kw): pass
+
+        def take_action(self, state):
+            self.seen.append(state.clone())
+            k = (state[:, :441].sum(dim=1).long() * 5 + (state[:, 441:] > 0).sum(dim=1).long()) % 8
+            return torch.where(k >= 6, k - 2, k % self.n)           # clean / zap twice as likely
+
+    E = 33
+    env = make_cleanup_env(E=E, seed=7, device="cuda:0")
+    ws = env.compile_spec()
+    co = H.COracle(ws, E)
+    co.grid[...] = env.world.grid.cpu().numpy()
+    co.pos[...] = env.world.agent_pos.cpu().numpy()
+    for t in range(1, 31):                                           # fused: on-device random actions
+        env.take_turn()
+        assert co.step(0, t, random_actions=True) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(env.obs.cpu().numpy(), co.obs), f"obs turn {t}"
+        assert np.array_equal(env.world.grid.cpu().numpy(), co.grid), f"grid turn {t}"
+        assert np.array_equal(env.rewards.cpu().numpy(), co.rewards)
+        assert np.array_equal(env.world.total_reward.cpu().numpy(), co.total)
+        assert np.array_equal(env.world.agent_dir.cpu().numpy(), co.agent_dir)
+    assert [a.direction for a in env.agents] == co.agent_dir[0].tolist()
+    pol = make_cleanup_env(E=E, seed=7, device="cuda:0", model_factory=BeamHappyPolicy)
+    co = H.COracle(ws, E)
+    co.grid[...] = pol.world.grid.cpu().numpy()
+    co.pos[...] = pol.world.agent_pos.cpu().numpy()
+    tab = None
+    for t in range(1, 13):                                           # phased: policy-driven
+        pol.take_turn()
+        torch.cuda.synchronize()
+        assert co.step(0, t, actions=pol.actions.cpu().numpy()) == 0  # same actions, whole turn at once
+        assert np.array_equal(pol.world.grid.cpu().numpy(), co.grid), f"phased grid turn {t}"
+        assert np.array_equal(pol.rewards.cpu().numpy(), co.rewards)
+        assert np.array_equal(pol.world.total_reward.cpu().numpy(), co.total)
+        assert np.array_equal(pol.world.agent_dir.cpu().numpy(), co.agent_dir)
+        for a, agent in enumerate(pol.agents):                       # what each policy saw = the oracle's pov-time view
+            seen = agent.model.seen[-1].cpu().numpy()
+            assert np.array_equal(seen[:, :441], co.obs[:, a].reshape(E, -1)), (t, a)
+    assert (co.grid[:, 2] != ws.default_type).any() or (co.total != 0).any()
+
+
 def test_host_built_template_world(torch_cuda):
     """populate_environment with plain world.add(...) calls (the reference's imperative style): the same
     template in every env, basic entities, a user-defined MovingAgent subclass, explicit actions."""

@@ -17,7 +17,7 @@ def test_fixture_inventory():
     names = H.golden_names()
     for must in ("c1_treasurehunt_10x10", "c2_treasurehunt_16x16", "c3_treasurehunt_32x32", "crowded_6x6",
                  "ragged_9x13_rmax", "c5_small_dense", "scripted_noop", "basic_doublewall", "basic_1layer",
-                 "float_appearance_3layer", "rgb_treasurehunt", "tag_9x9", "tag_crowded_6x7", "stock_np_random"):
+                 "float_appearance_3layer", "rgb_treasurehunt", "tag_9x9", "tag_crowded_6x7", "cleanup_15x16", "stock_np_random"):
         assert must in names
 
 
@@ -62,8 +62,9 @@ def test_python_oracle_matches_reference(name):
     turns = d["obs"].shape[0]
     epoch = int(d["epoch"]) if "epoch" in d else 0
     scripted = d["scripted"] if "scripted" in d else None
-    mine = O.rollout(spec, [int(e) for e in d["env_ids"]], turns, epoch=epoch, actions=scripted)
-    for k in KEYS + (("agent_state", "state_at_pov") if "agent_state" in d else ()):
+    injected = (d["grid0"], d["pos0"]) if name in H.INJECTED_FIXTURES else None
+    mine = O.rollout(spec, [int(e) for e in d["env_ids"]], turns, epoch=epoch, actions=scripted, initial=injected)
+    for k in KEYS + (("agent_state", "state_at_pov") if "state_at_pov" in d else ()) + (("agent_dir",) if "agent_dir" in d else ()):
         assert np.array_equal(mine[k], d[k]), f"{name}: {k} differs from the reference"
     assert not d["dones"].any()
 
@@ -76,7 +77,10 @@ def test_c_oracle_matches_reference(name):
     epoch = int(d["epoch"]) if "epoch" in d else 0
     for n, env_id in enumerate(int(e) for e in d["env_ids"]):
         co = H.COracle(ws, 1, first_env_id=env_id, threads=1)
-        co.reset(epoch)
+        if name in H.INJECTED_FIXTURES:      # worlds populated by host code: start from the stored state
+            co.grid[0], co.pos[0] = d["grid0"][n], d["pos0"][n]
+        else:
+            co.reset(epoch)
         assert np.array_equal(co.grid[0], d["grid0"][n]), f"{name}: reset grid"
         assert np.array_equal(co.pos[0], d["pos0"][n]), f"{name}: reset pos"
         for t in range(turns):
@@ -91,6 +95,8 @@ def test_c_oracle_matches_reference(name):
             assert co.total[0] == d["total_reward"][t, n], f"{name}: total_reward turn {t}"
             assert np.array_equal(co.grid[0], d["grid"][t, n]), f"{name}: grid turn {t}"
             assert np.array_equal(co.pos[0], d["pos"][t, n]), f"{name}: pos turn {t}"
+            if "agent_dir" in d:
+                assert np.array_equal(co.agent_dir[0], d["agent_dir"][t, n]), f"{name}: agent_dir turn {t}"
             if "agent_state" in d:
                 assert np.array_equal(co.agent_state[0], d["agent_state"][t, n]), f"{name}: agent_state turn {t}"
                 assert np.array_equal(co.state_at_pov[0], d["state_at_pov"][t, n]), f"{name}: state_at_pov turn {t}"

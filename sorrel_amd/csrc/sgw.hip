@@ -621,6 +621,25 @@ __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, 
     }
 }
 
+#ifdef SGW_STAMPS
+// Diagnostic build only (-DSGW_STAMPS, read with tools/stamps.py): coarse s_memtime stamps per wave, stored per
+// env and segment with plain stores (atomics would serialise), plus where and when the wave started.  Read the
+// SHARES, not the run time.  No stamp executes in the product build.
+constexpr int kStampEnvs = 65536;
+__device__ unsigned long long g_stamps[kStampEnvs * 8];
+#define STAMP(i)                                                                                             \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (lane == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;                \
+        tprev_ = t_;                                                                                         \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
@@ -632,6 +651,14 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps all env-indexed address math scalar
     const int64_t env = (int64_t)blockIdx.x * 4 + sub;
     if (env >= p.E) return;   // whole wave exits together
+#ifdef SGW_STAMPS
+    unsigned long long tprev_ = 0;
+    STAMP(0);
+    if (lane == 0 && env < kStampEnvs) {   // where and when this wave started
+        g_stamps[env * 8 + 6] = tprev_;
+        g_stamps[env * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#endif
 
     const int L = TL ? TL : p.L;
     const int C = TC ? TC : p.C;
@@ -701,6 +728,10 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     {
         double tot = p.do_move ? p.total[env] : 0.0;
 
+#ifdef SGW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(1);   // global loads have arrived
         // ---- grid -> LDS; the Bernoulli half of the sweep runs on the registers
         uint32_t hits[NU];
         if constexpr (!kStatic) {
@@ -736,6 +767,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             gsync<1>();
         }
 
+        STAMP(2);   // sweep done
         // ---- everything about agent `lane`'s move that does not depend on the other agents
         const uint32_t py = yx & 0xFFu, px = yx >> 8;
         uint32_t taddr_v = 0xFFFFFFFFu;          // target cell (LDS byte offset) or "invalid"
@@ -762,6 +794,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         const uint32_t oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;   // own cell
         uint32_t rew_bits = 0, moved = 0;
 
+        STAMP(3);   // move inputs (action draw) done
         // ---- agents, strictly in list order
         for (int a = p.a0; a < p.a1; ++a) {
             const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
@@ -891,6 +924,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             gsync<1>();
         }
 
+        STAMP(4);   // agent loop done
         if (dirty) {
             uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll
@@ -907,6 +941,11 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             if (TAG && p.agent_state && lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)atype;   // a tag can flip any agent
             if (lane == 0) p.total[env] = tot;
         }
+        STAMP(5);   // all stores issued
+#ifdef SGW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(6);   // all stores acknowledged
     }
 }
 
@@ -1644,6 +1683,12 @@ int time_end(sgw_engine* e, hipStream_t s) {
 extern "C" {
 
 const char* sgw_last_error(void) { return g_err; }
+#ifdef SGW_STAMPS
+int sgw_debug_stamps(unsigned long long* out) {   // diagnostic builds only; not part of the ABI: [kStampEnvs][8] of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * kStampEnvs) == hipSuccess ? 0 : -1;
+}
+#endif
+
 const char* sgw_version(void) { return "sgw 0.1 (gfx950)"; }
 
 int64_t sgw_obs_elems_per_env(const sgw_config* c) {

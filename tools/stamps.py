@@ -1,0 +1,62 @@
+"""Diagnostic: per-segment share of a step_fast wave's lifetime, slot relaunch gaps and per-SIMD occupancy.
+Needs a -DSGW_STAMPS build of the library: SGW_LIB=<that .so> PYTHONPATH=. python tools/stamps.py [E]."""
+import ctypes as C
+import sys
+
+import torch
+
+from sorrel_amd import _native as N
+from sorrel_amd.engine import GridEngine
+from sorrel_amd.spec import treasurehunt_spec
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+spec = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=0)
+eng = GridEngine(spec, E, device="cuda:0")
+eng.reset(0)
+lib = N.load()
+import numpy as np
+
+buf = np.zeros((65536, 8), np.uint64)
+for _ in range(10):
+    eng.step(random_actions=True)
+torch.cuda.synchronize()
+lib.sgw_debug_stamps(buf.ctypes.data_as(C.c_void_p))
+b = buf[:E, :6].astype(np.float64)
+names = ["launch->loads arrived", "grid->LDS + sweep", "move inputs (action draw)", "agent loop (obs + moves)", "write-back issue", "store drain"]
+tot = b.sum(axis=1)
+for i, n in enumerate(names):
+    print(f"{n:28s} mean {b[:, i].mean():9.0f}  median {np.median(b[:, i]):9.0f}  p90 {np.percentile(b[:, i], 90):9.0f} ticks  {100.0 * b[:, i].sum() / tot.sum():5.1f} %")
+print(f"{'total':28s} mean {tot.mean():9.0f}  median {np.median(tot):9.0f} ticks per wave")
+# ---- timeline: per SIMD, how long is a wave slot empty between two waves?
+start = buf[:E, 6].astype(np.int64)
+end = start + buf[:E, :6].sum(axis=1).astype(np.int64)
+hw = buf[:E, 7]
+wave_id = (hw & 0xF).astype(np.int64)
+simd = ((hw >> 4) & 3).astype(np.int64)
+cu = ((hw >> 8) & 0xF).astype(np.int64)
+sh = ((hw >> 12) & 1).astype(np.int64)
+se = ((hw >> 13) & 7).astype(np.int64)
+xcc = ((hw >> 32) & 0xF).astype(np.int64)
+print("distinct xcc", len(np.unique(xcc)), "se", len(np.unique(se)), "sh", len(np.unique(sh)), "cu", len(np.unique(cu)), "simd", len(np.unique(simd)), "wave ids", np.unique(wave_id))
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+slot = key * 16 + wave_id
+print("distinct SIMDs used", len(np.unique(key)), "distinct slots", len(np.unique(slot)))
+gaps, lives = [], []
+for x in np.unique(xcc):
+    m = xcc == x
+    t0 = start[m].min()
+    print(f"xcc {x}: waves {m.sum()}  first start 0  last end {(end[m].max() - t0)} ticks")
+order = np.lexsort((start, slot))
+ss, st, en = slot[order], start[order], end[order]
+same = ss[1:] == ss[:-1]
+gap = (st[1:] - en[:-1])[same]
+print(f"slot relaunch gap: mean {gap.mean():.0f}  median {np.median(gap):.0f}  p90 {np.percentile(gap, 90):.0f}  max {gap.max()} ticks  (wave life mean {np.mean(en - st):.0f})")
+# per-SIMD occupancy over the kernel: sum(life) / (8 slots * span)
+occ = []
+for k in np.unique(key)[:2000]:
+    m = key == k
+    span = end[m].max() - start[m].min()
+    occ.append((end[m] - start[m]).sum() / (8.0 * span))
+print(f"per-SIMD occupancy over its own span: mean {np.mean(occ):.3f}  min {np.min(occ):.3f}")
+per_simd = np.bincount(np.unique(key, return_inverse=True)[1])
+print("waves per SIMD: min", per_simd.min(), "max", per_simd.max(), "mean", per_simd.mean())

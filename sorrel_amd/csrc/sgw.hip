@@ -622,7 +622,7 @@ __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, 
 }
 
 #ifdef SGW_STAMPS
-// Diagnostic build only (-DSGW_STAMPS, read with tools/stamps.py): coarse s_memtime stamps per wave, stored per
+// Diagnostic build only (-DSGW_STAMPS, read with tools/stamps.py): coarse s_memrealtime stamps (10 ns, chip-wide) per wave, stored per
 // env and segment with plain stores (atomics would serialise), plus where and when the wave started.  Read the
 // SHARES, not the run time.  No stamp executes in the product build.
 constexpr int kStampEnvs = 65536;
@@ -631,7 +631,7 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         unsigned long long t_;                                                                               \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   /* 100 MHz, chip-wide */                          \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (lane == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;                \
         tprev_ = t_;                                                                                         \

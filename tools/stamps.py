@@ -60,3 +60,20 @@ for k in np.unique(key)[:2000]:
 print(f"per-SIMD occupancy over its own span: mean {np.mean(occ):.3f}  min {np.min(occ):.3f}")
 per_simd = np.bincount(np.unique(key, return_inverse=True)[1])
 print("waves per SIMD: min", per_simd.min(), "max", per_simd.max(), "mean", per_simd.mean())
+
+# ---- phase mix over time on one XCD: do the waves run in convoys (all loading, then all storing)?
+x = xcc == np.unique(xcc)[0]
+t0 = start[x].min()
+seg = np.cumsum(np.concatenate([np.zeros((x.sum(), 1)), buf[:E][x][:, :6].astype(np.float64)], axis=1), axis=1) + (start[x] - t0)[:, None]
+T = seg[:, -1].max()
+bins = np.arange(0, T, 100.0)   # 1 us
+names2 = ["loadwait", "sweep", "action", "agents", "wb+drain"]
+rows = []
+for tb in bins:
+    c = [int(((seg[:, i] <= tb) & (seg[:, i + 1] > tb)).sum()) for i in range(4)]
+    c.append(int(((seg[:, 4] <= tb) & (seg[:, 6] > tb)).sum()))
+    rows.append(c)
+rows = np.array(rows)
+print("time(us)   " + " ".join(f"{n:>9s}" for n in names2) + "   resident")
+for tb, r in list(zip(bins, rows))[:: max(1, len(bins) // 120)]:
+    print(f"{tb / 100:9.1f}  " + " ".join(f"{v:9d}" for v in r) + f"   {r.sum():7d}")

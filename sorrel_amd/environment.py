@@ -89,6 +89,7 @@ class Environment:
         self.epoch = 0
         self._engine = None
         self._engine_version = -1
+        self._aux_engines = {}
         self._device_populated = False
         self.world.create_world()
         self.stop_if_done = stop_if_done
@@ -132,11 +133,15 @@ class Environment:
         eng = self._ensure_engine()
         eng.reset(epoch=self.epoch)
 
-    def compile_spec(self) -> WorldSpec:
-        """Entities, agents, observation spec and action spec -> the engine's tables."""
+    def compile_spec(self, ospec=None) -> WorldSpec:
+        """Entities, agents, observation spec and action spec -> the engine's tables.  ``ospec``
+        compiles another observation spec than the agents' own (on-demand observations)."""
         w, agents = self.world, self.agents
-        ospec, aspec = agents[0].observation_spec, agents[0].action_spec
-        for a in agents[1:]:
+        aspec = agents[0].action_spec
+        shared = ospec is None
+        if shared:
+            ospec = agents[0].observation_spec
+        for a in agents[1:] if shared else ():
             o = a.observation_spec
             if type(o) is not type(ospec) or o.vision_radius != ospec.vision_radius or \
                     o.fill_entity_kind != ospec.fill_entity_kind or \
@@ -144,7 +149,7 @@ class Environment:
                     any(not np.array_equal(o.entity_map[k], ospec.entity_map[k]) for k in o.entity_map) or \
                     a.action_spec.names != aspec.names:
                 raise ValueError("all agents of one batched Environment must share observation and action specs")
-        if ospec.full_view:
+        if ospec.full_view and shared:
             raise ValueError("full_view observation specs are not part of the fused step; use observe() on demand")
         rule = getattr(agents[0], "interaction_rule", None)
         extra = dict(agent_rule=0)
@@ -288,17 +293,46 @@ class Environment:
                 agent.transition(self.world)
 
     # ------------------------------------------------------------------ kernels behind the agent hooks
-    def _observe(self, who):
-        """[E, C, V, V] float32 of an agent slot (Agent / int), or from a (y, x, z) cell."""
+    @staticmethod
+    def _ospec_key(ospec):
+        return (type(ospec).__name__, int(ospec.vision_radius), ospec.fill_entity_kind, int(getattr(ospec, "obs_post", 0)),
+                tuple((k, np.asarray(v, dtype=np.float64).tobytes()) for k, v in ospec.entity_map.items()))
+
+    def _engine_for(self, ospec):
+        """The engine whose tables were compiled from ``ospec``: the step engine when it is (equal to) the
+        agents' own spec, otherwise a second handle over the same grid / position tensors, built on first
+        use (``observe`` with another entity map, radius or fill kind -- ``visual_field`` with arguments)."""
         eng = self._ensure_engine()
+        if ospec is None or self._ospec_key(ospec) == self._ospec_key(self.agents[0].observation_spec):
+            return eng
+        from sorrel_amd.engine import GridEngine
+
+        key = (self._ospec_key(ospec), self.world.registry.version)
+        aux = self._aux_engines.get(key)
+        if aux is None:
+            w = self.world
+            spec = self.compile_spec(ospec)
+            if len(w.registry) != eng.spec.num_types:     # the new spec registered a fill type: rebuild the step engine too
+                eng = self._ensure_engine()
+                key = (self._ospec_key(ospec), w.registry.version)
+            aux = GridEngine(spec, w.num_envs, device=w.device, first_env_id=getattr(w, "first_env_id", 0),
+                             tensors=dict(grid=w.grid, agent_pos=w.agent_pos), allocate_obs=False)
+            self._aux_engines = {k: v for k, v in self._aux_engines.items() if k[1] == w.registry.version}
+            self._aux_engines[key] = aux
+        return aux
+
+    def _observe(self, who, ospec=None):
+        """[E, C, V, V] float32 of an agent slot (Agent / int), or from a (y, x, z) cell, as seen through
+        ``ospec`` (default: the agents' own observation spec)."""
+        eng = self._engine_for(ospec)
+        own = eng is self._engine
         if isinstance(who, Agent):
             who = who.slot
         if isinstance(who, int):
-            eng.observe(who, who + 1)
-            return eng.obs[:, who]
-        y, x, z = (int(v) for v in who)
-        if z != self.world.agent_layer:
-            pass  # the window is layer-summed: only (y, x) matters
+            out = eng.obs if own else eng.scratch_obs()
+            eng.observe(who, who + 1, out=out)
+            return out[:, who]
+        y, x, _z = (int(v) for v in who)          # the window is layer-summed: only (y, x) matters
         pos = torch.zeros_like(eng.agent_pos)
         pos[:, 0, 0], pos[:, 0, 1] = y, x
         eng.observe(0, 1, pos=pos, out=eng.scratch_obs())
@@ -307,7 +341,7 @@ class Environment:
     def _full_view(self, ospec):
         """Whole-map appearance summed over layers, ``[E, C, H, W]`` (``visual_field.py:41-55``)."""
         w = self.world
-        spec = self.compile_spec()
+        spec = self.compile_spec(ospec)
         app = torch.tensor(spec.appearance, dtype=torch.float64, device=w.device)        # [T, C]
         out = app[w.grid.long()].sum(dim=1).permute(0, 3, 1, 2).contiguous()
         if getattr(ospec, "obs_post", 0) == 1:

@@ -71,7 +71,7 @@ class ObservationSpec:
             raise RuntimeError("the world is not attached to an Environment (the engine is compiled there)")
         if self.full_view:
             return env._full_view(self)
-        return env._observe(location)
+        return env._observe(location, self)
 
 
 class OneHotObservationSpec(ObservationSpec):

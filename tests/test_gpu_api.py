@@ -139,6 +139,49 @@ def test_observe_from_arbitrary_cell_and_full_view(torch_cuda):
         assert np.array_equal(fv[e], want)
 
 
+def test_other_observation_specs_and_visual_field_on_demand(torch_cuda):
+    """A spec that differs from the agents' own (radius, entity map, fill kind) gets its own compiled
+    handle over the same grid; ``visual_field`` takes the same road (reference signature)."""
+    torch = torch_cuda
+    from sorrel_amd.observation.observation_spec import OneHotObservationSpec
+    from sorrel_amd.observation.visual_field import visual_field
+    from sorrel_amd.examples.treasurehunt.env import ENTITY_LIST
+
+    E = 5
+    env = make_env(12, 12, 2, 2, E, dense=0.3)
+    base = H.oracle_spec(env.compile_spec())
+    states = [O.reset_env(base, e, epoch=0) for e in range(E)]
+    wide = OneHotObservationSpec(ENTITY_LIST, full_view=False, vision_radius=4, fill_entity_kind="Gem")
+    ospec_wide = H.oracle_spec(env.compile_spec(wide))
+    assert ospec_wide.vision_radius == 4 and ospec_wide.fill_type != base.fill_type
+    got = wide.observe(env.world, env.agents[1]).cpu().numpy()
+    own = env.agents[1].observation_spec.observe(env.world, env.agents[1]).cpu().numpy()
+    assert got.shape == (E, 6, 9, 9) and own.shape == (E, 6, 5, 5)
+    for e in range(E):
+        y, x = states[e].pos[1]
+        assert np.array_equal(got[e], O.visual_field(ospec_wide, states[e].grid, int(y), int(x)).astype(np.float32))
+        assert np.array_equal(own[e], O.visual_field(base, states[e].grid, int(y), int(x)).astype(np.float32))
+    # visual_field(world, entity_map, vision, location, fill_entity_kind): a float table, from a cell
+    emap = {k: np.array([i * 0.5, 1.0]) for i, k in enumerate(ENTITY_LIST)}
+    vf = visual_field(env.world, emap, vision=3, location=(2, 9, 1), fill_entity_kind="Wall").cpu().numpy()
+    adhoc = OneHotObservationSpec(ENTITY_LIST, full_view=False, vision_radius=3)
+    adhoc.override_entity_map(emap)
+    ospec_f = H.oracle_spec(env.compile_spec(adhoc))
+    assert vf.shape == (E, 2, 7, 7)
+    for e in range(E):
+        assert np.array_equal(vf[e], O.visual_field(ospec_f, states[e].grid, 2, 9).astype(np.float32))
+    full = visual_field(env.world, emap).cpu().numpy()              # vision None -> whole map
+    for e in range(E):
+        assert np.array_equal(full[e], ospec_f.appearance[states[e].grid].sum(axis=0).transpose(2, 0, 1))
+    with pytest.raises(KeyError):                                    # a placed kind the map does not know
+        visual_field(env.world, {"EmptyEntity": np.zeros(2), "Wall": np.ones(2)}, vision=2, location=(3, 3, 1))
+    # the step engine is untouched by all this
+    env.take_turn()
+    for e in range(E):
+        o, a, r = O.step_env(base, states[e], e, 0, 1)
+        assert np.array_equal(env.obs[e].cpu().numpy(), o)
+
+
 def test_rgb_observation_spec_through_the_api(torch_cuda):
     """config model.observation_spec = "rgb" (examples/treasurehunt/main.py:24): clip(sum, 0, 255) / 255."""
     torch = torch_cuda

@@ -32,3 +32,59 @@ run("tag 32x32x1 A8 r3", tag_spec(32, 32, 8, 3), 65536)
 run("treasurehunt 10x10x2 A2 r2 (ragged)", treasurehunt_spec(10, 10, 2, 2), 65536)
 run("treasurehunt 21x21x2 A2 r2 (default)", treasurehunt_spec(21, 21, 2, 2), 65536)
 run("treasurehunt 32x32x2 A8 r3 (fast)", treasurehunt_spec(32, 32, 8, 3), 65536)
+
+
+def run_observe(name, spec, E, K=100):
+    """K1 alone: sgw_observe of all agents (grid read + observation stores, no sweep, no moves)."""
+    eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
+    for _ in range(5): eng.observe()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(K): eng.observe()
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) / K * 1000
+    byt = (spec.grid_bytes_per_env() + spec.num_agents * spec.num_channels * spec.window ** 2 * 4) * E
+    print(f"{name:34s} E={E:7d} {us:8.1f} us/call  {byt/us/1e3:7.1f} GB/s")
+
+
+def cleanup_spec(h, w, a, r):
+    """The Cleanup tables of tests/golden/cleanup_15x16 at another size (types as in oracle/make_golden.py)."""
+    import json
+    d = np.load("tests/golden/cleanup_15x16.npz", allow_pickle=True)
+    s = json.loads(str(d["spec_json"]))
+    s.update(height=h, width=w, num_agents=a, vision_radius=r, agent_type=[11] * a, spawn_prob=[0, 0, 0, 0.009, 0, 0.002] + [0] * 6)
+    names = WorldSpec.__dataclass_fields__.keys()
+    kw = {k: v for k, v in s.items() if k in names}
+    kw["appearance"] = np.asarray(s["appearance"], dtype=np.float64)
+    kw["spawn_choices"] = s["spawn_choices"]
+    return WorldSpec(**kw)
+
+
+run_observe("observe only 32x32x2 A8 r3", treasurehunt_spec(32, 32, 8, 3), 65536)
+
+
+def run_cleanup(E=16384, K=50):
+    spec = cleanup_spec(21, 31, 10, 5)
+    eng = GridEngine(spec, E, device="cuda:0")
+    # the reference's map: walls around, river on top, orchard at the bottom, agents on the sand in between
+    g = np.zeros((3, 21, 31), np.uint8)
+    g[:, 0, :] = g[:, -1, :] = 2; g[:, :, 0] = g[:, :, -1] = 2
+    g[0, 1:7, 1:-1] = 3; g[0, 14:20, 1:-1] = 5; g[0, 7:14, 1:-1] = 1
+    pos = np.array([[8 + (i // 5) * 2, 3 + (i % 5) * 5] for i in range(10)], np.uint8)
+    for (y, x) in pos: g[1, y, x] = 11
+    eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+    eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+    for _ in range(5): eng.step(random_actions=True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(K): eng.step(random_actions=True)
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) / K * 1000
+    byt = spec.algorithmic_bytes_per_env_step() * E
+    print(f"{'cleanup 21x31x3 A10 r5 (generic)':34s} E={E:7d} {us:8.1f} us/step  {E*10/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)")
+    assert eng.status() == 0
+
+
+run_cleanup()

@@ -1916,7 +1916,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
     p.env_lds = e->step_env_lds;
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
-    if (p.spawn_mask == 0) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
+    if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), e->step_lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);

@@ -157,3 +157,66 @@ def oracle_spec(ws: WorldSpec) -> O.Spec:
         action_kind=list(ws.action_kind), beam_radius=ws.beam_radius, clean_beam_type=ws.clean_beam_type,
         zap_beam_type=ws.zap_beam_type, beam_block_mask=ws.beam_block_mask, reward_total_factor=ws.reward_total_factor,
     )
+
+
+def random_rule_world(rng):
+    """A random layered world for the widened rule set: 2-4 layers, spawners and BECOME_IF rules with random
+    layer / mask / successor tables, timers (unconditional become chains), Cleanup or Tag agents, random map."""
+    from sorrel_amd.spec import WorldSpec, action_deltas, NO_BORDER
+    from sorrel_amd import _native as N
+
+    L = int(rng.integers(2, 5))
+    h, w = int(rng.integers(6, 26)), int(rng.integers(6, 26))
+    r = int(rng.integers(1, min((min(h, w) - 1) // 2, 4) + 1))
+    a = int(rng.integers(1, min(10, (h - 2) * (w - 2) // 2) + 1))
+    zA = int(rng.integers(0, L - 1))                      # a layer above the agents always exists
+    mode = rng.choice(["cleanup", "move", "tag"], p=[0.5, 0.3, 0.2])
+    cleanup = mode == "cleanup"
+    # types: 0 empty (passable), 1 wall, 2..T-2 random things, T-1 agent (+ T-2 second agent type for Tag)
+    T = int(rng.integers(6, 14))
+    agent_t = T - 1
+    C = int(rng.integers(2, 9))
+    app = np.zeros((T, C))
+    for t in range(1, T):
+        app[t, int(rng.integers(0, C))] = 1.0 if rng.random() < 0.8 else float(rng.integers(2, 5))
+    value = [0.0, -1.0] + [float(rng.choice([0, 1, -1, 5, 0.5])) for _ in range(T - 3)] + [0.0]
+    passable = [1, 0] + [int(rng.random() < 0.5) for _ in range(T - 3)] + [0]
+    rule, sp, sc = [0] * T, [0.0] * T, [[] for _ in range(T)]
+    rl, rm, rb = [0] * T, [0] * T, [0] * T
+    for t in range(2, T - 1):
+        u = rng.random()
+        if u < 0.3:
+            rule[t] = N.RULE_SPAWN
+            sp[t] = float(rng.choice([0.02, 0.2, 1.0]))
+            sc[t] = [int(x) for x in rng.integers(0, T - 1, size=int(rng.integers(1, 4)))]
+        elif u < 0.65:
+            rule[t] = N.RULE_BECOME_IF
+            rl[t] = int(rng.integers(-1, L))
+            rm[t] = int(rng.integers(0, 1 << T))
+            rb[t] = int(rng.integers(0, T - 1))
+    if mode == "tag":               # two impassable agent types: T-2 = "it", T-1 = not "it"
+        rule[T - 2], sp[T - 2], sc[T - 2], value[T - 2], passable[T - 2] = 0, 0.0, [], 0.0, 0
+    names = ["up", "down", "left", "right"] + (["clean", "zap"] if cleanup else ["stay"])
+    dy, dx = action_deltas(names)
+    kw = {}
+    if cleanup:
+        kw = dict(agent_rule=2, action_kind=[0, 0, 0, 0, 1, 2], beam_radius=int(rng.integers(0, 5)),
+                  clean_beam_type=int(rng.integers(2, T - 1)), zap_beam_type=int(rng.integers(2, T - 1)),
+                  beam_block_mask=int(rng.integers(0, 1 << T)) | 2, reward_total_factor=int(rng.integers(1, 3)))
+    if mode == "tag":
+        kw = dict(agent_rule=1, tag_it_type=T - 2, tag_notit_type=T - 1, tag_reward=float(rng.choice([10, 1, 0.5])))
+    ws = WorldSpec(height=h, width=w, layers=L, num_agents=a, vision_radius=r, num_channels=C, agent_layer=zA,
+                   default_type=0, fill_type=1, action_dy=dy, action_dx=dx, agent_type=[agent_t] * a,
+                   type_value=value, type_passable=passable, type_rule=rule, spawn_prob=sp, spawn_choices=sc,
+                   appearance=app, seed=int(rng.integers(0, 2**40)), layer_fill_type=[0] * L,
+                   layer_border_type=[1] * L, rule_layer=rl, rule_mask=rm, rule_become=rb, **kw)
+    # the map: walls around every layer, random things inside, agents on distinct interior cells of their layer
+    g = np.zeros((L, h, w), np.uint8)
+    g[:, 0, :] = g[:, -1, :] = g[:, :, 0] = g[:, :, -1] = 1
+    inner = rng.random((L, h - 2, w - 2)) < 0.35
+    g[:, 1:-1, 1:-1] = np.where(inner, rng.integers(2, T - 2, size=inner.shape), 0).astype(np.uint8)
+    cells = rng.permutation((h - 2) * (w - 2))[:a]
+    pos = np.stack([cells // (w - 2) + 1, cells % (w - 2) + 1], axis=1).astype(np.uint8)
+    for y, x in pos:
+        g[zA, y, x] = agent_t
+    return ws, g, pos

@@ -4,6 +4,8 @@ on the same seeded inputs at sizes it finishes in seconds, and (3) size-independ
 properties at BASELINE.json's full sizes.  Integer / byte / index work: bit-exact.
 Observations and rewards are float32 holding exactly representable values and are
 compared bit-exactly as well (np.array_equal)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -299,7 +301,7 @@ def _random_world(rng):
     return ws
 
 
-@pytest.mark.parametrize("case", range(48))
+@pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "48"))))
 def test_random_worlds_vs_oracle(torch_cuda, case):
     """Soak: random shapes / agent counts / radii / rates through whichever kernel the dispatcher
     picks (step_fast, step_big, generic), a few dozen envs, every tensor compared every turn."""
@@ -307,6 +309,37 @@ def test_random_worlds_vs_oracle(torch_cuda, case):
     ws = _random_world(rng)
     rollout_vs_oracle(ws, int(rng.integers(3, 40)), int(rng.integers(2, 7)), first=int(rng.integers(0, 2**31)),
                       epoch=int(rng.integers(0, 50)))
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "64"))))
+def test_random_rule_worlds_vs_oracle(torch_cuda, case):
+    """Soak for the widened rule set (ordered BECOME_IF sweep across layers, timers, several spawners, Cleanup
+    beams / facing / all-layer reward) from random maps: every tensor against the C oracle every turn."""
+    import torch
+    rng = np.random.default_rng(7000 + case)
+    ws, g, pos = H.random_rule_world(rng)
+    E, T = int(rng.integers(2, 30)), int(rng.integers(3, 12))
+    first = int(rng.integers(0, 2**31))
+    eng = make_engine(ws, E, first=first)
+    co = H.COracle(ws, E, first_env_id=first)
+    eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+    eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+    eng.total_reward.zero_()
+    co.grid[...] = g
+    co.pos[...] = pos
+    co.total[...] = 0
+    epoch = int(rng.integers(0, 9))
+    eng.epoch = epoch
+    for t in range(1, T + 1):
+        eng.step(random_actions=True)
+        assert co.step(epoch, t, random_actions=True) == 0
+        assert_same(eng, co, ctx=f"case {case} turn {t}")
+        if eng.agent_dir is not None:
+            assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), f"case {case} turn {t}: agent_dir"
+        if eng.agent_state is not None:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), f"case {case} turn {t}: agent_state"
+            assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov), f"case {case} turn {t}: state_at_pov"
+    assert eng.status() == 0
 
 
 def test_high_spawn_prob_and_certain_spawn(torch_cuda):

@@ -330,10 +330,17 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case):
     co.total[...] = 0
     epoch = int(rng.integers(0, 9))
     eng.epoch = epoch
+    phased = case % 3 == 1          # a third of the cases: sweep-only call, then one call per agent (policy path)
     for t in range(1, T + 1):
-        eng.step(random_actions=True)
         assert co.step(epoch, t, random_actions=True) == 0
-        assert_same(eng, co, ctx=f"case {case} turn {t}")
+        if phased:
+            acts = torch.from_numpy(co.actions.copy())
+            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t, advance_turn=False)
+            for a in range(ws.num_agents):
+                eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t, advance_turn=False)
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+        assert_same(eng, co, ctx=f"case {case} turn {t}{' (phased)' if phased else ''}")
         if eng.agent_dir is not None:
             assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), f"case {case} turn {t}: agent_dir"
         if eng.agent_state is not None:

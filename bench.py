@@ -100,6 +100,19 @@ def main() -> int:
     ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
     args = ap.parse_args()
 
+    # the C-ABI library travels with the tree; if it is missing or older than its source (a fresh checkout on a box
+    # with hipcc) build it once -- ranks of one node take turns on a lock file, the first one builds
+    import fcntl
+
+    import __graft_entry__ as graft
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            graft.build_hip()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
     import torch
     import torch.distributed as dist
 

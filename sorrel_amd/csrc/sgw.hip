@@ -106,6 +106,7 @@ struct Params {
     double* total;
     const DevTables* tab;
     int* status;
+    int obs_stage;    // step_fast: bytes of the per-wave LDS observation staging area (0: observations go straight to HBM)
 };
 
 // ---------------------------------------------------------------- RNG
@@ -709,6 +710,12 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(wl);
     uint8_t* lg = wl + p.tab_bytes;
     uint4* lg16 = reinterpret_cast<uint4*>(lg);
+    // One-hot observations of a whole env are staged in LDS as byte counts in their final [A][C][V][V] order and
+    // leave for HBM in one burst of 16-byte stores after the agent loop (instead of 6 dword stores per agent
+    // dribbling out over the wave's life): the chip then has far fewer half-written observation streams open.
+    uint8_t* ob = lg + ((cells + 15) & ~15);
+    // (fixed-shape kernels only: the run-time-shape variants sit at the 64-VGPR limit and the extra code makes them spill)
+    const bool stage = ONEHOT && (TL && TH && TW) && p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A;
 
     // per-lane window geometry: up to two cells per lane
     int wdi[2], wdj[2], woff[2];
@@ -831,7 +838,17 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                             }
 #pragma unroll
                             for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
-                            if (!p.obs_u8) {
+                            if (stage) {
+                                uint8_t* os = ob + (a * C) * VV + w;
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) os[c * VV] = (uint8_t)(cnt[q] >> (8 * b));
+                                    }
+                                }
+                            } else if (!p.obs_u8) {
 #pragma unroll
                                 for (int q = 0; q < NW; ++q) {
 #pragma unroll
@@ -926,6 +943,21 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         }
 
         STAMP(4);   // agent loop done
+        if (stage && write_obs) {
+            gsync<1>();
+            const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
+            const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
+            if (!p.obs_u8) {
+                float4* o4 = reinterpret_cast<float4*>(p.obs + env * (int64_t)(p.A * C * VV));
+                for (int i = lane; i < nd; i += 64) {
+                    const uint32_t b = ob4[i];
+                    o4[i] = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24));
+                }
+            } else {
+                uint32_t* o1 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.obs) + env * (int64_t)(p.A * C * VV));
+                for (int i = lane; i < nd; i += 64) o1[i] = ob4[i];
+            }
+        }
         if (dirty) {
             uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll
@@ -1521,6 +1553,7 @@ struct sgw_engine {
     size_t lds_bytes = 0;       // reset / generic step
     size_t step_lds_bytes = 0;  // step kernel actually launched
     int step_env_lds = 0;
+    int obs_stage = 0;     // bytes of LDS observation staging per wave (step_fast, one-hot)
     int fast_tab_bytes = 0;
     int grid_blocks = 1;
     int fast_wg_cap = 6;   // step_fast workgroups per CU when writing float32 observations of a large batch (0: no cap)
@@ -1828,12 +1861,20 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
     e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move && simple_rules;
-    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
+    {   // LDS staging of one-hot observations: whole envs of a multiple of 4 elements, at most 4 KiB of byte counts
+        const int ob_elems = c.num_agents * c.num_channels * p.VV;
+        const bool fixed_shape = c.layers == 2 && c.num_channels == 6 && ((c.height == 32 && c.width == 32 && c.vision_radius == 3) ||
+                                                                         (c.height == 16 && c.width == 16 && c.vision_radius == 2));   // = pick_fast's fixed-shape kernels
+        e->obs_stage = (e->fast && onehot && fixed_shape && c.agent_rule != SGW_AGENT_RULE_TAG && (ob_elems & 3) == 0 && ob_elems <= 4096) ? ((ob_elems + 15) & ~15) : 0;
+        if (const char* f = getenv("SGW_NO_STAGE")) { if (f[0] == '1') e->obs_stage = 0; }   // test / tuning hook
+    }
+    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad + e->obs_stage : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
         if (f[0] == '1') e->fast = e->big = false;
     }
-    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad : p.env_lds;
+    if (!e->fast) e->obs_stage = 0;
+    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad + e->obs_stage : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
@@ -1919,12 +1960,14 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
     p.env_lds = e->step_env_lds;
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
+    p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // float32 observations of a large batch: six instead of eight waves per SIMD run 7 % faster (config 3: 183 ->
-    // 170 us, 524 288 envs: 1.48 -> 1.37 ms; fewer concurrent write streams into HBM), the uint8 format and
-    // small batches are fastest at full occupancy.  The cap is an LDS request that fits 6 workgroups per CU.
+    // float32 observations written straight from the agent loop (no LDS staging) of a large batch: six instead of
+    // eight waves per SIMD run 7 % faster (config 3: 183 -> 170 us, 524 288 envs: 1.48 -> 1.37 ms; fewer half-written
+    // observation streams open in HBM); the staged burst emit, the uint8 format and small batches are fastest at
+    // full occupancy.  The cap is an LDS request that fits 6 workgroups per CU.
     size_t lds = e->step_lds_bytes;
-    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 > p.a0 &&
+    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 > p.a0 && !p.obs_stage &&
         p.E >= (int64_t)e->num_cus * 32 * 2)
         lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap) & ~(size_t)511);
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);

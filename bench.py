@@ -87,7 +87,7 @@ def cpu_baseline(spec, seconds_target: float = 12.0):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the config's)")

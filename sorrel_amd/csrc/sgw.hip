@@ -1962,12 +1962,13 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // float32 observations of a large batch: six instead of eight waves per SIMD (an LDS request that fits 6
-    // workgroups per CU).  Boxes of the pool differ: at full occupancy the staged kernel runs config 3 in 153 us on
-    // some and 188 us on others, with the cap in 156 and 164 us; unstaged 166/184 -> 161/171 us.  The uint8 format
-    // and small batches are fastest at full occupancy.
+    // The staged float32 emit of a large batch (configs 3/4): six instead of eight waves per SIMD (an LDS request that
+    // fits 6 workgroups per CU).  Boxes of the pool differ: at full occupancy this kernel runs config 3 in 153 us
+    // on some and 188 us on others, with the cap in 156 and 164 us.  Everything else -- the uint8 format, small
+    // batches, and the shapes with small windows, which are latency- rather than memory-bound (Tag 11x11: 164 us at
+    // full occupancy, 192 us capped) -- is fastest at full occupancy and is not capped.
     size_t lds = e->step_lds_bytes;
-    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 > p.a0 &&
+    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 > p.a0 && p.obs_stage &&
         p.E >= (int64_t)e->num_cus * 32 * 2)
         lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap) & ~(size_t)511);
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);

@@ -119,6 +119,7 @@ extern "C" {
 #define SGW_STATUS_OOB_MOVE 1   /* an agent targeted a cell outside the grid (reference: IndexError / wrap) */
 #define SGW_STATUS_BAD_ACTION 2 /* action index >= num_actions */
 #define SGW_STATUS_BAD_TYPE 4   /* grid holds a type id >= num_types */
+#define SGW_STATUS_BAD_POS 8    /* an agent position outside the grid was passed in (treated as (0, 0): memory-safe, result undefined) */
 
 typedef struct sgw_config {
     int32_t height, width, layers;

@@ -16,7 +16,7 @@ OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
 ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2
 OBS_F32, OBS_U8 = 0, 1
-STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE = 1, 2, 4
+STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE, STATUS_BAD_POS = 1, 2, 4, 8
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
 

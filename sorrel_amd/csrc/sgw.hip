@@ -334,7 +334,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
         double tot = 0.0;
         if (gtid == 0 && p.do_move) tot = p.total[env];
         if (gtid < p.A) {
-            const uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
+            uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
+            if ((yx & 0xFF) >= p.H || (yx >> 8) >= p.W) {   // garbage in: stay inside this env's LDS slice, and say so
+                yx = 0;
+                atomicOr(p.status, SGW_STATUS_BAD_POS);
+            }
             reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
             s_type[gtid] = p.agent_state ? p.agent_state[env * p.A + gtid] : tab->agent_type[gtid];
             s_dir[gtid] = p.agent_dir ? p.agent_dir[env * p.A + gtid] : (uint8_t)2;
@@ -691,6 +695,10 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
     uint32_t yx = 0, act = 0;
     if (lane < p.A) yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + lane];
+    if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside this env's LDS slice, and say so
+        yx = 0;
+        atomicOr(p.status, SGW_STATUS_BAD_POS);
+    }
     if (mine && p.do_move && !rnd) act = p.actions[env * p.A + lane];
     // register-resident tables: lane t holds value[t] (f64 bits + its f32 rounding); lane a holds agent a's type
     const double vtab = gtab->value[lane & 31];
@@ -1121,6 +1129,10 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     if (wv == 0) {
         if (tid < p.A) {
             yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
+            if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside the LDS grid, and say so
+                yx = 0;
+                atomicOr(p.status, SGW_STATUS_BAD_POS);
+            }
             const uint32_t py = yx & 0xFFu, px = yx >> 8;
             oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;
             npos_v = yx;

@@ -210,6 +210,8 @@ class GridEngine:
             raise KeyError("action index outside the ActionSpec")
         if s & N.STATUS_BAD_TYPE:
             raise KeyError("grid holds an entity type id that was never registered")
+        if s & N.STATUS_BAD_POS:
+            raise IndexError("an agent position outside the grid was passed to the engine")
 
     # ------------------------------------------------------------------ timing
     def set_timing(self, enable: bool):

@@ -476,6 +476,42 @@ def test_status_flags_bad_action_and_unwalled_border(torch_cuda):
         eng.raise_on_status()
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 8, 3, 64), (12, 9, 3, 2, 7), (128, 128, 64, 5, 3)])
+def test_garbage_positions_are_flagged_and_memory_safe(torch_cuda, shape, monkeypatch):
+    """Positions outside the grid (an uninitialised agent_pos tensor): every kernel treats them as (0, 0), stays
+    inside its env's LDS slice, raises SGW_STATUS_BAD_POS, and leaves the other envs bit-exact."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+
+    h, w, a, r, E = shape
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.01, seed=4)
+    for force_generic in (False, True):
+        if force_generic:
+            monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+        eng = make_engine(ws, E)
+        co = H.COracle(ws, E)
+        eng.reset(0)
+        co.reset(0)
+        bad_env = E // 2
+        eng.agent_pos[bad_env] = 250                      # (250, 250): far outside
+        eng.step(random_actions=True)
+        co.step(0, 1, random_actions=True)
+        torch.cuda.synchronize()
+        assert eng.status() & N.STATUS_BAD_POS
+        keep = np.arange(E) != bad_env
+        assert np.array_equal(eng.grid.cpu().numpy()[keep], co.grid[keep])
+        assert np.array_equal(eng.obs.cpu().numpy()[keep], co.obs[keep])
+        assert np.array_equal(eng.agent_pos.cpu().numpy()[keep], co.pos[keep])
+        eng.agent_pos[bad_env, 0, 1] = 255                # (the step wrote clamped positions back)
+        eng.observe()                                     # K1 flags it too
+        assert eng.status() & N.STATUS_BAD_POS
+        with pytest.raises(IndexError):
+            eng.agent_pos[bad_env] = 251
+            eng.step(random_actions=True)
+            eng.raise_on_status()
+
+
 def test_create_rejects_invalid_configs(torch_cuda):
     from sorrel_amd.spec import treasurehunt_spec
 

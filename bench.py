@@ -222,7 +222,7 @@ def main() -> int:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "step_fast<...> (sgw_step)" if spec.grid_bytes_per_env() <= 4096 else "step_kernel<4,...> (sgw_step)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": "step_fast<...> (sgw_step)" if spec.grid_bytes_per_env() <= 4096 else "step_big<...> (sgw_step)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },
             "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status},

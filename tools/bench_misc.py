@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic throughput of the shapes that run on the generic / Tag paths (run on the GPU box)."""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 import numpy as np, torch
 from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import WorldSpec, treasurehunt_spec, action_deltas

@@ -7,10 +7,12 @@
 //   * larger worlds (e.g. 128x128x2): one 256-thread workgroup per env.
 // The env's grid (uint8 type ids, [L][H][W]) is staged once into LDS with
 // 16-byte loads, the entity sweep and all sequential agent phases run against
-// LDS, observation windows are gathered from LDS and streamed to HBM as
-// contiguous dword stores (lane = window cell, loop over channels), and the
-// grid is written back once with 16-byte stores.  Integer / indexing work only:
-// no MFMA, bound = HBM bandwidth (observation stores dominate).
+// LDS, observation windows are gathered from LDS (lane = window cell) and leave
+// for HBM either per agent as contiguous dword stores (loop over channels) or --
+// the fixed-shape kernels of the BASELINE configs -- staged as byte counts in
+// LDS and emitted once per env in a burst of 16-byte stores; the grid is written
+// back once with 16-byte stores.  Integer / indexing work only: no MFMA, bound =
+// HBM bandwidth (observation stores dominate).
 //
 // Semantics follow the reference Python step loop bit for bit; see
 // include/sgw.h for the reference file:line each entry point replaces and
@@ -580,11 +582,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
 constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
 constexpr size_t kLdsPerCu = 160 * 1024;
 
-#ifdef SGW_OBS_NT
-#define OBS_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
+// (non-temporal observation stores were measured: slower)
 #define OBS_STORE(ptr, val) (*(ptr) = (val))
-#endif
 
 __device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
     // 0x80 in every byte of v that equals the corresponding byte of pat (exact, no carries between bytes)

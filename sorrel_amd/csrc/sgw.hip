@@ -71,6 +71,7 @@ struct Params {
     int tab_bytes;  // LDS bytes of the table block
     uint32_t default_type, fill_type;
     uint32_t spawn_mask, thr_full_mask, pass_mask;
+    uint32_t become_mask;      // types that carry SGW_RULE_BECOME_IF
     uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
     uint32_t fill_delta[4];
     // single-spawner fast path (exactly one type carries SGW_RULE_SPAWN)
@@ -565,6 +566,23 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
     }
 }
 
+// Rule tables of the RULES variant of step_fast, copied per wave into LDS: three contiguous pieces of DevTables.
+struct RuleLds {
+    uint32_t thr_lo[SGW_MAX_TYPES];
+    uint8_t spawn_choice[SGW_MAX_TYPES][SGW_MAX_CHOICES];
+    uint8_t spawn_count[SGW_MAX_TYPES];
+    uint8_t rule[SGW_MAX_TYPES];
+    int8_t rule_layer[SGW_MAX_TYPES];
+    uint8_t rule_become[SGW_MAX_TYPES];
+    uint8_t pad2_[SGW_MAX_TYPES];
+    uint32_t rule_mask[SGW_MAX_TYPES];
+};
+constexpr int kRuleLds = (int)sizeof(RuleLds);
+static_assert(kRuleLds == 672 && kRuleLds % 16 == 0, "RuleLds mirrors three pieces of DevTables");
+static_assert(offsetof(DevTables, spawn_count) == offsetof(DevTables, spawn_choice) + SGW_MAX_TYPES * SGW_MAX_CHOICES, "piece B is contiguous");
+static_assert(offsetof(DevTables, rule_mask) == offsetof(DevTables, rule) + 4 * SGW_MAX_TYPES, "piece C is contiguous");
+static_assert(SGW_MAX_CHOICES == 8, "RuleLds copy assumes 8 choices");
+
 // ---------------------------------------------------------------- fast step kernel
 // Wave-per-env specialisation for worlds whose byte count is a multiple of 16 and
 // <= 4 KiB with at most one spawning type (all BASELINE configs up to 32x32x2):
@@ -645,7 +663,10 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 #define STAMP(i)
 #endif
 
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false>
+// RULES: the layered rule set on the wave-per-env kernel -- an ordered LDS sweep, one dword (four
+// cells, one Philox block) per lane and layer by layer, for any number of spawners and SGW_RULE_BECOME_IF types,
+// and CleanupAgent.act (facing, beams on the layer above, all-layer reward) in the agent loop.
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
@@ -715,8 +736,22 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     }
     const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(wl);                 // [NW][32]
     const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(wl);
-    uint8_t* lg = wl + p.tab_bytes;
+    uint8_t* lg = wl + p.tab_bytes + (RULES ? kRuleLds : 0);
     uint4* lg16 = reinterpret_cast<uint4*>(lg);
+    [[maybe_unused]] const RuleLds* rt = reinterpret_cast<const RuleLds*>(wl + p.tab_bytes);
+    [[maybe_unused]] uint32_t adir = 2;        // lane a: facing of agent a (Cleanup)
+    [[maybe_unused]] uint32_t kind_v = 0;      // lane a: SGW_ACTION_* of its action
+    if constexpr (RULES) {
+        uint32_t* rd = reinterpret_cast<uint32_t*>(wl + p.tab_bytes);
+        const uint32_t* gA = reinterpret_cast<const uint32_t*>(gtab->thr_lo);
+        const uint32_t* gB = reinterpret_cast<const uint32_t*>(gtab->spawn_choice);   // + spawn_count: 72 dwords
+        const uint32_t* gC = reinterpret_cast<const uint32_t*>(gtab->rule);           // rule .. rule_mask: 64 dwords
+        if (lane < 32) rd[lane] = gA[lane];
+        rd[32 + lane] = gB[lane];
+        if (lane < 8) rd[96 + lane] = gB[64 + lane];
+        rd[104 + lane] = gC[lane];
+        if (p.agent_dir && lane < p.A) adir = p.agent_dir[env * p.A + lane];
+    }
     // One-hot observations of a whole env are staged in LDS as byte counts in their final [A][C][V][V] order and
     // leave for HBM in one burst of 16-byte stores after the agent loop (instead of 6 dword stores per agent
     // dribbling out over the wave's life): the chip then has far fewer half-written observation streams open.
@@ -748,7 +783,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
 #endif
         STAMP(1);   // global loads have arrived
         // ---- grid -> LDS; the Bernoulli half of the sweep runs on the registers
-        uint32_t hits[NU];
+        [[maybe_unused]] uint32_t hits[NU];
         if constexpr (!kStatic) {
             if (cells & 15) {   // ragged world: bytes past the last cell are not cells (no type, no RNG index)
 #pragma unroll
@@ -766,20 +801,73 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                     }
             }
         }
-#pragma unroll
-        for (int k = 0; k < NU; ++k) {
-            hits[k] = 0;
-            if (lane + 64 * k < nunits) {
-                lg16[lane + 64 * k] = u[k];
-                if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id);
-            }
-        }
-        gsync<1>();
-        if (do_sweep) {
+        if constexpr (RULES) {
 #pragma unroll
             for (int k = 0; k < NU; ++k)
-                if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id);
+                if (lane + 64 * k < nunits) lg16[lane + 64 * k] = u[k];
             gsync<1>();
+            if (do_sweep) {
+                // Ordered sweep in LDS.  The reference visits cells in (y, x, z) order and a rule may read another
+                // layer of its own column (environment.py:88-91): going layer by layer, lower layers first, gives every
+                // cell the same view (lower layers already swept, higher ones not yet); rules write their own cell only.
+                const uint32_t* lg32 = reinterpret_cast<const uint32_t*>(lg);
+                for (int z = 0; z < L; ++z) {
+                    const int lo = z * HW, hi = lo + HW;
+                    for (int d = (lo >> 2) + lane; d < ((hi + 3) >> 2); d += 64) {   // one dword = four cells = one Philox block
+                        const uint32_t word = lg32[d];
+                        uint32_t tj[4];
+                        bool spj[4], bcj[4];
+                        bool any_sp = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int off = 4 * d + j;
+                            tj[j] = (word >> (8 * j)) & 0xFFu;
+                            const bool in = off >= lo && off < hi && tj[j] < (uint32_t)SGW_MAX_TYPES;
+                            spj[j] = in && ((p.spawn_mask >> (tj[j] & 31u)) & 1u);
+                            bcj[j] = in && ((p.become_mask >> (tj[j] & 31u)) & 1u);
+                            any_sp = any_sp || spj[j];
+                        }
+                        if (any_sp) {
+                            const U4 w = philox4x32_10(opaque((uint32_t)d), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                            uint32_t hit = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (spj[j] && (((p.thr_full_mask >> tj[j]) & 1u) || word_of(w, j) < rt->thr_lo[tj[j]])) hit |= 1u << j;
+                            if (hit) {   // rare: what spawns
+                                const U4 kw = philox4x32_10(opaque((uint32_t)d), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if ((hit >> j) & 1u)
+                                        lg[4 * d + j] = rt->spawn_choice[tj[j]][__umulhi(word_of(kw, j), (uint32_t)rt->spawn_count[tj[j]])];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (bcj[j]) {
+                                const int zl = rt->rule_layer[tj[j]];
+                                const bool fire = zl < 0 || ((rt->rule_mask[tj[j]] >> (lg[zl * HW + (4 * d + j - lo)] & 31u)) & 1u);
+                                if (fire) lg[4 * d + j] = rt->rule_become[tj[j]];
+                            }
+                    }
+                    gsync<1>();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                hits[k] = 0;
+                if (lane + 64 * k < nunits) {
+                    lg16[lane + 64 * k] = u[k];
+                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id);
+                }
+            }
+            gsync<1>();
+            if (do_sweep) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id);
+                gsync<1>();
+            }
         }
 
         STAMP(2);   // sweep done
@@ -796,8 +884,16 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 p.actions[env * p.A + lane] = (uint8_t)act;
             }
             const bool act_ok = act < (uint32_t)p.nact;
-            const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
-            const int dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+            int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
+            int dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+            if constexpr (RULES) {
+                if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {   // clean / zap stay in place; a move action also turns the agent
+                    const uint32_t kind = act_ok ? (p.kind_pack >> (2 * (act & 15u))) & 3u : 0u;
+                    if (kind != SGW_ACTION_MOVE || !act_ok) dy = dx = 0;
+                    const uint32_t ndir = (dy == -1 && dx == 0) ? 0u : (dy == 1 && dx == 0) ? 2u : (dy == 0 && dx == -1) ? 3u : (dy == 0 && dx == 1) ? 1u : 4u;
+                    kind_v = kind | (act_ok ? 4u : 0u) | (ndir << 4);
+                }
+            }
             const int ty = (int)py + dy, tx = (int)px + dx;
             const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
             if (act_ok && inb) {
@@ -890,6 +986,56 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             const uint32_t s_t = (uint32_t)__builtin_amdgcn_readlane((int)taddr_v, a);
             const uint32_t my_type = (uint32_t)__builtin_amdgcn_readlane((int)atype, a);
             const bool valid = s_t != 0xFFFFFFFFu;
+            if constexpr (RULES) {
+                if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {
+                    // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:92-177); everything below is wave-uniform
+                    const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)kind_v, a);
+                    const uint32_t kind = kd & 3u, ndir = kd >> 4;
+                    const bool aok = (kd & 4u) != 0;
+                    const uint32_t facing = (uint32_t)__builtin_amdgcn_readlane((int)adir, a) & 3u;
+                    const int ay = __builtin_amdgcn_readlane((int)py, a), ax = __builtin_amdgcn_readlane((int)px, a);
+                    if (aok && kind != SGW_ACTION_MOVE && p.zA + 1 < L) {
+                        // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
+                        if (lane < 3 * p.beam_radius) {
+                            const int arm = lane / p.beam_radius, i = lane - arm * p.beam_radius;
+                            const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
+                            const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
+                            const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                            const int by = ay + side * ry + step * fy, bx = ax + side * rx + step * fx;
+                            if ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) {
+                                const int boff = (p.zA + 1) * HW + by * W + bx;
+                                if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
+                                    lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
+                            }
+                        }
+                        gsync<1>();
+                    }
+                    double val = 0.0;           // reward: every layer of the target cell, BEFORE the move
+                    uint32_t t = 0xFFu;
+                    if (valid) {
+                        const int tc = (int)s_t - zoff;
+                        for (int zl = 0; zl < L; ++zl) {
+                            const uint32_t tz = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[zl * HW + tc]) & 31u;
+                            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)vt_lo, (int)tz);
+                            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)vt_hi, (int)tz);
+                            val += __longlong_as_double(((long long)hi_ << 32) | lo_);
+                        }
+                        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[s_t]);
+                    }
+                    const bool pass = valid && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                    if (pass && lane == 0) {
+                        lg[s_t] = (uint8_t)my_type;
+                        lg[s_o] = (uint8_t)p.default_type;
+                    }
+                    moved = lane == a ? (pass ? 1u : 0u) : moved;
+                    adir = (lane == a && aok && kind == SGW_ACTION_MOVE && ndir < 4u) ? ndir : adir;   // movement() turns the agent even if the move fails
+                    rew_bits = lane == a ? __float_as_uint((float)val) : rew_bits;
+                    tot += val * (double)(p.total_factor - 1);   // the extra add inside act() (agents.py:172) ...
+                    tot += val;                                  // ... and Agent.transition's own (agent.py:172)
+                    gsync<1>();
+                    continue;
+                }
+            }
             const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[valid ? s_t : (uint32_t)s_o]);
             const bool tok = valid && t < (uint32_t)p.T;
             const uint32_t tl = t & 31u;
@@ -979,6 +1125,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 if (st_lane) atomicOr(p.status, st_lane);
             }
             if (TAG && p.agent_state && lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)atype;   // a tag can flip any agent
+            if (RULES && p.agent_dir && lane < p.A) p.agent_dir[env * p.A + lane] = (uint8_t)adir;
             if (lane == 0) p.total[env] = tot;
         }
         STAMP(5);   // all stores issued
@@ -1563,6 +1710,7 @@ struct sgw_engine {
     void (*reset_fn)(const Params) = nullptr;
     size_t lds_bytes = 0;       // reset / generic step
     size_t step_lds_bytes = 0;  // step kernel actually launched
+    bool fast_rules = false;   // the RULES variant of step_fast applies
     int step_env_lds = 0;
     int obs_stage = 0;     // bytes of LDS observation staging per wave (step_fast, one-hot)
     int fast_tab_bytes = 0;
@@ -1690,7 +1838,8 @@ StepFn pick_big(bool onehot, int L, int C, int r) {
     return step_big<true, 0, 0, 0>;
 }
 
-StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag) {
+StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules) {
+    if (rules) return onehot ? step_fast<true, 0, 0, 0, 0, 0, false, true> : step_fast<false, 0, 0, 0, 0, 0, false, true>;
     if (tag) return onehot ? step_fast<true, 0, 0, 0, 0, 0, true> : step_fast<false, 0, 0, 0, 0, 0, true>;
     if (!onehot) return step_fast<false, 0, 0, 0, 0, 0>;
     if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) return step_fast<true, 2, 6, 3, 32, 32>;   // BASELINE configs 3/4 (headline)
@@ -1849,8 +1998,12 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tag_notit = c.tag_notit_type;
     p.tag_reward = c.tag_reward;
     p.has_become = 0;
+    p.become_mask = 0;
     for (int t = 0; t < c.num_types; ++t)
-        if (c.type_rule[t] == SGW_RULE_BECOME_IF) p.has_become = 1;
+        if (c.type_rule[t] == SGW_RULE_BECOME_IF) {
+            p.has_become = 1;
+            p.become_mask |= 1u << t;
+        }
     p.kind_pack = 0;
     for (int a = 0; a < c.num_actions; ++a) p.kind_pack |= (uint32_t)(c.action_kind[a] & 3u) << (2 * a);
     p.beam_radius = c.beam_radius;
@@ -1867,6 +2020,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     const bool simple_rules = !p.has_become && c.agent_rule != SGW_AGENT_RULE_CLEANUP;   // else: generic kernel
     const bool vec16 = (p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad;   // 16-byte loads/stores per env are legal
     e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
+    // the layered rule set on the wave-per-env kernel (RULES variant): any spawners, BECOME_IF rules, Cleanup or plain agents
+    e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && p.VV <= 128 &&
+                    c.agent_rule != SGW_AGENT_RULE_TAG;
+    if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') e->fast_rules = false; }   // test hook: generic kernel instead
+    e->fast = e->fast || e->fast_rules;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
@@ -1876,16 +2034,16 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         const int ob_elems = c.num_agents * c.num_channels * p.VV;
         const bool fixed_shape = c.layers == 2 && c.num_channels == 6 && ((c.height == 32 && c.width == 32 && c.vision_radius == 3) ||
                                                                          (c.height == 16 && c.width == 16 && c.vision_radius == 2));   // = pick_fast's fixed-shape kernels
-        e->obs_stage = (e->fast && onehot && fixed_shape && c.agent_rule != SGW_AGENT_RULE_TAG && (ob_elems & 3) == 0 && ob_elems <= 4096) ? ((ob_elems + 15) & ~15) : 0;
+        e->obs_stage = (e->fast && !e->fast_rules && onehot && fixed_shape && c.agent_rule != SGW_AGENT_RULE_TAG && (ob_elems & 3) == 0 && ob_elems <= 4096) ? ((ob_elems + 15) & ~15) : 0;
         if (const char* f = getenv("SGW_NO_STAGE")) { if (f[0] == '1') e->obs_stage = 0; }   // test / tuning hook
     }
-    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad + e->obs_stage : p.env_lds;
+    e->step_env_lds = e->fast ? e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad + e->obs_stage : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
-        if (f[0] == '1') e->fast = e->big = false;
+        if (f[0] == '1') e->fast = e->big = e->fast_rules = false;
     }
     if (!e->fast) e->obs_stage = 0;
-    e->step_env_lds = e->fast ? e->fast_tab_bytes + p.cells_pad + e->obs_stage : p.env_lds;
+    e->step_env_lds = e->fast ? e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad + e->obs_stage : p.env_lds;
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
@@ -1907,7 +2065,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG)
+    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius)
                          : pick_step(e->wpe, e->onehot);
     StepFn rk = pick_reset(e->wpe);
@@ -1973,13 +2131,14 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // The staged float32 emit of a large batch (configs 3/4): six instead of eight waves per SIMD (an LDS request that
-    // fits 6 workgroups per CU).  Boxes of the pool differ: at full occupancy this kernel runs config 3 in 153 us
-    // on some and 188 us on others, with the cap in 156 and 164 us.  Everything else -- the uint8 format, small
-    // batches, and the shapes with small windows, which are latency- rather than memory-bound (Tag 11x11: 164 us at
-    // full occupancy, 192 us capped) -- is fastest at full occupancy and is not capped.
+    // float32 observations of 8 KiB or more per env, whole turns of a large batch (configs 3/4, Cleanup): six instead
+    // of eight waves per SIMD (an LDS request that fits 6 workgroups per CU).  Boxes of the pool differ: at full
+    // occupancy the staged kernel runs config 3 in 153 us on some and 188 us on others, with the cap in 156 and 164 us;
+    // Cleanup 21x31x3 at 65 536 envs 893 -> 801 us.  Everything else -- the uint8 format, small batches, and the shapes
+    // with small windows, which are latency- rather than memory-bound (Tag 11x11, 6.5 KB per env: 164 us at full
+    // occupancy, 192 us capped) -- is fastest at full occupancy and is not capped.
     size_t lds = e->step_lds_bytes;
-    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 > p.a0 && p.obs_stage &&
+    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
         p.E >= (int64_t)e->num_cus * 32 * 2)
         lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap) & ~(size_t)511);
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);

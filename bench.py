@@ -110,6 +110,10 @@ def main() -> int:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             graft.build_hip()
+        except Exception as exc:   # no compiler on this box: an existing library is still the product under test
+            if not os.path.isfile(graft.HIP_LIB):
+                raise
+            print(f"bench.py: could not rebuild libsgw.so ({exc}); using the existing library", file=sys.stderr)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 

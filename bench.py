@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HBM_COPY_GBS = 6290.0   # measured float4-copy ceiling (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 CONFIGS = {
@@ -226,6 +227,7 @@ def main() -> int:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,   # both denominators
                 "kernel": "step_fast<...> (sgw_step)" if spec.grid_bytes_per_env() <= 4096 else "step_big<...> (sgw_step)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },

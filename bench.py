@@ -65,10 +65,10 @@ def cpu_baseline(spec, seconds_target: float = 12.0):
 
     lib.sgo_reset(C.byref(cfg), p(grid), p(pos), p(tot), C.c_uint32(0), C.c_int(0), C.c_void_p(0))
 
-    def run(t0, n):
+    def run(t0, n, threads=0):
         for t in range(t0, t0 + n):
             lib.sgo_step(C.byref(cfg), p(grid), p(pos), p(act), p(obs), p(rew), p(tot), C.c_uint32(0), C.c_uint32(t),
-                         C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+                         C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(threads), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
 
     run(1, 2)                                   # warm-up + page-in
     t = time.perf_counter()
@@ -78,10 +78,20 @@ def cpu_baseline(spec, seconds_target: float = 12.0):
     t = time.perf_counter()
     run(6, turns)
     dt = time.perf_counter() - t
+    # the same code on ONE thread (total, per core, and the single-core figure), a ~3 s sample
+    t1 = time.perf_counter()
+    run(6 + turns, 1, threads=1)
+    per_turn1 = time.perf_counter() - t1
+    turns1 = max(1, min(50, int(3.0 / max(per_turn1, 1e-6))))
+    t1 = time.perf_counter()
+    run(7 + turns, turns1, threads=1)
+    dt1 = time.perf_counter() - t1
+    value = E * A * turns / dt
     return {
-        "value": E * A * turns / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+        "value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+        "per_core": value / cores, "single_core_value": E * A * turns1 / dt1,
         "sample": f"oracle/gridstep_oracle.c (OpenMP, {cores} threads), {E} envs x {turns} turns of the same "
-                  f"{spec.height}x{spec.width}x{A}-agent workload, {dt:.1f} s",
+                  f"{spec.height}x{spec.width}x{A}-agent workload, {dt:.1f} s; single thread: {turns1} turns, {dt1:.1f} s",
     }
 
 

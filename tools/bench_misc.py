@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic throughput of the shapes that run on the generic / Tag paths (run on the GPU box)."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)

@@ -7,7 +7,6 @@ import tests.helpers as TH
 lib = C.CDLL("oracle/libgridstep_oracle_asan.so")
 TH._ORACLE = lib
 TH.oracle_lib = lambda: lib
-from oracle import gridstep_oracle as O
 n = 0
 for name in [n for n in H.golden_names() if n != "stock_np_random"]:
     d, spec = H.load_golden(name)

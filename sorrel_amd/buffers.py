@@ -76,3 +76,45 @@ class Buffer:
 
     def __repr__(self):
         return f"Buffer(capacity={self.capacity}, obs_shape={self.obs_shape}, num_envs={self.num_envs})"
+
+
+class TurnBuffer:
+    """Joint ring over ALL agents for fused rollouts: one slot holds one ``take_turn`` of every env --
+    ``obs [capacity, E, A, *obs_shape]`` float32 (or uint8 for the compact format), ``actions`` uint8,
+    ``rewards`` float32 ``[capacity, E, A]``.  ``Environment.collect`` points the step kernel's observation
+    output at the slot, so the 617 MB of a config-3 turn are written once, by the kernel, where the learner reads
+    them (the per-agent ``Buffer`` above gets a device-to-device copy per agent instead).  ``agent_view(a)``
+    gives the reference's per-agent layout back as views."""
+
+    def __init__(self, capacity: int, num_envs: int, obs_shape: Sequence[int], device=None, obs_dtype=torch.float32):
+        self.capacity, self.num_envs, self.obs_shape = capacity, num_envs, tuple(obs_shape)    # obs_shape = (A, C, V, V)
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        A = self.obs_shape[0]
+        self.obs = torch.zeros((capacity, num_envs, *self.obs_shape), dtype=obs_dtype, device=self.device)
+        self.actions = torch.zeros((capacity, num_envs, A), dtype=torch.uint8, device=self.device)
+        self.rewards = torch.zeros((capacity, num_envs, A), dtype=torch.float32, device=self.device)
+        self.dones = torch.zeros((capacity, num_envs, A), dtype=torch.float32, device=self.device)   # all-zero inside an epoch (SURVEY A.9)
+        self.idx = 0
+        self.size = 0
+
+    def slot(self) -> int:
+        """The slot the next turn goes to (``commit`` advances)."""
+        return self.idx
+
+    def commit(self, actions: torch.Tensor, rewards: torch.Tensor) -> None:
+        i = self.idx
+        self.actions[i].copy_(actions)
+        self.rewards[i].copy_(rewards)
+        self.idx = (self.idx + 1) % self.capacity
+        self.size = min(self.size + 1, self.capacity)
+
+    def agent_view(self, a: int):
+        """(states ``[capacity, E, C, V, V]``, actions, rewards, dones ``[capacity, E]``) of one agent slot: views."""
+        return self.obs[:, :, a], self.actions[:, :, a], self.rewards[:, :, a], self.dones[:, :, a]
+
+    def clear(self):
+        self.idx = self.size = 0
+
+    def __len__(self):
+        return self.size

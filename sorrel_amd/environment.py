@@ -292,6 +292,21 @@ class Environment:
             for agent in self.agents:
                 agent.transition(self.world)
 
+    def collect(self, turns: int, buffer, actions=None) -> None:
+        """``turns`` fused ``take_turn``s whose observations the step kernel writes straight into ``buffer``
+        (a ``sorrel_amd.buffers.TurnBuffer``): no per-step copy of the observation tensor.  ``actions``: optional
+        ``[turns, E, A]`` uint8 tensor of policy actions; default = on-device random actions (``RandomModel``)."""
+        eng = self._ensure_engine()
+        for t in range(turns):
+            self.turn += 1
+            eng.epoch, eng.turn = self.epoch, self.turn
+            out = buffer.obs[buffer.slot()]
+            if actions is None:
+                eng.step(random_actions=True, turn=self.turn, obs_out=out)
+            else:
+                eng.step(actions[t], turn=self.turn, obs_out=out)
+            buffer.commit(eng.actions, eng.rewards)
+
     # ------------------------------------------------------------------ kernels behind the agent hooks
     @staticmethod
     def _ospec_key(ospec):

@@ -349,6 +349,37 @@ def test_host_built_template_world(torch_cuda):
     assert env.agents[0].location == (int(states[0].pos[0, 0]), int(states[0].pos[0, 1]), 0)
 
 
+def test_collect_writes_observations_straight_into_the_turn_buffer(torch_cuda):
+    """Environment.collect: the step kernel's observation output is the ring slot itself (staged burst path for the
+    config-3 shape, direct stores otherwise); contents equal the oracle's, ring wraps."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import TurnBuffer
+
+    for (h, w, a, r) in ((32, 32, 8, 3), (12, 12, 3, 2)):
+        E, T, cap = 9, 7, 5
+        env = make_env(h, w, a, r, E, p=0.05)
+        ospec = H.oracle_spec(env.compile_spec())
+        states = [O.reset_env(ospec, e, epoch=0) for e in range(E)]
+        buf = TurnBuffer(cap, E, env.compile_spec().obs_shape, device="cuda:0")
+        env.collect(T, buf)
+        torch.cuda.synchronize()
+        assert len(buf) == cap and buf.idx == T % cap
+        want = {}
+        for t in range(1, T + 1):
+            for e in range(E):
+                want[(t, e)] = O.step_env(ospec, states[e], e, 0, t)
+        for t in range(T - cap + 1, T + 1):                     # the last `cap` turns are still in the ring
+            slot = (t - 1) % cap
+            for e in range(E):
+                o, act, rew = want[(t, e)]
+                assert np.array_equal(buf.obs[slot, e].cpu().numpy(), o), (h, t, e)
+                assert np.array_equal(buf.actions[slot, e].cpu().numpy(), act)
+                assert np.array_equal(buf.rewards[slot, e].cpu().numpy(), rew)
+        st, ac, rw, dn = buf.agent_view(1)
+        assert st.shape == (cap, E) + tuple(env.compile_spec().obs_shape[1:]) and float(dn.sum()) == 0.0
+        assert np.array_equal(env.world.grid.cpu().numpy(), np.stack([s.grid for s in states]))
+
+
 def test_run_experiment_thin_loop(torch_cuda):
     env = make_env(10, 10, 2, 2, 32)
     hist = env.run_experiment(epochs=1, max_turns=5, all_reduce=False)

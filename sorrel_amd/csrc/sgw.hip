@@ -72,6 +72,7 @@ struct Params {
     uint32_t default_type, fill_type;
     uint32_t spawn_mask, thr_full_mask, pass_mask;
     uint32_t become_mask;      // types that carry SGW_RULE_BECOME_IF
+    uint32_t agent_mask;       // types the agents have
     uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
     uint32_t fill_delta[4];
     // single-spawner fast path (exactly one type carries SGW_RULE_SPAWN)
@@ -1168,6 +1169,25 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t env = blockIdx.x;
     const uint32_t env_id = p.first_env + (uint32_t)env;
+#ifdef SGW_STAMPS
+    unsigned long long tprev_ = 0;
+#define STAMPB(i)                                                                                            \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (tid == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;                 \
+        tprev_ = t_;                                                                                         \
+    } while (0)
+    STAMPB(0);
+    if (tid == 0 && env < kStampEnvs) {
+        g_stamps[env * 8 + 6] = tprev_;
+        g_stamps[env * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#else
+#define STAMPB(i)
+#endif
 
     const int L = TL ? TL : p.L;
     const int C = TC ? TC : p.C;
@@ -1309,6 +1329,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
         s_ta[tid] = 0;           // journal: empty
     }
     __syncthreads();             // grid (+ sweep patches) and tables visible to every wave
+    STAMPB(1);                   // load + sweep done
 
     // ---- phase M: the strictly sequential part, by wave 0 alone, entirely in registers.
     // All targets are read from the pre-move grid in ONE LDS round trip (lane a = agent a).  What
@@ -1322,7 +1343,28 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
         const bool validv = ta_v != 0xFFFFFFFFu;
         const uint32_t t0_v = lg[validv ? ta_v : oaddr_v];
         uint32_t passed_v = 0;
-        for (int a = p.a0; a < p.a1; ++a) {
+        // Most turns no agent interferes with another: what an agent finds on its target can differ from the pre-move
+        // grid only if an earlier mover entered that cell (two agents share a target) or left it (the target is another
+        // agent's cell).  Detect both conservatively -- a mark in a spare bit of the target's LDS byte (type ids are
+        // < 32) catches the second claimant of a cell, the type itself tells an agent's cell -- and resolve every
+        // agent at once when neither occurs; only otherwise walk the agents in order.
+        bool cf = false;
+        const bool markable = mine && validv && t0_v < 32u && !((p.agent_mask >> t0_v) & 1u);
+        uint32_t* gw = reinterpret_cast<uint32_t*>(lg);
+        const uint32_t msh = 8u * (ta_v & 3u);
+        if (mine && validv && !markable) cf = true;
+        if (markable) cf = ((atomicOr(&gw[ta_v >> 2], 0x40u << msh) >> msh) & 0x40u) != 0;
+        const bool conflict = __ballot(cf) != 0ull;
+        if (markable) atomicAnd(&gw[ta_v >> 2], ~(0x40u << msh));   // marks off again before anyone else reads the grid
+        if (!conflict) {
+            const bool tok = validv && t0_v < (uint32_t)p.T;
+            const bool pass = tok && ((p.pass_mask >> (t0_v & 31u)) & 1u);
+            if (mine) {
+                jr = (t0_v & 0xFFu) | (tok ? 0x100u : 0u) | (pass ? 0x200u : 0u) | ((validv && !tok) ? 0x400u : 0u);
+                passed_v = pass ? 1u : 0u;
+            }
+        }
+        for (int a = conflict ? p.a0 : p.a1; a < p.a1; ++a) {
             const uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)ta_v, a);
             const bool valid = X != 0xFFFFFFFFu;
             uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t0_v, a);
@@ -1350,6 +1392,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
         if (jr & 0x400u) st_lane |= SGW_STATUS_BAD_TYPE;
     }
     __syncthreads();
+    STAMPB(2);                   // phase M done
 
     // ---- phase R: observations, all waves in parallel (agent a -> wave (a - a0) mod waves).
     // LDS now holds the grid AFTER all moves of this call; agent a must see it after the moves of
@@ -1476,12 +1519,19 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     }
     // windows wider than NP*64 cells (not a BASELINE shape): handled by the generic kernel (host dispatch)
     __syncthreads();
+    STAMPB(3);                   // phase R done (all waves)
 
     // ---- write-back
     if (dirty) {
         uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
         for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[idx];
     }
+    STAMPB(4);                   // write-back issued
+#ifdef SGW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMPB(5);                   // wave 0's stores acknowledged
+    STAMPB(6);
     if (p.do_move) {
         if (wv == 0 && mine) {
             reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)((jr & 0x200u) ? npos_v : yx);
@@ -1997,6 +2047,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tag_it = c.tag_it_type;
     p.tag_notit = c.tag_notit_type;
     p.tag_reward = c.tag_reward;
+    p.agent_mask = 0;
+    for (int a = 0; a < c.num_agents; ++a) p.agent_mask |= 1u << (c.agent_type[a] & 31u);
     p.has_become = 0;
     p.become_mask = 0;
     for (int t = 0; t < c.num_types; ++t)

@@ -349,3 +349,20 @@ def test_cleanup_populate_draws_per_env_without_replacement():
     before = g.copy()
     env.reset()                                                                 # new epoch -> new draw, same template
     assert not np.array_equal(env.world.grid.numpy(), before)
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under sorrel_amd/ (Python or HIP) may import, load or name it,
+    nor the reference tree."""
+    import os
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sorrel_amd")
+    bad = []
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "libgridstep_oracle" in src or "/root/reference" in src:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -75,3 +75,11 @@ def test_engine_fails_loudly_without_gpu():
         GridEngine(treasurehunt_spec(16, 16, 4, 2), 8, device="cuda")
     with pytest.raises(N.SgwError):
         GridEngine(treasurehunt_spec(16, 16, 4, 2), 8, device="cpu")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No built extension -> SgwError naming the build command; nothing else is tried."""
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", "/nonexistent/libsgw.so")
+    with pytest.raises(N.SgwError, match="no CPU fallback"):
+        N.load()

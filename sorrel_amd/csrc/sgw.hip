@@ -1765,7 +1765,7 @@ struct sgw_engine {
     int obs_stage = 0;     // bytes of LDS observation staging per wave (step_fast, one-hot)
     int fast_tab_bytes = 0;
     int grid_blocks = 1;
-    int fast_wg_cap = 6;   // step_fast workgroups per CU when writing float32 observations of a large batch (0: no cap)
+    int fast_wg_cap = 5;   // step_fast workgroups per CU when writing large float32 observations of a large batch (0: no cap)
     int reset_blocks = 1;
     int num_cus = 256;
     // timing
@@ -2183,16 +2183,17 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // float32 observations of 8 KiB or more per env, whole turns of a large batch (configs 3/4, Cleanup): six instead
-    // of eight waves per SIMD (an LDS request that fits 6 workgroups per CU).  Boxes of the pool differ: at full
-    // occupancy the staged kernel runs config 3 in 153 us on some and 188 us on others, with the cap in 156 and 164 us;
-    // Cleanup 21x31x3 at 65 536 envs 893 -> 801 us.  Everything else -- the uint8 format, small batches, and the shapes
-    // with small windows, which are latency- rather than memory-bound (Tag 11x11, 6.5 KB per env: 164 us at full
-    // occupancy, 192 us capped) -- is fastest at full occupancy and is not capped.
+    // float32 observations of 8 KiB or more per env, whole turns of a large batch (configs 3/4, Cleanup): five instead
+    // of eight waves per SIMD (an LDS request that fits 5 workgroups per CU).  Boxes of the pool differ: at full
+    // occupancy the staged kernel runs config 3 in 153 us on some and 188 us on others, with the cap in 156 and 165 us
+    // (6 per CU: 169 us on the slower kind, 7: 178, 4: 178); Cleanup 21x31x3 at 65 536 envs 893 -> 801 us.
+    // Everything else -- the uint8 format, small batches, and the shapes with small windows, which are latency-
+    // rather than memory-bound (Tag 11x11, 6.5 KB per env: 164 us at full occupancy, 192 us capped) -- is fastest at
+    // full occupancy and is not capped.
     size_t lds = e->step_lds_bytes;
     if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
         p.E >= (int64_t)e->num_cus * 32 * 2)
-        lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap) & ~(size_t)511);
+        lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);

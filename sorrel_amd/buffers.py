@@ -11,12 +11,13 @@ from typing import Sequence
 
 import torch
 
+from sorrel_amd.spec import resolve_device
+
 
 class Buffer:
     def __init__(self, capacity: int, obs_shape: Sequence[int], n_frames: int = 1, num_envs: int = 1, device=None):
         self.capacity, self.obs_shape, self.n_frames, self.num_envs = capacity, tuple(obs_shape), n_frames, num_envs
-        self.device = torch.device(device) if device is not None else torch.device(
-            "cuda" if torch.cuda.is_available() else "cpu")
+        self.device = resolve_device(device)
         E = num_envs
         self.states = torch.zeros((capacity, E, *self.obs_shape), dtype=torch.float32, device=self.device)
         self.actions = torch.zeros((capacity, E), dtype=torch.int64, device=self.device)
@@ -88,8 +89,7 @@ class TurnBuffer:
 
     def __init__(self, capacity: int, num_envs: int, obs_shape: Sequence[int], device=None, obs_dtype=torch.float32):
         self.capacity, self.num_envs, self.obs_shape = capacity, num_envs, tuple(obs_shape)    # obs_shape = (A, C, V, V)
-        self.device = torch.device(device) if device is not None else torch.device(
-            "cuda" if torch.cuda.is_available() else "cpu")
+        self.device = resolve_device(device)
         A = self.obs_shape[0]
         self.obs = torch.zeros((capacity, num_envs, *self.obs_shape), dtype=obs_dtype, device=self.device)
         self.actions = torch.zeros((capacity, num_envs, A), dtype=torch.uint8, device=self.device)

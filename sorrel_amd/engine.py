@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _native as N
-from .spec import WorldSpec, alloc_grid
+from .spec import WorldSpec, alloc_grid, resolve_device
 
 
 class GridEngine:
@@ -29,7 +29,7 @@ class GridEngine:
         self.spec = spec
         self.num_envs = int(num_envs)
         self.first_env_id = int(first_env_id)
-        self.device = torch.device(device)
+        self.device = resolve_device(device)
         if self.device.type != "cuda":
             raise N.SgwError(
                 "GridEngine needs a HIP device (torch device 'cuda'); the step/observe path has no CPU fallback"

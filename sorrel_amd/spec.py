@@ -25,6 +25,19 @@ NO_BORDER = N.NO_BORDER
 _MOVES = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
 
 
+def resolve_device(device=None):
+    """``torch.device`` with an explicit index: ``"cuda"`` / ``None`` mean the current HIP device (tensors report
+    ``cuda:0``, so a bare ``cuda`` would never compare equal), ``None`` falls back to the CPU without a GPU."""
+    import torch
+
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def alloc_grid(num_envs: int, layers: int, height: int, width: int, device):
     """``uint8 [E, L, H, W]`` view whose env stride is padded to a multiple of 16 bytes, so that
     worlds of any byte count (e.g. the tutorial's 21x21x2 = 882 B) can use the 16-byte load/store

@@ -22,7 +22,7 @@ import torch
 from sorrel_amd.entities.entity import Entity
 from sorrel_amd.entities.rules import SpawnRule
 from sorrel_amd.location import Location
-from sorrel_amd.spec import alloc_grid
+from sorrel_amd.spec import alloc_grid, resolve_device
 
 
 class World:
@@ -70,8 +70,7 @@ class Gridworld(World):
         self.height, self.width, self.layers = int(height), int(width), int(layers)
         self.default_entity = default_entity
         self.num_envs = int(num_envs)
-        self.device = torch.device(device) if device is not None else torch.device(
-            "cuda" if torch.cuda.is_available() else "cpu")
+        self.device = resolve_device(device)
         self.seed = int(seed)
         self.registry = TypeRegistry()
         self.default_type = self.registry.register(default_entity)

@@ -392,3 +392,23 @@ def test_run_experiment_thin_loop(torch_cuda):
             O.step_env(ospec, st, e, 2, t)
         tot += st.total_reward
     assert hist[1]["sum_total_reward"] == tot
+
+
+def test_example_mains_run_with_default_device(torch_cuda):
+    """The runnable examples build their worlds without an explicit device (bare "cuda"): worlds, engines and
+    buffers must agree on the indexed device."""
+    import runpy
+
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.entities import EmptyEntity
+    from sorrel_amd.examples.tag.env import TagEnv
+    from sorrel_amd.worlds import Gridworld
+
+    cfg = {"experiment": {"epochs": 1, "max_turns": 3}, "agent": {"num_agents": 3, "vision_radius": 2}}
+    world = Gridworld(9, 9, 1, EmptyEntity(), num_envs=8)                     # no device argument
+    assert world.device.index is not None and Buffer(4, (3,), num_envs=2).device == world.device
+    env = TagEnv(world, cfg)
+    env.take_turn()
+    assert env.obs.device == world.device
+    for mod in ("sorrel_amd.examples.treasurehunt.main", "sorrel_amd.examples.tag.main", "sorrel_amd.examples.cleanup.main"):
+        runpy.run_module(mod, run_name="__main__")                             # 4096 envs, 2-3 short epochs each

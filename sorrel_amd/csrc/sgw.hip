@@ -1102,14 +1102,24 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
             if (!p.obs_u8) {
-                float4* o4 = reinterpret_cast<float4*>(p.obs + env * (int64_t)(p.A * C * VV));
+                // Non-temporal (streaming) stores: every wave instruction here writes eight whole 128-byte lines that
+                // nothing reads again in this launch; keeping them out of the caches leaves those to the grids (134 MB,
+                // re-read next turn) and takes config 3 from 167 to 125-132 us.  (The same hint on the per-agent dword
+                // stores of the unstaged path, which write partial lines, was measured SLOWER.)
+                typedef float vfloat4 __attribute__((ext_vector_type(4)));
+                vfloat4* o4 = reinterpret_cast<vfloat4*>(p.obs + env * (int64_t)(p.A * C * VV));
                 for (int i = lane; i < nd; i += 64) {
                     const uint32_t b = ob4[i];
-                    o4[i] = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24));
+                    vfloat4 v;
+                    v.x = (float)(b & 0xFFu);
+                    v.y = (float)((b >> 8) & 0xFFu);
+                    v.z = (float)((b >> 16) & 0xFFu);
+                    v.w = (float)(b >> 24);
+                    __builtin_nontemporal_store(v, &o4[i]);
                 }
             } else {
                 uint32_t* o1 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.obs) + env * (int64_t)(p.A * C * VV));
-                for (int i = lane; i < nd; i += 64) o1[i] = ob4[i];
+                for (int i = lane; i < nd; i += 64) __builtin_nontemporal_store(ob4[i], &o1[i]);   // two whole lines per wave instruction
             }
         }
         if (dirty) {
@@ -2183,15 +2193,14 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // float32 observations of 8 KiB or more per env, whole turns of a large batch (configs 3/4, Cleanup): five instead
-    // of eight waves per SIMD (an LDS request that fits 5 workgroups per CU).  Boxes of the pool differ: at full
-    // occupancy the staged kernel runs config 3 in 153 us on some and 188 us on others, with the cap in 156 and 165 us
-    // (6 per CU: 169 us on the slower kind, 7: 178, 4: 178); Cleanup 21x31x3 at 65 536 envs 893 -> 801 us.
-    // Everything else -- the uint8 format, small batches, and the shapes with small windows, which are latency-
-    // rather than memory-bound (Tag 11x11, 6.5 KB per env: 164 us at full occupancy, 192 us capped) -- is fastest at
-    // full occupancy and is not capped.
+    // Unstaged float32 observations of 8 KiB or more per env, whole turns of a large batch (Cleanup): five instead of
+    // eight waves per SIMD (an LDS request that fits 5 workgroups per CU): 21x31x3 at 65 536 envs 893 -> 801 us.  The
+    // per-agent dword stores of that path leave many half-written lines open; fewer concurrent waves, fewer of them.
+    // The staged emit with its streaming full-line stores (configs 2/3/4) is fastest at full occupancy (config 3:
+    // 124 us at 8 and 7 per CU, 126 at 6, 131 at 5), as are the uint8 format, small batches and the shapes with
+    // small windows, which are latency-bound (Tag 11x11, 6.5 KB per env: 164 us at full occupancy, 192 us capped).
     size_t lds = e->step_lds_bytes;
-    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
+    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && !p.obs_stage && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
         p.E >= (int64_t)e->num_cus * 32 * 2)
         lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);

@@ -600,6 +600,7 @@ static_assert(SGW_MAX_CHOICES == 8, "RuleLds copy assumes 8 choices");
 //     so gather/emit is branch-free: v_cvt_f32_ubyteN + global_store_dword.
 constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
 constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kCacheResidentGrid = (size_t)384 << 20;   // grids of a batch up to about this size stay in the 256 MB Infinity Cache + L2 from turn to turn
 
 // (non-temporal observation stores were measured: slower)
 #define OBS_STORE(ptr, val) (*(ptr) = (val))
@@ -2193,14 +2194,18 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // Unstaged float32 observations of 8 KiB or more per env, whole turns of a large batch (Cleanup): five instead of
-    // eight waves per SIMD (an LDS request that fits 5 workgroups per CU): 21x31x3 at 65 536 envs 893 -> 801 us.  The
-    // per-agent dword stores of that path leave many half-written lines open; fewer concurrent waves, fewer of them.
-    // The staged emit with its streaming full-line stores (configs 2/3/4) is fastest at full occupancy (config 3:
-    // 124 us at 8 and 7 per CU, 126 at 6, 131 at 5), as are the uint8 format, small batches and the shapes with
-    // small windows, which are latency-bound (Tag 11x11, 6.5 KB per env: 164 us at full occupancy, 192 us capped).
+    // Occupancy cap (an LDS request that fits 5 workgroups per CU = 5 waves per SIMD) for whole-turn float32
+    // observation writes of 8 KiB or more per env in large batches, where fewer concurrent waves mean fewer
+    // half-written lines open in HBM:
+    //  - the unstaged path (Cleanup, 21x31x3 at 65 536 envs: 893 -> 801 us);
+    //  - the staged path only when the grids of the batch no longer fit the caches (262 144 envs of config 3:
+    //    662 -> 578 us, 524 288: 1375 -> 1146 us).  While they do fit (configs 3/4: 65 536 envs, 134 MB) the staged
+    //    emit with its streaming full-line stores is fastest at full occupancy (124 us at 8 and 7 per CU, 126 at 6,
+    //    131 at 5; 131 072 envs: 248 vs 281 us).
+    // The uint8 format, small batches and the shapes with small windows, which are latency-bound (Tag 11x11, 6.5 KB
+    // per env: 164 us at full occupancy, 192 us capped), are not capped.
     size_t lds = e->step_lds_bytes;
-    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && !p.obs_stage && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
+    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && (!p.obs_stage || (size_t)p.E * (size_t)p.env_stride > kCacheResidentGrid) && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
         p.E >= (int64_t)e->num_cus * 32 * 2)
         lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);

@@ -13,12 +13,23 @@ random actions drawn on device.  Workload at N=1 = BASELINE.json configs[2]
 shard with no data-path collective; the only collective is one all-reduce (RCCL)
 of the 4-double metric vector at the end of the rollout.
 
+Order of a run: build check (before anything touches the GPU) -> reset -> P untimed
+clock-ramp steps (``--prewarm-steps``, reported; the GPU's clocks take tens of
+milliseconds of load to settle and the driver's default ``--steps 20 --warmup 5`` is 3 ms
+of work) -> W untimed warm-up steps -> barrier + synchronize -> EXACTLY K timed steps
+(``value`` / ``ms_per_step`` / ``roofline.kernel_ms`` come from here; nothing but the K
+launches and two HIP events is in the region) -> barrier + synchronize -> the same K
+steps once more with a pair of HIP events around EVERY launch (``roofline.series``:
+per-launch median / p10 / p90 / mean of the first five) -> end-of-rollout metric
+all-reduce -> (rank 0, N=1) the CPU baseline.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,6 +40,8 @@ if ROOT not in sys.path:
 
 HBM_COPY_GBS = 6290.0   # measured float4-copy ceiling (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+CACHE_RESIDENT_GRID_BYTES = 384 << 20   # = kCacheResidentGrid in sgw.hip: grids of a batch up to this size are re-read
+                                        # from the 256 MiB Infinity Cache + 32 MiB of L2 on the next turn, not from HBM
 
 CONFIGS = {
     # name: (H, W, agents, radius, envs per GPU, spawn_prob, dense_prob)
@@ -37,62 +50,136 @@ CONFIGS = {
     "c5": (128, 128, 64, 5, 2048, 0.05, 0.25),
 }
 
+# The true reference (Python, one core, Xeon 2.1 GHz, build container) on one env of each shape: BASELINE.md section 2,
+# code timed = sorrel/environment.py:81-93 through the oracle loader.  It cannot travel to the GPU box.
+REFERENCE_PYTHON_AGENT_STEPS_PER_S = {"c2": 1701.0, "c3": 641.0, "c5": 44.0}
 
-def cpu_baseline(spec, seconds_target: float = 12.0):
-    """The C oracle ("port") timed on this host's cores on a bounded sample of the
-    same workload.  Only the checker is used here, never as the thing measured above."""
+
+def host_cores() -> int:
+    """CPU cores this process may really use: the scheduler affinity, cut down to the cgroup's CPU quota (a GPU box
+    shows 128 logical CPUs but grants a 1-GPU job a share of them; 128 OpenMP threads on a 16-CPU quota is what made
+    last round's 'parallel' baseline 4 % efficient)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    period = float(fh.read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(math.ceil(float(quota) / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(spec, config_name: str, seconds_target: float = 12.0):
+    """The C oracle ("port": oracle/gridstep_oracle.c, the reference's step loop restated, parity-pinned) timed on this
+    host's cores on a bounded sample of the same workload: envs in parallel, each thread playing its own block of envs
+    through all the turns (persistent threads, one fork/join per rollout).  Only the checker is used here, never as
+    the thing measured above.  Loads the library built at the top of main(); compiles nothing."""
     import ctypes as C
 
     import numpy as np
 
     import __graft_entry__ as g
 
-    lib = C.CDLL(g.build_oracle())
-    lib.sgo_threads.argtypes = [C.c_int]
-    cores = int(lib.sgo_threads(0))
+    lib = C.CDLL(g.ORACLE_LIB)
+    cores = host_cores()
     A = spec.num_agents
-    E = 4096 if spec.grid_bytes_per_env() <= 4096 else 256
-    cfg = spec.to_config(E, 0)
-    grid = np.zeros((E, spec.layers, spec.height, spec.width), np.uint8)
-    pos = np.zeros((E, A, 2), np.uint8)
-    act = np.zeros((E, A), np.uint8)
-    obs = np.zeros((E,) + spec.obs_shape, np.float32)
-    rew = np.zeros((E, A), np.float32)
-    tot = np.zeros((E,), np.float64)
+    small = spec.grid_bytes_per_env() <= 4096
+
+    def make(E):
+        cfg = spec.to_config(E, 0)
+        arr = dict(grid=np.zeros((E, spec.layers, spec.height, spec.width), np.uint8), pos=np.zeros((E, A, 2), np.uint8),
+                   act=np.zeros((E, A), np.uint8), obs=np.zeros((E,) + spec.obs_shape, np.float32),
+                   rew=np.zeros((E, A), np.float32), tot=np.zeros((E,), np.float64))
+        return cfg, arr
 
     def p(a):
         return a.ctypes.data_as(C.c_void_p)
 
-    lib.sgo_reset(C.byref(cfg), p(grid), p(pos), p(tot), C.c_uint32(0), C.c_int(0), C.c_void_p(0))
+    def rollout(cfg, arr, t0, turns, threads):
+        t = time.perf_counter()
+        lib.sgo_rollout(C.byref(cfg), p(arr["grid"]), p(arr["pos"]), p(arr["act"]), p(arr["obs"]), p(arr["rew"]), p(arr["tot"]),
+                        C.c_uint32(0), C.c_uint32(t0), C.c_uint32(turns), C.c_int(threads), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+        return time.perf_counter() - t
 
-    def run(t0, n, threads=0):
-        for t in range(t0, t0 + n):
-            lib.sgo_step(C.byref(cfg), p(grid), p(pos), p(act), p(obs), p(rew), p(tot), C.c_uint32(0), C.c_uint32(t),
-                         C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(threads), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+    def measure(E, threads, seconds):
+        cfg, arr = make(E)
+        lib.sgo_reset(C.byref(cfg), p(arr["grid"]), p(arr["pos"]), p(arr["tot"]), C.c_uint32(0), C.c_int(threads), C.c_void_p(0))
+        rollout(cfg, arr, 1, 1, threads)                       # page-in + thread pool start
+        per_turn = rollout(cfg, arr, 2, 2, threads) / 2
+        turns = max(2, min(5000, int(seconds / max(per_turn, 1e-7))))
+        dt = rollout(cfg, arr, 4, turns, threads)
+        return E * A * turns / dt, turns, dt
 
-    run(1, 2)                                   # warm-up + page-in
-    t = time.perf_counter()
-    run(3, 3)
-    per_turn = (time.perf_counter() - t) / 3
-    turns = max(3, min(2000, int(seconds_target / max(per_turn, 1e-6))))
-    t = time.perf_counter()
-    run(6, turns)
-    dt = time.perf_counter() - t
-    # the same code on ONE thread (SURVEY 8d: total, per core, and the single-core figure), a ~3 s sample
-    t1 = time.perf_counter()
-    run(6 + turns, 1, threads=1)
-    per_turn1 = time.perf_counter() - t1
-    turns1 = max(1, min(50, int(3.0 / max(per_turn1, 1e-6))))
-    t1 = time.perf_counter()
-    run(7 + turns, turns1, threads=1)
-    dt1 = time.perf_counter() - t1
-    value = E * A * turns / dt
-    return {
+    E = 32768 if small else max(256, 16 * cores)               # >= 32 768 envs of the config-3 shape (VERDICT r01 item 6)
+    value, turns, dt = measure(E, cores, seconds_target)
+    E1 = 512 if small else 16
+    single, turns1, dt1 = measure(E1, 1, 3.0)
+    out = {
         "value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-        "per_core": value / cores, "single_core_value": E * A * turns1 / dt1,
-        "sample": f"oracle/gridstep_oracle.c (OpenMP, {cores} threads), {E} envs x {turns} turns of the same "
-                  f"{spec.height}x{spec.width}x{A}-agent workload, {dt:.1f} s; single thread: {turns1} turns, {dt1:.1f} s",
+        "per_core": value / cores, "single_core_value": single,
+        "sample": f"oracle/gridstep_oracle.c sgo_rollout (envs outer / turns inner, OpenMP static blocks, {cores} threads = this "
+                  f"process's CPU share), {E} envs x {turns} turns of the same {spec.height}x{spec.width}x{A}-agent workload, "
+                  f"{dt:.1f} s; one thread: {E1} envs x {turns1} turns, {dt1:.1f} s",
     }
+    ref = REFERENCE_PYTHON_AGENT_STEPS_PER_S.get(config_name)
+    if ref is not None:
+        out["reference_python_single_core"] = ref
+        out["reference_python_source"] = ("BASELINE.md section 2: the reference's own Environment.take_turn (sorrel/environment.py:81-93), "
+                                          "one env of this shape, one Xeon 2.1 GHz core of the build container (the Python reference "
+                                          "cannot travel to the GPU box)")
+    return out
+
+
+def ensure_built() -> None:
+    """Both native libraries, checked (and, outside a profiler, rebuilt if stale) BEFORE torch or anything else touches
+    the GPU: no compiler is ever started from a GPU-initialised process.  Ranks of one node take turns on a lock."""
+    import fcntl
+
+    import __graft_entry__ as graft
+
+    profiled = any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if graft.libs_up_to_date():
+                return
+            if profiled:
+                raise SystemExit("bench.py: libsgw.so / libgridstep_oracle.so are stale or missing and this process runs under a "
+                                 "profiler (its preload has already initialised the GPU): run "
+                                 "`python3 -c 'import __graft_entry__ as g; g.build()'` first")
+            try:
+                graft.build_hip()
+                graft.build_oracle()
+            except Exception as exc:   # no compiler on this box: an existing library is still the product under test
+                if not (os.path.isfile(graft.HIP_LIB) and os.path.isfile(graft.ORACLE_LIB)):
+                    raise
+                print(f"bench.py: could not rebuild the native libraries ({exc}); using the existing ones", file=sys.stderr)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def series_stats(ms):
+    if not ms:
+        return None
+    s = sorted(ms)
+
+    def q(f):
+        return s[min(len(s) - 1, int(f * len(s)))]
+
+    return {"n": len(ms), "median_ms": q(0.5), "p10_ms": q(0.1), "p90_ms": q(0.9), "min_ms": s[0], "max_ms": s[-1],
+            "mean_ms": sum(ms) / len(ms), "first5_mean_ms": sum(ms[:5]) / len(ms[:5])}
 
 
 def main() -> int:
@@ -102,7 +189,13 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the config's)")
+    ap.add_argument("--prewarm-steps", type=int, default=1500,
+                    help="untimed clock-ramp steps before the W warm-up steps (0 = none); reported in the JSON line")
+    ap.add_argument("--max-turns", type=int, default=0,
+                    help="epoch length: every env is auto-reset (K3, inside sgw_step) after this many turns, inside the "
+                         "timed loop too; 0 = one endless epoch (SURVEY 8d: no reset in the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-series", action="store_true", help="skip the per-launch timing pass after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip observation stores (NOT a valid bench line)")
     ap.add_argument("--diag-agents", type=int, default=-1, help="diagnostic: step only the first N agents (NOT valid)")
@@ -111,26 +204,12 @@ def main() -> int:
     ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
     args = ap.parse_args()
 
-    # the C-ABI library travels with the tree; if it is missing or older than its source (a fresh checkout on a box
-    # with hipcc) build it once -- ranks of one node take turns on a lock file, the first one builds
-    import fcntl
-
-    import __graft_entry__ as graft
-
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".build.lock"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        try:
-            graft.build_hip()
-        except Exception as exc:   # no compiler on this box: an existing library is still the product under test
-            if not os.path.isfile(graft.HIP_LIB):
-                raise
-            print(f"bench.py: could not rebuild libsgw.so ({exc}); using the existing library", file=sys.stderr)
-        finally:
-            fcntl.flock(lock, fcntl.LOCK_UN)
+    ensure_built()
 
     import torch
     import torch.distributed as dist
 
+    import __graft_entry__ as graft
     from sorrel_amd.engine import GridEngine
     from sorrel_amd.spec import treasurehunt_spec
 
@@ -163,6 +242,8 @@ def main() -> int:
     obs_dtype = torch.float32 if args.obs_dtype == "f32" else torch.uint8
     eng = GridEngine(spec, E, device=dev, first_env_id=rank * E, obs_dtype=obs_dtype)   # global env ids: re-sharding is bit-exact
     eng.reset(epoch=0)
+    if args.max_turns > 0:
+        eng.set_auto_reset(args.max_turns)
 
     def barrier():
         if world > 1:
@@ -177,18 +258,42 @@ def main() -> int:
     if args.diag_agents >= 0:
         _orig_step = eng.step
         eng.step = lambda *a, **k: _orig_step(*a, agent_end=args.diag_agents, **k)
-    for _ in range(args.warmup):
+
+    def step():
         eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
+
+    for _ in range(max(0, args.prewarm_steps)):    # clock ramp: untimed, reported
+        step()
+    for _ in range(args.warmup):
+        step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                   # on the stream sgw_step launches on
     for _ in range(args.steps):
-        eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
+        step()
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events over the timed region, per launch
+
+    # the same K steps again, every launch between its own pair of HIP events (outside the timed region: two event
+    # packets per launch would sit in the measured stream otherwise)
+    series = None
+    if not args.no_series:
+        eng.set_timing(True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        series_wall = time.perf_counter() - t1
+        per_launch = eng.step_times_ms()
+        eng.set_timing(False)
+        series = series_stats(per_launch)
+        if series is not None:
+            series["pass_wall_ms_per_step"] = series_wall / args.steps * 1e3
+            series["what"] = ("a second pass of the same K steps right after the timed region, one pair of HIP events per launch on the "
+                              "launch stream (sgw_set_timing); first5_mean = the first five launches of that pass")
 
     # end-of-rollout metrics: on-device reduction + the one collective
     metrics = eng.reduce_metrics().clone()
@@ -204,27 +309,43 @@ def main() -> int:
     if rank == 0:
         total_envs = E * world
         value = total_envs * A * args.steps / dt
+        grid_bytes = spec.grid_bytes_per_env() * E
         alg_bytes = spec.algorithmic_bytes_per_env_step() * E          # per launch (one rank's kernel)
         if not write_obs:
             alg_bytes -= E * A * spec.num_channels * spec.window ** 2 * 4
         elif args.obs_dtype == "u8":
             alg_bytes -= E * A * spec.num_channels * spec.window ** 2 * 3      # C*V*V*1 instead of *4
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # What of that the design says never reaches HBM: while the batch's grids fit the Infinity Cache + L2 (the
+        # observation bursts are streaming stores and leave the caches to the grids), the grid READ of a turn is
+        # served on-die.  The write-back is still counted as HBM traffic (a memory-side cache may keep it too).
+        cache_served = grid_bytes if grid_bytes <= CACHE_RESIDENT_GRID_BYTES else 0
+        hbm_side = (alg_bytes - cache_served) / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), collected by
-        # tools/profile_gpu.sh on this same command and committed under profiles/; null when no matching pass exists
-        traffic = None
+        # tools/profile_gpu.sh on this same command and committed under profiles/; null unless that file was measured
+        # on exactly this kernel source (hash) and workload
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         try:
-            with open(os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")) as fh:
+            with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get("envs") == E and write_obs and sweep and args.obs_dtype == "f32":
-                traffic = tj["hbm_bytes_per_launch"]
+            src_hash = graft.source_digest()
+            if tj.get("envs") == E and write_obs and sweep and args.obs_dtype == "f32" and args.max_turns == 0:
+                if tj.get("sgw_source_sha256") == src_hash:
+                    traffic = tj["hbm_bytes_per_launch"]
+                    traffic_source = f"profiles/traffic_{args.config}.json (rocprofv3 --pmc passes on kernel source {src_hash[:12]}; not measured in this run)"
+                else:
+                    traffic_source = (f"profiles/traffic_{args.config}.json was measured on kernel source {str(tj.get('sgw_source_sha256'))[:12]}, "
+                                      f"this run is {src_hash[:12]}: stale, not reported")
         except (OSError, ValueError, KeyError):
             pass
         out = {
             "metric": "agent-steps/sec" if args.obs_dtype == "f32" else "agent-steps/sec (compact uint8 observations; NOT the contract metric)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm_steps),
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 grid, " + args.obs_dtype + " obs",   # entity type ids are uint8 (the path's arithmetic); observations leave as float32
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: {H}x{W} grid x {spec.layers} layers, {A} agents, {spec.window}x{spec.window} window, "
@@ -232,19 +353,26 @@ def main() -> int:
                 "envs_per_gpu": E, "global_envs": total_envs, "agents": A, "grid": [H, W, spec.layers],
                 "window": spec.window, "channels": spec.num_channels, "spawn_prob": p_spawn, "dense_prob": p_dense,
                 "sharding": f"env-batch x{world}, no data-path collective; one 32-byte all-reduce at end of rollout",
-                "obs_written": write_obs, "sweep": sweep,
+                "obs_written": write_obs, "sweep": sweep, "max_turns": args.max_turns,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "what": "ALGORITHMIC bytes per launch (SURVEY 8d) / average launch duration; it can exceed the copy ceiling because "
+                        "cache-served bytes are in the numerator -- see hbm_side_*",
                 "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,   # both denominators
-                "kernel": "step_fast<...> (sgw_step)" if spec.grid_bytes_per_env() <= 4096 else "step_big<...> (sgw_step)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "hbm_side_achieved": hbm_side, "hbm_side_frac": hbm_side / HBM_PEAK_GBS,
+                "hbm_side_frac_of_copy_ceiling": hbm_side / HBM_COPY_GBS, "cache_served_bytes_per_launch": cache_served,
+                "hbm_side_what": "algorithmic bytes minus the grid READ of a turn, which the Infinity Cache serves while the batch's grids "
+                                 f"({grid_bytes / 1e6:.0f} MB here) stay resident (<= {CACHE_RESIDENT_GRID_BYTES >> 20} MiB); 0 subtracted otherwise",
+                "kernel": eng.launch_info(), "kernel_ms": kernel_ms, "series": series,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },
             "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(spec, args.config, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()

@@ -34,9 +34,13 @@
  *   - all array arguments are DEVICE pointers owned by the caller (PyTorch);
  *     the library owns only the engine handle, its constant tables and a small
  *     reduction workspace;
- *   - all work is enqueued asynchronously on the HIP stream passed as `stream`
- *     (a hipStream_t, NULL = default stream); no call synchronises except
- *     sgw_get_status;
+ *   - all kernels are enqueued asynchronously on the HIP stream passed as `stream`
+ *     (a hipStream_t, NULL = default stream).  The calls that block the host are:
+ *     sgw_create / sgw_destroy (allocate and upload the constant tables with blocking
+ *     copies), sgw_get_status, sgw_get_step_time_ms and sgw_get_step_times_ms (they
+ *     wait for the events / the status word they read), and -- only while timing is
+ *     enabled with sgw_set_timing -- every 4096th sgw_step / sgw_observe, which waits
+ *     for its oldest pair of events when the event pool wraps;
  *   - one engine per device, not thread-safe per engine (the reference is
  *     single-threaded);
  *   - there is no CPU fallback: without a HIP device every launch fails.
@@ -107,6 +111,11 @@ extern "C" {
 #define SGW_STEP_SWEEP 1u           /* run the entity-transition sweep first */
 #define SGW_STEP_RANDOM_ACTIONS 2u  /* draw actions from STREAM_ACTION and STORE them to `actions` */
 #define SGW_STEP_NO_OBS 4u          /* do not write observations (obs may be NULL) */
+#define SGW_STEP_OBS_NEXT 8u        /* policy-driven (phased) stepping: do NOT write the observations of the stepped
+                                     * agents; instead write the observation of agent `agent_end` (if < num_agents) from
+                                     * the grid AFTER the moves of [agent_begin, agent_end) -- exactly what that agent's
+                                     * pov() sees next (sorrel/agents/agent.py:167), so a policy turn costs 1 + A
+                                     * launches instead of 1 + 2A */
 #define SGW_STEP_DEFAULT (SGW_STEP_SWEEP)
 
 /* error codes */
@@ -229,10 +238,31 @@ int64_t sgw_grid_bytes_per_env(const sgw_config* cfg);
 /* Algorithmic HBM bytes of one env-step (SURVEY.md 8d formula). */
 int64_t sgw_algorithmic_bytes_per_env_step(const sgw_config* cfg);
 
-/* Name and duration (ms, HIP events on `stream`) bookkeeping for the LAST
- * sgw_step launch when timing is enabled with sgw_set_timing(eng, 1). */
+/* Launch timing: with sgw_set_timing(eng, 1) every sgw_step / sgw_observe launch is bracketed by a pair of
+ * HIP events on its stream.  sgw_get_step_time_ms returns (and clears) the sum and the number of launches since
+ * the last read; sgw_get_step_times_ms copies the per-launch durations since the last read (oldest first, at most
+ * `capacity`; *count = how many were written) to the HOST array `out_ms` and clears them.  Both wait for the
+ * events they read. */
 int sgw_set_timing(sgw_engine* eng, int enable);
 int sgw_get_step_time_ms(sgw_engine* eng, double* total_ms, int64_t* launches);
+int sgw_get_step_times_ms(sgw_engine* eng, float* out_ms, int64_t capacity, int64_t* count);
+
+/* Auto-reset (Environment.run_experiment's epoch loop, sorrel/environment.py:148-171): once armed with
+ * max_turns > 0, the sgw_step call that steps the LAST agent (agent_end == num_agents) of turn == max_turns also,
+ * on the same stream and after the step kernel, copies total_reward to `episode_return` (device, double [E]; may be
+ * NULL) and runs sgw_reset for epoch + 1 on the grid / agent_pos / total_reward it was given.  The caller goes on
+ * with (epoch + 1, turn 1).  max_turns == 0 disarms. */
+int sgw_set_auto_reset(sgw_engine* eng, uint32_t max_turns, double* episode_return);
+
+/* Launch tuning of the wave-per-env step kernel.  Large float32 observation bursts of large batches run fastest
+ * with fewer waves per CU than the register budget allows (fewer half-written observation streams open in HBM; see
+ * DESIGN.md section 6); the only launch-time lever for that is the dynamic-LDS request, which bounds the workgroups
+ * a CU admits.  wg_per_cu = 0 selects the documented automatic rule (a cap of 5 for whole-turn float32 observation
+ * writes of >= 8 KiB per env when the batch's grids outgrow the caches or the emit is unstaged), 1..8 forces that
+ * many workgroups per CU, -1 never caps.  sgw_launch_info writes a one-line description of what sgw_step launches
+ * (kernel variant, threads, LDS bytes, workgroups per CU) into buf. */
+int sgw_set_wg_per_cu(sgw_engine* eng, int wg_per_cu);
+int sgw_launch_info(sgw_engine* eng, char* buf, int64_t capacity);
 
 const char* sgw_last_error(void);
 const char* sgw_version(void);

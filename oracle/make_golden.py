@@ -899,5 +899,29 @@ def make_buffer_fixture():
     np.savez_compressed(path, **out)
     print(f"  wrote {path} ({os.path.getsize(path)} bytes)")
 
+    # Files written by the reference's OWN Buffer.save / SavedGames.save (sorrel/buffers.py:168-179, 361-379): what
+    # the product's Buffer.load must read, and what its save must reproduce for the same history.
+    from sorrel.buffers import SavedGames
+
+    path = os.path.join(GOLDEN_DIR, "buffer_saved_by_reference.npz")
+    buf.save(path)
+    print(f"  wrote {path} ({os.path.getsize(path)} bytes)")
+    # generate_memories' container (sorrel/environment.py:235-240, 297-300): two "games" of 4 turns appended from a
+    # model memory that carries positions and is NOT cleared between games (the reference re-appends it whole)
+    mem = Buffer(capacity=16, obs_shape=(obs,), n_frames=1, positions=(2,))
+    sg = SavedGames(capacity=2 * 4, obs_shape=(obs,), n_frames=1, positions=(2,))
+    k = 0
+    for game in range(2):
+        for _ in range(4):
+            mem.add(states[k], int(actions[k]), float(rewards[k]), bool(dones[k]), positions=(k + 1, 2 * k))
+            k += 1
+        sg.add_from_buffer(mem)
+    path = os.path.join(GOLDEN_DIR, "savedgames_by_reference.npz")
+    sg.save(path)
+    print(f"  wrote {path} ({os.path.getsize(path)} bytes)")
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["buffers"]:      # only the replay-buffer fixtures
+        make_buffer_fixture()
+        sys.exit(0)
     sys.exit(main())

@@ -11,7 +11,7 @@ import os
 MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
 RULE_NONE, RULE_SPAWN, RULE_BECOME_IF = 0, 1, 2
 NO_BORDER = 255
-STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS = 1, 2, 4
+STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT = 1, 2, 4, 8
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
 ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2
@@ -64,7 +64,8 @@ LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")
 EXPORTS = (
     "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_reduce_metrics",
     "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
-    "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms",
+    "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
+    "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info",
     "sgw_last_error", "sgw_version",
 )
 
@@ -137,6 +138,14 @@ def load():
     lib.sgw_set_timing.restype = C.c_int
     lib.sgw_get_step_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.sgw_get_step_time_ms.restype = C.c_int
+    lib.sgw_get_step_times_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]
+    lib.sgw_get_step_times_ms.restype = C.c_int
+    lib.sgw_set_auto_reset.argtypes = [vp, C.c_uint32, f64p]
+    lib.sgw_set_auto_reset.restype = C.c_int
+    lib.sgw_set_wg_per_cu.argtypes = [vp, C.c_int]
+    lib.sgw_set_wg_per_cu.restype = C.c_int
+    lib.sgw_launch_info.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.sgw_launch_info.restype = C.c_int
     lib.sgw_last_error.argtypes = []
     lib.sgw_last_error.restype = C.c_char_p
     lib.sgw_version.argtypes = []

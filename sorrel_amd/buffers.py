@@ -7,15 +7,22 @@ round trip).  dtypes follow the reference: states float32, actions int64, reward
 float32, dones float32 (``sorrel/buffers.py:31-34``)."""
 from __future__ import annotations
 
+from pathlib import Path
 from typing import Sequence
 
+import numpy as np
 import torch
 
 from sorrel_amd.spec import resolve_device
 
 
 class Buffer:
-    def __init__(self, capacity: int, obs_shape: Sequence[int], n_frames: int = 1, num_envs: int = 1, device=None):
+    """``extra`` keyword arguments declare additional int64 columns exactly as in the reference
+    (``Buffer(capacity, obs_shape, positions=(2,))``, ``sorrel/buffers.py:39-44``): a tuple gives the trailing
+    shape, anything else a scalar column; ``add(..., positions=...)`` fills them."""
+
+    def __init__(self, capacity: int, obs_shape: Sequence[int], n_frames: int = 1, num_envs: int = 1, device=None,
+                 **extra):
         self.capacity, self.obs_shape, self.n_frames, self.num_envs = capacity, tuple(obs_shape), n_frames, num_envs
         self.device = resolve_device(device)
         E = num_envs
@@ -25,23 +32,103 @@ class Buffer:
         self.dones = torch.zeros((capacity, E), dtype=torch.float32, device=self.device)
         self.idx = 0
         self.size = 0
+        self.extra_data = {}
+        for key, value in extra.items():
+            shape = (capacity, E, *value) if isinstance(value, tuple) else (capacity, E)
+            self.extra_data[key] = torch.zeros(shape, dtype=torch.int64, device=self.device)
 
-    def add(self, obs, action, reward, done):
+    def add(self, obs, action, reward, done, **extra):
         """Append one turn: ``obs [E, *obs_shape]``, ``action [E]``, ``reward [E]``, ``done`` scalar or ``[E]``."""
         i = self.idx
         self.states[i].copy_(obs.reshape(self.states[i].shape))
         self.actions[i].copy_(action)
         self.rewards[i].copy_(reward)
         self.dones[i] = done
+        for key, value in extra.items():
+            self.extra_data[key][i] = torch.as_tensor(value, device=self.device)
         self.idx = (self.idx + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
+
+    def add_from_buffer(self, buffer: "Buffer") -> None:
+        """Append the first ``min(capacity - idx, buffer.size)`` rows of another buffer, the reference's
+        ``add_from_buffer`` exactly (``sorrel/buffers.py:71-99``): no wrap-around, ``idx`` only advances, ``size``
+        is left alone; extra columns the source carries are created on demand."""
+        if tuple(self.obs_shape) != tuple(buffer.obs_shape):
+            raise AssertionError("Cannot add from a buffer with different state shapes.")
+        n = min(self.capacity - self.idx, buffer.size)
+        lo, hi = self.idx, self.idx + n
+        self.states[lo:hi].copy_(buffer.states[:n])
+        self.actions[lo:hi].copy_(buffer.actions[:n])
+        self.rewards[lo:hi].copy_(buffer.rewards[:n])
+        self.dones[lo:hi].copy_(buffer.dones[:n])
+        for key, value in buffer.extra_data.items():
+            if key not in self.extra_data:
+                self.extra_data[key] = torch.zeros((self.capacity, *value.shape[1:]), dtype=value.dtype, device=self.device)
+            self.extra_data[key][lo:hi].copy_(value[:n])
+        self.idx = hi
+
+    # -- files: the reference's ``Buffer.save`` / ``Buffer.load`` format (``sorrel/buffers.py:168-201``)
+    def _file_arrays(self) -> dict:
+        """One env: exactly the reference's arrays (all ``capacity`` rows, scalar ``idx``).  Several envs: the rows
+        of env ``e`` follow those of env ``e - 1`` (each block = that env's ring in storage order, what the reference
+        would have saved for that one world), plus ``num_envs`` so that ``load`` can fold them back; a reader that
+        does not know about batches (the reference's ``Buffer.load``) sees one long valid buffer."""
+        E = self.num_envs
+
+        def flat(t):
+            t = t.detach().cpu()
+            return t.transpose(0, 1).reshape((E * self.capacity,) + tuple(t.shape[2:])).contiguous().numpy()
+
+        out = dict(states=flat(self.states), actions=flat(self.actions), rewards=flat(self.rewards), dones=flat(self.dones),
+                   n_frames=self.n_frames, idx=self.idx if E == 1 else E * self.idx)
+        for key, value in self.extra_data.items():
+            out[key] = flat(value)
+        if E > 1:
+            out["num_envs"] = E
+        return out
+
+    def save(self, output_file) -> None:
+        arrays = self._file_arrays()
+        arrays = {k: v for k, v in arrays.items() if k in ("states", "actions", "rewards", "dones", "n_frames", "idx", "num_envs")}
+        np.savez_compressed(Path(output_file), **arrays)
+
+    @classmethod
+    def load(cls, input_file, device="cpu") -> "Buffer":
+        """Reads files written by this class or by the reference's ``Buffer.save`` / ``SavedGames.save``; like the
+        reference, the loaded buffer counts as full (``size = len(states)`` per env)."""
+        with np.load(Path(input_file)) as data:
+            arrays = {k: data[k] for k in data.files}
+        E = int(arrays.pop("num_envs", 1))
+        n_frames, idx = int(arrays.pop("n_frames")), int(arrays.pop("idx"))
+        rows = len(arrays["actions"]) // E
+        extra = {k: tuple(v.shape[1:]) or None for k, v in arrays.items() if k not in ("states", "actions", "rewards", "dones")}
+        out = cls(capacity=rows, obs_shape=arrays["states"].shape[1:], n_frames=n_frames, num_envs=E, device=device,
+                  **{k: (v if v is not None else 0) for k, v in extra.items()})
+
+        def fold(a, like):
+            t = torch.from_numpy(np.ascontiguousarray(a)).reshape((E, rows) + tuple(a.shape[1:])).transpose(0, 1)
+            return t.to(device=like.device, dtype=like.dtype).contiguous()
+
+        out.states, out.actions = fold(arrays["states"], out.states), fold(arrays["actions"], out.actions)
+        out.rewards, out.dones = fold(arrays["rewards"], out.rewards), fold(arrays["dones"], out.dones)
+        for k in extra:
+            out.extra_data[k] = fold(arrays[k], out.extra_data[k])
+        out.idx = idx if E == 1 else idx // E
+        out.size = rows
+        return out
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, i):
+        return self.states[i], self.actions[i], self.rewards[i], self.dones[i]
 
     def add_empty(self):
         self.idx = (self.idx + self.n_frames - 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
 
     def clear(self):
-        for t in (self.states, self.actions, self.rewards, self.dones):
+        for t in (self.states, self.actions, self.rewards, self.dones, *self.extra_data.values()):
             t.zero_()
         self.idx = self.size = 0
 
@@ -79,6 +166,29 @@ class Buffer:
         return f"Buffer(capacity={self.capacity}, obs_shape={self.obs_shape}, num_envs={self.num_envs})"
 
 
+class SavedGames(Buffer):
+    """The container ``generate_memories`` fills and writes (``sorrel/buffers.py:358-379``): a ``Buffer`` whose
+    ``save`` also stores the extra columns (``positions``)."""
+
+    def save(self, output_file) -> None:
+        np.savez_compressed(Path(output_file), **self._file_arrays())
+
+    def add_turns(self, states, actions, rewards, dones, **extra) -> None:
+        """Append ``T`` turns at once from ``[T, E, ...]`` tensors (views of a ``TurnBuffer``); truncates at capacity
+        like ``add_from_buffer``."""
+        n = min(self.capacity - self.idx, states.shape[0])
+        lo, hi = self.idx, self.idx + n
+        self.states[lo:hi].copy_(states[:n].reshape((n,) + tuple(self.states.shape[1:])))
+        self.actions[lo:hi].copy_(actions[:n])
+        self.rewards[lo:hi].copy_(rewards[:n])
+        self.dones[lo:hi].copy_(dones[:n])
+        for key, value in extra.items():
+            if value is not None and key in self.extra_data:
+                self.extra_data[key][lo:hi].copy_(value[:n])
+        self.idx = hi
+        self.size = min(self.size + n, self.capacity)
+
+
 class TurnBuffer:
     """Joint ring over ALL agents for fused rollouts: one slot holds one ``take_turn`` of every env --
     ``obs [capacity, E, A, *obs_shape]`` float32 (or uint8 for the compact format), ``actions`` uint8,
@@ -87,7 +197,8 @@ class TurnBuffer:
     them (the per-agent ``Buffer`` above gets a device-to-device copy per agent instead).  ``agent_view(a)``
     gives the reference's per-agent layout back as views."""
 
-    def __init__(self, capacity: int, num_envs: int, obs_shape: Sequence[int], device=None, obs_dtype=torch.float32):
+    def __init__(self, capacity: int, num_envs: int, obs_shape: Sequence[int], device=None, obs_dtype=torch.float32,
+                 positions: bool = False):
         self.capacity, self.num_envs, self.obs_shape = capacity, num_envs, tuple(obs_shape)    # obs_shape = (A, C, V, V)
         self.device = resolve_device(device)
         A = self.obs_shape[0]
@@ -95,6 +206,8 @@ class TurnBuffer:
         self.actions = torch.zeros((capacity, num_envs, A), dtype=torch.uint8, device=self.device)
         self.rewards = torch.zeros((capacity, num_envs, A), dtype=torch.float32, device=self.device)
         self.dones = torch.zeros((capacity, num_envs, A), dtype=torch.float32, device=self.device)   # all-zero inside an epoch
+        # optional: every agent's (y, x) AFTER its move, what add_memory stores as ``positions`` (sorrel/agents/agent.py:127-130)
+        self.positions = torch.zeros((capacity, num_envs, A, 2), dtype=torch.uint8, device=self.device) if positions else None
         self.idx = 0
         self.size = 0
 
@@ -102,10 +215,12 @@ class TurnBuffer:
         """The slot the next turn goes to (``commit`` advances)."""
         return self.idx
 
-    def commit(self, actions: torch.Tensor, rewards: torch.Tensor) -> None:
+    def commit(self, actions: torch.Tensor, rewards: torch.Tensor, agent_pos: torch.Tensor = None) -> None:
         i = self.idx
         self.actions[i].copy_(actions)
         self.rewards[i].copy_(rewards)
+        if self.positions is not None and agent_pos is not None:
+            self.positions[i].copy_(agent_pos)
         self.idx = (self.idx + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
 

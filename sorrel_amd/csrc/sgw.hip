@@ -111,6 +111,7 @@ struct Params {
     const DevTables* tab;
     int* status;
     int obs_stage;    // step_fast: bytes of the per-wave LDS observation staging area (0: observations go straight to HBM)
+    int obs_next;     // SGW_STEP_OBS_NEXT: write only the observation of agent a1, after the moves of [a0, a1)
 };
 
 // ---------------------------------------------------------------- RNG
@@ -370,10 +371,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
         }
 
         int st_bits = 0;
-        for (int a = p.a0; a < p.a1; ++a) {
+        const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;   // OBS_NEXT: one extra, observe-only iteration
+        for (int a = p.a0; a < a_end; ++a) {
             const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
             // ---- pov: egocentric window (visual_field.py:9-101)
-            if (write_obs) {
+            if (p.obs_next ? a == p.a1 : write_obs) {
                 float* obase = p.obs + ((env * p.A + a) * (int64_t)p.C) * p.VV;
                 auto render = [&](const int w, const int i, const int j) {
                     const int gy = y - p.r + i, gx = x - p.r + j;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                     render(w, i, w - i * p.V);
                 }
             }
-            if (!p.do_move) continue;
+            if (!p.do_move || a >= p.a1) continue;
             if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {
                 // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
                 // same LDS bytes, so all control flow here is uniform; single threads do the writes.
@@ -908,10 +910,11 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         uint32_t rew_bits = 0, moved = 0;
 
         STAMP(3);   // move inputs (action draw) done
-        // ---- agents, strictly in list order
-        for (int a = p.a0; a < p.a1; ++a) {
+        // ---- agents, strictly in list order (SGW_STEP_OBS_NEXT: one extra, observe-only iteration for agent a1)
+        const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;
+        for (int a = p.a0; a < a_end; ++a) {
             const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
-            if (write_obs) {
+            if (p.obs_next ? a == p.a1 : write_obs) {
                 const int y = __builtin_amdgcn_readlane((int)py, a);
                 const int x = __builtin_amdgcn_readlane((int)px, a);
                 const int cbase = s_o - zoff;
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                     }
                 }
             }
-            if (!p.do_move) continue;
+            if (!p.do_move || a >= p.a1) continue;
             // ---- the sequential part (agent.py:219-221, gridworld.py:110-122): scalar
             const uint32_t s_t = (uint32_t)__builtin_amdgcn_readlane((int)taddr_v, a);
             const uint32_t my_type = (uint32_t)__builtin_amdgcn_readlane((int)atype, a);
@@ -1409,7 +1412,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     // LDS now holds the grid AFTER all moves of this call; agent a must see it after the moves of
     // agents < a only, so the moves of agents b >= a that touch a's window (one ballot) are undone
     // in registers, latest first; an undo restores the two cells the move changed.
-    if (write_obs) {
+    if (write_obs || p.obs_next) {
         // per-lane window geometry: NP cells per lane
         int wdi[NP], wdj[NP], woff[NP];
 #pragma unroll
@@ -1424,7 +1427,9 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
         const uint32_t jb = s_ta[lane], srcb = s_oa[lane], dstb = s_np[lane], atb = s_atype[lane];
         const bool movedb = p.do_move && (jb & 0x200u) && lane >= p.a0 && lane < p.a1;
         const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
-        for (int a = p.a0 + wv; a < p.a1; a += kBigWaves) {
+        // SGW_STEP_OBS_NEXT: only agent a1, which sees the grid after ALL moves of this call (nothing to undo)
+        const int r_lo = p.obs_next ? p.a1 : p.a0, r_hi = p.obs_next ? (p.a1 < p.A ? p.a1 + 1 : p.a1) : p.a1;
+        for (int a = r_lo + wv; a < r_hi; a += kBigWaves) {
             const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
             const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
             const int cbase = y * W + x;
@@ -1777,6 +1782,10 @@ struct sgw_engine {
     int fast_tab_bytes = 0;
     int grid_blocks = 1;
     int fast_wg_cap = 5;   // step_fast workgroups per CU when writing large float32 observations of a large batch (0: no cap)
+    int wg_per_cu = 0;     // sgw_set_wg_per_cu: 0 = the automatic rule above, 1..8 = forced, -1 = never capped
+    const char* kernel_name = "?";
+    uint32_t auto_max_turns = 0;       // sgw_set_auto_reset
+    double* episode_return = nullptr;  // caller-owned
     int reset_blocks = 1;
     int num_cus = 256;
     // timing
@@ -1785,6 +1794,7 @@ struct sgw_engine {
     int ev_used = 0;
     double ms_acc = 0.0;
     int64_t launches = 0;
+    std::vector<float> series;   // per-launch durations since the last sgw_get_step_times_ms
 };
 
 namespace {
@@ -1887,41 +1897,66 @@ int occupancy_blocks(K kernel, size_t lds, int num_cus, int* out) {
 
 using StepFn = void (*)(const Params);
 
-StepFn pick_step(int wpe, bool onehot) {
-    if (wpe == 1) return onehot ? step_kernel<1, true> : step_kernel<1, false>;
-    return onehot ? step_kernel<4, true> : step_kernel<4, false>;
+#define PICK(...)                 \
+    do {                          \
+        *name = #__VA_ARGS__;     \
+        return __VA_ARGS__;       \
+    } while (0)
+
+StepFn pick_step(int wpe, bool onehot, const char** name) {
+    if (wpe == 1) {
+        if (onehot) PICK(step_kernel<1, true>);
+        PICK(step_kernel<1, false>);
+    }
+    if (onehot) PICK(step_kernel<4, true>);
+    PICK(step_kernel<4, false>);
 }
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
-StepFn pick_big(bool onehot, int L, int C, int r) {
-    if (!onehot) return step_big<false, 0, 0, 0>;
-    if (L == 2 && C == 6 && r == 5) return step_big<true, 2, 6, 5>;   // BASELINE config 5
-    return step_big<true, 0, 0, 0>;
+StepFn pick_big(bool onehot, int L, int C, int r, const char** name) {
+    if (!onehot) PICK(step_big<false, 0, 0, 0>);
+    if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5>);   // BASELINE config 5
+    PICK(step_big<true, 0, 0, 0>);
 }
 
-StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules) {
-    if (rules) return onehot ? step_fast<true, 0, 0, 0, 0, 0, false, true> : step_fast<false, 0, 0, 0, 0, 0, false, true>;
-    if (tag) return onehot ? step_fast<true, 0, 0, 0, 0, 0, true> : step_fast<false, 0, 0, 0, 0, 0, true>;
-    if (!onehot) return step_fast<false, 0, 0, 0, 0, 0>;
-    if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) return step_fast<true, 2, 6, 3, 32, 32>;   // BASELINE configs 3/4 (headline)
-    if (L == 2 && C == 6 && r == 2 && H == 16 && W == 16) return step_fast<true, 2, 6, 2, 16, 16>;   // BASELINE config 2
-    if (L == 2 && C == 6) return step_fast<true, 2, 6, 0, 0, 0>;   // treasurehunt-shaped, any size
-    return step_fast<true, 0, 0, 0, 0, 0>;
+StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, const char** name) {
+    if (rules) {
+        if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true>);
+        PICK(step_fast<false, 0, 0, 0, 0, 0, false, true>);
+    }
+    if (tag) {
+        if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, true>);
+        PICK(step_fast<false, 0, 0, 0, 0, 0, true>);
+    }
+    if (!onehot) PICK(step_fast<false, 0, 0, 0, 0, 0>);
+    if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32>);   // BASELINE configs 3/4 (headline)
+    if (L == 2 && C == 6 && r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16>);   // BASELINE config 2
+    if (L == 2 && C == 6) PICK(step_fast<true, 2, 6, 0, 0, 0>);   // treasurehunt-shaped, any size
+    PICK(step_fast<true, 0, 0, 0, 0, 0>);
 }
 
 int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+constexpr size_t kSeriesCap = (size_t)1 << 20;
+
+// Waits for the recorded event pairs and folds them into the running sum and the per-launch series.
+int time_drain(sgw_engine* e) {
+    if (e->ev_used == 0) return SGW_OK;
+    HIP_TRY(hipEventSynchronize(e->ev1[e->ev_used - 1]));
+    for (int i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
+        e->ms_acc += ms;
+        if (e->series.size() < kSeriesCap) e->series.push_back(ms);
+    }
+    e->ev_used = 0;
+    return SGW_OK;
+}
+
 int time_begin(sgw_engine* e, hipStream_t s) {
     if (!e->timing) return SGW_OK;
-    if (e->ev_used == kEventPool) {
-        HIP_TRY(hipEventSynchronize(e->ev1[e->ev_used - 1]));
-        for (int i = 0; i < e->ev_used; ++i) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
-            e->ms_acc += ms;
-        }
-        e->ev_used = 0;
-    }
+    if (e->ev_used == kEventPool)   // the pool wraps: the one place a launch call waits (include/sgw.h, Conventions)
+        if (int rc = time_drain(e)) return rc;
     HIP_TRY(hipEventRecord(e->ev0[e->ev_used], s));
     return SGW_OK;
 }
@@ -2128,9 +2163,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules)
-                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius)
-                         : pick_step(e->wpe, e->onehot);
+    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, &e->kernel_name)
+                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name)
+                         : pick_step(e->wpe, e->onehot, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
     e->step_fn = sk;
@@ -2164,8 +2199,7 @@ void sgw_destroy(sgw_engine* e) {
     delete e;
 }
 
-int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_reward, uint32_t epoch, void* stream) {
-    if (!e || !grid || !agent_pos || !total_reward) return fail(SGW_EINVAL, "sgw_reset: NULL argument");
+static int launch_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_reward, uint32_t epoch, void* stream) {
     const sgw_config& c = e->cfg;
     const int b = c.layer_border_type[c.agent_layer];
     if (b == SGW_NO_BORDER || c.type_passable[b])
@@ -2178,6 +2212,11 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
     hipLaunchKernelGGL(e->reset_fn, dim3(e->reset_blocks), dim3(kBlock), e->lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
+}
+
+int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_reward, uint32_t epoch, void* stream) {
+    if (!e || !grid || !agent_pos || !total_reward) return fail(SGW_EINVAL, "sgw_reset: NULL argument");
+    return launch_reset(e, grid, agent_pos, total_reward, epoch, stream);
 }
 
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
@@ -2204,10 +2243,15 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     //    131 at 5; 131 072 envs: 248 vs 281 us).
     // The uint8 format, small batches and the shapes with small windows, which are latency-bound (Tag 11x11, 6.5 KB
     // per env: 164 us at full occupancy, 192 us capped), are not capped.
+    // The policy is explicit (sgw_set_wg_per_cu, include/sgw.h): 0 = this automatic rule, 1..8 = forced, -1 = never.
     size_t lds = e->step_lds_bytes;
-    if (e->fast && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 && (!p.obs_stage || (size_t)p.E * (size_t)p.env_stride > kCacheResidentGrid) && p.a1 == p.A && p.a0 == 0 && (size_t)p.A * p.C * p.VV * 4 >= 8192 &&
-        p.E >= (int64_t)e->num_cus * 32 * 2)
-        lds = std::max(lds, (size_t)(kLdsPerCu / e->fast_wg_cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
+    int cap = 0;
+    if (e->fast && e->wg_per_cu > 0) cap = e->wg_per_cu;
+    else if (e->fast && e->wg_per_cu == 0 && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 &&
+             (!p.obs_stage || (size_t)p.E * (size_t)p.env_stride > kCacheResidentGrid) && p.a1 == p.A && p.a0 == 0 &&
+             (size_t)p.A * p.C * p.VV * 4 >= 8192 && p.E >= (int64_t)e->num_cus * 32 * 2)
+        cap = e->fast_wg_cap;
+    if (cap > 0) lds = std::max(lds, (size_t)(kLdsPerCu / cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
     hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
@@ -2229,6 +2273,7 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
              uint32_t flags, void* stream) {
     if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward)
         return fail(SGW_EINVAL, "sgw_step: NULL argument");
+    if (!obs && (flags & SGW_STEP_OBS_NEXT)) return fail(SGW_EINVAL, "sgw_step: SGW_STEP_OBS_NEXT needs obs");
     if (!obs && !(flags & SGW_STEP_NO_OBS)) return fail(SGW_EINVAL, "sgw_step: obs is NULL without SGW_STEP_NO_OBS");
     if (agent_begin < 0 || agent_end > e->cfg.num_agents || agent_begin > agent_end)
         return fail(SGW_EINVAL, "sgw_step: agent range [%d, %d) invalid", agent_begin, agent_end);
@@ -2236,7 +2281,20 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
     p.epoch = epoch; p.turn = turn; p.a0 = agent_begin; p.a1 = agent_end; p.flags = flags; p.do_move = 1;
-    return launch_step(e, p, static_cast<hipStream_t>(stream));
+    if (flags & SGW_STEP_OBS_NEXT) {   // the stepped agents' own observations are not written
+        p.obs_next = 1;
+        p.flags |= SGW_STEP_NO_OBS;
+    }
+    if (int rc = launch_step(e, p, static_cast<hipStream_t>(stream))) return rc;
+    if (e->auto_max_turns && turn == e->auto_max_turns && agent_end == e->cfg.num_agents) {
+        // end of the epoch: keep the returns, then create_world + populate_environment for the next one
+        if (epoch + 1 >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+        if (e->episode_return)
+            HIP_TRY(hipMemcpyAsync(e->episode_return, total_reward, sizeof(double) * (size_t)e->cfg.num_envs,
+                                   hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+        return launch_reset(e, grid, agent_pos, total_reward, epoch + 1, stream);
+    }
+    return SGW_OK;
 }
 
 int sgw_set_obs_format(sgw_engine* e, int format) {
@@ -2317,24 +2375,49 @@ int sgw_set_timing(sgw_engine* e, int enable) {
     e->ev_used = 0;
     e->ms_acc = 0.0;
     e->launches = 0;
+    e->series.clear();
     return SGW_OK;
 }
 
 int sgw_get_step_time_ms(sgw_engine* e, double* total_ms, int64_t* launches) {
     if (!e || !total_ms || !launches) return fail(SGW_EINVAL, "sgw_get_step_time_ms: NULL argument");
-    if (e->ev_used > 0) {
-        HIP_TRY(hipEventSynchronize(e->ev1[e->ev_used - 1]));
-        for (int i = 0; i < e->ev_used; ++i) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
-            e->ms_acc += ms;
-        }
-        e->ev_used = 0;
-    }
+    if (int rc = time_drain(e)) return rc;
     *total_ms = e->ms_acc;
     *launches = e->launches;
     e->ms_acc = 0.0;
     e->launches = 0;
+    return SGW_OK;
+}
+
+int sgw_get_step_times_ms(sgw_engine* e, float* out_ms, int64_t capacity, int64_t* count) {
+    if (!e || !count || (capacity > 0 && !out_ms)) return fail(SGW_EINVAL, "sgw_get_step_times_ms: NULL argument");
+    if (int rc = time_drain(e)) return rc;
+    const int64_t n = std::min<int64_t>((int64_t)e->series.size(), std::max<int64_t>(capacity, 0));
+    for (int64_t i = 0; i < n; ++i) out_ms[i] = e->series[(size_t)i];
+    *count = n;
+    e->series.clear();
+    return SGW_OK;
+}
+
+int sgw_set_auto_reset(sgw_engine* e, uint32_t max_turns, double* episode_return) {
+    if (!e) return fail(SGW_EINVAL, "sgw_set_auto_reset: NULL engine");
+    e->auto_max_turns = max_turns;
+    e->episode_return = max_turns ? episode_return : nullptr;
+    return SGW_OK;
+}
+
+int sgw_set_wg_per_cu(sgw_engine* e, int wg_per_cu) {
+    if (!e) return fail(SGW_EINVAL, "sgw_set_wg_per_cu: NULL engine");
+    if (wg_per_cu < -1 || wg_per_cu > 8) return fail(SGW_EINVAL, "wg_per_cu must be -1 (never cap), 0 (automatic) or 1..8");
+    e->wg_per_cu = wg_per_cu;
+    return SGW_OK;
+}
+
+int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
+    if (!e || !buf || capacity < 1) return fail(SGW_EINVAL, "sgw_launch_info: NULL argument");
+    snprintf(buf, (size_t)capacity, "%s threads=%d lds=%zu env_lds=%d obs_stage=%d grid=%d wg_per_cu=%s%d", e->kernel_name,
+             e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->grid_blocks,
+             e->wg_per_cu == 0 ? "auto:" : "", e->wg_per_cu == 0 ? e->fast_wg_cap : e->wg_per_cu);
     return SGW_OK;
 }
 

@@ -27,7 +27,13 @@ def init_from_env(backend: str = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # one process per GPU: bind this rank to ITS device before the group exists, or every rank's tensors
+            # (and RCCL's communicator) land on cuda:0
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
 
 

@@ -86,6 +86,8 @@ class GridEngine:
         self.epoch = 0
         self.turn = 0
         self._scratch_obs = None
+        self.max_turns = 0              # set_auto_reset: epoch length (0 = no auto-reset)
+        self.episode_return = None      # [E] float64: total_reward of the epoch that just ended
         # per-env agent state (current entity type of each agent): needed by interaction rules (Tag)
         self.agent_state = self.state_at_pov = None
         if spec.agent_rule == N.AGENT_RULE_TAG:
@@ -114,6 +116,25 @@ class GridEngine:
     def _ptr(t: Optional[torch.Tensor]):
         return C.c_void_p(0 if t is None else t.data_ptr())
 
+    def _check_obs(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        """An observation destination handed to a kernel as a raw pointer must be exactly what the kernel writes:
+        ``E * A * C * V * V`` elements of the engine's observation dtype, contiguous, on the engine's device --
+        anything else would be an out-of-bounds device write."""
+        want = (self.num_envs,) + tuple(self.spec.obs_shape)
+        if not torch.is_tensor(t) or t.dtype != self.obs_dtype or tuple(t.shape) != want or t.device != self.device \
+                or not t.is_contiguous():
+            got = (tuple(t.shape), t.dtype, t.device) if torch.is_tensor(t) else type(t)
+            raise ValueError(f"{name} must be a contiguous {self.obs_dtype} tensor of shape {want} on {self.device} "
+                             f"(got {got}); the step kernel writes exactly that many bytes")
+        return t
+
+    def _check_pos(self, t: torch.Tensor) -> torch.Tensor:
+        want = (self.num_envs, self.spec.num_agents, 2)
+        if not torch.is_tensor(t) or t.dtype != torch.uint8 or tuple(t.shape) != want or t.device != self.device \
+                or not t.is_contiguous():
+            raise ValueError(f"pos must be a contiguous uint8 tensor of shape {want} on {self.device}")
+        return t
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.sgw_destroy(self._h)
@@ -139,10 +160,10 @@ class GridEngine:
                 pos: Optional[torch.Tensor] = None):
         """Stateless egocentric observation of the agents (K1).  ``pos`` (uint8 ``[E, A, 2]``)
         observes from other cells than the agents' own."""
-        out = self.obs if out is None else out
+        out = self.obs if out is None else self._check_obs(out, "out")
         if out is None:
             raise ValueError("engine was built with allocate_obs=False; pass `out`")
-        pos = self.agent_pos if pos is None else pos
+        pos = self.agent_pos if pos is None else self._check_pos(pos)
         agent_end = self.spec.num_agents if agent_end is None else agent_end
         with torch.cuda.device(self.device):
             N.check(self._lib.sgw_observe(self._h, self._ptr(self.grid), self._ptr(pos), self._ptr(out),
@@ -156,12 +177,17 @@ class GridEngine:
 
     def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,
              write_obs: bool = True, agent_begin: int = 0, agent_end: Optional[int] = None,
-             turn: Optional[int] = None, advance_turn: bool = True, obs_out: Optional[torch.Tensor] = None):
+             turn: Optional[int] = None, advance_turn: bool = True, obs_out: Optional[torch.Tensor] = None,
+             obs_next: bool = False):
         """One ``Environment.take_turn`` for every env (K2).
 
         ``actions``: uint8 ``[E, A]`` chosen by a policy; or ``random_actions=True``
         to draw them on device from the counter RNG (they are stored to
-        ``self.actions``)."""
+        ``self.actions``).  ``obs_next=True`` (policy-driven stepping): instead of the stepped
+        agents' own observations, write the observation of agent ``agent_end`` as it stands
+        after their moves.  With ``set_auto_reset`` armed, the call that completes turn
+        ``max_turns`` also resets every env for the next epoch (``self.epoch`` / ``self.turn``
+        follow when the engine keeps the counters, i.e. ``turn`` is not passed)."""
         if advance_turn and turn is None:
             self.turn += 1
         t = self.turn if turn is None else int(turn)
@@ -170,16 +196,35 @@ class GridEngine:
             self.actions.copy_(actions.to(device=self.device, dtype=torch.uint8).reshape(self.actions.shape))
         actions = self.actions
         flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
-        obs = self.obs if obs_out is None else obs_out
-        if not write_obs or obs is None:
+        obs = self.obs if obs_out is None else self._check_obs(obs_out, "obs_out")
+        if obs_next:
+            if obs is None:
+                raise ValueError("obs_next needs an observation tensor")
+            flags |= N.STEP_OBS_NEXT
+        elif not write_obs or obs is None:
             flags |= N.STEP_NO_OBS
             obs = None
         agent_end = self.spec.num_agents if agent_end is None else agent_end
+        epoch = self.epoch
         with torch.cuda.device(self.device):
             N.check(self._lib.sgw_step(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(actions),
                                        self._ptr(obs), self._ptr(self.rewards), self._ptr(self.total_reward),
-                                       self.epoch, t, agent_begin, agent_end, flags, self._stream()))
+                                       epoch, t, agent_begin, agent_end, flags, self._stream()))
+        if self.max_turns and t == self.max_turns and agent_end == self.spec.num_agents:
+            self.epoch = epoch + 1        # the library has reset every env for the next epoch (sgw_set_auto_reset)
+            if turn is None:
+                self.turn = 0
         return obs, self.rewards
+
+    def set_auto_reset(self, max_turns: int):
+        """Arm (``max_turns > 0``) or disarm the in-stream reset at the end of turn ``max_turns``;
+        ``self.episode_return`` then holds each env's ``total_reward`` of the epoch that just ended."""
+        self.max_turns = int(max_turns)
+        if self.max_turns and self.episode_return is None:
+            self.episode_return = torch.zeros((self.num_envs,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(self._lib.sgw_set_auto_reset(self._h, self.max_turns,
+                                                 self._ptr(self.episode_return if self.max_turns else None)))
 
     def random_actions(self, turn: Optional[int] = None):
         t = self.turn + 1 if turn is None else int(turn)
@@ -221,3 +266,19 @@ class GridEngine:
         ms, n = C.c_double(0.0), C.c_int64(0)
         N.check(self._lib.sgw_get_step_time_ms(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def step_times_ms(self, capacity: int = 1 << 16):
+        """Per-launch durations (ms, HIP events on the launch stream) since the last read, oldest first."""
+        buf = (C.c_float * capacity)()
+        n = C.c_int64(0)
+        N.check(self._lib.sgw_get_step_times_ms(self._h, buf, capacity, C.byref(n)))
+        return [float(buf[i]) for i in range(int(n.value))]
+
+    def set_wg_per_cu(self, n: int):
+        """Launch tuning of the wave-per-env kernel: 0 automatic, 1..8 forced, -1 never capped (include/sgw.h)."""
+        N.check(self._lib.sgw_set_wg_per_cu(self._h, int(n)))
+
+    def launch_info(self) -> str:
+        buf = C.create_string_buffer(512)
+        N.check(self._lib.sgw_launch_info(self._h, buf, 512))
+        return buf.value.decode()

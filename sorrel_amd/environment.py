@@ -6,14 +6,24 @@ Subclass it exactly like the reference: implement ``setup_agents`` (assign
 
 * fused (one kernel launch): every agent's model is a ``RandomModel`` (actions drawn
   on device) or an ``actions [E, A]`` tensor is passed;
-* phased (1 + 2A launches): policy-driven agents -- the entity sweep, then for each
+* phased (1 + A launches): policy-driven agents -- the entity sweep, then for each
   agent in list order ``agent.transition(world)`` = observe -> policy -> act, so
-  agent i+1 observes agent i's move exactly as in the reference.
+  agent i+1 observes agent i's move exactly as in the reference.  The launch that
+  moves agent i also renders agent i+1's observation (``SGW_STEP_OBS_NEXT``): nothing
+  intervenes between the two in the reference either (``sorrel/agents/agent.py:167-169``).
+
+The device status word (off-grid move, bad action index, unregistered type id -- where the
+reference raises ``IndexError`` / ``KeyError``) is polled once per epoch by ``run_experiment`` /
+``generate_memories`` and at the end of ``collect``; a bare ``take_turn`` loop should call
+``env.raise_on_status()`` itself now and then (it synchronises, so not every turn).
 """
 from __future__ import annotations
 
 from abc import abstractmethod
 from typing import List, Optional
+
+import os
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -81,12 +91,30 @@ class Environment:
     agents: List[Agent]
     stop_if_done: bool
 
+    _obs_dtype = torch.float32
+
+    @property
+    def obs_dtype(self):
+        """Element type of the step's observation tensor: float32 (what the reference's replay stores, the default)
+        or uint8 (compact one-hot counts).  Assigning rebuilds the engine handle on the next use; world state is kept."""
+        return self._obs_dtype
+
+    @obs_dtype.setter
+    def obs_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.uint8):
+            raise ValueError("obs_dtype must be torch.float32 or torch.uint8")
+        if dtype != self._obs_dtype:
+            self._obs_dtype = dtype
+            self._engine_version = -1
+            self._fresh_obs = None
+
     def __init__(self, world, config, stop_if_done: bool = False) -> None:
         self.config = _normalise_config(config)
         self.world = world
         world._environment = self
         self.turn = 0
         self.epoch = 0
+        self._fresh_obs = None       # (slot, world mutation count): eng.obs[:, slot] was rendered by the last launch
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
@@ -246,7 +274,9 @@ class Environment:
             tensors["agent_state"] = w.agent_state          # survives engine rebuilds (and resets)
         if getattr(w, "agent_dir", None) is not None:
             tensors["agent_dir"] = w.agent_dir
-        self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first, tensors=tensors)
+        self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first, tensors=tensors,
+                                  obs_dtype=self.obs_dtype)
+        self._fresh_obs = None
         w.agent_state = self._engine.agent_state
         w.agent_dir = self._engine.agent_dir
         self._engine_version = w.registry.version
@@ -271,6 +301,7 @@ class Environment:
         """``turn = 0``, fresh world, re-populate, reset agents (``environment.py:72-79``)."""
         self.turn = 0
         self.epoch += 1
+        self._fresh_obs = None
         self.world.is_done = False
         self.world.create_world()
         self.populate_environment()
@@ -283,20 +314,35 @@ class Environment:
         eng = self._ensure_engine()
         self.turn += 1
         eng.epoch, eng.turn = self.epoch, self.turn
+        self._fresh_obs = None
         if actions is not None:
             eng.step(actions, turn=self.turn)
         elif all(getattr(a.model, "device_random", False) for a in self.agents):
             eng.step(random_actions=True, turn=self.turn)
         else:
-            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)   # entity sweep only
+            # entity sweep; the same launch renders agent 0's observation (nothing intervenes before its pov)
+            eng.step(sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=self.turn)
+            self._fresh_obs = (0, self.world.mutations)
             for agent in self.agents:
                 agent.transition(self.world)
+
+    def raise_on_status(self) -> None:
+        """Synchronising poll of the device status word: raises what the reference would have raised
+        (``IndexError`` for a move off an un-walled border, ``KeyError`` for an action index outside the
+        ``ActionSpec`` or an unregistered entity type)."""
+        self._ensure_engine().raise_on_status()
 
     def collect(self, turns: int, buffer, actions=None) -> None:
         """``turns`` fused ``take_turn``s whose observations the step kernel writes straight into ``buffer``
         (a ``sorrel_amd.buffers.TurnBuffer``): no per-step copy of the observation tensor.  ``actions``: optional
         ``[turns, E, A]`` uint8 tensor of policy actions; default = on-device random actions (``RandomModel``)."""
         eng = self._ensure_engine()
+        want = (buffer.capacity, eng.num_envs) + tuple(eng.spec.obs_shape)
+        if tuple(buffer.obs.shape) != want or buffer.obs.dtype != eng.obs_dtype or buffer.obs.device != eng.device:
+            raise ValueError(f"buffer.obs must be {eng.obs_dtype} {want} on {eng.device} (the step kernel writes its "
+                             f"observations straight into a slot); got {buffer.obs.dtype} {tuple(buffer.obs.shape)} on "
+                             f"{buffer.obs.device}.  Set Environment.obs_dtype to match a uint8 buffer.")
+        self._fresh_obs = None
         for t in range(turns):
             self.turn += 1
             eng.epoch, eng.turn = self.epoch, self.turn
@@ -305,7 +351,8 @@ class Environment:
                 eng.step(random_actions=True, turn=self.turn, obs_out=out)
             else:
                 eng.step(actions[t], turn=self.turn, obs_out=out)
-            buffer.commit(eng.actions, eng.rewards)
+            buffer.commit(eng.actions, eng.rewards, eng.agent_pos)
+        eng.raise_on_status()
 
     # ------------------------------------------------------------------ kernels behind the agent hooks
     @staticmethod
@@ -344,6 +391,8 @@ class Environment:
         if isinstance(who, Agent):
             who = who.slot
         if isinstance(who, int):
+            if own and self._fresh_obs == (who, self.world.mutations):
+                return eng.obs[:, who]          # rendered by the launch that moved the previous agent (SGW_STEP_OBS_NEXT)
             out = eng.obs if own else eng.scratch_obs()
             eng.observe(who, who + 1, out=out)
             return out[:, who]
@@ -354,7 +403,10 @@ class Environment:
         return eng.scratch_obs()[:, 0]
 
     def _full_view(self, ospec):
-        """Whole-map appearance summed over layers, ``[E, C, H, W]`` (``visual_field.py:41-55``)."""
+        """Whole-map appearance summed over layers, ``[E, C, H, W]`` (``visual_field.py:41-55``).  Host-side
+        plumbing (a PyTorch table lookup), NOT the engine: ``full_view`` specs are rejected for the fused step
+        (``compile_spec``), no example on the path uses them, and this exists only so that an on-demand
+        ``observe`` / ``visual_field`` call with ``full_view=True`` answers as the reference does."""
         w = self.world
         spec = self.compile_spec(ospec)
         app = torch.tensor(spec.appearance, dtype=torch.float64, device=w.device)        # [T, C]
@@ -369,7 +421,9 @@ class Environment:
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
         eng.actions[:, a] = action.to(torch.uint8)
-        eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn)
+        nxt = a + 1 < len(self.agents) and eng.obs is not None
+        eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn, obs_next=nxt)
+        self._fresh_obs = (a + 1, self.world.mutations) if nxt else None
         return eng.rewards[:, a]
 
     # ------------------------------------------------------------------ step outputs (batched additions)
@@ -395,16 +449,42 @@ class Environment:
     def total_reward(self):
         return self.world.total_reward
 
-    # ------------------------------------------------------------------ thin epoch loop (environment.py:108-211)
-    def run_experiment(self, epochs: Optional[int] = None, max_turns: Optional[int] = None, logger=None,
-                       all_reduce: bool = True):
-        """reset -> ``max_turns`` x take_turn -> per-epoch metrics (sum / mean of
-        ``total_reward`` over ALL envs of ALL ranks: the one RCCL all-reduce)."""
+    # ------------------------------------------------------------------ epoch loops (environment.py:108-300)
+    def _output_dir(self, output_dir) -> Path:
+        if output_dir is None:
+            exp = self.config.experiment
+            output_dir = Path(exp.output_dir) if hasattr(exp, "output_dir") or "output_dir" in exp else Path("./data/")
+        output_dir = Path(output_dir)
+        os.makedirs(output_dir, exist_ok=True)
+        return output_dir
+
+    def _cfg_model(self, key, default=None):
+        model = getattr(self.config, "model", None) if not isinstance(self.config, dict) else self.config.get("model")
+        if model is None:
+            return default
+        try:
+            return model[key] if key in model else default
+        except TypeError:
+            return getattr(model, key, default)
+
+    def run_experiment(self, animate: bool = False, logging: bool = True, logger=None, output_dir=None,
+                       epochs: Optional[int] = None, max_turns: Optional[int] = None, all_reduce: bool = True):
+        """``for epoch in range(epochs + 1)``: reset -> start-of-epoch hooks -> ``max_turns`` x take_turn ->
+        ``world.is_done = True`` -> end-of-epoch hooks -> ``train_step`` per agent (the loss logged is the LAST
+        agent's, as in the reference: assignment, not a sum) -> ``logger.record_turn(epoch, loss, reward, epsilon)``
+        -> epsilon decay -> model checkpoint every ``record_period`` epochs when ``config.model.save_weights``
+        (``sorrel/environment.py:148-211``).  The reward logged is the mean of ``world.total_reward`` over ALL
+        envs of ALL ranks (the one RCCL all-reduce); the per-epoch metric dicts are returned.  ``animate`` is
+        accepted for signature compatibility; sprite rendering is outside this engine."""
         from sorrel_amd import distributed as D
 
         exp = self.config.experiment
         epochs = int(exp.epochs) if epochs is None else epochs
         max_turns = int(exp.max_turns) if max_turns is None else max_turns
+        record_period = int(exp.record_period) if (hasattr(exp, "record_period") or "record_period" in exp) else 1
+        save_weights = bool(self._cfg_model("save_weights", False))
+        decay = self._cfg_model("epsilon_decay", None)
+        out_dir = self._output_dir(output_dir) if save_weights else None
         history = []
         for epoch in range(epochs + 1):
             self.reset()
@@ -415,10 +495,131 @@ class Environment:
                 if self.world.is_done and self.stop_if_done:
                     break
             self.world.is_done = True
+            self.raise_on_status()
             m = D.rollout_metrics(self._ensure_engine(), all_reduce=all_reduce)
-            history.append(m)
             for agent in self.agents:
                 agent.model.end_epoch_action(epoch=epoch)
-            if logger is not None:
-                logger.record_turn(epoch, 0.0, m["mean_total_reward"], getattr(self.agents[0].model, "epsilon", 0.0))
+            total_loss = 0
+            for agent in self.agents:
+                total_loss = agent.model.train_step()
+            m["loss"] = float(total_loss) if total_loss is not None else 0.0
+            m["epsilon"] = float(getattr(self.agents[0].model, "epsilon", 0.0))
+            history.append(m)
+            if logging and logger is not None:
+                logger.record_turn(epoch, total_loss, m["mean_total_reward"], m["epsilon"])
+            for i, agent in enumerate(self.agents):
+                if decay is not None:
+                    agent.model.epsilon_decay(float(decay))
+                if epoch % record_period == 0 and save_weights and hasattr(agent.model, "save"):
+                    os.makedirs(out_dir / "checkpoints", exist_ok=True)
+                    agent.model.save(out_dir / "checkpoints" / f"epoch{epoch}-agent-{i}.pkl")
         return history
+
+    def generate_memories(self, num_games: int = 1000, animate: bool = False, output_dir=None,
+                          record_positions: bool = False):
+        """Play ``num_games`` games of ``max_turns`` turns with the existing models and write one replay file per
+        agent, ``<output_dir>/memories/agent{i}.npz`` (``sorrel/environment.py:213-300``).
+
+        File format = the reference's ``SavedGames.save`` (``sorrel/buffers.py:361-379``): ``states`` float32
+        ``[N, *obs_shape]``, ``actions`` int64 ``[N]``, ``rewards`` / ``dones`` float32 ``[N]``, ``positions`` int64
+        ``[N, 2]``, ``n_frames``, ``idx`` -- the reference's ``Buffer.load`` reads it.  The batch is laid out env
+        by env: rows ``[e * G * T, (e + 1) * G * T)`` are env ``e``'s ``G`` games of ``T`` turns in play order, i.e.
+        what the reference would have saved for that one world.
+
+        Policy-driven agents (phased turns): after every game the agent's whole ``model.memory`` is appended with
+        ``add_from_buffer``, the reference's own call -- so, as there, ``positions`` are stored only if that memory
+        carries them, and a memory the model does not clear per game is appended again from its start
+        (``sorrel/environment.py:297``, ``buffers.py:71-99``).  Device-random models (``RandomModel``): the turns run
+        fused, the step kernel writes the observations straight into a device ring (``collect``) and every game is
+        appended once; ``positions`` stay zero unless ``record_positions`` (then: each agent's cell after its move)."""
+        from sorrel_amd.buffers import SavedGames, TurnBuffer
+
+        out_dir = self._output_dir(output_dir)
+        T = int(self.config.experiment.max_turns)
+        E, A = self.num_envs, len(self.agents)
+        saved = []
+        for agent in self.agents:
+            n_frames = getattr(agent.model, "n_frames", 1)
+            obs_shape = tuple(agent.observation_spec.input_size)
+            saved.append(SavedGames(capacity=num_games * T, obs_shape=obs_shape, n_frames=n_frames, num_envs=E,
+                                    device="cpu", positions=(2,)))
+            if hasattr(agent.model, "eval"):
+                agent.model.eval()
+        fused = all(getattr(a.model, "device_random", False) for a in self.agents)
+        ring = None
+        for game in range(num_games):
+            self.reset()
+            for agent in self.agents:
+                agent.model.start_epoch_action(epoch=game)
+            eng = self._ensure_engine()
+            if fused:
+                if ring is None:
+                    ring = TurnBuffer(T, E, eng.spec.obs_shape, device=eng.device, obs_dtype=eng.obs_dtype,
+                                      positions=record_positions)
+                ring.clear()
+                self.collect(T, ring)
+                for a, sg in enumerate(saved):
+                    sg.add_turns(*ring.agent_view(a), positions=None if ring.positions is None else ring.positions[:, :, a])
+            else:
+                while self.turn < T:
+                    self.take_turn()
+                    if self.world.is_done and self.stop_if_done:
+                        break
+            self.world.is_done = True
+            self.raise_on_status()
+            for agent, sg in zip(self.agents, saved):
+                agent.model.end_epoch_action(epoch=game)
+                if not fused:
+                    sg.add_from_buffer(agent.model.memory)
+        os.makedirs(out_dir / "memories", exist_ok=True)
+        paths = []
+        for i, sg in enumerate(saved):
+            paths.append(out_dir / "memories" / f"agent{i}.npz")
+            sg.save(paths[-1])
+        return paths
+
+    # ------------------------------------------------------------------ world-state checkpoint (the reference leaves
+    # "# TODO: ability to save/load?" at sorrel/environment.py:107; SURVEY.md section 5)
+    def state_dict(self) -> dict:
+        """Everything a rollout needs to continue bit-exactly: the grid, agent positions, ``total_reward``, the
+        per-agent state / facing tensors, the epoch / turn counters, the RNG seed and the first global env id."""
+        w = self.world
+        eng = self._ensure_engine()
+        sd = dict(version=1, grid=w.grid.cpu().clone(), agent_pos=w.agent_pos.cpu().clone(),
+                  total_reward=w.total_reward.cpu().clone(), epoch=int(self.epoch), turn=int(self.turn),
+                  seed=int(w.seed), first_env_id=int(getattr(w, "first_env_id", 0)), num_envs=int(w.num_envs),
+                  shape=(w.layers, w.height, w.width), is_done=bool(w.is_done),
+                  type_names=[type(p).__name__ for p in w.registry.prototypes])
+        if eng.agent_state is not None:
+            sd["agent_state"] = eng.agent_state.cpu().clone()
+        if eng.agent_dir is not None:
+            sd["agent_dir"] = eng.agent_dir.cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        w = self.world
+        eng = self._ensure_engine()
+        if tuple(sd["shape"]) != (w.layers, w.height, w.width) or int(sd["num_envs"]) != w.num_envs:
+            raise ValueError("checkpoint was taken from a world of another shape or batch size")
+        if int(sd["seed"]) != int(w.seed) or int(sd["first_env_id"]) != int(getattr(w, "first_env_id", 0)):
+            raise ValueError("checkpoint was taken with another seed / first global env id: the rollout would not continue bit-exactly")
+        if list(sd["type_names"]) != [type(p).__name__ for p in w.registry.prototypes]:
+            raise ValueError("checkpoint was taken with another entity type table")
+        w.grid.copy_(sd["grid"].to(w.device))
+        w.agent_pos.copy_(sd["agent_pos"].to(w.device))
+        w.total_reward.copy_(sd["total_reward"].to(w.device))
+        if "agent_state" in sd and eng.agent_state is not None:
+            eng.agent_state.copy_(sd["agent_state"].to(w.device))
+        if "agent_dir" in sd and eng.agent_dir is not None:
+            eng.agent_dir.copy_(sd["agent_dir"].to(w.device))
+        self.epoch, self.turn = int(sd["epoch"]), int(sd["turn"])
+        eng.epoch, eng.turn = self.epoch, self.turn
+        w.is_done = bool(sd.get("is_done", False))
+        w.mutations += 1
+        self._fresh_obs = None
+
+    def save_checkpoint(self, path) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path) -> None:
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))

@@ -84,6 +84,7 @@ class Gridworld(World):
         self.agent_dir: Optional[torch.Tensor] = None     # [E, A] facing of each agent (Cleanup)
         # declarative reset layout (set_layout) -- None = host-built template
         self.layout = None
+        self.mutations = 0          # bumped by every host-side write to the grid / positions (invalidates cached observations)
         self.create_world()
         self.turn = 0
         self.max_turns = 0
@@ -95,6 +96,7 @@ class Gridworld(World):
         (``gridworld.py:47-65``)."""
         self.grid.fill_(self.default_type)
         self.total_reward.zero_()
+        self.mutations += 1
 
     def _envsel(self, env):
         return slice(None) if env is None else env
@@ -113,6 +115,7 @@ class Gridworld(World):
         entity.location = (y, x, z)
         tid = self.registry.register(entity)
         self.grid[self._envsel(env), z, y, x] = tid
+        self.mutations += 1
         slot = getattr(entity, "slot", None)
         if slot is not None and self.agent_pos is not None:
             self.agent_pos[self._envsel(env), slot, 0] = y
@@ -128,6 +131,7 @@ class Gridworld(World):
         y, x, z = self._yxz(target_location)
         prev = self.observe((y, x, z), env=env)
         self.grid[self._envsel(env), z, y, x] = self.default_type
+        self.mutations += 1
         return prev
 
     def move(self, entity: Entity, new_location, env: int = 0) -> bool:
@@ -139,6 +143,7 @@ class Gridworld(World):
         oy, ox, oz = self._yxz(entity.location)
         self.grid[env, z, y, x] = self.registry.register(entity)
         self.grid[env, oz, oy, ox] = self.default_type
+        self.mutations += 1
         entity.location = (y, x, z)
         slot = getattr(entity, "slot", None)
         if slot is not None and self.agent_pos is not None:
@@ -220,6 +225,7 @@ class Gridworld(World):
         for (y, x, z), e in np.ndenumerate(entities):
             ids[z, y, x] = self.default_type if e is None else self.registry.register(e)
         self.grid.copy_(torch.from_numpy(ids).to(self.device).expand_as(self.grid))
+        self.mutations += 1
 
     def scatter_random(self, cells: Sequence, count: int, entity: Entity, generator: torch.Generator) -> torch.Tensor:
         """In every env put ``entity`` on ``count`` of the candidate ``cells`` [(y, x, z)], drawn without
@@ -235,6 +241,7 @@ class Gridworld(World):
         sel = pts[pick]                                                          # [E, count, 3]
         dev = self.device
         self.grid[e_idx.to(dev), sel[..., 2].to(dev), sel[..., 0].to(dev), sel[..., 1].to(dev)] = tid
+        self.mutations += 1
         return pick
 
     def spawn_rule_of(self, proto: Entity):

@@ -20,7 +20,7 @@ from sorrel_amd.spec import WorldSpec  # noqa: E402
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
-NON_WORLD_FIXTURES = {"buffer_ring"}   # fixtures that are not step-loop traces
+NON_WORLD_FIXTURES = {"buffer_ring", "buffer_saved_by_reference", "savedgames_by_reference"}   # fixtures that are not step-loop traces
 INJECTED_FIXTURES = {"cleanup_15x16"}  # worlds populated by host code: runs start from the stored grid0 / pos0
 
 
@@ -87,6 +87,7 @@ def oracle_lib():
         lib.sgo_random_actions.argtypes = [cfgp, vp, C.c_uint32, C.c_uint32]
         lib.sgo_reduce_metrics.argtypes = [cfgp, vp, vp]
         lib.sgo_threads.argtypes = [C.c_int]
+        lib.sgo_rollout.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]
         _olib = lib
     return _olib
 

@@ -366,3 +366,26 @@ def test_product_never_touches_the_oracle_or_the_reference():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "libgridstep_oracle" in src or "/root/reference" in src:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_engine_rejects_observation_destinations_the_kernel_would_overrun():
+    """GridEngine.step(obs_out=...) / observe(out=..., pos=...) hand raw pointers to the kernels: anything but a
+    contiguous tensor of exactly the engine's observation dtype / shape / device must be refused on the host
+    (a uint8 ring slot would receive 4x its size in float32).  Pure host logic, no GPU."""
+    import torch
+
+    from sorrel_amd.engine import GridEngine
+    from sorrel_amd.spec import treasurehunt_spec
+
+    eng = GridEngine.__new__(GridEngine)            # the checks need no device handle
+    eng.spec, eng.num_envs, eng.obs_dtype, eng.device, eng._h = treasurehunt_spec(16, 16, 4, 2), 6, torch.float32, torch.device("cpu"), None
+    good = torch.zeros((6, 4, 6, 5, 5), dtype=torch.float32)
+    assert eng._check_obs(good, "obs_out") is good
+    for bad in (good.to(torch.uint8), good[:5], good[:, :2], good.double(), good.transpose(3, 4), torch.zeros((6, 600)), "nope"):
+        with pytest.raises(ValueError):
+            eng._check_obs(bad, "obs_out")
+    pos = torch.zeros((6, 4, 2), dtype=torch.uint8)
+    assert eng._check_pos(pos) is pos
+    for bad in (pos.long(), pos[:, :3], pos.transpose(0, 1)):
+        with pytest.raises(ValueError):
+            eng._check_pos(bad)

@@ -1,0 +1,363 @@
+"""GPU tests of the round-2 additions, all through the C ABI: SGW_STEP_OBS_NEXT (a policy turn in 1 + A launches),
+auto-reset inside sgw_step across epoch boundaries, per-launch timing, world-state checkpoints, generate_memories
+files, the epoch-loop hooks, and the N>1 control path of bench.py run as real child processes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from oracle import gridstep_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = H.ROOT
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no silent CPU fallback)")
+    return torch
+
+
+def make_engine(ws, E, first=0, **kw):
+    from sorrel_amd.engine import GridEngine
+
+    return GridEngine(ws, E, device="cuda:0", first_env_id=first, **kw)
+
+
+def _tag_spec(h, w, a, r):
+    d, spec = H.load_golden("tag_9x9")
+    ws = H.world_spec(spec)
+    ws.height, ws.width, ws.num_agents, ws.vision_radius, ws.agent_type = h, w, a, r, [ws.agent_type[0]] * a
+    return ws
+
+
+def _cleanup_spec():
+    d, spec = H.load_golden("cleanup_15x16")
+    return H.world_spec(spec), d
+
+
+KERNEL_CASES = [
+    ("fast_static_c3", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.05, seed=11), {}, 37),
+    ("fast_runtime_21", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=12), {}, 50),
+    ("fast_tag", lambda: _tag_spec(11, 11, 5, 4), {}, 40),
+    ("big_64", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(64, 64, 12, 4, spawn_prob=0.05, seed=13, dense_prob=0.2), {}, 9),
+    ("generic", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(18, 14, 4, 3, spawn_prob=0.05, seed=14), {"SGW_FORCE_GENERIC": "1"}, 21),
+]
+
+
+@pytest.mark.parametrize("case", KERNEL_CASES, ids=[c[0] for c in KERNEL_CASES])
+def test_obs_next_phased_turn_equals_fused(torch_cuda, case, monkeypatch):
+    """Sweep + obs of agent 0 in one launch, then ONE launch per agent that moves it and renders the next agent's
+    observation: every observation, reward and the final state equal the fused take_turn (which equals the oracle),
+    in 1 + A launches."""
+    torch = torch_cuda
+    _, mk, env, E = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ws = mk()
+    A = ws.num_agents
+    fused, phased = make_engine(ws, E, first=5), make_engine(ws, E, first=5)
+    co = H.COracle(ws, E, first_env_id=5)
+    for e in (fused, phased):
+        e.reset(0)
+    co.reset(0)
+    if fused.agent_state is not None:
+        co.agent_state[...] = fused.agent_state.cpu().numpy()
+    for t in range(1, 6):
+        acts = fused.random_actions(turn=t).clone()
+        fused.step(acts, turn=t)
+        co.step(0, t, actions=acts.cpu().numpy())
+        phased.set_timing(True)
+        seen = torch.zeros_like(fused.obs)
+        rew = torch.zeros_like(phased.rewards)
+        phased.obs.fill_(-7.0)
+        phased.step(acts, sweep=True, agent_begin=0, agent_end=0, turn=t, obs_next=True)     # sweep + pov of agent 0
+        for a in range(A):
+            seen[:, a] = phased.obs[:, a]                                                      # what agent a's policy would read
+            phased.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t, obs_next=a + 1 < A, write_obs=False)
+            rew[:, a] = phased.rewards[:, a]
+        ms, launches = phased.step_time_ms()
+        phased.set_timing(False)
+        assert launches == 1 + A
+        torch.cuda.synchronize()
+        assert torch.equal(seen, fused.obs), f"turn {t}: phased observations differ"
+        assert np.array_equal(fused.obs.cpu().numpy(), co.obs), f"turn {t}: fused observations differ from the oracle"
+        assert torch.equal(fused.grid, phased.grid) and torch.equal(fused.agent_pos, phased.agent_pos)
+        assert torch.equal(fused.rewards, rew) and torch.equal(fused.total_reward, phased.total_reward)
+        if fused.agent_state is not None:
+            assert torch.equal(fused.agent_state, phased.agent_state)
+    assert fused.status() == 0 and phased.status() == 0
+
+
+def test_obs_next_on_the_rules_kernel(torch_cuda):
+    """Cleanup (the RULES variant of the wave-per-env kernel, facing + beams): phased with OBS_NEXT == fused."""
+    torch = torch_cuda
+    ws, d = _cleanup_spec()
+    E, A = 6, ws.num_agents
+    fused, phased = make_engine(ws, E), make_engine(ws, E)
+    g0 = torch.from_numpy(np.broadcast_to(d["grid0"][0], (E,) + d["grid0"][0].shape).copy())
+    p0 = torch.from_numpy(np.broadcast_to(d["pos0"][0], (E,) + d["pos0"][0].shape).copy())
+    for e in (fused, phased):
+        e.grid.copy_(g0)
+        e.agent_pos.copy_(p0)
+        e.total_reward.zero_()
+    for t in range(1, 9):
+        acts = fused.random_actions(turn=t).clone()
+        fused.step(acts, turn=t)
+        seen = torch.zeros_like(fused.obs)
+        phased.step(acts, sweep=True, agent_begin=0, agent_end=0, turn=t, obs_next=True)
+        for a in range(A):
+            seen[:, a] = phased.obs[:, a]
+            phased.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t, obs_next=a + 1 < A, write_obs=False)
+        torch.cuda.synchronize()
+        assert torch.equal(seen, fused.obs), t
+        assert torch.equal(fused.grid, phased.grid) and torch.equal(fused.agent_dir, phased.agent_dir)
+        assert torch.equal(fused.total_reward, phased.total_reward)
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 8, 3, 33, {}), (21, 21, 2, 2, 20, {}), (64, 64, 10, 4, 5, {}),
+                                   (12, 10, 3, 2, 9, {"SGW_FORCE_GENERIC": "1"})],
+                         ids=["fast_static", "fast_runtime", "big", "generic"])
+def test_auto_reset_rolls_across_epoch_boundaries_vs_oracle(torch_cuda, shape, monkeypatch):
+    """sgw_set_auto_reset: the step that completes turn max_turns also keeps the returns and resets every env for
+    the next epoch (K3 inside sgw_step).  Rolled across three boundaries against the oracle stepping and resetting
+    explicitly."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    h, w, a, r, E, env = shape
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=21, dense_prob=0.1)
+    eng = make_engine(ws, E, first=3)
+    co = H.COracle(ws, E, first_env_id=3)
+    eng.reset(0)
+    co.reset(0)
+    max_turns = 4
+    eng.set_auto_reset(max_turns)
+    epoch, turn = 0, 0
+    for k in range(3 * max_turns + 2):
+        eng.step(random_actions=True)
+        turn += 1
+        assert co.step(epoch, turn, random_actions=True) == 0
+        torch.cuda.synchronize()
+        for name, mine, ref in (("obs", eng.obs, co.obs), ("rewards", eng.rewards, co.rewards), ("actions", eng.actions, co.actions)):
+            assert np.array_equal(mine.cpu().numpy(), ref), (k, name)
+        if turn == max_turns:
+            assert np.array_equal(eng.episode_return.cpu().numpy(), co.total), f"step {k}: episode returns"
+            epoch, turn = epoch + 1, 0
+            co.reset(epoch)
+            assert (eng.epoch, eng.turn) == (epoch, 0)
+        for name, mine, ref in (("grid", eng.grid, co.grid), ("pos", eng.agent_pos, co.pos), ("total", eng.total_reward, co.total)):
+            assert np.array_equal(mine.cpu().numpy(), ref), (k, name)
+    assert eng.epoch == 3 and eng.status() == 0
+    eng.set_auto_reset(0)                     # disarmed: the epoch just goes on
+    for _ in range(max_turns + 1):
+        eng.step(random_actions=True)
+    assert eng.epoch == 3 and eng.turn == 2 + max_turns + 1
+
+
+def test_per_launch_timing_series(torch_cuda):
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    eng = make_engine(treasurehunt_spec(32, 32, 8, 3, seed=1), 4096)
+    eng.reset(0)
+    eng.set_timing(True)
+    for _ in range(12):
+        eng.step(random_actions=True)
+    series = eng.step_times_ms()
+    assert len(series) == 12 and all(0.0 < ms < 50.0 for ms in series)
+    total, n = eng.step_time_ms()
+    assert n == 12 and abs(total - sum(series)) < 1e-3
+    assert eng.step_times_ms() == []          # read-and-clear
+    info = eng.launch_info()
+    assert "step_fast<true, 2, 6, 3, 32, 32>" in info and "threads=256" in info
+    eng.set_wg_per_cu(3)
+    assert "wg_per_cu=3" in eng.launch_info()
+    eng.step(random_actions=True)
+    with pytest.raises(ValueError):
+        eng.set_wg_per_cu(9)
+
+
+def make_env(h, w, a, r, E, p=0.02, seed=5, model_factory=None, max_turns=100, extra_model=None):
+    from sorrel_amd.examples.treasurehunt.entities import EmptyEntity
+    from sorrel_amd.examples.treasurehunt.env import TreasurehuntEnv
+    from sorrel_amd.examples.treasurehunt.main import make_config
+    from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
+
+    cfg = make_config(h, w, a, r, spawn_prob=p, max_turns=max_turns)
+    cfg["model"].update(extra_model or {})
+    world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=seed)
+    return TreasurehuntEnv(world, cfg, model_factory=model_factory)
+
+
+def test_world_state_checkpoint_resumes_bit_exactly(torch_cuda, tmp_path):
+    torch = torch_cuda
+    a, b = make_env(14, 14, 3, 2, 40, p=0.05), make_env(14, 14, 3, 2, 40, p=0.05)
+    for _ in range(4):
+        a.take_turn()
+    a.save_checkpoint(tmp_path / "world.pt")
+    for _ in range(5):
+        a.take_turn()
+    b.take_turn()                               # b is somewhere else entirely before it loads
+    b.load_checkpoint(tmp_path / "world.pt")
+    assert (b.epoch, b.turn) == (0, 4)
+    for _ in range(5):
+        b.take_turn()
+    torch.cuda.synchronize()
+    for name in ("grid", "agent_pos", "total_reward"):
+        assert torch.equal(getattr(a.world, name), getattr(b.world, name)), name
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards) and torch.equal(a.actions, b.actions)
+    other = make_env(14, 14, 3, 2, 40, p=0.05, seed=6)
+    with pytest.raises(ValueError):
+        other.load_checkpoint(tmp_path / "world.pt")      # another seed would not continue the same rollout
+
+
+def test_generate_memories_fused_files_vs_oracle(torch_cuda, tmp_path):
+    """RandomModel agents: fused turns into the device ring, one reference-format file per agent, env by env."""
+    from sorrel_amd.buffers import Buffer
+
+    E, G, T = 5, 2, 3
+    env = make_env(12, 12, 2, 2, E, p=0.05, max_turns=T)
+    paths = env.generate_memories(num_games=G, output_dir=tmp_path)
+    ospec = H.oracle_spec(env.compile_spec())
+    want = {}
+    for e in range(E):
+        for g in range(G):
+            st = O.reset_env(ospec, e, epoch=1 + g)            # ctor = epoch 0, every game resets
+            for t in range(1, T + 1):
+                want[(e, g, t)] = O.step_env(ospec, st, e, 1 + g, t)
+    assert [os.path.basename(p) for p in paths] == ["agent0.npz", "agent1.npz"]
+    for a, path in enumerate(paths):
+        with np.load(path) as f:
+            assert f["states"].shape == (E * G * T, 6 * 25) and f["states"].dtype == np.float32 and f["actions"].dtype == np.int64
+            assert int(f["num_envs"]) == E and int(f["idx"]) == E * G * T and "positions" in f.files
+            for e in range(E):
+                for g in range(G):
+                    for t in range(1, T + 1):
+                        row = (e * G + g) * T + (t - 1)
+                        o, act, rew = want[(e, g, t)]
+                        assert np.array_equal(f["states"][row], o[a].reshape(-1)), (a, e, g, t)
+                        assert f["actions"][row] == act[a] and f["rewards"][row] == rew[a] and f["dones"][row] == 0.0
+        back = Buffer.load(path)
+        assert back.num_envs == E and back.capacity == G * T
+
+
+def test_generate_memories_phased_and_epoch_hooks(torch_cuda, tmp_path):
+    """Policy-driven agents: generate_memories appends each agent's model memory after every game (the reference's
+    add_from_buffer); run_experiment calls the per-epoch hooks, logs the LAST agent's loss, decays epsilon."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+
+    E, T = 6, 3
+    calls = []
+
+    class Toy(BaseModel):
+        n = [0]
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=64, epsilon=0.5, num_envs=E, device="cuda:0")
+            self.slot = Toy.n[0]
+            Toy.n[0] += 1
+
+        def take_action(self, state):
+            return (state.sum(dim=1).long() + self.slot) % 4
+
+        def start_epoch_action(self, **kw):
+            calls.append(("start", self.slot, kw["epoch"]))
+
+        def end_epoch_action(self, **kw):
+            calls.append(("end", self.slot, kw["epoch"]))
+
+        def train_step(self):
+            return 10.0 + self.slot
+
+        def save(self, path):
+            calls.append(("save", self.slot, os.path.basename(str(path))))
+
+    class Log:
+        rows = []
+
+        def record_turn(self, epoch, loss, reward, epsilon):
+            Log.rows.append((epoch, loss, reward, epsilon))
+
+    Toy.n[0] = 0
+    env = make_env(10, 10, 2, 2, E, p=0.05, model_factory=Toy, max_turns=T, extra_model={"epsilon_decay": 0.1, "save_weights": True})
+    env.config.experiment["record_period"] = 2
+    hist = env.run_experiment(epochs=2, logger=Log(), output_dir=tmp_path, all_reduce=False)
+    assert len(hist) == 3 and [r[0] for r in Log.rows] == [0, 1, 2]
+    assert all(r[1] == 11.0 for r in Log.rows)                                  # the last agent's loss, not the sum
+    assert Log.rows[0][3] == 0.5 and abs(Log.rows[1][3] - 0.45) < 1e-12 and abs(Log.rows[2][3] - 0.405) < 1e-12
+    assert ("start", 0, 0) in calls and ("end", 1, 2) in calls
+    assert sorted(c[2] for c in calls if c[0] == "save") == ["epoch0-agent-0.pkl", "epoch0-agent-1.pkl", "epoch2-agent-0.pkl", "epoch2-agent-1.pkl"]
+    assert Log.rows[2][2] == hist[2]["mean_total_reward"]
+    # the memories so far: 3 epochs x T turns per agent; generate_memories appends the WHOLE memory after each game
+    mem = env.agents[0].model.memory
+    assert mem.size == 3 * T
+    paths = env.generate_memories(num_games=2, output_dir=tmp_path)
+    with np.load(paths[0]) as f:
+        cap = 2 * T
+        assert f["states"].shape == (E * cap, 6 * 25)
+        blk = f["states"][:cap]                                                 # env 0's rows
+        assert np.array_equal(blk, mem.states[:cap, 0].cpu().numpy())           # game 1 re-appends from the start, truncated at capacity
+    torch.cuda.synchronize()
+
+
+def test_collect_rejects_a_buffer_the_kernel_would_overrun(torch_cuda):
+    torch = torch_cuda
+    from sorrel_amd.buffers import TurnBuffer
+
+    env = make_env(12, 12, 3, 2, 8)
+    shape = env.compile_spec().obs_shape
+    with pytest.raises(ValueError):
+        env.collect(1, TurnBuffer(4, 8, shape, device="cuda:0", obs_dtype=torch.uint8))     # 4x fewer bytes per slot than the kernel writes
+    with pytest.raises(ValueError):
+        env.collect(1, TurnBuffer(4, 7, shape, device="cuda:0"))                              # wrong env count
+    u8 = make_env(12, 12, 3, 2, 8)
+    u8.obs_dtype = torch.uint8
+    buf = TurnBuffer(4, 8, shape, device="cuda:0", obs_dtype=torch.uint8)
+    u8.collect(2, buf)
+    env.collect(2, TurnBuffer(4, 8, shape, device="cuda:0"))
+    torch.cuda.synchronize()
+    assert buf.obs.dtype == torch.uint8 and len(buf) == 2
+    eng = env._ensure_engine()
+    with pytest.raises(ValueError):
+        eng.step(random_actions=True, obs_out=eng.obs[:, :2])                                 # a view of the wrong shape
+    with pytest.raises(ValueError):
+        eng.observe(out=eng.obs.double())
+
+
+def _run_bench(args, nproc, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.pop("SGW_FORCE_GENERIC", None)
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", "29613", os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_run_the_product_and_agree_with_one_process(built):
+    """The N>1 control path of bench.py (process group, global-env-id sharding, barrier, max-over-ranks timing, the one
+    all-reduce) with the PRODUCT engine in every rank: two ranks on this one GPU (SGW_BENCH_REHEARSAL: gloo collectives)
+    must report the same rollout as one process over the same 8 192 global envs.  This test makes no GPU call itself."""
+    common = ["--steps", "8", "--warmup", "2", "--prewarm-steps", "0", "--no-cpu-baseline", "--no-series"]
+    two = _run_bench(["--gpus", "2", "--envs", "4096"] + common, 2, {"SGW_BENCH_REHEARSAL": "1"})
+    one = _run_bench(["--gpus", "1", "--envs", "8192"] + common, 1, {})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["global_envs"] == one["config"]["global_envs"] == 8192
+    assert two["rollout"]["envs"] == one["rollout"]["envs"] == 8192.0
+    assert two["rollout"]["sum_total_reward"] == one["rollout"]["sum_total_reward"]
+    assert two["rollout"]["status"] == 0 and two["value"] > 0 and two["scaling"] == "weak"

@@ -177,3 +177,24 @@ def test_c_oracle_equals_python_oracle_on_random_rule_worlds(case):
             assert np.array_equal(co.pos[0], ref["pos"][t, n])
             if ws.agent_rule == 2:
                 assert np.array_equal(co.agent_dir[0], ref["agent_dir"][t, n])
+
+
+def test_rollout_entry_point_equals_turn_by_turn_steps():
+    """sgo_rollout (bench.py's cpu_baseline leg: envs outer, turns inner, one parallel region) is the same arithmetic
+    as calling sgo_step once per turn."""
+    import ctypes as C
+
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.05, seed=9, dense_prob=0.1)
+    a, b = H.COracle(ws, 50, first_env_id=7), H.COracle(ws, 50, first_env_id=7, threads=3)
+    a.reset(2)
+    b.reset(2)
+    for t in range(1, 8):
+        a.step(2, t, random_actions=True)
+    lib = H.oracle_lib()
+    rc = lib.sgo_rollout(C.byref(b.cfg), H._p(b.grid), H._p(b.pos), H._p(b.actions), H._p(b.obs), H._p(b.rewards), H._p(b.total),
+                         C.c_uint32(2), C.c_uint32(1), C.c_uint32(7), C.c_int(3), None, None, None)
+    assert rc == 0
+    for name in ("grid", "pos", "actions", "obs", "rewards", "total"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name

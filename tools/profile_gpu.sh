@@ -6,10 +6,13 @@ TAG=${1:-r01}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# build BEFORE any profiled process exists: under rocprofv3 the preload has initialised the GPU before python starts,
+# and bench.py refuses to start a compiler from such a process (it exits non-zero on a stale library instead)
+python3 -c 'import sys; sys.path.insert(0, "'$REPO'"); import __graft_entry__ as g; g.build()' || exit 1
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --no-cpu-baseline $@"
+ARGS="--steps 50 --warmup 5 --prewarm-steps 0 --no-series --no-cpu-baseline $@"
 # the timing pass runs long enough for the clocks to settle (the counter passes below stay short)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 500 --warmup 20 --no-cpu-baseline "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 500 --warmup 20 --no-series --no-cpu-baseline "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err

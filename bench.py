@@ -48,6 +48,9 @@ CONFIGS = {
     "c2": (16, 16, 4, 2, 4096, 0.005, 0.0),
     "c3": (32, 32, 8, 3, 65536, 0.005, 0.0),
     "c5": (128, 128, 64, 5, 2048, 0.05, 0.25),
+    # diagnostic shapes (not BASELINE configs): the reference's Treasurehunt example default and a ragged small world
+    "th21": (21, 21, 2, 2, 65536, 0.005, 0.0),
+    "th10": (10, 10, 2, 2, 65536, 0.005, 0.0),
 }
 
 # The true reference (Python, one core, Xeon 2.1 GHz, build container) on one env of each shape: BASELINE.md section 2,

@@ -111,7 +111,11 @@ struct Params {
     const DevTables* tab;
     int* status;
     int obs_stage;    // step_fast: bytes of the per-wave LDS observation staging area (0: observations go straight to HBM)
+    int stage_agents; // step_fast<..., STAGE>: agents whose observations are staged together and leave in one burst
     int obs_next;     // SGW_STEP_OBS_NEXT: write only the observation of agent a1, after the moves of [a0, a1)
+    int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
+    int big_stagger;  // step_big: start delay (units of ~2.7 us) of every other co-resident workgroup of the first round
+    int big_stagger_shift;
 };
 
 // ---------------------------------------------------------------- RNG
@@ -293,10 +297,15 @@ constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it obse
 constexpr int kDirOff = kPovOff + SGW_MAX_AGENTS;       // its facing (Cleanup)
 constexpr int kAgentLds = kDirOff + SGW_MAX_AGENTS;     // 640 bytes, multiple of 16
 
-template <int WPE, bool ONEHOT>
+// G = threads per environment: 256 (a workgroup per env, worlds above 4 KiB), 64 (a wave per env) or, for small worlds,
+// 32 / 16 lanes of a wave -- two or four envs share a wave and its instruction stream.  The kernel keeps every piece of
+// per-env state in the group's LDS slice and uses no cross-lane instruction, so a sub-wave group needs nothing but the
+// wave-level ordering of DS instructions; what it buys is that the per-env instruction count, which bounds small worlds
+// (a 21x21x2 world keeps 29 of 64 lanes busy in the sweep and 25 in the window gather), is shared by 2 or 4 envs.
+template <int G, bool ONEHOT>
 __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int G = WPE * kWave;     // threads per env group
+    constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
     constexpr int EPB = kBlock / G;    // envs per workgroup
     const int tid = threadIdx.x;
     const int sub = tid / G;
@@ -670,7 +679,14 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // RULES: the layered rule set on the wave-per-env kernel -- an ordered LDS sweep, one dword (four
 // cells, one Philox block) per lane and layer by layer, for any number of spawners and SGW_RULE_BECOME_IF types,
 // and CleanupAgent.act (facing, beams on the layer above, all-layer reward) in the agent loop.
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false>
+// STAGE (run-time-shape variants): the one-hot observations of `stage_agents` agents at a time are staged as bytes in LDS
+// and leave as one burst of streaming 16-byte stores, aligned in GLOBAL memory whatever A * C * V * V is (the chunk's
+// first element need not sit on a 16-byte boundary: the staging area is shifted by its misalignment, edge elements
+// leave as single stores).  A STAGE kernel has no direct-store path at all (the two together do not fit the 64-register
+// budget of 8 waves per SIMD); the host launches the plain variant for calls that cannot be staged (a range of agents,
+// SGW_STEP_OBS_NEXT, an observation pointer that is not 16-byte aligned).  The fixed-shape kernels of the BASELINE
+// configs keep their own, simpler whole-env burst and ignore the parameter.
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
@@ -760,8 +776,11 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // leave for HBM in one burst of 16-byte stores after the agent loop (instead of 6 dword stores per agent
     // dribbling out over the wave's life): the chip then has far fewer half-written observation streams open.
     uint8_t* ob = lg + ((cells + 15) & ~15);
-    // (fixed-shape kernels only: the run-time-shape variants sit at the 64-VGPR limit and the extra code makes them spill)
-    const bool stage = ONEHOT && (TL && TH && TW) && p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A;
+    constexpr bool kStageAlways = ONEHOT && STAGE && !(TL && TH && TW);
+    const bool stage = kStageAlways || (ONEHOT && (TL && TH && TW) && p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A);
+    [[maybe_unused]] int ch_a0 = 0;            // first agent of the chunk being staged (STAGE)
+    [[maybe_unused]] uint32_t ch_shift = 0;    // misalignment (in elements) of the chunk's first element in global memory
+    if constexpr (kStageAlways) ch_shift = (uint32_t)(env * (int64_t)(p.A * C * VV)) & 3u;
 
     // per-lane window geometry: up to two cells per lane
     int wdi[2], wdj[2], woff[2];
@@ -910,9 +929,62 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         uint32_t rew_bits = 0, moved = 0;
 
         STAMP(3);   // move inputs (action draw) done
+        // STAGE: the staged chunk [a_lo, a_hi) leaves for HBM.  Dword i of the (shifted) staging area is the 16-byte
+        // aligned float4 number i of the chunk's span in global memory; the span's first and last float4 may also hold
+        // elements of a neighbouring chunk / env, so those two leave element by element.
+        [[maybe_unused]] auto emit_chunk = [&](const int a_lo, const int a_hi) {
+            gsync<1>();
+            typedef float vfloat4 __attribute__((ext_vector_type(4)));
+            const int N = (a_hi - a_lo) * C * VV;
+            const int64_t e0 = (env * p.A + a_lo) * (int64_t)(C * VV);
+            const int sh = (int)ch_shift;
+            const int nd = (sh + N + 3) >> 2;
+            const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
+            if (!p.obs_u8) {
+                float* gb = p.obs + (e0 - sh);
+                for (int i = lane; i < nd; i += 64) {
+                    const uint32_t b = ob4[i];
+                    vfloat4 v;
+                    v.x = (float)(b & 0xFFu);
+                    v.y = (float)((b >> 8) & 0xFFu);
+                    v.z = (float)((b >> 16) & 0xFFu);
+                    v.w = (float)(b >> 24);
+                    const int lo = 4 * i - sh;       // chunk element held by byte 0 of this dword
+                    if (lo >= 0 && lo + 4 <= N) {
+                        __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
+                    } else {
+                        if (lo >= 0 && lo < N) gb[4 * i] = v.x;
+                        if (lo + 1 >= 0 && lo + 1 < N) gb[4 * i + 1] = v.y;
+                        if (lo + 2 >= 0 && lo + 2 < N) gb[4 * i + 2] = v.z;
+                        if (lo + 3 >= 0 && lo + 3 < N) gb[4 * i + 3] = v.w;
+                    }
+                }
+            } else {
+                uint8_t* gb = reinterpret_cast<uint8_t*>(p.obs) + (e0 - sh);
+                for (int i = lane; i < nd; i += 64) {
+                    const uint32_t b = ob4[i];
+                    const int lo = 4 * i - sh;
+                    if (lo >= 0 && lo + 4 <= N) {
+                        __builtin_nontemporal_store(b, reinterpret_cast<uint32_t*>(gb + 4 * i));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (lo + j >= 0 && lo + j < N) gb[4 * i + j] = (uint8_t)(b >> (8 * j));
+                    }
+                }
+            }
+            gsync<1>();
+        };
         // ---- agents, strictly in list order (SGW_STEP_OBS_NEXT: one extra, observe-only iteration for agent a1)
         const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;
         for (int a = p.a0; a < a_end; ++a) {
+            if constexpr (kStageAlways) {
+                if (a - ch_a0 == p.stage_agents) {   // the staging area is full: out with it, start the next chunk
+                    if (write_obs) emit_chunk(ch_a0, a);
+                    ch_a0 = a;
+                    ch_shift = (uint32_t)((env * p.A + a) * (int64_t)(C * VV)) & 3u;
+                }
+            }
             const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
             if (p.obs_next ? a == p.a1 : write_obs) {
                 const int y = __builtin_amdgcn_readlane((int)py, a);
@@ -947,7 +1019,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
 #pragma unroll
                             for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
                             if (stage) {
-                                uint8_t* os = ob + (a * C) * VV + w;
+                                uint8_t* os = ob + (kStageAlways ? (int)ch_shift + ((a - ch_a0) * C) * VV : (a * C) * VV) + w;
 #pragma unroll
                                 for (int q = 0; q < NW; ++q) {
 #pragma unroll
@@ -956,6 +1028,8 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                                         if (c < C) os[c * VV] = (uint8_t)(cnt[q] >> (8 * b));
                                     }
                                 }
+                            } else if constexpr (kStageAlways) {
+                                // unreachable: a STAGE kernel always stages
                             } else if (!p.obs_u8) {
 #pragma unroll
                                 for (int q = 0; q < NW; ++q) {
@@ -1101,7 +1175,9 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         }
 
         STAMP(4);   // agent loop done
-        if (stage && write_obs) {
+        if constexpr (kStageAlways) {
+            if (write_obs) emit_chunk(ch_a0, p.a1);
+        } else if (stage && write_obs) {
             gsync<1>();
             const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
@@ -1168,15 +1244,17 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
 // registers + barrier 118-122.  The last is kept: it has no cross-wave race to reason about.
 // Requires impassable agent types (a passable agent could be "entered" twice in one turn, which the
 // two-batch patch cannot order); the host dispatch checks it.
+// Eight waves per workgroup, four workgroups per CU = the CU's 32 wave slots: measured 115 us per config-5 launch
+// against 123 us with four waves per workgroup and 143 us with two (round 2, same box, interleaved A/B).
 #ifndef SGW_BIG_THREADS
-#define SGW_BIG_THREADS 256
+#define SGW_BIG_THREADS 512
 #endif
 constexpr int kBigThreads = SGW_BIG_THREADS;
 constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
 
 template <bool ONEHOT, int TL, int TC, int TR>
-__global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_big(const Params p) {
+__global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1207,12 +1285,28 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     const int C = TC ? TC : p.C;
     const int r = TR ? TR : p.r;
     const int V = 2 * r + 1, VV = V * V;
-    const int H = p.H, W = p.W, HW = H * W;
+    const int H = p.H, W = p.W;
+    // LDS image of the grid: rows of P >= W bytes.  With P == W + 16 (worlds whose width is a multiple of 16) window row
+    // i of an observation starts (W + 16) / 4 = 4 (mod 32) banks after row i - 1, so the ~3 rows a 32-lane group of the
+    // 11x11 gather touches fall on disjoint banks; with P == W (a 128-byte pitch) they all fell on the same ones
+    // (34 % of the LDS cycles of config 5 were bank conflicts).
+    const int P = p.big_pitch, HW = H * P;           // HW: LDS bytes of one layer
+    const int upr = W >> 4;                           // 16-byte units per row (used only when P != W)
+    const bool padded = P != W;
     const int cells = p.cells;
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     const int zoff = p.zA * HW;
     constexpr int NW = TC ? (TC + 3) / 4 : 4;
     constexpr int NP = TR ? ((2 * TR + 1) * (2 * TR + 1) + 63) / 64 : 2;   // window passes per wave held in registers
+    // HBM unit index / byte offset -> LDS unit index / byte offset (one pad unit per row)
+    auto lunit = [&](int idx) { return padded ? idx + idx / upr : idx; };
+    auto lbyte = [&](uint32_t off) { return padded ? off + (off / (uint32_t)W) * 16u : off; };
+    if (p.big_stagger > 0 && blockIdx.x < 1024 && ((blockIdx.x >> p.big_stagger_shift) & 1)) {
+        // First round only: every other workgroup that shares a CU (blocks are dealt round-robin over XCDs and CUs, so b
+        // and b + 256 land together) starts late, so that one half of a CU's workgroups is in its vector-ALU phases
+        // (sweep, moves) while the other half is in its HBM phases (observation stores, write-back).
+        for (int i = 0; i < p.big_stagger; ++i) __builtin_amdgcn_s_sleep(100);
+    }
 
     // LDS: [tables][agent arrays][grid]
     uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // journal entry of each agent (phase M -> R)
@@ -1271,7 +1365,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
                 const int idx = base + k * kBigThreads + tid;
                 hits[k] = 0;
                 if (idx < nunits) {
-                    lg16[idx] = u[k];
+                    lg16[lunit(idx)] = u[k];
                     if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)idx, p, env_id);
                 }
             }
@@ -1294,7 +1388,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
                         const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
                                                    p.seed_lo, p.seed_hi);
                         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
-                        lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+                        lg[lbyte(off)] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
                     }
                 }
             }
@@ -1314,7 +1408,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
                 atomicOr(p.status, SGW_STATUS_BAD_POS);
             }
             const uint32_t py = yx & 0xFFu, px = yx >> 8;
-            oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;
+            oaddr_v = (uint32_t)zoff + py * (uint32_t)P + px;
             npos_v = yx;
             if (p.do_move && mine) {
                 uint32_t act;
@@ -1332,7 +1426,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
                 const int ty = (int)py + dy, tx = (int)px + dx;
                 const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
                 if (act_ok && inb) {
-                    ta_v = (uint32_t)(zoff + ty * W + tx);
+                    ta_v = (uint32_t)(zoff + ty * P + tx);
                     npos_v = (uint32_t)ty | ((uint32_t)tx << 8);
                 }
                 st_lane = !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
@@ -1357,33 +1451,39 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
         const bool validv = ta_v != 0xFFFFFFFFu;
         const uint32_t t0_v = lg[validv ? ta_v : oaddr_v];
         uint32_t passed_v = 0;
-        // Most turns no agent interferes with another: what an agent finds on its target can differ from the pre-move
-        // grid only if an earlier mover entered that cell (two agents share a target) or left it (the target is another
-        // agent's cell).  Detect both conservatively -- a mark in a spare bit of the target's LDS byte (type ids are
-        // < 32) catches the second claimant of a cell, the type itself tells an agent's cell -- and resolve every
-        // agent at once when neither occurs; only otherwise walk the agents in order.
+        // What an agent finds on its target can differ from the pre-move grid only if an earlier mover entered that cell
+        // (two agents share a target) or left it (the target is another agent's cell).  An agent INTERFERES if it shares
+        // its target with another agent or targets another agent's cell; everyone else resolves at once from the
+        // pre-move grid, and only the interfering agents (typically none, or a pair) are walked, in agent order.
         bool cf = false;
+        const bool self = validv && ta_v == oaddr_v;     // targets its own cell (a non-move action): finds itself, whoever moves
         const bool markable = mine && validv && t0_v < 32u && !((p.agent_mask >> t0_v) & 1u);
         uint32_t* gw = reinterpret_cast<uint32_t*>(lg);
         const uint32_t msh = 8u * (ta_v & 3u);
-        if (mine && validv && !markable) cf = true;
+        if (mine && validv && !markable && !self) cf = true;
+        // two spare bits of the target's LDS byte (type ids are < 32): 0x40 = claimed, 0x80 = claimed more than once
         if (markable) cf = ((atomicOr(&gw[ta_v >> 2], 0x40u << msh) >> msh) & 0x40u) != 0;
-        const bool conflict = __ballot(cf) != 0ull;
-        if (markable) atomicAnd(&gw[ta_v >> 2], ~(0x40u << msh));   // marks off again before anyone else reads the grid
-        if (!conflict) {
+        if (markable && cf) atomicOr(&gw[ta_v >> 2], 0x80u << msh);
+        if (markable) cf = ((atomicOr(&gw[ta_v >> 2], 0u) >> msh) & 0x80u) != 0;   // every claimant of a contested cell, the first one too (an RMW: ordered behind the marks)
+        unsigned long long cmask = __ballot(cf);
+        if (markable) atomicAnd(&gw[ta_v >> 2], ~(0xC0u << msh));   // marks off again before anyone else reads the grid
+        {
             const bool tok = validv && t0_v < (uint32_t)p.T;
             const bool pass = tok && ((p.pass_mask >> (t0_v & 31u)) & 1u);
-            if (mine) {
+            if (mine) {   // final for the agents that do not interfere, provisional (and not yet visible, see `lane < a`) for the others
                 jr = (t0_v & 0xFFu) | (tok ? 0x100u : 0u) | (pass ? 0x200u : 0u) | ((validv && !tok) ? 0x400u : 0u);
                 passed_v = pass ? 1u : 0u;
             }
         }
-        for (int a = conflict ? p.a0 : p.a1; a < p.a1; ++a) {
+        while (cmask) {
+            const int a = __builtin_ctzll(cmask);
+            cmask &= cmask - 1ull;
             const uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)ta_v, a);
             const bool valid = X != 0xFFFFFFFFu;
             uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t0_v, a);
-            const unsigned long long m_dst = __ballot(passed_v && ta_v == X);
-            const unsigned long long m_src = __ballot(passed_v && oaddr_v == X);
+            // what earlier movers did to that cell: the latest one that entered or left it decides
+            const unsigned long long m_dst = __ballot(passed_v && lane < a && ta_v == X);
+            const unsigned long long m_src = __ballot(passed_v && lane < a && oaddr_v == X);
             const unsigned long long m_any = m_dst | m_src;
             if (m_any) {
                 const int last = 63 - __builtin_clzll(m_any);
@@ -1421,7 +1521,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
             const int i = w / V, j = w - i * V;
             wdi[k] = i - r;
             wdj[k] = j - r;
-            woff[k] = wdi[k] * W + wdj[k];
+            woff[k] = wdi[k] * P + wdj[k];
         }
         // lane b: journal of agent b (where it was, where it went, what it found there)
         const uint32_t jb = s_ta[lane], srcb = s_oa[lane], dstb = s_np[lane], atb = s_atype[lane];
@@ -1432,7 +1532,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
         for (int a = r_lo + wv; a < r_hi; a += kBigWaves) {
             const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
             const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
-            const int cbase = y * W + x;
+            const int cbase = y * P + x;
             uint32_t tb[NP][2];
             bool inbk[NP];
 #pragma unroll
@@ -1540,7 +1640,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 256 ? 3 : 1) void step_
     // ---- write-back
     if (dirty) {
         uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
-        for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[idx];
+        for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[lunit(idx)];
     }
     STAMPB(4);                   // write-back issued
 #ifdef SGW_STAMPS
@@ -1769,10 +1869,14 @@ struct sgw_engine {
     uint8_t* state_at_pov = nullptr;
     uint8_t* agent_dir = nullptr;      // caller-owned, bound with sgw_bind_agent_dir
     int wpe = 1;          // waves per env
+    int group = 64;       // generic step kernel: threads per env (16 / 32: several envs share a wave)
     bool onehot = true;
     bool fast = false;    // step_fast specialisation applies
     bool big = false;     // step_big (workgroup per env, pipelined agents) applies
     void (*step_fn)(const Params) = nullptr;
+    void (*step_fn_plain)(const Params) = nullptr;   // run-time-shape STAGE kernels: the direct-store variant for calls that cannot be staged
+    const char* kernel_name_plain = "?";
+    int stage_agents = 0;      // agents per staged chunk (STAGE kernels)
     void (*reset_fn)(const Params) = nullptr;
     size_t lds_bytes = 0;       // reset / generic step
     size_t step_lds_bytes = 0;  // step kernel actually launched
@@ -1903,13 +2007,21 @@ using StepFn = void (*)(const Params);
         return __VA_ARGS__;       \
     } while (0)
 
-StepFn pick_step(int wpe, bool onehot, const char** name) {
-    if (wpe == 1) {
-        if (onehot) PICK(step_kernel<1, true>);
-        PICK(step_kernel<1, false>);
+StepFn pick_step(int group, bool onehot, const char** name) {
+    if (group == 16) {
+        if (onehot) PICK(step_kernel<16, true>);
+        PICK(step_kernel<16, false>);
     }
-    if (onehot) PICK(step_kernel<4, true>);
-    PICK(step_kernel<4, false>);
+    if (group == 32) {
+        if (onehot) PICK(step_kernel<32, true>);
+        PICK(step_kernel<32, false>);
+    }
+    if (group == 64) {
+        if (onehot) PICK(step_kernel<64, true>);
+        PICK(step_kernel<64, false>);
+    }
+    if (onehot) PICK(step_kernel<256, true>);
+    PICK(step_kernel<256, false>);
 }
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
@@ -1919,19 +2031,29 @@ StepFn pick_big(bool onehot, int L, int C, int r, const char** name) {
     PICK(step_big<true, 0, 0, 0>);
 }
 
-StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, const char** name) {
+bool fixed_fast_shape(int L, int C, int r, int H, int W) {
+    return L == 2 && C == 6 && ((r == 3 && H == 32 && W == 32) || (r == 2 && H == 16 && W == 16));
+}
+
+StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
     if (rules) {
+        if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true>);
         PICK(step_fast<false, 0, 0, 0, 0, 0, false, true>);
     }
     if (tag) {
+        if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, true, false, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, true>);
         PICK(step_fast<false, 0, 0, 0, 0, 0, true>);
     }
     if (!onehot) PICK(step_fast<false, 0, 0, 0, 0, 0>);
     if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32>);   // BASELINE configs 3/4 (headline)
     if (L == 2 && C == 6 && r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16>);   // BASELINE config 2
-    if (L == 2 && C == 6) PICK(step_fast<true, 2, 6, 0, 0, 0>);   // treasurehunt-shaped, any size
+    if (L == 2 && C == 6) {   // treasurehunt-shaped, any size
+        if (stage) PICK(step_fast<true, 2, 6, 0, 0, 0, false, false, true>);
+        PICK(step_fast<true, 2, 6, 0, 0, 0>);
+    }
+    if (stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, false, true>);
     PICK(step_fast<true, 0, 0, 0, 0, 0>);
 }
 
@@ -2128,22 +2250,68 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
     e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move && simple_rules;
-    {   // LDS staging of one-hot observations: whole envs of a multiple of 4 elements, at most 4 KiB of byte counts
+    bool stage_kernel = false;   // a run-time-shape STAGE kernel applies
+    {   // LDS staging of one-hot observations
         const int ob_elems = c.num_agents * c.num_channels * p.VV;
-        const bool fixed_shape = c.layers == 2 && c.num_channels == 6 && ((c.height == 32 && c.width == 32 && c.vision_radius == 3) ||
-                                                                         (c.height == 16 && c.width == 16 && c.vision_radius == 2));   // = pick_fast's fixed-shape kernels
-        e->obs_stage = (e->fast && !e->fast_rules && onehot && fixed_shape && c.agent_rule != SGW_AGENT_RULE_TAG && (ob_elems & 3) == 0 && ob_elems <= 4096) ? ((ob_elems + 15) & ~15) : 0;
-        if (const char* f = getenv("SGW_NO_STAGE")) { if (f[0] == '1') e->obs_stage = 0; }   // test / tuning hook
+        const int per_agent = c.num_channels * p.VV;
+        const bool fixed_shape = !e->fast_rules && c.agent_rule != SGW_AGENT_RULE_TAG &&
+                                 fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width);   // = pick_fast's fixed-shape kernels
+        e->obs_stage = 0;
+        if (e->fast && onehot && fixed_shape) {
+            // whole envs of a multiple of 4 elements, at most 4 KiB of byte counts
+            if ((ob_elems & 3) == 0 && ob_elems <= 4096) e->obs_stage = (ob_elems + 15) & ~15;
+        } else if (e->fast && onehot) {
+            // run-time shapes: as many agents per burst as fit the wave's share of LDS at full occupancy (8 workgroups
+            // of 4 waves per CU, 1 KiB granules: 5 120 bytes per wave); if not even one agent fits, at 5 workgroups per CU
+            const int base = e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad;
+            int budget = (int)(kLdsPerCu / 8 / 4) - base - 16;
+            if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16;
+            if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook
+            int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;
+            if (const char* f = getenv("SGW_STAGE_AGENTS")) apc = std::min(c.num_agents, atoi(f));   // A/B hook
+            if (apc > 0) {
+                e->stage_agents = apc;
+                e->obs_stage = (apc * per_agent + 3 + 15) & ~15;    // + 3: the chunk's misalignment in global memory
+                stage_kernel = true;
+            }
+        }
+        if (const char* f = getenv("SGW_NO_STAGE")) { if (f[0] == '1') { e->obs_stage = 0; stage_kernel = false; } }   // test / tuning hook
     }
-    e->step_env_lds = e->fast ? e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad + e->obs_stage : p.env_lds;
-    e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
     if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
         if (f[0] == '1') e->fast = e->big = e->fast_rules = false;
     }
-    if (!e->fast) e->obs_stage = 0;
+    // Tiny worlds (<= 256 bytes per env: 10x10x2, 11x11x1, ...): four envs per wave on the LDS-resident generic kernel.
+    // Measured at 65 536 envs (round 2): Treasurehunt 10x10x2 with 2 agents 53.6 us against 87.5 us on the wave-per-env
+    // kernel, Tag 11x11 165 against 172; from 21x21x2 upward the wave-per-env kernel wins (89 against 133 us), its
+    // leaner code outweighing its idle lanes.  SGW_GROUP = 16 / 32 forces a packing, 64 forbids it (A/B hook).
+    e->group = e->wpe * kWave;
+    if (e->wpe == 1) {
+        int g = p.cells_pad <= 256 ? 16 : 0;
+        if (const char* f = getenv("SGW_GROUP")) g = atoi(f);
+        const bool fits = (g == 16 || g == 32) && c.num_agents <= g &&
+                          (c.agent_rule != SGW_AGENT_RULE_CLEANUP || 3 * c.beam_radius <= g);
+        if (fits) {
+            e->group = g;
+            e->fast = e->fast_rules = false;
+        }
+    }
+    if (!e->fast) { e->obs_stage = 0; stage_kernel = false; }
+    const int epb_step = (e->fast || e->big) ? epb : kBlock / e->group;   // envs per workgroup of the step kernel
     e->step_env_lds = e->fast ? e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad + e->obs_stage : p.env_lds;
-    e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb * e->step_env_lds;
-    if (e->big) e->step_lds_bytes = (size_t)e->fast_tab_bytes + kBigAgentLds + p.cells_pad;
+    e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb_step * e->step_env_lds;
+    p.big_pitch = c.width;
+    if (e->big) {
+        // padded LDS rows (bank-conflict-free window gather) where a row is whole 16-byte units and the image still
+        // leaves four workgroups per CU (LDS is handed out in 1 KiB granules)
+        const size_t fixed = (size_t)e->fast_tab_bytes + kBigAgentLds;
+        const size_t padded = fixed + (size_t)c.layers * c.height * (c.width + 16);
+        if ((c.width & 15) == 0 && (p.cells & 15) == 0 && ((padded + 1023) & ~(size_t)1023) * 4 <= kLdsPerCu) p.big_pitch = c.width + 16;
+        if (const char* f = getenv("SGW_BIG_NO_PAD")) { if (f[0] == '1') p.big_pitch = c.width; }   // A/B hook
+        if (const char* f = getenv("SGW_BIG_STAGGER")) p.big_stagger = atoi(f);                      // A/B hook
+        p.big_stagger_shift = 8;
+        if (const char* f = getenv("SGW_BIG_STAGGER_SHIFT")) p.big_stagger_shift = atoi(f);
+        e->step_lds_bytes = fixed + (p.big_pitch == c.width ? (size_t)p.cells_pad : (size_t)c.layers * c.height * p.big_pitch);
+    }
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
     const size_t lds_max = 160 * 1024;
     if (e->lds_bytes > lds_max) {
@@ -2163,15 +2331,19 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tab = e->d_tab;
     p.status = e->d_status;
 
-    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, &e->kernel_name)
+    if (e->fast) e->step_fn_plain = pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, false, &e->kernel_name_plain);
+    p.stage_agents = e->stage_agents;
+    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name)
-                         : pick_step(e->wpe, e->onehot, &e->kernel_name);
+                         : pick_step(e->group, e->onehot, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
     e->step_fn = sk;
     e->reset_fn = rk;
     if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+        if (err == hipSuccess && e->step_fn_plain && e->step_fn_plain != sk)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err != hipSuccess) {
@@ -2182,7 +2354,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     int nb = 0;
     if (int rc = occupancy_blocks(sk, e->step_lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     // generic kernel: persistent grid; fast kernel: one env per wave, the dispatcher balances
-    e->grid_blocks = (e->fast || e->big) ? (int)ceil_div(p.E, epb) : (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
+    e->grid_blocks = (e->fast || e->big) ? (int)ceil_div(p.E, epb) : (int)std::min<int64_t>(ceil_div(p.E, epb_step), nb);
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     e->reset_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
     *out = e;
@@ -2252,7 +2424,12 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
              (size_t)p.A * p.C * p.VV * 4 >= 8192 && p.E >= (int64_t)e->num_cus * 32 * 2)
         cap = e->fast_wg_cap;
     if (cap > 0) lds = std::max(lds, (size_t)(kLdsPerCu / cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
-    hipLaunchKernelGGL(e->step_fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
+    // a run-time-shape STAGE kernel has no direct-store path: calls it cannot serve take the plain variant
+    StepFn fn = e->step_fn;
+    if (e->fast && e->stage_agents > 0 && e->step_fn_plain &&
+        (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS)))
+        fn = e->step_fn_plain;
+    hipLaunchKernelGGL(fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
 }
@@ -2415,8 +2592,8 @@ int sgw_set_wg_per_cu(sgw_engine* e, int wg_per_cu) {
 
 int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     if (!e || !buf || capacity < 1) return fail(SGW_EINVAL, "sgw_launch_info: NULL argument");
-    snprintf(buf, (size_t)capacity, "%s threads=%d lds=%zu env_lds=%d obs_stage=%d grid=%d wg_per_cu=%s%d", e->kernel_name,
-             e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->grid_blocks,
+    snprintf(buf, (size_t)capacity, "%s threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%s%d", e->kernel_name,
+             e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->stage_agents, e->grid_blocks,
              e->wg_per_cu == 0 ? "auto:" : "", e->wg_per_cu == 0 ? e->fast_wg_cap : e->wg_per_cu);
     return SGW_OK;
 }

@@ -19,9 +19,9 @@ for a in it:
 res = {n: [] for n, _ in variants}
 for r in range(rounds):
     for name, env in variants:
-        out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--steps", "300"] + bargs.split(),
+        out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-series", "--prewarm-steps", "300", "--steps", "300"] + bargs.split(),
                              env={**os.environ, **env}, capture_output=True, text=True).stdout.strip().splitlines()[-1]
-        res[name].append(json.loads(out)["ms_per_step"] * 1000)
+        res[name].append(json.loads(out)["roofline"]["kernel_ms"] * 1000)
 for name, v in res.items():
     v2 = sorted(v)
     print(f"{name:12s} min {v2[0]:7.1f}  med {v2[len(v2) // 2]:7.1f}  max {v2[-1]:7.1f} us   {['%.1f' % x for x in v]}")

@@ -17,13 +17,21 @@ def tag_spec(h, w, a, r):
                      spawn_choices=[[]] * 4, appearance=app, seed=1, layer_fill_type=[0], layer_border_type=[1],
                      agent_rule=1, tag_it_type=2, tag_notit_type=3, tag_reward=10.0)
 
+KW = dict(write_obs=os.environ.get("MISC_NO_OBS") != "1", sweep=os.environ.get("MISC_NO_SWEEP") != "1")   # diagnostic ablations
+if os.environ.get("MISC_AGENTS"):
+    KW["agent_end"] = int(os.environ["MISC_AGENTS"])
+ONLY = os.environ.get("MISC_ONLY", "")
+
+
 def run(name, spec, E, K=100):
+    if ONLY and ONLY not in name:
+        return
     eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
-    for _ in range(5): eng.step(random_actions=True)
+    for _ in range(200): eng.step(random_actions=True, **KW)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(K): eng.step(random_actions=True)
+    for _ in range(K): eng.step(random_actions=True, **KW)
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / K * 1000
     byt = spec.algorithmic_bytes_per_env_step() * E
@@ -38,6 +46,8 @@ run("treasurehunt 32x32x2 A8 r3 (fast)", treasurehunt_spec(32, 32, 8, 3), 65536)
 
 def run_observe(name, spec, E, K=100):
     """K1 alone: sgw_observe of all agents (grid read + observation stores, no sweep, no moves)."""
+    if ONLY and ONLY not in name:
+        return
     eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
     for _ in range(5): eng.observe()
     torch.cuda.synchronize()
@@ -67,6 +77,8 @@ run_observe("observe only 32x32x2 A8 r3", treasurehunt_spec(32, 32, 8, 3), 65536
 
 
 def run_cleanup(E=16384, K=50):
+    if ONLY and ONLY not in "cleanup":
+        return
     spec = cleanup_spec(21, 31, 10, 5)
     eng = GridEngine(spec, E, device="cuda:0")
     # the reference's map: walls around, river on top, orchard at the bottom, agents on the sand in between
@@ -77,11 +89,11 @@ def run_cleanup(E=16384, K=50):
     for (y, x) in pos: g[1, y, x] = 11
     eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
     eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
-    for _ in range(5): eng.step(random_actions=True)
+    for _ in range(100): eng.step(random_actions=True, **KW)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(K): eng.step(random_actions=True)
+    for _ in range(K): eng.step(random_actions=True, **KW)
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / K * 1000
     byt = spec.algorithmic_bytes_per_env_step() * E

@@ -116,6 +116,7 @@ struct Params {
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int big_stagger;  // step_big: start delay (units of ~2.7 us) of every other co-resident workgroup of the first round
     int big_stagger_shift;
+    int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
 };
 
 // ---------------------------------------------------------------- RNG
@@ -183,10 +184,27 @@ __device__ __forceinline__ void gsync() {
 template <int G>
 __device__ __forceinline__ void load_grid(const Params& p, const uint8_t* __restrict__ src,
                                           uint8_t* lds, int gtid) {
-    if ((p.cells & 15) == 0 && (p.env_stride & 15) == 0) {
+    if ((p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad) {
+        // whole 16-byte units, the env's pad bytes included (a ragged world in a padded stride: the bytes past the last
+        // cell are not cells -- no type, no RNG index -- and are masked to 0xFF in LDS)
         const uint4* s = reinterpret_cast<const uint4*>(src);
         uint4* d = reinterpret_cast<uint4*>(lds);
-        for (int i = gtid; i < (p.cells >> 4); i += G) d[i] = s[i];
+        const int nu = p.cells_pad >> 4;
+        for (int i = gtid; i < nu; i += G) {
+            uint4 v = s[i];
+            if (i == nu - 1 && (p.cells & 15)) {
+                const int tail = p.cells & 15;
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int keep = tail - 4 * q;   // valid bytes in this dword
+                    if (keep <= 0) w[q] = 0xFFFFFFFFu;
+                    else if (keep < 4) w[q] |= 0xFFFFFFFFu << (8 * keep);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            d[i] = v;
+        }
     } else if ((p.cells & 3) == 0 && (p.env_stride & 3) == 0) {
         const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
         uint32_t* d = reinterpret_cast<uint32_t*>(lds);
@@ -199,10 +217,10 @@ __device__ __forceinline__ void load_grid(const Params& p, const uint8_t* __rest
 template <int G>
 __device__ __forceinline__ void store_grid(const Params& p, uint8_t* __restrict__ dst,
                                            const uint8_t* lds, int gtid) {
-    if ((p.cells & 15) == 0 && (p.env_stride & 15) == 0) {
+    if ((p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad) {
         uint4* d = reinterpret_cast<uint4*>(dst);
         const uint4* s = reinterpret_cast<const uint4*>(lds);
-        for (int i = gtid; i < (p.cells >> 4); i += G) d[i] = s[i];
+        for (int i = gtid; i < (p.cells_pad >> 4); i += G) d[i] = s[i];   // the pad bytes of the stride are nobody's cells
     } else if ((p.cells & 3) == 0 && (p.env_stride & 3) == 0) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst);
         const uint32_t* s = reinterpret_cast<const uint32_t*>(lds);
@@ -212,7 +230,41 @@ __device__ __forceinline__ void store_grid(const Params& p, uint8_t* __restrict_
     }
 }
 
+__device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
+    // 0x80 in every byte of v that equals the corresponding byte of pat (exact, no carries between bytes)
+    const uint32_t x = v ^ pat;
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
 // ---------------------------------------------------------------- sweep
+// At most one spawning type (every Treasurehunt-shaped world): byte-parallel match of the spawner id, one Philox block
+// per dword that holds a spawner, thresholds and choices from scalar registers instead of per-byte table reads.
+template <int G>
+__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid) {
+    uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
+    const int ndw = (p.cells + 3) >> 2;
+    for (int d = gtid; d < ndw; d += G) {
+        const uint32_t m = match_bytes(g32[d], p.spawn_pat);
+        if (m == 0) continue;
+        const U4 w = philox4x32_10((uint32_t)d, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+        const bool f = p.spawn_full != 0;
+        uint32_t hits = 0;
+        hits |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
+        hits |= ((m & 0x8000u) && (f || w.y < p.spawn_thr)) ? 2u : 0u;
+        hits |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
+        hits |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
+        if (hits == 0) continue;
+        const U4 k = philox4x32_10((uint32_t)d, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if ((hits >> b) & 1u) {
+                const uint32_t pick = __umulhi(word_of(k, b), p.spawn_n);
+                lds_grid[4 * d + b] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+            }
+    }
+}
+
 // Entity transitions (reference: environment.py:88-91).  RNG index of a cell ==
 // its byte offset in the [L][H][W] slice, so one LDS dword == one Philox block.
 template <int G>
@@ -297,13 +349,16 @@ constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it obse
 constexpr int kDirOff = kPovOff + SGW_MAX_AGENTS;       // its facing (Cleanup)
 constexpr int kAgentLds = kDirOff + SGW_MAX_AGENTS;     // 640 bytes, multiple of 16
 
+#ifndef SGW_GENERIC_WAVES
+#define SGW_GENERIC_WAVES 6
+#endif
 // G = threads per environment: 256 (a workgroup per env, worlds above 4 KiB), 64 (a wave per env) or, for small worlds,
 // 32 / 16 lanes of a wave -- two or four envs share a wave and its instruction stream.  The kernel keeps every piece of
 // per-env state in the group's LDS slice and uses no cross-lane instruction, so a sub-wave group needs nothing but the
 // wave-level ordering of DS instructions; what it buys is that the per-env instruction count, which bounds small worlds
 // (a 21x21x2 world keeps 29 of 64 lanes busy in the sweep and 25 in the window gather), is shared by 2 or 4 envs.
-template <int G, bool ONEHOT>
-__global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
+template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE>
+__global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
     constexpr int EPB = kBlock / G;    // envs per workgroup
@@ -341,7 +396,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
     const int zoff = p.zA * p.H * p.W;
     const int HW = p.H * p.W;
 
-    for (int64_t env = (int64_t)blockIdx.x * EPB + sub; env < p.E; env += (int64_t)gridDim.x * EPB) {
+    // one env per group and launch (no persistent loop: nothing stays live from one env to the next, and the
+    // dispatcher balances the workgroups)
+    const int64_t env = (int64_t)blockIdx.x * EPB + sub;
+    if (env < p.E) {
         const uint32_t env_id = p.first_env + (uint32_t)env;
         uint8_t* ggrid = p.grid + env * p.env_stride;
         load_grid<G>(p, ggrid, lg, gtid);
@@ -374,7 +432,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             if (p.has_become) {
                 sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid);
             } else {
-                sweep<G>(p, tab, lg, env_id, gtid);
+                if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid);
+                else sweep<G>(p, tab, lg, env_id, gtid);
                 gsync<WPE>();
             }
         }
@@ -392,25 +451,38 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                     const int off = gy * p.W + gx;
                     float* o = obase + w;
                     if constexpr (ONEHOT) {
-                        uint32_t cnt[4] = {0u, 0u, 0u, 0u};
-                        const int nw = (p.C + 3) >> 2;
+                        constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
+                        const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
+                        uint32_t cnt[NWq];
+#pragma unroll
+                        for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
+                        const int nw = (Cn + 3) >> 2;
                         if (inb) {
-                            for (int z = 0; z < p.L; ++z) {
+#pragma unroll
+                            for (int z = 0; z < (TL ? TL : 1); ++z) {
                                 const uint32_t t = lg[z * HW + off] & 31u;
 #pragma unroll
-                                for (int q = 0; q < 4; ++q)
+                                for (int q = 0; q < NWq; ++q)
                                     if (q < nw) cnt[q] += tab->delta[q][t];
+                            }
+                            if constexpr (TL == 0) {
+                                for (int z = 1; z < Ln; ++z) {
+                                    const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                    for (int q = 0; q < NWq; ++q)
+                                        if (q < nw) cnt[q] += tab->delta[q][t];
+                                }
                             }
                         } else {   // fill entity's appearance, once (visual_field.py:89-94)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) cnt[q] = p.fill_delta[q];
+                            for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < NWq; ++q) {
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
                                 const int c = 4 * q + b;
-                                if (c < p.C) {
+                                if (c < Cn) {
                                     const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
                                     if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * p.VV] = (uint8_t)v;
                                     else o[c * p.VV] = (float)v;
@@ -435,13 +507,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                     const int w = gtid + k * G;
                     if (w < p.VV) render(w, wi[k], wj[k]);
                 }
-                for (int w = gtid + kMaxPass * G; w < p.VV; w += G) {
-                    const int i = w / p.V;
-                    render(w, i, w - i * p.V);
+                {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
+                    int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
+                    for (int w = gtid + kMaxPass * G; w < p.VV; w += G) {
+                        j += G;
+                        while (j >= p.V) { j -= p.V; ++i; }
+                        render(w, i, j);
+                    }
                 }
             }
             if (!p.do_move || a >= p.a1) continue;
-            if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {
+            if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
                 // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
                 // same LDS bytes, so all control flow here is uniform; single threads do the writes.
                 const uint32_t act = s_act[a];
@@ -510,7 +586,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
             const int oaddr = zoff + y * p.W + x;
             const uint32_t t = inb ? lg[taddr] : 0xFFu;
             const bool tok = t < (uint32_t)p.T;
-            double val = (inb && tok && p.agent_rule == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
+            double val = (inb && tok && RULE == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
             const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
             const int cy = pass ? ty : y, cx = pass ? tx : x;   // where the agent stands after the move
             gsync<WPE>();   // every thread has read s_type / the target before thread 0 rewrites them
@@ -525,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                 st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
                            ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
             }
-            if (p.agent_rule == SGW_AGENT_RULE_TAG) {
+            if constexpr (RULE == SGW_AGENT_RULE_TAG) {
                 // TagAgent.act (sorrel/examples/tag/agents.py:84-106): look at the four neighbours in
                 // Location.adjacent order (up, right, down, left; off-map skipped); an agent that is
                 // "it" hands the flag to the FIRST neighbour that is a NotIt agent.  Every thread
@@ -574,7 +650,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Params p) {
                 if (st_bits) atomicOr(p.status, st_bits);
             }
         }
-        gsync<WPE>();   // slice is reused by the next env of this group
     }
 }
 
@@ -616,12 +691,6 @@ constexpr size_t kCacheResidentGrid = (size_t)384 << 20;   // grids of a batch u
 // (non-temporal observation stores were measured: slower)
 #define OBS_STORE(ptr, val) (*(ptr) = (val))
 
-__device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
-    // 0x80 in every byte of v that equals the corresponding byte of pat (exact, no carries between bytes)
-    const uint32_t x = v ^ pat;
-    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ~(t | x | 0x7F7F7F7Fu);
-}
 
 // Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
 __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id) {
@@ -2007,21 +2076,27 @@ using StepFn = void (*)(const Params);
         return __VA_ARGS__;       \
     } while (0)
 
-StepFn pick_step(int group, bool onehot, const char** name) {
-    if (group == 16) {
-        if (onehot) PICK(step_kernel<16, true>);
-        PICK(step_kernel<16, false>);
+template <int G>
+StepFn pick_step_g(bool onehot, int L, int C, int rule, const char** name) {
+    if (rule == SGW_AGENT_RULE_CLEANUP) {
+        if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>);
+        PICK(step_kernel<G, false, 0, 0, SGW_AGENT_RULE_CLEANUP>);
     }
-    if (group == 32) {
-        if (onehot) PICK(step_kernel<32, true>);
-        PICK(step_kernel<32, false>);
+    if (rule == SGW_AGENT_RULE_TAG) {
+        if (onehot && L == 1 && C == 4) PICK(step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>);   // the Tag example's tables
+        if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>);
+        PICK(step_kernel<G, false, 0, 0, SGW_AGENT_RULE_TAG>);
     }
-    if (group == 64) {
-        if (onehot) PICK(step_kernel<64, true>);
-        PICK(step_kernel<64, false>);
-    }
-    if (onehot) PICK(step_kernel<256, true>);
-    PICK(step_kernel<256, false>);
+    if (onehot && L == 2 && C == 6) PICK(step_kernel<G, true, 2, 6>);                             // Treasurehunt-shaped tables
+    if (onehot) PICK(step_kernel<G, true>);
+    PICK(step_kernel<G, false>);
+}
+
+StepFn pick_step(int group, bool onehot, int L, int C, int rule, const char** name) {
+    if (group == 16) return pick_step_g<16>(onehot, L, C, rule, name);
+    if (group == 32) return pick_step_g<32>(onehot, L, C, rule, name);
+    if (group == 64) return pick_step_g<64>(onehot, L, C, rule, name);
+    return pick_step_g<256>(onehot, L, C, rule, name);
 }
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
@@ -2204,6 +2279,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             else p.choice_hi |= (uint32_t)c.spawn_choice[t][k] << (8 * (k - 4));
         }
     }
+    p.single_spawner = nspawn <= 1 ? 1 : 0;
     p.seed_lo = (uint32_t)c.seed;
     p.seed_hi = (uint32_t)(c.seed >> 32);
     p.first_env = (uint32_t)c.first_env_id;
@@ -2280,13 +2356,27 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
         if (f[0] == '1') e->fast = e->big = e->fast_rules = false;
     }
-    // Tiny worlds (<= 256 bytes per env: 10x10x2, 11x11x1, ...): four envs per wave on the LDS-resident generic kernel.
-    // Measured at 65 536 envs (round 2): Treasurehunt 10x10x2 with 2 agents 53.6 us against 87.5 us on the wave-per-env
-    // kernel, Tag 11x11 165 against 172; from 21x21x2 upward the wave-per-env kernel wins (89 against 133 us), its
-    // leaner code outweighing its idle lanes.  SGW_GROUP = 16 / 32 forces a packing, 64 forbids it (A/B hook).
+    // Small worlds: two or four envs per wave on the LDS-resident generic kernel (step_kernel<16 / 32>).  A wave-per-env
+    // kernel spends most of a small world's life on per-env work that keeps few lanes busy (a 21x21x2 world: 29 of 64
+    // lanes in the sweep, 25 in the 5x5 gather, one in the moves), and at ~700 instructions per env it is bound by
+    // instruction issue, not memory; packed, that stream is shared.  Rule from tools/group_sweep.py (65 536 envs, us per
+    // step, wave-per-env / 16 lanes / 32 lanes per env -- profiles/r02_group_sweep.txt):
+    //   10x10 A2 r2 88/29/42   16x16 A4 r2 81/46/55   21x21 A2 r2 90/46/55   21x21 A8 r2 132/118/105
+    //   24x24 A4 r3 134/137/124   32x32 A2 r2 93/96/78   28x28 A8 r3 167/243/223   32x32 A8 r3 118/282/206
+    //   Tag 11x11 A5 r4 171/155/111   Tag 32x32 A8 r3 194/156/140   Cleanup 21x31x3 A10 r5 694/1383/1246
+    // i.e. pack while the observation work per env (A * V * V window cells) is small, and only for batches that still
+    // fill the chip twice over once packed (a small batch is latency-bound: config 2, 4 096 envs, 11 us wave-per-env
+    // against 16-19 us packed).  SGW_GROUP = 16 / 32 forces a packing, 64 forbids it (A/B hook).
     e->group = e->wpe * kWave;
     if (e->wpe == 1) {
-        int g = p.cells_pad <= 256 ? 16 : 0;
+        const int64_t avv = (int64_t)c.num_agents * p.VV;
+        auto enough = [&](int G) { return c.num_agents <= G && (int64_t)c.num_envs * G / kWave >= 12288; };
+        int g = 0;
+        if (c.agent_rule == SGW_AGENT_RULE_TAG) g = enough(32) ? 32 : 0;
+        else if (c.agent_rule == SGW_AGENT_RULE_MOVE && !p.has_become) {
+            if (avv <= 100 && p.cells_pad <= 1024 && enough(16)) g = 16;
+            else if (avv <= 200 && enough(32)) g = 32;
+        }
         if (const char* f = getenv("SGW_GROUP")) g = atoi(f);
         const bool fits = (g == 16 || g == 32) && c.num_agents <= g &&
                           (c.agent_rule != SGW_AGENT_RULE_CLEANUP || 3 * c.beam_radius <= g);
@@ -2335,7 +2425,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.stage_agents = e->stage_agents;
     StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name)
-                         : pick_step(e->group, e->onehot, &e->kernel_name);
+                         : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
     e->step_fn = sk;
@@ -2354,7 +2444,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     int nb = 0;
     if (int rc = occupancy_blocks(sk, e->step_lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     // generic kernel: persistent grid; fast kernel: one env per wave, the dispatcher balances
-    e->grid_blocks = (e->fast || e->big) ? (int)ceil_div(p.E, epb) : (int)std::min<int64_t>(ceil_div(p.E, epb_step), nb);
+    (void)nb;
+    e->grid_blocks = (int)ceil_div(p.E, (e->fast || e->big) ? epb : epb_step);   // every step kernel: one env per group, the dispatcher balances
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     e->reset_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
     *out = e;
@@ -2592,7 +2683,8 @@ int sgw_set_wg_per_cu(sgw_engine* e, int wg_per_cu) {
 
 int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     if (!e || !buf || capacity < 1) return fail(SGW_EINVAL, "sgw_launch_info: NULL argument");
-    snprintf(buf, (size_t)capacity, "%s threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%s%d", e->kernel_name,
+    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%s%d", e->kernel_name,
+             (e->fast || e->big) ? e->wpe * kWave * (e->big ? kBigWaves / 4 : 1) : e->group,
              e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->stage_agents, e->grid_blocks,
              e->wg_per_cu == 0 ? "auto:" : "", e->wg_per_cu == 0 ? e->fast_wg_cap : e->wg_per_cu);
     return SGW_OK;

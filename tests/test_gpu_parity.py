@@ -217,6 +217,78 @@ def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
         assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
 
 
+@pytest.mark.parametrize("group", ["16", "32"])
+@pytest.mark.parametrize("name", ["c1_treasurehunt_10x10", "c2_treasurehunt_16x16", "crowded_6x6", "tag_9x9", "tag_crowded_6x7",
+                                  "rgb_treasurehunt", "basic_doublewall", "float_appearance_3layer", "ragged_9x13_rmax",
+                                  "scripted_noop", "cleanup_15x16", "basic_1layer", "c3_treasurehunt_32x32"])
+def test_packed_kernels_match_reference_golden(torch_cuda, name, group, monkeypatch):
+    """Two / four envs per wave (step_kernel<32> / <16>): every fixture small enough, bit for bit."""
+    monkeypatch.setenv("SGW_GROUP", group)
+    test_hip_matches_reference_golden(torch_cuda, name)
+
+
+@pytest.mark.parametrize("group", ["16", "32"])
+def test_packed_kernels_batches_vs_oracle(torch_cuda, group, monkeypatch):
+    """Batches that do not fill the last wave / workgroup, ragged byte counts, windows wider than the group (several
+    render passes), the uint8 format, phased stepping with OBS_NEXT, Tag -- on the packed kernels."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_GROUP", group)
+    for (h, w, a, r, E) in ((21, 21, 2, 2, 1003), (10, 10, 2, 2, 517), (16, 16, 4, 2, 64), (13, 9, 5, 4, 77), (32, 32, 8, 3, 130)):
+        eng, co = rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=31, dense_prob=0.1), E, 5, first=11)
+        assert "step_kernel<" in eng.launch_info() and f"group={group} " in eng.launch_info()
+    d, spec = H.load_golden("tag_9x9")
+    ws = H.world_spec(spec)
+    eng, co = make_engine(ws, 333, first=9), H.COracle(ws, 333, first_env_id=9)
+    eng.reset(0)
+    co.reset(0)
+    for t in range(1, 12):
+        eng.step(random_actions=True)
+        co.step(0, t, random_actions=True)
+        assert_same(eng, co, ctx=f"packed tag turn {t}")
+        assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
+    # compact uint8 observations
+    ws = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=5)
+    e8, e32 = make_engine(ws, 200, obs_dtype=torch.uint8), make_engine(ws, 200)
+    for e in (e8, e32):
+        e.reset(0)
+    for _ in range(4):
+        e8.step(random_actions=True)
+        e32.step(random_actions=True)
+    torch.cuda.synchronize()
+    assert torch.equal(e8.obs.float(), e32.obs) and torch.equal(e8.grid, e32.grid)
+
+
+def test_dispatch_rule_packs_small_worlds_of_large_batches(torch_cuda):
+    """The automatic rule (sgw_create): 65 536 envs of the reference's Treasurehunt default (21x21, 2 agents, r = 2) run
+    four to a wave, a small batch of the same world and the BASELINE config-3 shape stay on the wave-per-env kernel;
+    a strided sample of the big packed batch is checked against the oracle."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(21, 21, 2, 2, spawn_prob=0.02, seed=77)
+    big = make_engine(ws, 65536, first=100)
+    assert "step_kernel<" in big.launch_info() and "group=16 " in big.launch_info()
+    assert "step_fast" in make_engine(ws, 512).launch_info()
+    assert "step_fast<true, 2, 6, 3, 32, 32>" in make_engine(treasurehunt_spec(32, 32, 8, 3), 65536).launch_info()
+    big.reset(0)
+    ids = list(range(0, 65536, 4099)) + [65535]
+    cos = []
+    for i in ids:
+        co = H.COracle(ws, 1, first_env_id=100 + i)
+        co.reset(0)
+        cos.append(co)
+    for t in range(1, 7):
+        big.step(random_actions=True)
+        torch.cuda.synchronize()
+        for i, co in zip(ids, cos):
+            co.step(0, t, random_actions=True)
+            assert np.array_equal(big.obs[i].cpu().numpy(), co.obs[0]), (t, i)
+            assert np.array_equal(big.grid[i].cpu().numpy(), co.grid[0]) and big.total_reward[i].item() == co.total[0]
+    assert big.status() == 0
+
+
 @pytest.mark.parametrize("shape", [(32, 32, 8, 3, 300), (21, 21, 2, 2, 100), (128, 128, 64, 5, 6)])
 def test_compact_uint8_observations(torch_cuda, shape, monkeypatch):
     """SGW_OBS_U8: same layout, the float32 counts as bytes (fast, big and generic kernels)."""
@@ -302,11 +374,13 @@ def _random_world(rng):
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "48"))))
-def test_random_worlds_vs_oracle(torch_cuda, case):
+def test_random_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     """Soak: random shapes / agent counts / radii / rates through whichever kernel the dispatcher
     picks (step_fast, step_big, generic), a few dozen envs, every tensor compared every turn."""
     rng = np.random.default_rng(1000 + case)
     ws = _random_world(rng)
+    if case % 3 and ws.num_agents <= 16 and ws.layers * ws.height * ws.width <= 4096:     # two thirds of the small cases: packed kernels
+        monkeypatch.setenv("SGW_GROUP", "16" if case % 3 == 1 else "32")
     rollout_vs_oracle(ws, int(rng.integers(3, 40)), int(rng.integers(2, 7)), first=int(rng.integers(0, 2**31)),
                       epoch=int(rng.integers(0, 50)))
 

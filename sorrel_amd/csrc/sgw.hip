@@ -114,8 +114,6 @@ struct Params {
     int stage_agents; // step_fast<..., STAGE>: agents whose observations are staged together and leave in one burst
     int obs_next;     // SGW_STEP_OBS_NEXT: write only the observation of agent a1, after the moves of [a0, a1)
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
-    int big_stagger;  // step_big: start delay (units of ~2.7 us) of every other co-resident workgroup of the first round
-    int big_stagger_shift;
     int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
 };
 
@@ -405,12 +403,14 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         load_grid<G>(p, ggrid, lg, gtid);
         double tot = 0.0;
         if (gtid == 0 && p.do_move) tot = p.total[env];
+        uint32_t yx0 = 0;                     // this thread's agent: position at the start of the call
         if (gtid < p.A) {
             uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
             if ((yx & 0xFF) >= p.H || (yx >> 8) >= p.W) {   // garbage in: stay inside this env's LDS slice, and say so
                 yx = 0;
                 atomicOr(p.status, SGW_STATUS_BAD_POS);
             }
+            yx0 = yx;
             reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
             s_type[gtid] = p.agent_state ? p.agent_state[env * p.A + gtid] : tab->agent_type[gtid];
             s_dir[gtid] = p.agent_dir ? p.agent_dir[env * p.A + gtid] : (uint8_t)2;
@@ -636,7 +636,22 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             gsync<WPE>();
         }
 
-        if (dirty) store_grid<G>(p, ggrid, lg, gtid);
+        if (dirty) {
+            if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP)) {
+                // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
+                // not the whole grid (with agents i < j both touching a cell, both write its FINAL content: no race)
+                if (gtid >= p.a0 && gtid < p.a1) {
+                    const uint32_t now = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
+                    if (now != yx0) {
+                        const int o0 = zoff + (int)(yx0 & 0xFFu) * p.W + (int)(yx0 >> 8), o1 = zoff + (int)(now & 0xFFu) * p.W + (int)(now >> 8);
+                        ggrid[o0] = lg[o0];
+                        ggrid[o1] = lg[o1];
+                    }
+                }
+            } else {
+                store_grid<G>(p, ggrid, lg, gtid);
+            }
+        }
         if (p.do_move) {
             if (gtid >= p.a0 && gtid < p.a1) {
                 reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
@@ -1272,10 +1287,20 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             }
         }
         if (dirty) {
-            uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
+            if (!TAG && !RULES && !do_sweep) {
+                // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
+                // not the whole grid (two movers touching one cell both write its FINAL content: no race)
+                if (mine && moved) {
+                    uint8_t* g = p.grid + env * p.env_stride;
+                    g[oaddr_v] = lg[oaddr_v];
+                    g[taddr_v] = lg[taddr_v];
+                }
+            } else {
+                uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll
-            for (int k = 0; k < NU; ++k)
-                if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
+            }
         }
         if (p.do_move) {
             if (mine) {
@@ -1370,12 +1395,6 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     // HBM unit index / byte offset -> LDS unit index / byte offset (one pad unit per row)
     auto lunit = [&](int idx) { return padded ? idx + idx / upr : idx; };
     auto lbyte = [&](uint32_t off) { return padded ? off + (off / (uint32_t)W) * 16u : off; };
-    if (p.big_stagger > 0 && blockIdx.x < 1024 && ((blockIdx.x >> p.big_stagger_shift) & 1)) {
-        // First round only: every other workgroup that shares a CU (blocks are dealt round-robin over XCDs and CUs, so b
-        // and b + 256 land together) starts late, so that one half of a CU's workgroups is in its vector-ALU phases
-        // (sweep, moves) while the other half is in its HBM phases (observation stores, write-back).
-        for (int i = 0; i < p.big_stagger; ++i) __builtin_amdgcn_s_sleep(100);
-    }
 
     // LDS: [tables][agent arrays][grid]
     uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // journal entry of each agent (phase M -> R)
@@ -1707,7 +1726,14 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     STAMPB(3);                   // phase R done (all waves)
 
     // ---- write-back
-    if (dirty) {
+    if (dirty && !do_sweep) {
+        // a policy-driven phase (no sweep): only the movers' two cells changed -- write those bytes, not the whole grid
+        if (wv == 0 && mine && (jr & 0x200u)) {
+            uint8_t* g = p.grid + env * p.env_stride + p.zA * H * W;
+            g[(yx & 0xFFu) * W + (yx >> 8)] = lg[oaddr_v];
+            g[(npos_v & 0xFFu) * W + (npos_v >> 8)] = lg[ta_v];
+        }
+    } else if (dirty) {
         uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
         for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[lunit(idx)];
     }
@@ -2397,9 +2423,6 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         const size_t padded = fixed + (size_t)c.layers * c.height * (c.width + 16);
         if ((c.width & 15) == 0 && (p.cells & 15) == 0 && ((padded + 1023) & ~(size_t)1023) * 4 <= kLdsPerCu) p.big_pitch = c.width + 16;
         if (const char* f = getenv("SGW_BIG_NO_PAD")) { if (f[0] == '1') p.big_pitch = c.width; }   // A/B hook
-        if (const char* f = getenv("SGW_BIG_STAGGER")) p.big_stagger = atoi(f);                      // A/B hook
-        p.big_stagger_shift = 8;
-        if (const char* f = getenv("SGW_BIG_STAGGER_SHIFT")) p.big_stagger_shift = atoi(f);
         e->step_lds_bytes = fixed + (p.big_pitch == c.width ? (size_t)p.cells_pad : (size_t)c.layers * c.height * p.big_pitch);
     }
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;

@@ -471,13 +471,17 @@ def test_observe_kernel_vs_oracle(torch_cuda):
     assert_same(eng, co, ("obs",), ctx="observe [2,4)")
 
 
-def test_policy_phase_stepping_equals_fused(torch_cuda):
-    """sweep once, then one sgw_step per agent (observe -> act), == one fused take_turn."""
+@pytest.mark.parametrize("shape", [(16, 16, 4, 2, 200), (32, 32, 8, 3, 70), (21, 21, 3, 2, 33), (13, 9, 5, 4, 50), (64, 64, 9, 5, 5)])
+@pytest.mark.parametrize("phase_kernel", ["1", "0"])
+def test_policy_phase_stepping_equals_fused(torch_cuda, shape, phase_kernel, monkeypatch):
+    """sweep once, then per agent sgw_observe + sgw_step (round 1's 1 + 2A launches) == one fused take_turn; and the plain
+    per-agent step that writes the mover's own pre-move observation.  With and without the phase kernel."""
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    ws = treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.05, seed=6)
-    E = 200
+    monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0" if phase_kernel == "1" else "1")
+    h, w, a_, r_, E = shape
+    ws = treasurehunt_spec(h, w, a_, r_, spawn_prob=0.05, seed=6, dense_prob=0.1)
     fused, phased = make_engine(ws, E), make_engine(ws, E)
     fused.reset(0)
     phased.reset(0)
@@ -497,6 +501,21 @@ def test_policy_phase_stepping_equals_fused(torch_cuda):
         assert torch.equal(fused.rewards, rew)
         assert torch.equal(fused.total_reward, phased.total_reward)
         assert torch.equal(fused.agent_pos, phased.agent_pos)
+    # the plain per-agent step: one call that writes the mover's own (pre-move) observation and moves it
+    third = make_engine(ws, E)
+    third.reset(0)
+    fused.reset(0)
+    for t in range(1, 5):
+        acts = fused.random_actions(turn=t).clone()
+        fused.step(acts, turn=t)
+        third.obs.fill_(-3.0)
+        third.step(acts, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)
+        for a in range(ws.num_agents):
+            third.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t)
+        torch.cuda.synchronize()
+        assert torch.equal(fused.obs, third.obs) and torch.equal(fused.grid, third.grid)
+        assert torch.equal(fused.total_reward, third.total_reward) and torch.equal(fused.agent_pos, third.agent_pos)
+    assert fused.status() == 0 and phased.status() == 0 and third.status() == 0
 
 
 def test_resharding_is_bit_exact(torch_cuda):

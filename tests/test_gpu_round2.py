@@ -52,8 +52,9 @@ KERNEL_CASES = [
 ]
 
 
+@pytest.mark.parametrize("phase_kernel", ["phase_kernel", "staging_kernels"])
 @pytest.mark.parametrize("case", KERNEL_CASES, ids=[c[0] for c in KERNEL_CASES])
-def test_obs_next_phased_turn_equals_fused(torch_cuda, case, monkeypatch):
+def test_obs_next_phased_turn_equals_fused(torch_cuda, case, phase_kernel, monkeypatch):
     """Sweep + obs of agent 0 in one launch, then ONE launch per agent that moves it and renders the next agent's
     observation: every observation, reward and the final state equal the fused take_turn (which equals the oracle),
     in 1 + A launches."""
@@ -61,6 +62,8 @@ def test_obs_next_phased_turn_equals_fused(torch_cuda, case, monkeypatch):
     _, mk, env, E = case
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    if phase_kernel == "staging_kernels":      # the phases on the step kernels themselves (what Tag / Cleanup phases always use)
+        monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "1")
     ws = mk()
     A = ws.num_agents
     fused, phased = make_engine(ws, E, first=5), make_engine(ws, E, first=5)

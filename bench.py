@@ -197,6 +197,9 @@ def main() -> int:
     ap.add_argument("--max-turns", type=int, default=0,
                     help="epoch length: every env is auto-reset (K3, inside sgw_step) after this many turns, inside the "
                          "timed loop too; 0 = one endless epoch (SURVEY 8d: no reset in the timed region)")
+    ap.add_argument("--turns-per-launch", type=int, default=50,
+                    help="after the timed region: the same workload through sgw_rollout, this many turns per call (the env's "
+                         "grid stays in LDS from turn to turn); reported beside the per-turn numbers as fused_rollout; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-series", action="store_true", help="skip the per-launch timing pass after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -298,6 +301,35 @@ def main() -> int:
             series["what"] = ("a second pass of the same K steps right after the timed region, one pair of HIP events per launch on the "
                               "launch stream (sgw_set_timing); first5_mean = the first five launches of that pass")
 
+    # the same workload through sgw_rollout: T turns per call, the grid resident in LDS between turns (reported BESIDE
+    # the per-turn numbers: a launch no longer moves the grid of every turn, so the algorithmic-bytes accounting of the
+    # per-turn launch does not describe it; its own HBM-side bytes are the observation / action / reward / position
+    # writes of every turn plus one grid read + write-back per call)
+    fused = None
+    if args.turns_per_launch > 0 and write_obs and sweep and args.diag_agents < 0 and args.max_turns == 0:
+        T = max(1, min(args.turns_per_launch, args.steps))
+        calls = max(1, args.steps // T)
+        eng.rollout(T)                                  # warm
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tw = time.perf_counter()
+        e0.record()
+        for _ in range(calls):
+            eng.rollout(T)
+        e1.record()
+        barrier()
+        fwall = time.perf_counter() - tw
+        fms = e0.elapsed_time(e1) / (calls * T)
+        per_turn_moved = E * (A * (spec.num_channels * spec.window ** 2 * (4 if args.obs_dtype == "f32" else 1) + 1 + 4)) \
+            + (E * (2 * spec.grid_bytes_per_env() + A * 4 + 16)) / T
+        fused = {"turns_per_launch": T, "calls": calls, "ms_per_step": fms, "wall_ms_per_step": fwall / (calls * T) * 1e3,
+                 "value_one_rank": E * A / (fms * 1e-3), "unit": "agent-steps/s",
+                 "bytes_moved_per_step": per_turn_moved, "hbm_side_achieved": per_turn_moved / (fms * 1e-3) / 1e9,
+                 "hbm_side_frac": per_turn_moved / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "what": "sgw_rollout: T whole turns per call; every turn's observations, actions and rewards are written, the grid "
+                         "is read once and written back once per call (it stays in LDS in between), so a step moves fewer bytes than "
+                         "SURVEY 8d's per-turn-launch formula -- hence its own bytes_moved_per_step instead of roofline.frac"}
+
     # end-of-rollout metrics: on-device reduction + the one collective
     metrics = eng.reduce_metrics().clone()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -372,6 +404,7 @@ def main() -> int:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },
+            "fused_rollout": fused,
             "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status},
         }
         if world == 1 and not args.no_cpu_baseline:

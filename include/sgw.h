@@ -25,6 +25,7 @@
  *                   -> Agent.transition (pov, act, reward)    sorrel/agents/agent.py:155-173
  *                   -> MovingAgent.act -> Gridworld.move      sorrel/agents/agent.py:215-225,
  *                                                             sorrel/worlds/gridworld.py:95-122
+ *   sgw_rollout     the turn loop of run_experiment           sorrel/environment.py:160-166
  *   sgw_reduce_metrics  world.total_reward read-out           sorrel/environment.py:193-199
  *
  * Conventions
@@ -201,6 +202,20 @@ int sgw_observe(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_pos, 
 int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs,
              float* rewards, double* total_reward, uint32_t epoch, uint32_t turn,
              int32_t agent_begin, int32_t agent_end, uint32_t flags, void* stream);
+
+/* `num_turns` whole take_turns (all agents, in order) with one call -- Environment.run_experiment's inner loop
+ * `while turn < max_turns: take_turn()` (sorrel/environment.py:160-166) for actions that need no host in between: drawn
+ * on device (SGW_STEP_RANDOM_ACTIONS) or given up front.  Turn t of the call (t = 0 .. num_turns-1, Environment.turn =
+ * first_turn + t) reads / writes its actions, observations and rewards `t * *_turn_stride` ELEMENTS after the pointers
+ * passed (a stride of 0 makes every turn overwrite the same tensor; a ring of replay slots passes the slot size); grid,
+ * agent_pos and total_reward hold the state after the last turn.  Where the step kernel supports it the turns run
+ * inside ONE launch with the env's grid resident in LDS from turn to turn (no grid read / write-back and no kernel
+ * boundary between turns); elsewhere the call is a loop of sgw_step launches.  Results are identical either way, and
+ * identical to num_turns calls of sgw_step.  With sgw_set_auto_reset armed an epoch boundary inside the range is
+ * honoured (the turn counter restarts at 1 in epoch + 1). */
+int sgw_rollout(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs, float* rewards,
+                double* total_reward, uint32_t epoch, uint32_t first_turn, uint32_t num_turns, int64_t obs_turn_stride,
+                int64_t actions_turn_stride, int64_t rewards_turn_stride, uint32_t flags, void* stream);
 
 /* out (device, 4 doubles) = { sum(total_reward), sum(total_reward^2), E, 0 },
  * summed in a fixed order (bitwise reproducible). */

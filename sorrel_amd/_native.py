@@ -62,7 +62,7 @@ LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")
 
 # every symbol include/sgw.h declares
 EXPORTS = (
-    "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_reduce_metrics",
+    "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_rollout", "sgw_reduce_metrics",
     "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info",
@@ -117,6 +117,9 @@ def load():
     lib.sgw_step.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, f64p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                              C.c_uint32, vp]
     lib.sgw_step.restype = C.c_int
+    lib.sgw_rollout.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64,
+                                C.c_int64, C.c_uint32, vp]
+    lib.sgw_rollout.restype = C.c_int
     lib.sgw_reduce_metrics.argtypes = [vp, f64p, f64p, vp]
     lib.sgw_reduce_metrics.restype = C.c_int
     lib.sgw_random_actions.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]

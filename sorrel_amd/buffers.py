@@ -224,6 +224,12 @@ class TurnBuffer:
         self.idx = (self.idx + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
 
+    def advance(self, n: int) -> None:
+        """``n`` consecutive slots starting at ``idx`` were filled in place (``Environment.collect`` through
+        ``sgw_rollout``); the caller guarantees they do not wrap."""
+        self.idx = (self.idx + n) % self.capacity
+        self.size = min(self.size + n, self.capacity)
+
     def agent_view(self, a: int):
         """(states ``[capacity, E, C, V, V]``, actions, rewards, dones ``[capacity, E]``) of one agent slot: views."""
         return self.obs[:, :, a], self.actions[:, :, a], self.rewards[:, :, a], self.dones[:, :, a]

@@ -115,6 +115,10 @@ struct Params {
     int obs_next;     // SGW_STEP_OBS_NEXT: write only the observation of agent a1, after the moves of [a0, a1)
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
+    // sgw_rollout: `nturns` whole turns in ONE launch (the env's grid stays in LDS from turn to turn); turn t of the call
+    // writes its observations / actions / rewards `t * ts_*` elements further on (0 = every turn overwrites the same tensors)
+    uint32_t nturns;
+    int64_t ts_obs, ts_act, ts_rew;
 };
 
 // ---------------------------------------------------------------- RNG
@@ -239,13 +243,13 @@ __device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
 // At most one spawning type (every Treasurehunt-shaped world): byte-parallel match of the spawner id, one Philox block
 // per dword that holds a spawner, thresholds and choices from scalar registers instead of per-byte table reads.
 template <int G>
-__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid) {
+__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn) {
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
     const int ndw = (p.cells + 3) >> 2;
     for (int d = gtid; d < ndw; d += G) {
         const uint32_t m = match_bytes(g32[d], p.spawn_pat);
         if (m == 0) continue;
-        const U4 w = philox4x32_10((uint32_t)d, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+        const U4 w = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
         const bool f = p.spawn_full != 0;
         uint32_t hits = 0;
         hits |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
@@ -253,7 +257,7 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
         hits |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
         hits |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
         if (hits == 0) continue;
-        const U4 k = philox4x32_10((uint32_t)d, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
             if ((hits >> b) & 1u) {
@@ -267,7 +271,7 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
 // its byte offset in the [L][H][W] slice, so one LDS dword == one Philox block.
 template <int G>
 __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uint8_t* lds_grid,
-                                      uint32_t env_id, int gtid) {
+                                      uint32_t env_id, int gtid, uint32_t turn) {
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
     const int ndw = (p.cells + 3) >> 2;
     const uint32_t c3 = (p.epoch << 4) | SGW_STREAM_SPAWN;
@@ -281,7 +285,7 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
             m |= is << b;
         }
         if (m == 0) continue;
-        const U4 w = philox4x32_10((uint32_t)d, p.turn, env_id, c3, p.seed_lo, p.seed_hi);
+        const U4 w = philox4x32_10((uint32_t)d, turn, env_id, c3, p.seed_lo, p.seed_hi);
         uint32_t hits = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -292,7 +296,7 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
             }
         }
         if (hits == 0) continue;
-        const U4 k = philox4x32_10((uint32_t)d, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
                                    p.seed_lo, p.seed_hi);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -313,7 +317,7 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
 // already transitioned when a higher one is visited and a higher one has not when a lower one is.
 // Columns never read each other, so: one pass per layer, all cells of the layer in parallel.
 template <int WPE, int G>
-__device__ __forceinline__ void sweep_ordered(const Params& p, const DevTables* tab, uint8_t* lg, uint32_t env_id, int gtid) {
+__device__ __forceinline__ void sweep_ordered(const Params& p, const DevTables* tab, uint8_t* lg, uint32_t env_id, int gtid, uint32_t turn) {
     const int HW = p.H * p.W;
     for (int z = 0; z < p.L; ++z) {
         for (int cidx = gtid; cidx < HW; cidx += G) {
@@ -326,9 +330,9 @@ __device__ __forceinline__ void sweep_ordered(const Params& p, const DevTables* 
                 const bool fire = zl < 0 || ((tab->rule_mask[t] >> (lg[zl * HW + cidx] & 31u)) & 1u);
                 if (fire) lg[off] = tab->rule_become[t];
             } else if (rule == SGW_RULE_SPAWN) {
-                const U4 w = philox4x32_10((uint32_t)off >> 2, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                const U4 w = philox4x32_10((uint32_t)off >> 2, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
                 if (((p.thr_full_mask >> t) & 1u) || word_of(w, off & 3) < tab->thr_lo[t]) {
-                    const U4 k = philox4x32_10((uint32_t)off >> 2, p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+                    const U4 k = philox4x32_10((uint32_t)off >> 2, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
                     lg[off] = tab->spawn_choice[t][__umulhi(word_of(k, off & 3), (uint32_t)tab->spawn_count[t])];
                 }
             }
@@ -414,37 +418,41 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
             s_type[gtid] = p.agent_state ? p.agent_state[env * p.A + gtid] : tab->agent_type[gtid];
             s_dir[gtid] = p.agent_dir ? p.agent_dir[env * p.A + gtid] : (uint8_t)2;
-            if (p.do_move && gtid >= p.a0 && gtid < p.a1) {
-                uint32_t act;
-                if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
-                    const U4 w = philox4x32_10((uint32_t)gtid >> 2, p.turn, env_id,
-                                               (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
-                    act = (uint32_t)(((uint64_t)word_of(w, gtid & 3) * (uint32_t)p.nact) >> 32);
-                    p.actions[env * p.A + gtid] = (uint8_t)act;
-                } else {
-                    act = p.actions[env * p.A + gtid];
-                }
-                s_act[gtid] = (uint8_t)act;
+        }
+        int st_bits = 0;
+        // sgw_rollout: nturns whole turns on the LDS-resident env (nturns == 1: an ordinary sgw_step / sgw_observe)
+        for (uint32_t tix = 0; tix < p.nturns; ++tix) {
+        const uint32_t turn = p.turn + tix;
+        if (gtid < p.A && p.do_move && gtid >= p.a0 && gtid < p.a1) {
+            uint8_t* acts = p.actions + tix * p.ts_act;
+            uint32_t act;
+            if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
+                const U4 w = philox4x32_10((uint32_t)gtid >> 2, turn, env_id,
+                                           (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+                act = (uint32_t)(((uint64_t)word_of(w, gtid & 3) * (uint32_t)p.nact) >> 32);
+                acts[env * p.A + gtid] = (uint8_t)act;
+            } else {
+                act = acts[env * p.A + gtid];
             }
+            s_act[gtid] = (uint8_t)act;
         }
         gsync<WPE>();
         if (p.flags & SGW_STEP_SWEEP) {
             if (p.has_become) {
-                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid);
+                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid, turn);
             } else {
-                if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid);
-                else sweep<G>(p, tab, lg, env_id, gtid);
+                if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid, turn);
+                else sweep<G>(p, tab, lg, env_id, gtid, turn);
                 gsync<WPE>();
             }
         }
 
-        int st_bits = 0;
         const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;   // OBS_NEXT: one extra, observe-only iteration
         for (int a = p.a0; a < a_end; ++a) {
             const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
             // ---- pov: egocentric window (visual_field.py:9-101)
             if (p.obs_next ? a == p.a1 : write_obs) {
-                float* obase = p.obs + ((env * p.A + a) * (int64_t)p.C) * p.VV;
+                float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * p.VV;
                 auto render = [&](const int w, const int i, const int j) {
                     const int gy = y - p.r + i, gx = x - p.r + j;
                     const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
@@ -635,6 +643,11 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             }
             gsync<WPE>();
         }
+        if (p.do_move && gtid >= p.a0 && gtid < p.a1) {      // this turn's rewards (and what TagAgent.pov appends)
+            p.rewards[tix * p.ts_rew + env * p.A + gtid] = s_rew[gtid];
+            if (p.state_at_pov) p.state_at_pov[env * p.A + gtid] = s_pov[gtid];
+        }
+        }   // turns
 
         if (dirty) {
             if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP)) {
@@ -653,11 +666,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             }
         }
         if (p.do_move) {
-            if (gtid >= p.a0 && gtid < p.a1) {
+            if (gtid >= p.a0 && gtid < p.a1)
                 reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
-                p.rewards[env * p.A + gtid] = s_rew[gtid];
-                if (p.state_at_pov) p.state_at_pov[env * p.A + gtid] = s_pov[gtid];
-            }
             if (gtid < p.A && p.agent_state) p.agent_state[env * p.A + gtid] = s_type[gtid];   // a tag can flip any agent
             if (gtid < p.A && p.agent_dir) p.agent_dir[env * p.A + gtid] = s_dir[gtid];
             if (gtid == 0) {
@@ -708,14 +718,14 @@ constexpr size_t kCacheResidentGrid = (size_t)384 << 20;   // grids of a batch u
 
 
 // Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
-__device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id) {
+__device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id, const uint32_t turn) {
     uint32_t hits = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t dv = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
         const uint32_t m = match_bytes(dv, p.spawn_pat);
         if (m) {
-            const U4 w = philox4x32_10(opaque(unit * 4 + k), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+            const U4 w = philox4x32_10(opaque(unit * 4 + k), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
             const bool f = p.spawn_full != 0;
             uint32_t hb = 0;
             hb |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
@@ -730,12 +740,12 @@ __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t un
 
 // Rare second draw: what spawns in each hit cell; written straight into the LDS grid.
 __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, uint8_t* lg, const Params& p,
-                                            const uint32_t env_id) {
+                                            const uint32_t env_id, const uint32_t turn) {
     while (hits) {
         const uint32_t cell = (uint32_t)__ffs(hits) - 1u;
         hits &= hits - 1u;
         const uint32_t off = unit * 16u + cell;   // byte offset == RNG index
-        const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const U4 kw = philox4x32_10(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
         lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
     }
@@ -770,7 +780,10 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // budget of 8 waves per SIMD); the host launches the plain variant for calls that cannot be staged (a range of agents,
 // SGW_STEP_OBS_NEXT, an observation pointer that is not 16-byte aligned).  The fixed-shape kernels of the BASELINE
 // configs keep their own, simpler whole-env burst and ignore the parameter.
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false>
+// MULTI: the variant sgw_rollout launches for nturns > 1 (a turn loop around sweep / agents / emit, the grid staying in
+// LDS).  It is a separate instantiation because the loop costs registers (config 3's kernel: 39 -> 64 VGPRs), which the
+// single-turn kernel must not pay.
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
@@ -908,10 +921,16 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                     }
             }
         }
-        if constexpr (RULES) {
+        // the env's grid goes to LDS once; sgw_rollout's turns (nturns > 1) all run on it
 #pragma unroll
-            for (int k = 0; k < NU; ++k)
-                if (lane + 64 * k < nunits) lg16[lane + 64 * k] = u[k];
+        for (int k = 0; k < NU; ++k)
+            if (lane + 64 * k < nunits) lg16[lane + 64 * k] = u[k];
+        int st_lane = 0;
+        uint32_t taddr_v = 0xFFFFFFFFu, oaddr_v = 0, npos = 0, rew_bits = 0, moved = 0;   // per turn; the write-back reads the last turn's
+        const uint32_t nturns = MULTI ? p.nturns : 1u;
+        for (uint32_t tix = 0; tix < nturns; ++tix) {
+        const uint32_t turn = p.turn + tix;
+        if constexpr (RULES) {
             gsync<1>();
             if (do_sweep) {
                 // Ordered sweep in LDS.  The reference visits cells in (y, x, z) order and a rule may read another
@@ -935,13 +954,13 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                             any_sp = any_sp || spj[j];
                         }
                         if (any_sp) {
-                            const U4 w = philox4x32_10(opaque((uint32_t)d), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                            const U4 w = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
                             uint32_t hit = 0;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (spj[j] && (((p.thr_full_mask >> tj[j]) & 1u) || word_of(w, j) < rt->thr_lo[tj[j]])) hit |= 1u << j;
                             if (hit) {   // rare: what spawns
-                                const U4 kw = philox4x32_10(opaque((uint32_t)d), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+                                const U4 kw = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
                                     if ((hit >> j) & 1u)
@@ -960,19 +979,22 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 }
             }
         } else {
+            if (tix > 0) {   // later turns of a rollout: the units come back from LDS (moves and spawns of the turns before)
+                gsync<1>();
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) u[k] = lg16[lane + 64 * k];
+            }
 #pragma unroll
             for (int k = 0; k < NU; ++k) {
                 hits[k] = 0;
-                if (lane + 64 * k < nunits) {
-                    lg16[lane + 64 * k] = u[k];
-                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id);
-                }
+                if (lane + 64 * k < nunits && do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
             }
             gsync<1>();
             if (do_sweep) {
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
-                    if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id);
+                    if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn);
                 gsync<1>();
             }
         }
@@ -980,15 +1002,16 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         STAMP(2);   // sweep done
         // ---- everything about agent `lane`'s move that does not depend on the other agents
         const uint32_t py = yx & 0xFFu, px = yx >> 8;
-        uint32_t taddr_v = 0xFFFFFFFFu;          // target cell (LDS byte offset) or "invalid"
-        uint32_t npos = yx;                      // position if the move succeeds
-        int st_lane = 0;
+        taddr_v = 0xFFFFFFFFu;                   // target cell (LDS byte offset) or "invalid"
+        npos = yx;                               // position if the move succeeds
         if (p.do_move && mine) {
             if (rnd) {
-                const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
                                            p.seed_lo, p.seed_hi);
                 act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
-                p.actions[env * p.A + lane] = (uint8_t)act;
+                p.actions[tix * p.ts_act + env * p.A + lane] = (uint8_t)act;
+            } else if (tix > 0) {
+                act = p.actions[tix * p.ts_act + env * p.A + lane];
             }
             const bool act_ok = act < (uint32_t)p.nact;
             int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
@@ -1007,10 +1030,16 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 taddr_v = (uint32_t)(zoff + ty * W + tx);
                 npos = (uint32_t)ty | ((uint32_t)tx << 8);
             }
-            st_lane = !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
+            st_lane |= !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
         }
-        const uint32_t oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;   // own cell
-        uint32_t rew_bits = 0, moved = 0;
+        oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;   // own cell
+        rew_bits = 0;
+        moved = 0;
+        const int64_t turn_obs = tix * p.ts_obs;   // this turn's observation slot (elements)
+        if constexpr (kStageAlways) {
+            ch_a0 = 0;
+            ch_shift = (uint32_t)(turn_obs + env * (int64_t)(p.A * C * VV)) & 3u;
+        }
 
         STAMP(3);   // move inputs (action draw) done
         // STAGE: the staged chunk [a_lo, a_hi) leaves for HBM.  Dword i of the (shifted) staging area is the 16-byte
@@ -1020,7 +1049,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
             gsync<1>();
             typedef float vfloat4 __attribute__((ext_vector_type(4)));
             const int N = (a_hi - a_lo) * C * VV;
-            const int64_t e0 = (env * p.A + a_lo) * (int64_t)(C * VV);
+            const int64_t e0 = turn_obs + (env * p.A + a_lo) * (int64_t)(C * VV);
             const int sh = (int)ch_shift;
             const int nd = (sh + N + 3) >> 2;
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
@@ -1066,7 +1095,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 if (a - ch_a0 == p.stage_agents) {   // the staging area is full: out with it, start the next chunk
                     if (write_obs) emit_chunk(ch_a0, a);
                     ch_a0 = a;
-                    ch_shift = (uint32_t)((env * p.A + a) * (int64_t)(C * VV)) & 3u;
+                    ch_shift = (uint32_t)(turn_obs + (env * p.A + a) * (int64_t)(C * VV)) & 3u;
                 }
             }
             const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
@@ -1074,7 +1103,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 const int y = __builtin_amdgcn_readlane((int)py, a);
                 const int x = __builtin_amdgcn_readlane((int)px, a);
                 const int cbase = s_o - zoff;
-                float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
+                float* obase = p.obs + turn_obs + ((env * p.A + a) * (int64_t)C) * VV;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (64 * k >= VV) break;
@@ -1271,7 +1300,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                 // re-read next turn) and takes config 3 from 167 to 125-132 us.  (The same hint on the per-agent dword
                 // stores of the unstaged path, which write partial lines, was measured SLOWER.)
                 typedef float vfloat4 __attribute__((ext_vector_type(4)));
-                vfloat4* o4 = reinterpret_cast<vfloat4*>(p.obs + env * (int64_t)(p.A * C * VV));
+                vfloat4* o4 = reinterpret_cast<vfloat4*>(p.obs + turn_obs + env * (int64_t)(p.A * C * VV));
                 for (int i = lane; i < nd; i += 64) {
                     const uint32_t b = ob4[i];
                     vfloat4 v;
@@ -1282,10 +1311,16 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
                     __builtin_nontemporal_store(v, &o4[i]);
                 }
             } else {
-                uint32_t* o1 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.obs) + env * (int64_t)(p.A * C * VV));
+                uint32_t* o1 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.obs) + turn_obs + env * (int64_t)(p.A * C * VV));
                 for (int i = lane; i < nd; i += 64) __builtin_nontemporal_store(ob4[i], &o1[i]);   // two whole lines per wave instruction
             }
         }
+        if (p.do_move && mine) {      // this turn's rewards (and what TagAgent.pov appends)
+            p.rewards[tix * p.ts_rew + env * p.A + lane] = __uint_as_float(rew_bits);
+            if (p.state_at_pov) p.state_at_pov[env * p.A + lane] = (uint8_t)pov_type;
+        }
+        if (tix + 1 < nturns) yx = moved ? npos : yx;   // the next turn starts where this one ended
+        }   // turns
         if (dirty) {
             if (!TAG && !RULES && !do_sweep) {
                 // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
@@ -1305,8 +1340,6 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         if (p.do_move) {
             if (mine) {
                 reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)(moved ? npos : yx);
-                p.rewards[env * p.A + lane] = __uint_as_float(rew_bits);
-                if (p.state_at_pov) p.state_at_pov[env * p.A + lane] = (uint8_t)pov_type;
                 if (st_lane) atomicOr(p.status, st_lane);
             }
             if (TAG && p.agent_state && lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)atype;   // a tag can flip any agent
@@ -1347,7 +1380,9 @@ constexpr int kBigThreads = SGW_BIG_THREADS;
 constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
 
-template <bool ONEHOT, int TL, int TC, int TR>
+// MULTI: sgw_rollout's variant -- a turn loop around sweep / moves / observations with the env's 32 KiB resident in LDS
+// (later turns sweep the units read back from LDS; only the last turn is followed by the write-back).
+template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false>
 __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -1426,7 +1461,23 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(smem);
     const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(smem);
 
-    // ---- grid -> LDS, sweep on the registers, 4 units per thread per round
+    // per-agent state of wave 0 (lane a = agent a), carried from turn to turn of a rollout
+    uint32_t yx = 0;
+    int st_lane = 0;
+    const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
+    uint32_t ta_v = 0xFFFFFFFFu, npos_v = 0, oaddr_v = 0, jr = 0;
+    if (wv == 0 && tid < p.A) {
+        yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
+        if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside the LDS grid, and say so
+            yx = 0;
+            atomicOr(p.status, SGW_STATUS_BAD_POS);
+        }
+    }
+    double tot = (tid == 0 && p.do_move) ? p.total[env] : 0.0;
+    const uint32_t nturns = MULTI ? p.nturns : 1u;
+    for (uint32_t tix = 0; tix < nturns; ++tix) {
+    const uint32_t turn = p.turn + tix;
+    // ---- grid -> LDS (first turn), sweep on the registers, 4 units per thread per round
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
         for (int base = 0; base < nunits; base += 4 * kBigThreads) {
@@ -1435,7 +1486,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = base + k * kBigThreads + tid;
-                if (idx < nunits) u[k] = src[idx];
+                if (idx < nunits) u[k] = (MULTI && tix > 0) ? lg16[lunit(idx)] : src[idx];
                 if ((cells & 15) && idx == nunits - 1) {   // ragged world: mask the bytes past the last cell
                     const int tail = cells & 15;
                     uint32_t d[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
@@ -1453,8 +1504,8 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
                 const int idx = base + k * kBigThreads + tid;
                 hits[k] = 0;
                 if (idx < nunits) {
-                    lg16[lunit(idx)] = u[k];
-                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)idx, p, env_id);
+                    if (!(MULTI && tix > 0)) lg16[lunit(idx)] = u[k];
+                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)idx, p, env_id, turn);
                 }
             }
             if (do_sweep) {
@@ -1473,7 +1524,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
                         h2 = k == 2 ? cleared : h2;
                         h3 = k == 3 ? cleared : h3;
                         const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
-                        const U4 kw = philox4x32_10(opaque(off >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                        const U4 kw = philox4x32_10(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
                                                    p.seed_lo, p.seed_hi);
                         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
                         lg[lbyte(off)] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
@@ -1484,29 +1535,22 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     }
 
     // ---- per-agent move inputs, all agents at once (wave 0: lane a = agent a)
-    uint32_t yx = 0;
-    int st_lane = 0;
-    const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
-    uint32_t ta_v = 0xFFFFFFFFu, npos_v = 0, oaddr_v = 0, jr = 0;
+    ta_v = 0xFFFFFFFFu;
+    jr = 0;
     if (wv == 0) {
         if (tid < p.A) {
-            yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
-            if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside the LDS grid, and say so
-                yx = 0;
-                atomicOr(p.status, SGW_STATUS_BAD_POS);
-            }
             const uint32_t py = yx & 0xFFu, px = yx >> 8;
             oaddr_v = (uint32_t)zoff + py * (uint32_t)P + px;
             npos_v = yx;
             if (p.do_move && mine) {
                 uint32_t act;
                 if (rnd) {
-                    const U4 w = philox4x32_10(opaque((uint32_t)tid >> 2), p.turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                    const U4 w = philox4x32_10(opaque((uint32_t)tid >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
                                                p.seed_lo, p.seed_hi);
                     act = __umulhi(word_of(w, tid & 3), (uint32_t)p.nact);
-                    p.actions[env * p.A + tid] = (uint8_t)act;
+                    p.actions[tix * p.ts_act + env * p.A + tid] = (uint8_t)act;
                 } else {
-                    act = p.actions[env * p.A + tid];
+                    act = p.actions[tix * p.ts_act + env * p.A + tid];
                 }
                 const bool act_ok = act < (uint32_t)p.nact;
                 const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
@@ -1517,7 +1561,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
                     ta_v = (uint32_t)(zoff + ty * P + tx);
                     npos_v = (uint32_t)ty | ((uint32_t)tx << 8);
                 }
-                st_lane = !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
+                st_lane |= !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
             }
         }
         s_oa[tid] = yx;          // packed (y, x) at the start of the turn
@@ -1592,6 +1636,10 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
         s_rm[lane] = __float_as_uint((float)val);
         s_ta[lane] = jr;                                                // journal for the render phase
         if (jr & 0x400u) st_lane |= SGW_STATUS_BAD_TYPE;
+        if (mine) p.rewards[tix * p.ts_rew + env * p.A + tid] = (float)val;   // this turn's rewards
+        gsync<1>();
+        if (tid == 0)
+            for (int a = p.a0; a < p.a1; ++a) tot += s_val[a];           // float64, agent order (agent.py:172)
     }
     __syncthreads();
     STAMPB(2);                   // phase M done
@@ -1670,7 +1718,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
                     }
                 }
             }
-            float* obase = p.obs + ((env * p.A + a) * (int64_t)C) * VV;
+            float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)C) * VV;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int w = lane + 64 * k;
@@ -1724,6 +1772,8 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     // windows wider than NP*64 cells (not a BASELINE shape): handled by the generic kernel (host dispatch)
     __syncthreads();
     STAMPB(3);                   // phase R done (all waves)
+    if (MULTI && tix + 1 < nturns && wv == 0 && tid < p.A) yx = (jr & 0x200u) ? npos_v : yx;   // the next turn starts where this one ended
+    }   // turns
 
     // ---- write-back
     if (dirty && !do_sweep) {
@@ -1746,14 +1796,9 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     if (p.do_move) {
         if (wv == 0 && mine) {
             reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)((jr & 0x200u) ? npos_v : yx);
-            p.rewards[env * p.A + tid] = __uint_as_float(s_rm[tid]);
             if (st_lane) atomicOr(p.status, st_lane);
         }
-        if (tid == 0) {
-            double tot = p.total[env];
-            for (int a = p.a0; a < p.a1; ++a) tot += s_val[a];   // float64, agent order (agent.py:172)
-            p.total[env] = tot;
-        }
+        if (tid == 0) p.total[env] = tot;
     }
 }
 
@@ -2126,9 +2171,12 @@ struct sgw_engine {
     bool big = false;     // step_big (workgroup per env, pipelined agents) applies
     void (*step_fn)(const Params) = nullptr;
     void (*step_fn_plain)(const Params) = nullptr;   // run-time-shape STAGE kernels: the direct-store variant for calls that cannot be staged
+    void (*step_fn_multi)(const Params) = nullptr;   // step_fast<..., MULTI>: sgw_rollout's turns in one launch
+    const char* kernel_name_multi = "-";
     const char* kernel_name_plain = "?";
     int stage_agents = 0;      // agents per staged chunk (STAGE kernels)
     bool phase_ok = false;     // the phase kernel applies (plain moves)
+    bool multi_turn = false;   // the step kernel in use runs sgw_rollout's turns in one launch
     void (*reset_fn)(const Params) = nullptr;
     size_t lds_bytes = 0;       // reset / generic step
     size_t step_lds_bytes = 0;  // step kernel actually launched
@@ -2281,6 +2329,16 @@ StepFn pick_step(int group, bool onehot, int L, int C, int rule, const char** na
     if (group == 64) return pick_step_g<64>(onehot, L, C, rule, name);
     return pick_step_g<256>(onehot, L, C, rule, name);
 }
+// the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
+// a loop of single-turn launches
+StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
+    if (!onehot || tag || rules || L != 2 || C != 6) return nullptr;
+    if (r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32, false, false, false, true>);
+    if (r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16, false, false, false, true>);
+    if (stage) PICK(step_fast<true, 2, 6, 0, 0, 0, false, false, true, true>);
+    return nullptr;
+}
+
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
 StepFn pick_big(bool onehot, int L, int C, int r, const char** name) {
@@ -2291,6 +2349,12 @@ StepFn pick_big(bool onehot, int L, int C, int r, const char** name) {
 
 bool fixed_fast_shape(int L, int C, int r, int H, int W) {
     return L == 2 && C == 6 && ((r == 3 && H == 32 && W == 32) || (r == 2 && H == 16 && W == 16));
+}
+
+StepFn pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
+    if (!onehot) PICK(step_big<false, 0, 0, 0, true>);
+    if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, true>);
+    PICK(step_big<true, 0, 0, 0, true>);
 }
 
 StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
@@ -2463,6 +2527,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         }
     }
     p.single_spawner = nspawn <= 1 ? 1 : 0;
+    p.nturns = 1;
     p.seed_lo = (uint32_t)c.seed;
     p.seed_hi = (uint32_t)(c.seed >> 32);
     p.first_env = (uint32_t)c.first_env_id;
@@ -2615,10 +2680,17 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
     e->step_fn = sk;
     e->reset_fn = rk;
+    if (e->fast)
+        e->step_fn_multi = pick_fast_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width,
+                                           c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name_multi);
+    if (e->big) e->step_fn_multi = pick_big_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_multi);
+    e->multi_turn = (e->fast || e->big) ? e->step_fn_multi != nullptr : true;   // kernels with sgw_rollout's turn loop
     if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess && e->step_fn_plain && e->step_fn_plain != sk)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+        if (err == hipSuccess && e->step_fn_multi)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err != hipSuccess) {
@@ -2702,7 +2774,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (cap > 0) lds = std::max(lds, (size_t)(kLdsPerCu / cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves): the phase
     // kernel, which does not stage the env (SGW_NO_PHASE_KERNEL=1: A/B and test hook).
-    if (e->phase_ok && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1)) {
+    if (e->phase_ok && p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1)) {
         Params q = p;
         q.env_lds = e->onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
         hipLaunchKernelGGL(e->onehot ? phase_kernel<true> : phase_kernel<false>, dim3((unsigned)ceil_div(p.E, 4)), dim3(kBlock),
@@ -2715,6 +2787,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast && e->stage_agents > 0 && e->step_fn_plain &&
         (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS)))
         fn = e->step_fn_plain;
+    if (p.nturns > 1 && (e->fast || e->big)) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
     hipLaunchKernelGGL(fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
@@ -2756,6 +2829,49 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
             HIP_TRY(hipMemcpyAsync(e->episode_return, total_reward, sizeof(double) * (size_t)e->cfg.num_envs,
                                    hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
         return launch_reset(e, grid, agent_pos, total_reward, epoch + 1, stream);
+    }
+    return SGW_OK;
+}
+
+int sgw_rollout(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs, float* rewards,
+                double* total_reward, uint32_t epoch, uint32_t first_turn, uint32_t num_turns, int64_t obs_turn_stride,
+                int64_t actions_turn_stride, int64_t rewards_turn_stride, uint32_t flags, void* stream) {
+    if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward)
+        return fail(SGW_EINVAL, "sgw_rollout: NULL argument");
+    if (!obs && !(flags & SGW_STEP_NO_OBS)) return fail(SGW_EINVAL, "sgw_rollout: obs is NULL without SGW_STEP_NO_OBS");
+    if (flags & SGW_STEP_OBS_NEXT) return fail(SGW_EINVAL, "sgw_rollout: SGW_STEP_OBS_NEXT is a per-agent flag of sgw_step");
+    if (obs_turn_stride < 0 || actions_turn_stride < 0 || rewards_turn_stride < 0)
+        return fail(SGW_EINVAL, "sgw_rollout: negative turn stride");
+    const int A = e->cfg.num_agents;
+    uint32_t done = 0;
+    while (done < num_turns) {
+        const uint32_t turn = first_turn + done;
+        // turns of one launch: up to the end of the epoch if auto-reset is armed; one per launch on kernels without a turn loop
+        uint32_t n = num_turns - done;
+        if (e->auto_max_turns && turn <= e->auto_max_turns) n = std::min(n, e->auto_max_turns - turn + 1);
+        if (!e->multi_turn) n = 1;
+        // the wave-per-env MULTI kernels stage their observations: every turn's slot must keep the 16-byte alignment
+        if (e->fast && (!obs || (flags & SGW_STEP_NO_OBS) || (reinterpret_cast<uintptr_t>(obs) & 15) || (obs_turn_stride & 3) || e->obs_stage == 0)) n = 1;
+        if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+        Params p = e->base;
+        p.grid = grid; p.pos = agent_pos; p.total = total_reward;
+        p.actions = actions + (int64_t)done * actions_turn_stride;
+        p.obs = obs ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(obs) + (int64_t)done * obs_turn_stride * (e->obs_format == SGW_OBS_U8 ? 1 : 4)) : nullptr;
+        p.rewards = rewards + (int64_t)done * rewards_turn_stride;
+        p.epoch = epoch; p.turn = turn; p.a0 = 0; p.a1 = A; p.flags = flags; p.do_move = 1;
+        p.nturns = n; p.ts_obs = obs_turn_stride; p.ts_act = actions_turn_stride; p.ts_rew = rewards_turn_stride;
+        if (int rc = launch_step(e, p, static_cast<hipStream_t>(stream))) return rc;
+        done += n;
+        if (e->auto_max_turns && first_turn + done - 1 == e->auto_max_turns) {
+            // end of the epoch: keep the returns, reset for the next one; the caller's turn counter restarts at 1
+            if (epoch + 1 >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+            if (e->episode_return)
+                HIP_TRY(hipMemcpyAsync(e->episode_return, total_reward, sizeof(double) * (size_t)e->cfg.num_envs,
+                                       hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+            if (int rc = launch_reset(e, grid, agent_pos, total_reward, epoch + 1, stream)) return rc;
+            epoch += 1;
+            first_turn = 1 - done;     // turn = first_turn + done continues at 1 (unsigned wrap-around is intended)
+        }
     }
     return SGW_OK;
 }

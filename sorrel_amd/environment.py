@@ -343,15 +343,33 @@ class Environment:
                              f"observations straight into a slot); got {buffer.obs.dtype} {tuple(buffer.obs.shape)} on "
                              f"{buffer.obs.device}.  Set Environment.obs_dtype to match a uint8 buffer.")
         self._fresh_obs = None
-        for t in range(turns):
-            self.turn += 1
-            eng.epoch, eng.turn = self.epoch, self.turn
-            out = buffer.obs[buffer.slot()]
-            if actions is None:
-                eng.step(random_actions=True, turn=self.turn, obs_out=out)
-            else:
-                eng.step(actions[t], turn=self.turn, obs_out=out)
-            buffer.commit(eng.actions, eng.rewards, eng.agent_pos)
+        if buffer.positions is None and eng.max_turns == 0:
+            # whole runs of consecutive ring slots in ONE call (sgw_rollout: where the kernel supports it the turns run
+            # inside one launch with every env's grid resident in LDS): observations, actions and rewards of turn t go
+            # straight to slot idx + t
+            done = 0
+            while done < turns:
+                i = buffer.slot()
+                n = min(turns - done, buffer.capacity - i)
+                eng.epoch, eng.turn = self.epoch, self.turn
+                eng.rollout(n, actions=None if actions is None else actions[done:done + n].to(device=eng.device, dtype=torch.uint8).contiguous(),
+                            obs_out=buffer.obs[i:i + n], actions_out=None if actions is not None else buffer.actions[i:i + n],
+                            rewards_out=buffer.rewards[i:i + n])
+                if actions is not None:
+                    buffer.actions[i:i + n].copy_(actions[done:done + n])
+                buffer.advance(n)
+                self.turn += n
+                done += n
+        else:
+            for t in range(turns):
+                self.turn += 1
+                eng.epoch, eng.turn = self.epoch, self.turn
+                out = buffer.obs[buffer.slot()]
+                if actions is None:
+                    eng.step(random_actions=True, turn=self.turn, obs_out=out)
+                else:
+                    eng.step(actions[t], turn=self.turn, obs_out=out)
+                buffer.commit(eng.actions, eng.rewards, eng.agent_pos)
         eng.raise_on_status()
 
     # ------------------------------------------------------------------ kernels behind the agent hooks

@@ -364,3 +364,98 @@ def test_bench_two_ranks_run_the_product_and_agree_with_one_process(built):
     assert two["rollout"]["envs"] == one["rollout"]["envs"] == 8192.0
     assert two["rollout"]["sum_total_reward"] == one["rollout"]["sum_total_reward"]
     assert two["rollout"]["status"] == 0 and two["value"] > 0 and two["scaling"] == "weak"
+
+
+ROLLOUT_CASES = [
+    ("fast_static_c3", (32, 32, 8, 3, 70), {}),
+    ("fast_static_c2", (16, 16, 4, 2, 33), {}),
+    ("fast_runtime_stage", (24, 24, 4, 3, 50), {}),
+    ("fast_runtime_plain", (24, 24, 4, 3, 50), {"SGW_NO_STAGE": "1"}),
+    ("packed_16", (21, 21, 2, 2, 133), {"SGW_GROUP": "16"}),
+    ("packed_32", (13, 9, 5, 4, 90), {"SGW_GROUP": "32"}),
+    ("generic_64", (18, 14, 4, 3, 21), {"SGW_FORCE_GENERIC": "1"}),
+    ("big", (64, 64, 10, 4, 7), {}),
+    ("generic_256", (64, 64, 10, 4, 5), {"SGW_FORCE_GENERIC": "1"}),
+]
+
+
+@pytest.mark.parametrize("case", ROLLOUT_CASES, ids=[c[0] for c in ROLLOUT_CASES])
+def test_rollout_equals_turn_by_turn_steps(torch_cuda, case, monkeypatch):
+    """sgw_rollout: T turns in one call (one launch where the kernel keeps the env in LDS across turns) == T calls of
+    sgw_step == the oracle, for every per-turn observation / action / reward slot and the final state; random actions
+    into ring slots, overwriting the engine's own tensors, scripted actions, and across an armed epoch boundary."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    _, (h, w, a, r, E), env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=41, dense_prob=0.1)
+    one, many = make_engine(ws, E, first=17), make_engine(ws, E, first=17)
+    co = H.COracle(ws, E, first_env_id=17)
+    for e in (one, many):
+        e.reset(0)
+    co.reset(0)
+    T = 5
+    ring_obs = torch.full((T, E) + tuple(ws.obs_shape), -1.0, device="cuda:0")
+    ring_act = torch.zeros((T, E, a), dtype=torch.uint8, device="cuda:0")
+    ring_rew = torch.zeros((T, E, a), dtype=torch.float32, device="cuda:0")
+    many.rollout(T, obs_out=ring_obs, actions_out=ring_act, rewards_out=ring_rew)
+    for t in range(T):
+        one.step(random_actions=True)
+        assert co.step(0, t + 1, random_actions=True) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(ring_obs[t], one.obs), f"turn {t}: obs slot"
+        assert torch.equal(ring_act[t], one.actions) and torch.equal(ring_rew[t], one.rewards)
+        assert np.array_equal(one.obs.cpu().numpy(), co.obs)
+    for name in ("grid", "agent_pos", "total_reward", "actions", "rewards"):
+        assert torch.equal(getattr(one, name), getattr(many, name)), name
+    assert np.array_equal(many.grid.cpu().numpy(), co.grid) and (many.turn, one.turn) == (T, T)
+    # overwriting mode: the engine's own tensors hold the last turn
+    many.rollout(3)
+    for _ in range(3):
+        one.step(random_actions=True)
+    torch.cuda.synchronize()
+    for name in ("grid", "agent_pos", "total_reward", "actions", "rewards", "obs"):
+        assert torch.equal(getattr(one, name), getattr(many, name)), name
+    # scripted actions [T, E, A]
+    acts = torch.randint(0, 4, (4, E, a), dtype=torch.uint8, device="cuda:0")
+    slots = torch.zeros((4, E) + tuple(ws.obs_shape), device="cuda:0")
+    many.rollout(4, actions=acts, obs_out=slots)
+    for t in range(4):
+        one.step(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(slots[t], one.obs), f"scripted turn {t}"
+    for name in ("grid", "agent_pos", "total_reward", "rewards", "actions"):
+        assert torch.equal(getattr(one, name), getattr(many, name)), name
+    # across epoch boundaries with the auto-reset armed (max_turns = 3, the engines sit at turn 12 = 0 mod 3)
+    for e in (one, many):
+        e.turn = 0
+        e.set_auto_reset(3)
+    many.rollout(8)
+    for _ in range(8):
+        one.step(random_actions=True)
+    torch.cuda.synchronize()
+    assert (one.epoch, one.turn) == (many.epoch, many.turn) == (2, 2)
+    for name in ("grid", "agent_pos", "total_reward", "actions", "rewards", "obs", "episode_return"):
+        assert torch.equal(getattr(one, name), getattr(many, name)), name
+    assert one.status() == 0 and many.status() == 0
+
+
+def test_rollout_compact_uint8_ring(torch_cuda, monkeypatch):
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    for env in ({}, {"SGW_GROUP": "16"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ws = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=5)
+        e8, e32 = make_engine(ws, 100, obs_dtype=torch.uint8), make_engine(ws, 100)
+        for e in (e8, e32):
+            e.reset(0)
+        r8 = torch.zeros((4, 100) + tuple(ws.obs_shape), dtype=torch.uint8, device="cuda:0")
+        r32 = torch.zeros((4, 100) + tuple(ws.obs_shape), dtype=torch.float32, device="cuda:0")
+        e8.rollout(4, obs_out=r8)
+        e32.rollout(4, obs_out=r32)
+        torch.cuda.synchronize()
+        assert torch.equal(r8.float(), r32) and torch.equal(e8.grid, e32.grid)

@@ -1,23 +1,34 @@
 // sgw.hip -- MI355X (gfx950 / CDNA4) batched gridworld step + observation engine.
 //
-// Hand-written HIP behind the C ABI of include/sgw.h.  One thread GROUP owns
-// one environment for a whole take_turn:
-//   * <= 4 KiB worlds (e.g. 32x32x2): one 64-lane wavefront per env, four envs
-//     per 256-thread workgroup, wave-level ordering only (no s_barrier);
-//   * larger worlds (e.g. 128x128x2): one 256-thread workgroup per env.
-// The env's grid (uint8 type ids, [L][H][W]) is staged once into LDS with
-// 16-byte loads, the entity sweep and all sequential agent phases run against
-// LDS, observation windows are gathered from LDS (lane = window cell) and leave
-// for HBM either per agent as contiguous dword stores (loop over channels) or --
-// the fixed-shape kernels of the BASELINE configs -- staged as byte counts in
-// LDS and emitted once per env in a burst of 16-byte stores; the grid is written
-// back once with 16-byte stores.  Integer / indexing work only: no MFMA, bound =
-// HBM bandwidth (observation stores dominate).
+// Hand-written HIP behind the C ABI of include/sgw.h.  One thread GROUP owns one environment for a whole take_turn
+// (or, through sgw_rollout, for T turns): the env's grid (uint8 type ids, [L][H][W]) is staged once into LDS with 16-byte
+// loads, the entity sweep and all sequential agent phases run against LDS, observation windows are gathered from LDS
+// (lane = window cell) and the grid is written back once.  Integer / indexing work only: no MFMA; the bound is HBM
+// bandwidth for the big shapes (observation stores dominate) and instruction issue for the small ones.
 //
-// Semantics follow the reference Python step loop bit for bit; see
-// include/sgw.h for the reference file:line each entry point replaces and
-// oracle/gridstep_oracle.py for the line-by-line CPU restatement the kernels
-// are tested against.
+// Kernels, in file order:
+//   step_kernel<G, ONEHOT, L, C, RULE>   every shape and rule; G = lanes per env: 256 (a workgroup per env, worlds above
+//                                        4 KiB), 64 (a wave per env), or 32 / 16 -- two / four SMALL envs share a wave and
+//                                        its instruction stream (what 10x10 ... 24x24 worlds of large batches run on);
+//                                        all per-env state in the group's LDS slice, no cross-lane instruction; turn loop
+//                                        for sgw_rollout built in
+//   step_fast<ONEHOT, L, C, r, H, W, TAG, RULES, STAGE, MULTI>
+//                                        a wave per env, worlds <= 4 KiB: register sweep, per-lane move inputs + scalar
+//                                        move resolution, compile-time window geometry for the BASELINE shapes; one-hot
+//                                        observations staged as bytes in LDS and emitted as one burst of streaming
+//                                        16-byte stores (fixed shapes: whole env; STAGE: chunks of agents, any alignment);
+//                                        MULTI = the turn loop of sgw_rollout
+//   step_big<ONEHOT, L, C, r, MULTI>     a 512-thread workgroup per env, worlds above 4 KiB (config 5): padded LDS row
+//                                        pitch, moves resolved in registers by wave 0 (only interfering agents are walked),
+//                                        observations rendered by all waves from the post-move grid with later moves
+//                                        undone in registers
+//   phase_kernel<ONEHOT>                 one policy-driven phase of a world above 4 KiB without staging the env
+//   reset_kernel, random_actions_kernel, init_agent_state_kernel, reduce_stage1/2
+// then the host side: validation, table building, kernel selection (sgw_create), the launchers.
+//
+// Semantics follow the reference Python step loop bit for bit; see include/sgw.h for the reference file:line each entry
+// point replaces and oracle/gridstep_oracle.py for the line-by-line CPU restatement the kernels are tested against
+// (the product never calls it).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -2343,6 +2343,7 @@ StepFn pick_step(int group, bool onehot, int L, int C, int rule, const char** na
 // the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
 // a loop of single-turn launches
 StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
+    if (onehot && rules && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true>);    // layered rule sets (Cleanup)
     if (!onehot || tag || rules || L != 2 || C != 6) return nullptr;
     if (r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32, false, false, false, true>);
     if (r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16, false, false, false, true>);

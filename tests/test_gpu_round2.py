@@ -459,3 +459,45 @@ def test_rollout_compact_uint8_ring(torch_cuda, monkeypatch):
         e32.rollout(4, obs_out=r32)
         torch.cuda.synchronize()
         assert torch.equal(r8.float(), r32) and torch.equal(e8.grid, e32.grid)
+
+
+@pytest.mark.parametrize("which", ["cleanup_rules_kernel", "cleanup_generic", "tag_fast", "tag_packed"])
+def test_rollout_on_the_widened_rule_sets(torch_cuda, which, monkeypatch):
+    """sgw_rollout == turn-by-turn stepping for Cleanup (facing, beams, layered sweep: the MULTI instance of the RULES
+    kernel, and the generic kernel's built-in loop) and Tag (a loop of single-turn launches on the wave-per-env kernel, the
+    built-in loop on the packed one)."""
+    torch = torch_cuda
+    if which.startswith("cleanup"):
+        ws, d = _cleanup_spec()
+        if which == "cleanup_generic":
+            monkeypatch.setenv("SGW_NO_FAST_RULES", "1")
+        E = 40
+        one, many = make_engine(ws, E), make_engine(ws, E)
+        g0 = torch.from_numpy(np.broadcast_to(d["grid0"][0], (E,) + d["grid0"][0].shape).copy())
+        p0 = torch.from_numpy(np.broadcast_to(d["pos0"][0], (E,) + d["pos0"][0].shape).copy())
+        for e in (one, many):
+            e.grid.copy_(g0)
+            e.agent_pos.copy_(p0)
+            e.total_reward.zero_()
+    else:
+        ws = _tag_spec(11, 11, 5, 4)
+        if which == "tag_packed":
+            monkeypatch.setenv("SGW_GROUP", "32")
+        E = 90
+        one, many = make_engine(ws, E, first=3), make_engine(ws, E, first=3)
+        for e in (one, many):
+            e.reset(0)
+    T = 7
+    ring = torch.zeros((T, E) + tuple(ws.obs_shape), device="cuda:0")
+    rew = torch.zeros((T, E, ws.num_agents), device="cuda:0")
+    many.rollout(T, obs_out=ring, rewards_out=rew)
+    for t in range(T):
+        one.step(random_actions=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ring[t], one.obs), (which, t)
+        assert torch.equal(rew[t], one.rewards), (which, t)
+    for name in ("grid", "agent_pos", "total_reward", "actions", "agent_state", "agent_dir", "state_at_pov"):
+        a, b = getattr(one, name, None), getattr(many, name, None)
+        if a is not None:
+            assert torch.equal(a, b), (which, name)
+    assert one.status() == 0 and many.status() == 0

@@ -14,7 +14,7 @@ for grp in "$@"; do
   i=$((i+1))
   # A group that does not finish is reported and fails the script (its counters are simply missing from the averages
   # otherwise).  Known on this pool: the TA_* groups never finish under rocprofv3 on gfx950 -- do not pass them.
-  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- python3 $REPO/bench.py --steps 30 --warmup 3 --prewarm-steps 0 --no-series --no-cpu-baseline $BARGS > /dev/null 2> $OUT/g$i.err
+  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- python3 $REPO/bench.py --steps 30 --warmup 3 --prewarm-steps 0 --no-series --turns-per-launch 0 --no-cpu-baseline $BARGS > /dev/null 2> $OUT/g$i.err
   rc=$?
   if [ $rc -ne 0 ]; then
     echo "pmc_pass: group $i ($grp) FAILED rc=$rc (124/137 = timed out); no further pass is started" >&2

@@ -10,7 +10,7 @@ mkdir -p $OUT
 # and bench.py refuses to start a compiler from such a process (it exits non-zero on a stale library instead)
 python3 -c 'import sys; sys.path.insert(0, "'$REPO'"); import __graft_entry__ as g; g.build()' || exit 1
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --prewarm-steps 0 --no-series --no-cpu-baseline $@"
+ARGS="--steps 50 --warmup 5 --prewarm-steps 0 --no-series --turns-per-launch 0 --no-cpu-baseline $@"
 # the timing pass runs long enough for the clocks to settle (the counter passes below stay short)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 500 --warmup 20 --no-series --no-cpu-baseline "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err

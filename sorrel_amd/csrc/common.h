@@ -1,0 +1,330 @@
+// common.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
+// Constants, the device tables and launch parameters, the counter RNG, group sync, grid <-> LDS copies, the entity sweeps.
+#pragma once
+
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+constexpr int kMaxPass = 2;  // window cells per thread held in registers
+
+// ---------------------------------------------------------------- tables
+// Constant per-engine tables: built on the host in sgw_create, kept in device
+// memory, copied into LDS at the start of every workgroup.
+struct DevTables {
+    uint32_t thr_lo[SGW_MAX_TYPES];    // spawn threshold, low 32 bits of floor(p * 2^32)
+    uint32_t delta[4][SGW_MAX_TYPES];  // one-hot: word c/4 holds 1 << 8*(c%4) for the type's channel c, else 0
+    double value[SGW_MAX_TYPES];
+    uint8_t spawn_choice[SGW_MAX_TYPES][SGW_MAX_CHOICES];
+    uint8_t spawn_count[SGW_MAX_TYPES];
+    uint8_t agent_type[SGW_MAX_AGENTS];
+    uint8_t dense_choice[SGW_MAX_CHOICES];
+    uint8_t layer_fill[8];
+    uint8_t layer_border[8];
+    uint8_t pad_[8];
+    uint8_t rule[SGW_MAX_TYPES];          // SGW_RULE_* per type
+    int8_t rule_layer[SGW_MAX_TYPES];     // SGW_RULE_BECOME_IF: layer to test (< 0: always)
+    uint8_t rule_become[SGW_MAX_TYPES];
+    uint8_t pad2_[SGW_MAX_TYPES];
+    uint32_t rule_mask[SGW_MAX_TYPES];
+    double appearance[SGW_MAX_TYPES][SGW_MAX_CHANNELS];  // general (non one-hot) path only
+};
+constexpr int kTabFastBytes = offsetof(DevTables, appearance);
+static_assert(kTabFastBytes % 16 == 0, "LDS table block must keep 16-byte alignment");
+static_assert(sizeof(DevTables) % 16 == 0, "LDS table block must keep 16-byte alignment");
+
+struct Params {
+    int H, W, L, A, r, V, VV, C, T, nact, zA;
+    int cells;      // L*H*W bytes of one env's grid
+    int64_t env_stride;  // bytes between envs in HBM (>= cells; multiple of 16 on the vector paths)
+    int cells_pad;  // rounded up to 16
+    int env_lds;    // LDS bytes per env slice
+    int tab_bytes;  // LDS bytes of the table block
+    uint32_t default_type, fill_type;
+    uint32_t spawn_mask, thr_full_mask, pass_mask;
+    uint32_t become_mask;      // types that carry SGW_RULE_BECOME_IF
+    uint32_t agent_mask;       // types the agents have
+    uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
+    uint32_t fill_delta[4];
+    // single-spawner fast path (exactly one type carries SGW_RULE_SPAWN)
+    uint32_t spawn_pat;      // type id replicated in 4 bytes
+    uint32_t spawn_thr;      // low 32 bits of floor(p * 2^32)
+    uint32_t spawn_full;     // p >= 1
+    uint32_t spawn_n;        // number of choices
+    uint32_t choice_lo, choice_hi;  // the <= 8 choice type ids, one per byte
+    uint32_t seed_lo, seed_hi;
+    uint32_t first_env;
+    int64_t E;
+    uint32_t epoch, turn, flags;
+    int a0, a1;
+    int do_move;  // 0: observe only
+    int obs_post; // SGW_OBS_POST_*
+    int obs_u8;   // SGW_OBS_U8: observations are uint8 counts (one-hot specs only)
+    int agent_rule;            // SGW_AGENT_RULE_*
+    uint32_t tag_it, tag_notit;
+    double tag_reward;
+    uint8_t* agent_state;      // optional [E][A]: current type of every agent
+    uint8_t* agent_dir;        // optional [E][A]: facing (SGW_AGENT_RULE_CLEANUP)
+    int has_become;            // some type carries SGW_RULE_BECOME_IF: ordered, layer-by-layer sweep
+    uint32_t kind_pack;        // 2 bits per action: SGW_ACTION_*
+    int beam_radius;
+    uint32_t clean_beam, zap_beam, beam_block_mask;
+    int total_factor;
+    uint8_t* state_at_pov;     // optional [E][A]: type at observation time
+    uint64_t dense_thr;
+    int dense_count;
+    uint8_t* grid;
+    uint8_t* pos;
+    uint8_t* actions;
+    float* obs;
+    float* rewards;
+    double* total;
+    const DevTables* tab;
+    int* status;
+    int obs_stage;    // step_fast: bytes of the per-wave LDS observation staging area (0: observations go straight to HBM)
+    int stage_agents; // step_fast<..., STAGE>: agents whose observations are staged together and leave in one burst
+    int obs_next;     // SGW_STEP_OBS_NEXT: write only the observation of agent a1, after the moves of [a0, a1)
+    int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
+    int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
+    // sgw_rollout: `nturns` whole turns in ONE launch (the env's grid stays in LDS from turn to turn); turn t of the call
+    // writes its observations / actions / rewards `t * ts_*` elements further on (0 = every turn overwrites the same tensors)
+    uint32_t nturns;
+    int64_t ts_obs, ts_act, ts_rew;
+};
+
+// ---------------------------------------------------------------- RNG
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+// a ^ b ^ k in one VALU op (gfx950: v_bitop3_b32 with truth table 0x96; there is no v_xor3_b32 on gfx9).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t k) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+
+// Philox-4x32-10 (Salmon et al., SC'11); key = (k0, k1) wave-uniform.
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// Keeps the compiler from hoisting the env-invariant first Philox round of every
+// (lane, block) pair out of the persistent env loop (that costs ~2 VGPRs per block).
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t word_of(const U4& v, int i) {
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// RGBObservationSpec: np.clip(obs, 0, 255) / 255 on the float64 layer sum (observation_spec.py:483)
+__device__ __forceinline__ float obs_finish(double acc, int post) {
+    if (post == SGW_OBS_POST_CLIP255_DIV255) acc = fmin(fmax(acc, 0.0), 255.0) / 255.0;
+    return (float)acc;
+}
+
+// ---------------------------------------------------------------- group sync
+// WPE == 1: the group is one wavefront.  DS instructions of a wave execute in
+// issue order, so a compiler-level fence is all that is needed.
+template <int WPE>
+__device__ __forceinline__ void gsync() {
+    if constexpr (WPE == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- grid <-> LDS
+template <int G>
+__device__ __forceinline__ void load_grid(const Params& p, const uint8_t* __restrict__ src,
+                                          uint8_t* lds, int gtid) {
+    if ((p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad) {
+        // whole 16-byte units, the env's pad bytes included (a ragged world in a padded stride: the bytes past the last
+        // cell are not cells -- no type, no RNG index -- and are masked to 0xFF in LDS)
+        const uint4* s = reinterpret_cast<const uint4*>(src);
+        uint4* d = reinterpret_cast<uint4*>(lds);
+        const int nu = p.cells_pad >> 4;
+        for (int i = gtid; i < nu; i += G) {
+            uint4 v = s[i];
+            if (i == nu - 1 && (p.cells & 15)) {
+                const int tail = p.cells & 15;
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int keep = tail - 4 * q;   // valid bytes in this dword
+                    if (keep <= 0) w[q] = 0xFFFFFFFFu;
+                    else if (keep < 4) w[q] |= 0xFFFFFFFFu << (8 * keep);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            d[i] = v;
+        }
+    } else if ((p.cells & 3) == 0 && (p.env_stride & 3) == 0) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d = reinterpret_cast<uint32_t*>(lds);
+        for (int i = gtid; i < (p.cells >> 2); i += G) d[i] = s[i];
+    } else {
+        for (int i = gtid; i < p.cells_pad; i += G) lds[i] = i < p.cells ? src[i] : (uint8_t)0xFF;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void store_grid(const Params& p, uint8_t* __restrict__ dst,
+                                           const uint8_t* lds, int gtid) {
+    if ((p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad) {
+        uint4* d = reinterpret_cast<uint4*>(dst);
+        const uint4* s = reinterpret_cast<const uint4*>(lds);
+        for (int i = gtid; i < (p.cells_pad >> 4); i += G) d[i] = s[i];   // the pad bytes of the stride are nobody's cells
+    } else if ((p.cells & 3) == 0 && (p.env_stride & 3) == 0) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(lds);
+        for (int i = gtid; i < (p.cells >> 2); i += G) d[i] = s[i];
+    } else {
+        for (int i = gtid; i < p.cells; i += G) dst[i] = lds[i];
+    }
+}
+
+__device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
+    // 0x80 in every byte of v that equals the corresponding byte of pat (exact, no carries between bytes)
+    const uint32_t x = v ^ pat;
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// ---------------------------------------------------------------- sweep
+// At most one spawning type (every Treasurehunt-shaped world): byte-parallel match of the spawner id, one Philox block
+// per dword that holds a spawner, thresholds and choices from scalar registers instead of per-byte table reads.
+template <int G>
+__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn) {
+    uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
+    const int ndw = (p.cells + 3) >> 2;
+    for (int d = gtid; d < ndw; d += G) {
+        const uint32_t m = match_bytes(g32[d], p.spawn_pat);
+        if (m == 0) continue;
+        const U4 w = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+        const bool f = p.spawn_full != 0;
+        uint32_t hits = 0;
+        hits |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
+        hits |= ((m & 0x8000u) && (f || w.y < p.spawn_thr)) ? 2u : 0u;
+        hits |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
+        hits |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
+        if (hits == 0) continue;
+        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if ((hits >> b) & 1u) {
+                const uint32_t pick = __umulhi(word_of(k, b), p.spawn_n);
+                lds_grid[4 * d + b] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+            }
+    }
+}
+
+// Entity transitions (reference: environment.py:88-91).  RNG index of a cell ==
+// its byte offset in the [L][H][W] slice, so one LDS dword == one Philox block.
+template <int G>
+__device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uint8_t* lds_grid,
+                                      uint32_t env_id, int gtid, uint32_t turn) {
+    uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
+    const int ndw = (p.cells + 3) >> 2;
+    const uint32_t c3 = (p.epoch << 4) | SGW_STREAM_SPAWN;
+    for (int d = gtid; d < ndw; d += G) {
+        uint32_t v = g32[d];
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t t = (v >> (8 * b)) & 0xFFu;
+            const uint32_t is = (t < SGW_MAX_TYPES) ? ((p.spawn_mask >> t) & 1u) : 0u;
+            m |= is << b;
+        }
+        if (m == 0) continue;
+        const U4 w = philox4x32_10((uint32_t)d, turn, env_id, c3, p.seed_lo, p.seed_hi);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if ((m >> b) & 1u) {
+                const uint32_t t = (v >> (8 * b)) & 31u;
+                const bool hit = ((p.thr_full_mask >> t) & 1u) || (word_of(w, b) < tab->thr_lo[t]);
+                hits |= (hit ? 1u : 0u) << b;
+            }
+        }
+        if (hits == 0) continue;
+        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                                   p.seed_lo, p.seed_hi);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if ((hits >> b) & 1u) {
+                const uint32_t t = (v >> (8 * b)) & 31u;
+                const uint32_t n = tab->spawn_count[t];
+                const uint32_t pick = (uint32_t)(((uint64_t)word_of(k, b) * n) >> 32);
+                const uint32_t nt = tab->spawn_choice[t][pick];
+                v = (v & ~(0xFFu << (8 * b))) | (nt << (8 * b));
+            }
+        }
+        g32[d] = v;
+    }
+}
+
+// Ordered sweep for rule sets with cross-layer conditions (SGW_RULE_BECOME_IF, e.g. Cleanup): the
+// reference visits cells in (y, x, z) order over a LIVE view, so within a column a lower layer has
+// already transitioned when a higher one is visited and a higher one has not when a lower one is.
+// Columns never read each other, so: one pass per layer, all cells of the layer in parallel.
+template <int WPE, int G>
+__device__ __forceinline__ void sweep_ordered(const Params& p, const DevTables* tab, uint8_t* lg, uint32_t env_id, int gtid, uint32_t turn) {
+    const int HW = p.H * p.W;
+    for (int z = 0; z < p.L; ++z) {
+        for (int cidx = gtid; cidx < HW; cidx += G) {
+            const int off = z * HW + cidx;
+            const uint32_t t = lg[off];
+            if (t >= SGW_MAX_TYPES) continue;
+            const uint32_t rule = tab->rule[t];
+            if (rule == SGW_RULE_BECOME_IF) {
+                const int zl = tab->rule_layer[t];
+                const bool fire = zl < 0 || ((tab->rule_mask[t] >> (lg[zl * HW + cidx] & 31u)) & 1u);
+                if (fire) lg[off] = tab->rule_become[t];
+            } else if (rule == SGW_RULE_SPAWN) {
+                const U4 w = philox4x32_10((uint32_t)off >> 2, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                if (((p.thr_full_mask >> t) & 1u) || word_of(w, off & 3) < tab->thr_lo[t]) {
+                    const U4 k = philox4x32_10((uint32_t)off >> 2, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+                    lg[off] = tab->spawn_choice[t][__umulhi(word_of(k, off & 3), (uint32_t)tab->spawn_count[t])];
+                }
+            }
+        }
+        gsync<WPE>();
+    }
+}
+
+// Rule tables of the RULES variant of step_fast, copied per wave into LDS: three contiguous pieces of DevTables.
+struct RuleLds {
+    uint32_t thr_lo[SGW_MAX_TYPES];
+    uint8_t spawn_choice[SGW_MAX_TYPES][SGW_MAX_CHOICES];
+    uint8_t spawn_count[SGW_MAX_TYPES];
+    uint8_t rule[SGW_MAX_TYPES];
+    int8_t rule_layer[SGW_MAX_TYPES];
+    uint8_t rule_become[SGW_MAX_TYPES];
+    uint8_t pad2_[SGW_MAX_TYPES];
+    uint32_t rule_mask[SGW_MAX_TYPES];
+};
+constexpr int kRuleLds = (int)sizeof(RuleLds);
+static_assert(kRuleLds == 672 && kRuleLds % 16 == 0, "RuleLds mirrors three pieces of DevTables");
+static_assert(offsetof(DevTables, spawn_count) == offsetof(DevTables, spawn_choice) + SGW_MAX_TYPES * SGW_MAX_CHOICES, "piece B is contiguous");
+static_assert(offsetof(DevTables, rule_mask) == offsetof(DevTables, rule) + 4 * SGW_MAX_TYPES, "piece C is contiguous");
+static_assert(SGW_MAX_CHOICES == 8, "RuleLds copy assumes 8 choices");
+

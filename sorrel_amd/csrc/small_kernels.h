@@ -1,0 +1,179 @@
+// small_kernels.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
+// reset_kernel (create_world + populate_environment), random actions, agent-state initialisation, the metric reduction.
+#pragma once
+
+// ---------------------------------------------------------------- reset kernel
+// create_world + populate_environment (gridworld.py:47-65, treasurehunt/env.py:114-147).
+template <int WPE>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int G = WPE * kWave;
+    constexpr int EPB = kBlock / G;
+    const int tid = threadIdx.x;
+    const int sub = tid / G;
+    const int gtid = tid - sub * G;
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(p.tab);
+        uint4* d = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < (p.tab_bytes >> 4); i += kBlock) d[i] = s[i];
+    }
+    __syncthreads();
+    const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
+    uint8_t* slice = smem + p.tab_bytes + sub * p.env_lds;
+    uint8_t* lg = slice;
+    uint8_t* s_pos = slice + p.cells_pad + kPosOff;
+    const int HW = p.H * p.W;
+    const int zoff = p.zA * HW;
+
+    for (int64_t env = (int64_t)blockIdx.x * EPB + sub; env < p.E; env += (int64_t)gridDim.x * EPB) {
+        const uint32_t env_id = p.first_env + (uint32_t)env;
+        // layers: fill + border
+        for (int i = gtid; i < p.cells_pad; i += G) {
+            uint8_t v = 0xFF;
+            if (i < p.cells) {
+                const int z = i / HW;
+                const int rem = i - z * HW;
+                const int y = rem / p.W, x = rem - y * p.W;
+                v = tab->layer_fill[z];
+                const uint8_t b = tab->layer_border[z];
+                if (b != SGW_NO_BORDER && (y == 0 || y == p.H - 1 || x == 0 || x == p.W - 1)) v = b;
+            }
+            lg[i] = v;
+        }
+        gsync<WPE>();
+        // optional dense pre-seeding of the agent layer's interior
+        if (p.dense_count > 0 && p.dense_thr > 0) {
+            const int d0 = zoff >> 2, d1 = (zoff + HW + 3) >> 2;
+            for (int d = d0 + gtid; d < d1; d += G) {
+                const U4 w = philox4x32_10((uint32_t)d, 0u, env_id, (p.epoch << 4) | SGW_STREAM_DENSE, p.seed_lo, p.seed_hi);
+                uint32_t hits = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * d + b - zoff;
+                    if (i < 0 || i >= HW) continue;
+                    const int y = i / p.W, x = i - y * p.W;
+                    if (y == 0 || y == p.H - 1 || x == 0 || x == p.W - 1) continue;
+                    if ((uint64_t)word_of(w, b) < p.dense_thr) hits |= 1u << b;
+                }
+                if (hits == 0) continue;
+                const U4 k = philox4x32_10((uint32_t)d, 0u, env_id, (p.epoch << 4) | SGW_STREAM_DENSE_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((hits >> b) & 1u)
+                        lg[4 * d + b] = tab->dense_choice[(uint32_t)(((uint64_t)word_of(k, b) * (uint32_t)p.dense_count) >> 32)];
+            }
+            gsync<WPE>();
+        }
+        // agent placement: sequential sampling without replacement, done by the
+        // lanes of the first wave (lane a draws its own u32; lane 0 resolves)
+        uint32_t u = 0;
+        if (gtid < p.A) {
+            const U4 w = philox4x32_10((uint32_t)gtid >> 2, 0u, env_id, (p.epoch << 4) | SGW_STREAM_PLACE, p.seed_lo, p.seed_hi);
+            u = word_of(w, gtid & 3);
+        }
+        uint32_t* s_u = reinterpret_cast<uint32_t*>(slice + p.cells_pad + kRewOff);
+        if (gtid < p.A) s_u[gtid] = u;
+        gsync<WPE>();
+        if (gtid == 0) {
+            const int n = (p.H - 2) * (p.W - 2);
+            const int iw = p.W - 2;
+            // s_u[j], j < i, is reused as the ascending list of taken indices
+            for (int i = 0; i < p.A; ++i) {
+                int d = (int)(((uint64_t)s_u[i] * (uint32_t)(n - i)) >> 32);
+                for (int j = 0; j < i; ++j)
+                    if (d >= (int)s_u[j]) ++d;
+                int j = i;
+                while (j > 0 && (int)s_u[j - 1] > d) {
+                    s_u[j] = s_u[j - 1];
+                    --j;
+                }
+                s_u[j] = (uint32_t)d;
+                const int y = 1 + d / iw, x = 1 + d - (d / iw) * iw;
+                s_pos[2 * i] = (uint8_t)y;
+                s_pos[2 * i + 1] = (uint8_t)x;
+                lg[zoff + y * p.W + x] = p.agent_state ? p.agent_state[env * p.A + i] : tab->agent_type[i];
+            }
+            p.total[env] = 0.0;
+        }
+        gsync<WPE>();
+        store_grid<G>(p, p.grid + env * p.env_stride, lg, gtid);
+        if (gtid < p.A)
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
+        gsync<WPE>();
+    }
+}
+
+// ---------------------------------------------------------------- small kernels
+__global__ void random_actions_kernel(const Params p) {
+    const int64_t n = p.E * p.A;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t env = i / p.A;
+        const int a = (int)(i - env * p.A);
+        const U4 w = philox4x32_10((uint32_t)a >> 2, p.turn, p.first_env + (uint32_t)env,
+                                   (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+        p.actions[i] = (uint8_t)(((uint64_t)word_of(w, a & 3) * (uint32_t)p.nact) >> 32);
+    }
+}
+
+// sgw_init_agent_state: configured types; Tag draws the initial "it" agent of every env
+__global__ void init_agent_state_kernel(const Params p) {
+    for (int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; env < p.E; env += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t* st = p.agent_state + env * p.A;
+        if (p.agent_rule == SGW_AGENT_RULE_TAG) {
+            const U4 w = philox4x32_10(0u, 0u, p.first_env + (uint32_t)env, SGW_STREAM_TAG_INIT, p.seed_lo, p.seed_hi);
+            const uint32_t it = __umulhi(w.x, (uint32_t)p.A);
+            for (int a = 0; a < p.A; ++a) st[a] = (uint8_t)((uint32_t)a == it ? p.tag_it : p.tag_notit);
+        } else {
+            for (int a = 0; a < p.A; ++a) st[a] = p.tab->agent_type[a];
+        }
+    }
+}
+
+constexpr int kRedBlocks = 256;
+
+// stage 1: block b sums elements b*256+t, stride 65536, in a fixed order
+__global__ __launch_bounds__(kBlock) void reduce_stage1(const double* __restrict__ x, int64_t n, double* __restrict__ part) {
+    __shared__ double s[kBlock], s2[kBlock];
+    double a = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)kRedBlocks * kBlock) {
+        const double v = x[i];
+        a += v;
+        a2 += v * v;
+    }
+    s[threadIdx.x] = a;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            s[threadIdx.x] += s[threadIdx.x + k];
+            s2[threadIdx.x] += s2[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s[0];
+        part[kRedBlocks + blockIdx.x] = s2[0];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_stage2(const double* __restrict__ part, int64_t n, double* __restrict__ out) {
+    __shared__ double s[kBlock], s2[kBlock];
+    s[threadIdx.x] = part[threadIdx.x];
+    s2[threadIdx.x] = part[kRedBlocks + threadIdx.x];
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            s[threadIdx.x] += s[threadIdx.x + k];
+            s2[threadIdx.x] += s2[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s[0];
+        out[1] = s2[0];
+        out[2] = (double)n;
+        out[3] = 0.0;
+    }
+}
+static_assert(kRedBlocks == kBlock, "stage 2 assumes one partial per thread");
+

@@ -1,0 +1,452 @@
+// step_big.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
+// step_big<...>: a 512-thread workgroup per env, worlds above 4 KiB (config 5).
+#pragma once
+
+// ---------------------------------------------------------------- big step kernel
+// Workgroup-per-env kernel for worlds above 4 KiB (BASELINE config 5: 128x128x2 = 32 KiB
+// of LDS per env, 64 agents, 11x11 windows).  Same ingredients as step_fast (register
+// sweep, per-agent move inputs computed in parallel, scalar sequential part), plus a
+// JOURNAL so that the A sequential agent phases do not serialise the observation work:
+//   phase M  wave 0 resolves all moves in registers: the targets of all agents are read from LDS at
+//            once, and a short scalar loop corrects each for earlier movers with two ballots (no LDS
+//            access, no cross-wave hand-off); it records what each agent found and whether it moved;
+//   phase R  all waves render the observations in parallel from the FINAL grid; agent a must see the
+//            grid after the moves of agents < a only, so the moves of agents >= a that touch its
+//            window (found with one ballot) are undone in registers, latest first.
+// History (config 5, 2048 envs, us per launch): generic kernel 274; turn word passed from wave to
+// wave 131 -> 113 (three dependent LDS round trips per agent); LDS move chain + journal 124;
+// the same with renderers racing the mover (progress words, dynamic queue) 108; moves resolved in
+// registers + barrier 118-122.  The last is kept: it has no cross-wave race to reason about.
+// Requires impassable agent types (a passable agent could be "entered" twice in one turn, which the
+// two-batch patch cannot order); the host dispatch checks it.
+// Eight waves per workgroup, four workgroups per CU = the CU's 32 wave slots: measured 115 us per config-5 launch
+// against 123 us with four waves per workgroup and 143 us with two (round 2, same box, interleaved A/B).
+#ifndef SGW_BIG_THREADS
+#define SGW_BIG_THREADS 512
+#endif
+constexpr int kBigThreads = SGW_BIG_THREADS;
+constexpr int kBigWaves = kBigThreads / 64;
+constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
+
+// MULTI: sgw_rollout's variant -- a turn loop around sweep / moves / observations with the env's 32 KiB resident in LDS
+// (later turns sweep the units read back from LDS; only the last turn is followed by the write-back).
+template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false>
+__global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t env = blockIdx.x;
+    const uint32_t env_id = p.first_env + (uint32_t)env;
+#ifdef SGW_STAMPS
+    unsigned long long tprev_ = 0;
+#define STAMPB(i)                                                                                            \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (tid == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;                 \
+        tprev_ = t_;                                                                                         \
+    } while (0)
+    STAMPB(0);
+    if (tid == 0 && env < kStampEnvs) {
+        g_stamps[env * 8 + 6] = tprev_;
+        g_stamps[env * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#else
+#define STAMPB(i)
+#endif
+
+    const int L = TL ? TL : p.L;
+    const int C = TC ? TC : p.C;
+    const int r = TR ? TR : p.r;
+    const int V = 2 * r + 1, VV = V * V;
+    const int H = p.H, W = p.W;
+    // LDS image of the grid: rows of P >= W bytes.  With P == W + 16 (worlds whose width is a multiple of 16) window row
+    // i of an observation starts (W + 16) / 4 = 4 (mod 32) banks after row i - 1, so the ~3 rows a 32-lane group of the
+    // 11x11 gather touches fall on disjoint banks; with P == W (a 128-byte pitch) they all fell on the same ones
+    // (34 % of the LDS cycles of config 5 were bank conflicts).
+    const int P = p.big_pitch, HW = H * P;           // HW: LDS bytes of one layer
+    const int upr = W >> 4;                           // 16-byte units per row (used only when P != W)
+    const bool padded = P != W;
+    const int cells = p.cells;
+    const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
+    const int zoff = p.zA * HW;
+    constexpr int NW = TC ? (TC + 3) / 4 : 4;
+    constexpr int NP = TR ? ((2 * TR + 1) * (2 * TR + 1) + 63) / 64 : 2;   // window passes per wave held in registers
+    // HBM unit index / byte offset -> LDS unit index / byte offset (one pad unit per row)
+    auto lunit = [&](int idx) { return padded ? idx + idx / upr : idx; };
+    auto lbyte = [&](uint32_t off) { return padded ? off + (off / (uint32_t)W) * 16u : off; };
+
+    // LDS: [tables][agent arrays][grid]
+    uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // journal entry of each agent (phase M -> R)
+    uint32_t* s_oa = s_ta + 64;                                             // packed (y, x) at the start of the turn
+    uint32_t* s_np = s_oa + 64;                                             // packed (y, x) if the move succeeds
+    uint32_t* s_rm = s_np + 64;                                             // reward f32 bits
+    double* s_val = reinterpret_cast<double*>(s_rm + 64);                   // reward f64 (for total, in agent order)
+    double* s_vtab = s_val + 64 + 2;                                         // value[32] (keeps global loads out of the chain)
+    uint8_t* s_atype = reinterpret_cast<uint8_t*>(s_vtab + 32);                       // agent_type[64]
+    uint8_t* lg = smem + p.tab_bytes + kBigAgentLds;
+    uint4* lg16 = reinterpret_cast<uint4*>(lg);
+    const DevTables* gtab = p.tab;
+
+    const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
+    const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
+    const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
+    const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
+
+    // ---- tables -> LDS
+    if constexpr (ONEHOT) {
+        uint32_t* wd = reinterpret_cast<uint32_t*>(smem);
+        if (tid < 4 * SGW_MAX_TYPES) wd[tid] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid];
+    } else {
+        double* wa = reinterpret_cast<double*>(smem);
+        for (int i = tid; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBigThreads) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
+    }
+    if (tid < 32) s_vtab[tid] = gtab->value[tid];
+    if (tid >= 64 && tid < 128) s_atype[tid - 64] = gtab->agent_type[tid - 64];
+    const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(smem);
+    const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(smem);
+
+    // per-agent state of wave 0 (lane a = agent a), carried from turn to turn of a rollout
+    uint32_t yx = 0;
+    int st_lane = 0;
+    const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
+    uint32_t ta_v = 0xFFFFFFFFu, npos_v = 0, oaddr_v = 0, jr = 0;
+    if (wv == 0 && tid < p.A) {
+        yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
+        if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside the LDS grid, and say so
+            yx = 0;
+            atomicOr(p.status, SGW_STATUS_BAD_POS);
+        }
+    }
+    double tot = (tid == 0 && p.do_move) ? p.total[env] : 0.0;
+    const uint32_t nturns = MULTI ? p.nturns : 1u;
+    for (uint32_t tix = 0; tix < nturns; ++tix) {
+    const uint32_t turn = p.turn + tix;
+    // ---- grid -> LDS (first turn), sweep on the registers, 4 units per thread per round
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
+        for (int base = 0; base < nunits; base += 4 * kBigThreads) {
+            uint4 u[4];
+            uint32_t hits[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * kBigThreads + tid;
+                if (idx < nunits) u[k] = (MULTI && tix > 0) ? lg16[lunit(idx)] : src[idx];
+                if ((cells & 15) && idx == nunits - 1) {   // ragged world: mask the bytes past the last cell
+                    const int tail = cells & 15;
+                    uint32_t d[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int keep = tail - 4 * q;
+                        if (keep <= 0) d[q] = 0xFFFFFFFFu;
+                        else if (keep < 4) d[q] |= 0xFFFFFFFFu << (8 * keep);
+                    }
+                    u[k] = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * kBigThreads + tid;
+                hits[k] = 0;
+                if (idx < nunits) {
+                    if (!(MULTI && tix > 0)) lg16[lunit(idx)] = u[k];
+                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)idx, p, env_id, turn);
+                }
+            }
+            if (do_sweep) {
+                // this thread wrote these units itself (DS ops of a wave are ordered), so the rare
+                // kind draws can patch LDS right away; one combined loop keeps the trip count low
+                uint32_t h0 = hits[0], h1 = hits[1], h2 = hits[2], h3 = hits[3];   // named: keeps them in registers
+                while (__builtin_amdgcn_readfirstlane(__any((h0 | h1 | h2 | h3) != 0))) {
+                    // this lane's next hit cell: lowest set bit of the first non-empty unit
+                    const int k = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+                    const uint32_t hk = h0 ? h0 : h1 ? h1 : h2 ? h2 : h3;
+                    if (hk) {
+                        const uint32_t cell = (uint32_t)__ffs(hk) - 1u;
+                        const uint32_t cleared = hk & (hk - 1u);
+                        h0 = k == 0 ? cleared : h0;
+                        h1 = k == 1 ? cleared : h1;
+                        h2 = k == 2 ? cleared : h2;
+                        h3 = k == 3 ? cleared : h3;
+                        const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
+                        const U4 kw = philox4x32_10(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                                                   p.seed_lo, p.seed_hi);
+                        const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
+                        lg[lbyte(off)] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- per-agent move inputs, all agents at once (wave 0: lane a = agent a)
+    ta_v = 0xFFFFFFFFu;
+    jr = 0;
+    if (wv == 0) {
+        if (tid < p.A) {
+            const uint32_t py = yx & 0xFFu, px = yx >> 8;
+            oaddr_v = (uint32_t)zoff + py * (uint32_t)P + px;
+            npos_v = yx;
+            if (p.do_move && mine) {
+                uint32_t act;
+                if (rnd) {
+                    const U4 w = philox4x32_10(opaque((uint32_t)tid >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                                               p.seed_lo, p.seed_hi);
+                    act = __umulhi(word_of(w, tid & 3), (uint32_t)p.nact);
+                    p.actions[tix * p.ts_act + env * p.A + tid] = (uint8_t)act;
+                } else {
+                    act = p.actions[tix * p.ts_act + env * p.A + tid];
+                }
+                const bool act_ok = act < (uint32_t)p.nact;
+                const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
+                const int dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+                const int ty = (int)py + dy, tx = (int)px + dx;
+                const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+                if (act_ok && inb) {
+                    ta_v = (uint32_t)(zoff + ty * P + tx);
+                    npos_v = (uint32_t)ty | ((uint32_t)tx << 8);
+                }
+                st_lane |= !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
+            }
+        }
+        s_oa[tid] = yx;          // packed (y, x) at the start of the turn
+        s_np[tid] = npos_v;      // packed (y, x) if the move succeeds
+        s_ta[tid] = 0;           // journal: empty
+    }
+    __syncthreads();             // grid (+ sweep patches) and tables visible to every wave
+    STAMPB(1);                   // load + sweep done
+
+    // ---- phase M: the strictly sequential part, by wave 0 alone, entirely in registers.
+    // All targets are read from the pre-move grid in ONE LDS round trip (lane a = agent a).  What
+    // agent a finds on its target when its turn comes differs from that only if an earlier mover
+    // left from or entered that very cell; the scalar loop below finds the latest such mover with
+    // two ballots (no LDS access inside the loop).  The grid is patched afterwards in two ordered
+    // batches: every mover's old cell <- default, then every mover's new cell <- its type (a cell
+    // can be left and then entered in one turn, never the other way round: an agent moves once).
+    if (wv == 0 && p.do_move) {
+        const uint32_t atype_v = s_atype[lane];
+        const bool validv = ta_v != 0xFFFFFFFFu;
+        const uint32_t t0_v = lg[validv ? ta_v : oaddr_v];
+        uint32_t passed_v = 0;
+        // What an agent finds on its target can differ from the pre-move grid only if an earlier mover entered that cell
+        // (two agents share a target) or left it (the target is another agent's cell).  An agent INTERFERES if it shares
+        // its target with another agent or targets another agent's cell; everyone else resolves at once from the
+        // pre-move grid, and only the interfering agents (typically none, or a pair) are walked, in agent order.
+        bool cf = false;
+        const bool self = validv && ta_v == oaddr_v;     // targets its own cell (a non-move action): finds itself, whoever moves
+        const bool markable = mine && validv && t0_v < 32u && !((p.agent_mask >> t0_v) & 1u);
+        uint32_t* gw = reinterpret_cast<uint32_t*>(lg);
+        const uint32_t msh = 8u * (ta_v & 3u);
+        if (mine && validv && !markable && !self) cf = true;
+        // two spare bits of the target's LDS byte (type ids are < 32): 0x40 = claimed, 0x80 = claimed more than once
+        if (markable) cf = ((atomicOr(&gw[ta_v >> 2], 0x40u << msh) >> msh) & 0x40u) != 0;
+        if (markable && cf) atomicOr(&gw[ta_v >> 2], 0x80u << msh);
+        if (markable) cf = ((atomicOr(&gw[ta_v >> 2], 0u) >> msh) & 0x80u) != 0;   // every claimant of a contested cell, the first one too (an RMW: ordered behind the marks)
+        unsigned long long cmask = __ballot(cf);
+        if (markable) atomicAnd(&gw[ta_v >> 2], ~(0xC0u << msh));   // marks off again before anyone else reads the grid
+        {
+            const bool tok = validv && t0_v < (uint32_t)p.T;
+            const bool pass = tok && ((p.pass_mask >> (t0_v & 31u)) & 1u);
+            if (mine) {   // final for the agents that do not interfere, provisional (and not yet visible, see `lane < a`) for the others
+                jr = (t0_v & 0xFFu) | (tok ? 0x100u : 0u) | (pass ? 0x200u : 0u) | ((validv && !tok) ? 0x400u : 0u);
+                passed_v = pass ? 1u : 0u;
+            }
+        }
+        while (cmask) {
+            const int a = __builtin_ctzll(cmask);
+            cmask &= cmask - 1ull;
+            const uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)ta_v, a);
+            const bool valid = X != 0xFFFFFFFFu;
+            uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t0_v, a);
+            // what earlier movers did to that cell: the latest one that entered or left it decides
+            const unsigned long long m_dst = __ballot(passed_v && lane < a && ta_v == X);
+            const unsigned long long m_src = __ballot(passed_v && lane < a && oaddr_v == X);
+            const unsigned long long m_any = m_dst | m_src;
+            if (m_any) {
+                const int last = 63 - __builtin_clzll(m_any);
+                const uint32_t at_last = (uint32_t)__builtin_amdgcn_readlane((int)atype_v, last);
+                t = ((m_dst >> last) & 1ull) ? at_last : p.default_type;
+            }
+            const bool tok = valid && t < (uint32_t)p.T;
+            const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
+            const uint32_t entry = (t & 0xFFu) | (tok ? 0x100u : 0u) | (pass ? 0x200u : 0u) | ((valid && !tok) ? 0x400u : 0u);
+            jr = lane == a ? entry : jr;
+            passed_v = lane == a ? (pass ? 1u : 0u) : passed_v;
+        }
+        if (passed_v) lg[oaddr_v] = (uint8_t)p.default_type;
+        gsync<1>();
+        if (passed_v) lg[ta_v] = (uint8_t)atype_v;
+        const double val = (jr & 0x100u) ? s_vtab[jr & 31u] : 0.0;     // reward = value of the target BEFORE the move
+        s_val[lane] = val;
+        s_rm[lane] = __float_as_uint((float)val);
+        s_ta[lane] = jr;                                                // journal for the render phase
+        if (jr & 0x400u) st_lane |= SGW_STATUS_BAD_TYPE;
+        if (mine) p.rewards[tix * p.ts_rew + env * p.A + tid] = (float)val;   // this turn's rewards
+        gsync<1>();
+        if (tid == 0)
+            for (int a = p.a0; a < p.a1; ++a) tot += s_val[a];           // float64, agent order (agent.py:172)
+    }
+    __syncthreads();
+    STAMPB(2);                   // phase M done
+
+    // ---- phase R: observations, all waves in parallel (agent a -> wave (a - a0) mod waves).
+    // LDS now holds the grid AFTER all moves of this call; agent a must see it after the moves of
+    // agents < a only, so the moves of agents b >= a that touch a's window (one ballot) are undone
+    // in registers, latest first; an undo restores the two cells the move changed.
+    if (write_obs || p.obs_next) {
+        // per-lane window geometry: NP cells per lane
+        int wdi[NP], wdj[NP], woff[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int w = lane + 64 * k;
+            const int i = w / V, j = w - i * V;
+            wdi[k] = i - r;
+            wdj[k] = j - r;
+            woff[k] = wdi[k] * P + wdj[k];
+        }
+        // lane b: journal of agent b (where it was, where it went, what it found there)
+        const uint32_t jb = s_ta[lane], srcb = s_oa[lane], dstb = s_np[lane], atb = s_atype[lane];
+        const bool movedb = p.do_move && (jb & 0x200u) && lane >= p.a0 && lane < p.a1;
+        const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
+        // SGW_STEP_OBS_NEXT: only agent a1, which sees the grid after ALL moves of this call (nothing to undo)
+        const int r_lo = p.obs_next ? p.a1 : p.a0, r_hi = p.obs_next ? (p.a1 < p.A ? p.a1 + 1 : p.a1) : p.a1;
+        for (int a = r_lo + wv; a < r_hi; a += kBigWaves) {
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
+            const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
+            const int cbase = y * P + x;
+            uint32_t tb[NP][2];
+            bool inbk[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int w = lane + 64 * k;
+                inbk[k] = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
+                const int off = (inbk[k] && w < VV) ? cbase + woff[k] : 0;
+                uint32_t lo = 0, hi = 0;
+                if constexpr (TL != 0) {
+#pragma unroll
+                    for (int z = 0; z < TL; ++z) {
+                        const uint32_t t = lg[z * HW + off];
+                        if (z < 4) lo |= (t & 31u) << (8 * z);
+                        else hi |= (t & 31u) << (8 * (z - 4));
+                    }
+                } else {
+                    for (int z = 0; z < L; ++z) {
+                        const uint32_t t = lg[z * HW + off];
+                        if (z < 4) lo |= (t & 31u) << (8 * z);
+                        else hi |= (t & 31u) << (8 * (z - 4));
+                    }
+                }
+                tb[k][0] = lo;
+                tb[k][1] = hi;
+            }
+            // which later moves touch this window?  (lane b tests move b)
+            const int sy = (int)(srcb & 0xFFu), sx = (int)((srcb >> 8) & 0xFFu);
+            const int ey = (int)(dstb & 0xFFu), ex = (int)((dstb >> 8) & 0xFFu);
+            const bool near_src = (unsigned)(sy - y + r) <= (unsigned)(2 * r) && (unsigned)(sx - x + r) <= (unsigned)(2 * r);
+            const bool near_dst = (unsigned)(ey - y + r) <= (unsigned)(2 * r) && (unsigned)(ex - x + r) <= (unsigned)(2 * r);
+            unsigned long long undo = __ballot(movedb && lane >= a && (near_src || near_dst));
+            while (undo) {
+                const int b = 63 - __builtin_clzll(undo);            // latest move first
+                undo &= ~(1ull << b);
+                const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)srcb, b);
+                const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)dstb, b);
+                const uint32_t oldt = (uint32_t)__builtin_amdgcn_readlane((int)jb, b) & 31u;    // what the target held
+                const uint32_t agt = (uint32_t)__builtin_amdgcn_readlane((int)atb, b) & 31u;    // the mover itself
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const uint32_t key = (uint32_t)((y + wdi[k]) & 0xFF) | ((uint32_t)((x + wdj[k]) & 0xFF) << 8);
+                    const bool at_dst = inbk[k] && key == dst, at_src = inbk[k] && key == src;
+                    if (at_dst || at_src) {
+                        const uint32_t nv = at_src ? agt : oldt;     // src restored last (matters only if src == dst)
+                        if (zw == 0) tb[k][0] = (tb[k][0] & ~(0xFFu << zsh)) | (nv << zsh);
+                        else tb[k][1] = (tb[k][1] & ~(0xFFu << zsh)) | (nv << zsh);
+                    }
+                }
+            }
+            float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)C) * VV;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int w = lane + 64 * k;
+                if (w < VV) {
+                    float* o = obase + w;
+                    if constexpr (ONEHOT) {
+                        uint32_t cnt[NW];
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) cnt[q] = 0;
+                        for (int z = 0; z < L; ++z) {
+                            const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) cnt[q] += wdelta[q * 32 + t];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) cnt[q] = inbk[k] ? cnt[q] : p.fill_delta[q];
+                        if (!p.obs_u8) {
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
+                                }
+                            }
+                        } else {   // compact format: the same counts as bytes
+                            uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
+                                }
+                            }
+                        }
+                    } else {
+                        for (int c = 0; c < C; ++c) {
+                            double acc = wapp[tb[k][0] & 31u][c];   // left-to-right float64 layer sum
+                            for (int z = 1; z < L; ++z) {
+                                const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
+                                acc += wapp[t][c];
+                            }
+                            OBS_STORE(o + c * VV, obs_finish(inbk[k] ? acc : wapp[p.fill_type][c], p.obs_post));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // windows wider than NP*64 cells (not a BASELINE shape): handled by the generic kernel (host dispatch)
+    __syncthreads();
+    STAMPB(3);                   // phase R done (all waves)
+    if (MULTI && tix + 1 < nturns && wv == 0 && tid < p.A) yx = (jr & 0x200u) ? npos_v : yx;   // the next turn starts where this one ended
+    }   // turns
+
+    // ---- write-back
+    if (dirty && !do_sweep) {
+        // a policy-driven phase (no sweep): only the movers' two cells changed -- write those bytes, not the whole grid
+        if (wv == 0 && mine && (jr & 0x200u)) {
+            uint8_t* g = p.grid + env * p.env_stride + p.zA * H * W;
+            g[(yx & 0xFFu) * W + (yx >> 8)] = lg[oaddr_v];
+            g[(npos_v & 0xFFu) * W + (npos_v >> 8)] = lg[ta_v];
+        }
+    } else if (dirty) {
+        uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
+        for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[lunit(idx)];
+    }
+    STAMPB(4);                   // write-back issued
+#ifdef SGW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMPB(5);                   // wave 0's stores acknowledged
+    STAMPB(6);
+    if (p.do_move) {
+        if (wv == 0 && mine) {
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)((jr & 0x200u) ? npos_v : yx);
+            if (st_lane) atomicOr(p.status, st_lane);
+        }
+        if (tid == 0) p.total[env] = tot;
+    }
+}
+

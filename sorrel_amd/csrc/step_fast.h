@@ -1,0 +1,663 @@
+// step_fast.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
+// step_fast<...>: a wave per env, worlds <= 4 KiB (the headline kernel and its STAGE / TAG / RULES / MULTI variants).
+#pragma once
+
+// ---------------------------------------------------------------- fast step kernel
+// Wave-per-env specialisation for worlds whose byte count is a multiple of 16 and
+// <= 4 KiB with at most one spawning type (all BASELINE configs up to 32x32x2):
+//   * the grid is loaded straight into registers (16 B per lane per unit) one env
+//     AHEAD of its use, so HBM latency hides under the previous env's work;
+//   * the Bernoulli half of the sweep runs on those registers (byte-parallel
+//     spawner match, one Philox block per dword); the rare "what spawns" draw is
+//     deferred to a short divergent loop that patches single bytes in LDS;
+//   * everything about an agent's move that does not depend on the other agents
+//     (action -> target cell, bounds, status) is computed for all agents at once,
+//     lane a = agent a; the strictly sequential part is a handful of scalar ops:
+//     read the target type from LDS, test passability, patch two bytes;
+//   * window geometry (L, C, r, and for the BASELINE shapes H, W) is compile-time,
+//     so gather/emit is branch-free: v_cvt_f32_ubyteN + global_store_dword.
+constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kCacheResidentGrid = (size_t)384 << 20;   // grids of a batch up to about this size stay in the 256 MB Infinity Cache + L2 from turn to turn
+
+// (non-temporal observation stores were measured: slower)
+#define OBS_STORE(ptr, val) (*(ptr) = (val))
+
+
+// Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
+__device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id, const uint32_t turn) {
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t dv = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
+        const uint32_t m = match_bytes(dv, p.spawn_pat);
+        if (m) {
+            const U4 w = philox4x32_10(opaque(unit * 4 + k), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+            const bool f = p.spawn_full != 0;
+            uint32_t hb = 0;
+            hb |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
+            hb |= ((m & 0x8000u) && (f || w.y < p.spawn_thr)) ? 2u : 0u;
+            hb |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
+            hb |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
+            hits |= hb << (4 * k);
+        }
+    }
+    return hits;
+}
+
+// Rare second draw: what spawns in each hit cell; written straight into the LDS grid.
+__device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, uint8_t* lg, const Params& p,
+                                            const uint32_t env_id, const uint32_t turn) {
+    while (hits) {
+        const uint32_t cell = (uint32_t)__ffs(hits) - 1u;
+        hits &= hits - 1u;
+        const uint32_t off = unit * 16u + cell;   // byte offset == RNG index
+        const U4 kw = philox4x32_10(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
+        lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+    }
+}
+
+#ifdef SGW_STAMPS
+// Diagnostic build only (-DSGW_STAMPS, read with tools/stamps.py): coarse s_memrealtime stamps (10 ns, chip-wide) per wave, stored per
+// env and segment with plain stores (atomics would serialise), plus where and when the wave started.  Read the
+// SHARES, not the run time.  No stamp executes in the product build.
+constexpr int kStampEnvs = 65536;
+__device__ unsigned long long g_stamps[kStampEnvs * 8];
+#define STAMP(i)                                                                                             \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   /* 100 MHz, chip-wide */                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (lane == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;                \
+        tprev_ = t_;                                                                                         \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
+// RULES: the layered rule set on the wave-per-env kernel -- an ordered LDS sweep, one dword (four
+// cells, one Philox block) per lane and layer by layer, for any number of spawners and SGW_RULE_BECOME_IF types,
+// and CleanupAgent.act (facing, beams on the layer above, all-layer reward) in the agent loop.
+// STAGE (run-time-shape variants): the one-hot observations of `stage_agents` agents at a time are staged as bytes in LDS
+// and leave as one burst of streaming 16-byte stores, aligned in GLOBAL memory whatever A * C * V * V is (the chunk's
+// first element need not sit on a 16-byte boundary: the staging area is shifted by its misalignment, edge elements
+// leave as single stores).  A STAGE kernel has no direct-store path at all (the two together do not fit the 64-register
+// budget of 8 waves per SIMD); the host launches the plain variant for calls that cannot be staged (a range of agents,
+// SGW_STEP_OBS_NEXT, an observation pointer that is not 16-byte aligned).  The fixed-shape kernels of the BASELINE
+// configs keep their own, simpler whole-env burst and ignore the parameter.
+// MULTI: the variant sgw_rollout launches for nturns > 1 (a turn loop around sweep / agents / emit, the grid staying in
+// LDS).  It is a separate instantiation because the loop costs registers (config 3's kernel: 39 -> 64 VGPRs), which the
+// single-turn kernel must not pay.
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false>
+__global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
+    // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
+    // workgroups measured 17 % faster than a persistent grid with software prefetch),
+    // wave-private LDS (grid slice + the table words this wave reads), no s_barrier.
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps all env-indexed address math scalar
+    const int64_t env = (int64_t)blockIdx.x * 4 + sub;
+    if (env >= p.E) return;   // whole wave exits together
+#ifdef SGW_STAMPS
+    unsigned long long tprev_ = 0;
+    STAMP(0);
+    if (lane == 0 && env < kStampEnvs) {   // where and when this wave started
+        g_stamps[env * 8 + 6] = tprev_;
+        g_stamps[env * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#endif
+
+    const int L = TL ? TL : p.L;
+    const int C = TC ? TC : p.C;
+    const int r = TR ? TR : p.r;
+    const int V = 2 * r + 1, VV = V * V;
+    const int H = TH ? TH : p.H, W = TW ? TW : p.W, HW = H * W;
+    constexpr bool kStatic = TL && TH && TW;
+    const int cells = kStatic ? TL * TH * TW : p.cells;
+    const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
+    constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane
+    const int zoff = p.zA * HW;
+    constexpr int NW = TC ? (TC + 3) / 4 : 4;   // counter words
+
+    // wave-private LDS: [table words][grid]
+    uint8_t* wl = smem + sub * p.env_lds;
+    const DevTables* gtab = p.tab;
+    const uint32_t env_id = p.first_env + (uint32_t)env;
+
+    // ---- issue every global load of this env first
+    uint4 u[NU];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+            if (lane + 64 * k < nunits) u[k] = src[lane + 64 * k];
+    }
+    const bool mine = lane >= p.a0 && lane < p.a1 && lane < p.A;   // this lane's agent is stepped in this call
+    const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
+    uint32_t yx = 0, act = 0;
+    if (lane < p.A) yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + lane];
+    if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside this env's LDS slice, and say so
+        yx = 0;
+        atomicOr(p.status, SGW_STATUS_BAD_POS);
+    }
+    if (mine && p.do_move && !rnd) act = p.actions[env * p.A + lane];
+    // register-resident tables: lane t holds value[t] (f64 bits + its f32 rounding); lane a holds agent a's type
+    const double vtab = gtab->value[lane & 31];
+    uint32_t atype = gtab->agent_type[lane];   // lane a: CURRENT entity type of agent a
+    if (p.agent_state && lane < p.A) atype = p.agent_state[env * p.A + lane];
+    uint32_t pov_type = atype;                 // ... and its type when it observed (TagAgent.pov)
+    if constexpr (ONEHOT) {
+        // the one-hot counter words this wave looks up, [NW][32] u32
+        uint32_t* wd = reinterpret_cast<uint32_t*>(wl);
+#pragma unroll
+        for (int q = 0; q < (NW + 1) / 2; ++q) wd[lane + 64 * q] = reinterpret_cast<const uint32_t*>(gtab->delta)[lane + 64 * q];
+    } else {
+        double* wa = reinterpret_cast<double*>(wl);
+        for (int i = lane; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += 64) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
+    }
+    const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(wl);                 // [NW][32]
+    const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(wl);
+    uint8_t* lg = wl + p.tab_bytes + (RULES ? kRuleLds : 0);
+    uint4* lg16 = reinterpret_cast<uint4*>(lg);
+    [[maybe_unused]] const RuleLds* rt = reinterpret_cast<const RuleLds*>(wl + p.tab_bytes);
+    [[maybe_unused]] uint32_t adir = 2;        // lane a: facing of agent a (Cleanup)
+    [[maybe_unused]] uint32_t kind_v = 0;      // lane a: SGW_ACTION_* of its action
+    if constexpr (RULES) {
+        uint32_t* rd = reinterpret_cast<uint32_t*>(wl + p.tab_bytes);
+        const uint32_t* gA = reinterpret_cast<const uint32_t*>(gtab->thr_lo);
+        const uint32_t* gB = reinterpret_cast<const uint32_t*>(gtab->spawn_choice);   // + spawn_count: 72 dwords
+        const uint32_t* gC = reinterpret_cast<const uint32_t*>(gtab->rule);           // rule .. rule_mask: 64 dwords
+        if (lane < 32) rd[lane] = gA[lane];
+        rd[32 + lane] = gB[lane];
+        if (lane < 8) rd[96 + lane] = gB[64 + lane];
+        rd[104 + lane] = gC[lane];
+        if (p.agent_dir && lane < p.A) adir = p.agent_dir[env * p.A + lane];
+    }
+    // One-hot observations of a whole env are staged in LDS as byte counts in their final [A][C][V][V] order and
+    // leave for HBM in one burst of 16-byte stores after the agent loop (instead of 6 dword stores per agent
+    // dribbling out over the wave's life): the chip then has far fewer half-written observation streams open.
+    uint8_t* ob = lg + ((cells + 15) & ~15);
+    constexpr bool kStageAlways = ONEHOT && STAGE && !(TL && TH && TW);
+    const bool stage = kStageAlways || (ONEHOT && (TL && TH && TW) && p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A);
+    [[maybe_unused]] int ch_a0 = 0;            // first agent of the chunk being staged (STAGE)
+    [[maybe_unused]] uint32_t ch_shift = 0;    // misalignment (in elements) of the chunk's first element in global memory
+    if constexpr (kStageAlways) ch_shift = (uint32_t)(env * (int64_t)(p.A * C * VV)) & 3u;
+
+    // per-lane window geometry: up to two cells per lane
+    int wdi[2], wdj[2], woff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int w = lane + 64 * k;
+        const int i = w / V, j = w - i * V;
+        wdi[k] = i - r;
+        wdj[k] = j - r;
+        woff[k] = wdi[k] * W + wdj[k];
+    }
+    const uint32_t vt_lo = (uint32_t)__double_as_longlong(vtab), vt_hi = (uint32_t)(__double_as_longlong(vtab) >> 32);
+    const uint32_t vt_f32 = __float_as_uint((float)vtab);
+    const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
+    const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
+    const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
+
+    {
+        double tot = p.do_move ? p.total[env] : 0.0;
+
+#ifdef SGW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(1);   // global loads have arrived
+        // ---- grid -> LDS; the Bernoulli half of the sweep runs on the registers
+        [[maybe_unused]] uint32_t hits[NU];
+        if constexpr (!kStatic) {
+            if (cells & 15) {   // ragged world: bytes past the last cell are not cells (no type, no RNG index)
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k == nunits - 1) {
+                        const int tail = cells & 15;
+                        uint32_t d[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int keep = tail - 4 * q;   // valid bytes in this dword
+                            if (keep <= 0) d[q] = 0xFFFFFFFFu;
+                            else if (keep < 4) d[q] |= 0xFFFFFFFFu << (8 * keep);
+                        }
+                        u[k] = make_uint4(d[0], d[1], d[2], d[3]);
+                    }
+            }
+        }
+        // the env's grid goes to LDS once; sgw_rollout's turns (nturns > 1) all run on it
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+            if (lane + 64 * k < nunits) lg16[lane + 64 * k] = u[k];
+        int st_lane = 0;
+        uint32_t taddr_v = 0xFFFFFFFFu, oaddr_v = 0, npos = 0, rew_bits = 0, moved = 0;   // per turn; the write-back reads the last turn's
+        const uint32_t nturns = MULTI ? p.nturns : 1u;
+        for (uint32_t tix = 0; tix < nturns; ++tix) {
+        const uint32_t turn = p.turn + tix;
+        if constexpr (RULES) {
+            gsync<1>();
+            if (do_sweep) {
+                // Ordered sweep in LDS.  The reference visits cells in (y, x, z) order and a rule may read another
+                // layer of its own column (environment.py:88-91): going layer by layer, lower layers first, gives every
+                // cell the same view (lower layers already swept, higher ones not yet); rules write their own cell only.
+                const uint32_t* lg32 = reinterpret_cast<const uint32_t*>(lg);
+                for (int z = 0; z < L; ++z) {
+                    const int lo = z * HW, hi = lo + HW;
+                    for (int d = (lo >> 2) + lane; d < ((hi + 3) >> 2); d += 64) {   // one dword = four cells = one Philox block
+                        const uint32_t word = lg32[d];
+                        uint32_t tj[4];
+                        bool spj[4], bcj[4];
+                        bool any_sp = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int off = 4 * d + j;
+                            tj[j] = (word >> (8 * j)) & 0xFFu;
+                            const bool in = off >= lo && off < hi && tj[j] < (uint32_t)SGW_MAX_TYPES;
+                            spj[j] = in && ((p.spawn_mask >> (tj[j] & 31u)) & 1u);
+                            bcj[j] = in && ((p.become_mask >> (tj[j] & 31u)) & 1u);
+                            any_sp = any_sp || spj[j];
+                        }
+                        if (any_sp) {
+                            const U4 w = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                            uint32_t hit = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (spj[j] && (((p.thr_full_mask >> tj[j]) & 1u) || word_of(w, j) < rt->thr_lo[tj[j]])) hit |= 1u << j;
+                            if (hit) {   // rare: what spawns
+                                const U4 kw = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if ((hit >> j) & 1u)
+                                        lg[4 * d + j] = rt->spawn_choice[tj[j]][__umulhi(word_of(kw, j), (uint32_t)rt->spawn_count[tj[j]])];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (bcj[j]) {
+                                const int zl = rt->rule_layer[tj[j]];
+                                const bool fire = zl < 0 || ((rt->rule_mask[tj[j]] >> (lg[zl * HW + (4 * d + j - lo)] & 31u)) & 1u);
+                                if (fire) lg[4 * d + j] = rt->rule_become[tj[j]];
+                            }
+                    }
+                    gsync<1>();
+                }
+            }
+        } else {
+            if (tix > 0) {   // later turns of a rollout: the units come back from LDS (moves and spawns of the turns before)
+                gsync<1>();
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) u[k] = lg16[lane + 64 * k];
+            }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                hits[k] = 0;
+                if (lane + 64 * k < nunits && do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
+            }
+            gsync<1>();
+            if (do_sweep) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn);
+                gsync<1>();
+            }
+        }
+
+        STAMP(2);   // sweep done
+        // ---- everything about agent `lane`'s move that does not depend on the other agents
+        const uint32_t py = yx & 0xFFu, px = yx >> 8;
+        taddr_v = 0xFFFFFFFFu;                   // target cell (LDS byte offset) or "invalid"
+        npos = yx;                               // position if the move succeeds
+        if (p.do_move && mine) {
+            if (rnd) {
+                const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                                           p.seed_lo, p.seed_hi);
+                act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
+                p.actions[tix * p.ts_act + env * p.A + lane] = (uint8_t)act;
+            } else if (tix > 0) {
+                act = p.actions[tix * p.ts_act + env * p.A + lane];
+            }
+            const bool act_ok = act < (uint32_t)p.nact;
+            int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
+            int dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+            if constexpr (RULES) {
+                if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {   // clean / zap stay in place; a move action also turns the agent
+                    const uint32_t kind = act_ok ? (p.kind_pack >> (2 * (act & 15u))) & 3u : 0u;
+                    if (kind != SGW_ACTION_MOVE || !act_ok) dy = dx = 0;
+                    const uint32_t ndir = (dy == -1 && dx == 0) ? 0u : (dy == 1 && dx == 0) ? 2u : (dy == 0 && dx == -1) ? 3u : (dy == 0 && dx == 1) ? 1u : 4u;
+                    kind_v = kind | (act_ok ? 4u : 0u) | (ndir << 4);
+                }
+            }
+            const int ty = (int)py + dy, tx = (int)px + dx;
+            const bool inb = (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+            if (act_ok && inb) {
+                taddr_v = (uint32_t)(zoff + ty * W + tx);
+                npos = (uint32_t)ty | ((uint32_t)tx << 8);
+            }
+            st_lane |= !act_ok ? SGW_STATUS_BAD_ACTION : (!inb ? SGW_STATUS_OOB_MOVE : 0);
+        }
+        oaddr_v = (uint32_t)zoff + py * (uint32_t)W + px;   // own cell
+        rew_bits = 0;
+        moved = 0;
+        const int64_t turn_obs = tix * p.ts_obs;   // this turn's observation slot (elements)
+        if constexpr (kStageAlways) {
+            ch_a0 = 0;
+            ch_shift = (uint32_t)(turn_obs + env * (int64_t)(p.A * C * VV)) & 3u;
+        }
+
+        STAMP(3);   // move inputs (action draw) done
+        // STAGE: the staged chunk [a_lo, a_hi) leaves for HBM.  Dword i of the (shifted) staging area is the 16-byte
+        // aligned float4 number i of the chunk's span in global memory; the span's first and last float4 may also hold
+        // elements of a neighbouring chunk / env, so those two leave element by element.
+        [[maybe_unused]] auto emit_chunk = [&](const int a_lo, const int a_hi) {
+            gsync<1>();
+            typedef float vfloat4 __attribute__((ext_vector_type(4)));
+            const int N = (a_hi - a_lo) * C * VV;
+            const int64_t e0 = turn_obs + (env * p.A + a_lo) * (int64_t)(C * VV);
+            const int sh = (int)ch_shift;
+            const int nd = (sh + N + 3) >> 2;
+            const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
+            if (!p.obs_u8) {
+                float* gb = p.obs + (e0 - sh);
+                for (int i = lane; i < nd; i += 64) {
+                    const uint32_t b = ob4[i];
+                    vfloat4 v;
+                    v.x = (float)(b & 0xFFu);
+                    v.y = (float)((b >> 8) & 0xFFu);
+                    v.z = (float)((b >> 16) & 0xFFu);
+                    v.w = (float)(b >> 24);
+                    const int lo = 4 * i - sh;       // chunk element held by byte 0 of this dword
+                    if (lo >= 0 && lo + 4 <= N) {
+                        __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
+                    } else {
+                        if (lo >= 0 && lo < N) gb[4 * i] = v.x;
+                        if (lo + 1 >= 0 && lo + 1 < N) gb[4 * i + 1] = v.y;
+                        if (lo + 2 >= 0 && lo + 2 < N) gb[4 * i + 2] = v.z;
+                        if (lo + 3 >= 0 && lo + 3 < N) gb[4 * i + 3] = v.w;
+                    }
+                }
+            } else {
+                uint8_t* gb = reinterpret_cast<uint8_t*>(p.obs) + (e0 - sh);
+                for (int i = lane; i < nd; i += 64) {
+                    const uint32_t b = ob4[i];
+                    const int lo = 4 * i - sh;
+                    if (lo >= 0 && lo + 4 <= N) {
+                        __builtin_nontemporal_store(b, reinterpret_cast<uint32_t*>(gb + 4 * i));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (lo + j >= 0 && lo + j < N) gb[4 * i + j] = (uint8_t)(b >> (8 * j));
+                    }
+                }
+            }
+            gsync<1>();
+        };
+        // ---- agents, strictly in list order (SGW_STEP_OBS_NEXT: one extra, observe-only iteration for agent a1)
+        const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;
+        for (int a = p.a0; a < a_end; ++a) {
+            if constexpr (kStageAlways) {
+                if (a - ch_a0 == p.stage_agents) {   // the staging area is full: out with it, start the next chunk
+                    if (write_obs) emit_chunk(ch_a0, a);
+                    ch_a0 = a;
+                    ch_shift = (uint32_t)(turn_obs + (env * p.A + a) * (int64_t)(C * VV)) & 3u;
+                }
+            }
+            const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
+            if (p.obs_next ? a == p.a1 : write_obs) {
+                const int y = __builtin_amdgcn_readlane((int)py, a);
+                const int x = __builtin_amdgcn_readlane((int)px, a);
+                const int cbase = s_o - zoff;
+                float* obase = p.obs + turn_obs + ((env * p.A + a) * (int64_t)C) * VV;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (64 * k >= VV) break;
+                    const int w = lane + 64 * k;
+                    if (w < VV) {
+                        const bool inb = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
+                        const int off = inb ? cbase + woff[k] : 0;   // clamped: the read is always in range
+                        float* o = obase + w;
+                        if constexpr (ONEHOT) {
+                            uint32_t cnt[NW];
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) cnt[q] = 0;
+#pragma unroll
+                            for (int z = 0; z < (TL ? TL : 1); ++z) {
+                                const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) cnt[q] += wdelta[q * 32 + t];
+                            }
+                            if constexpr (TL == 0) {
+                                for (int z = 1; z < L; ++z) {
+                                    const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                    for (int q = 0; q < NW; ++q) cnt[q] += wdelta[q * 32 + t];
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
+                            if (stage) {
+                                uint8_t* os = ob + (kStageAlways ? (int)ch_shift + ((a - ch_a0) * C) * VV : (a * C) * VV) + w;
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) os[c * VV] = (uint8_t)(cnt[q] >> (8 * b));
+                                    }
+                                }
+                            } else if constexpr (kStageAlways) {
+                                // unreachable: a STAGE kernel always stages
+                            } else if (!p.obs_u8) {
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
+                                    }
+                                }
+                            } else {   // compact format: the same counts as bytes
+                                uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
+                                    }
+                                }
+                            }
+                        } else {
+                            for (int c = 0; c < C; ++c) {
+                                double acc = wapp[lg[off] & 31u][c];   // left-to-right float64 layer sum
+                                for (int z = 1; z < L; ++z) acc += wapp[lg[z * HW + off] & 31u][c];
+                                OBS_STORE(o + c * VV, obs_finish(inb ? acc : wapp[p.fill_type][c], p.obs_post));
+                            }
+                        }
+                    }
+                }
+            }
+            if (!p.do_move || a >= p.a1) continue;
+            // ---- the sequential part (agent.py:219-221, gridworld.py:110-122): scalar
+            const uint32_t s_t = (uint32_t)__builtin_amdgcn_readlane((int)taddr_v, a);
+            const uint32_t my_type = (uint32_t)__builtin_amdgcn_readlane((int)atype, a);
+            const bool valid = s_t != 0xFFFFFFFFu;
+            if constexpr (RULES) {
+                if (p.agent_rule == SGW_AGENT_RULE_CLEANUP) {
+                    // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:92-177); everything below is wave-uniform
+                    const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)kind_v, a);
+                    const uint32_t kind = kd & 3u, ndir = kd >> 4;
+                    const bool aok = (kd & 4u) != 0;
+                    const uint32_t facing = (uint32_t)__builtin_amdgcn_readlane((int)adir, a) & 3u;
+                    const int ay = __builtin_amdgcn_readlane((int)py, a), ax = __builtin_amdgcn_readlane((int)px, a);
+                    if (aok && kind != SGW_ACTION_MOVE && p.zA + 1 < L) {
+                        // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
+                        if (lane < 3 * p.beam_radius) {
+                            const int arm = lane / p.beam_radius, i = lane - arm * p.beam_radius;
+                            const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
+                            const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
+                            const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                            const int by = ay + side * ry + step * fy, bx = ax + side * rx + step * fx;
+                            if ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) {
+                                const int boff = (p.zA + 1) * HW + by * W + bx;
+                                if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
+                                    lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
+                            }
+                        }
+                        gsync<1>();
+                    }
+                    double val = 0.0;           // reward: every layer of the target cell, BEFORE the move
+                    uint32_t t = 0xFFu;
+                    if (valid) {
+                        const int tc = (int)s_t - zoff;
+                        for (int zl = 0; zl < L; ++zl) {
+                            const uint32_t tz = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[zl * HW + tc]) & 31u;
+                            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)vt_lo, (int)tz);
+                            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)vt_hi, (int)tz);
+                            val += __longlong_as_double(((long long)hi_ << 32) | lo_);
+                        }
+                        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[s_t]);
+                    }
+                    const bool pass = valid && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                    if (pass && lane == 0) {
+                        lg[s_t] = (uint8_t)my_type;
+                        lg[s_o] = (uint8_t)p.default_type;
+                    }
+                    moved = lane == a ? (pass ? 1u : 0u) : moved;
+                    adir = (lane == a && aok && kind == SGW_ACTION_MOVE && ndir < 4u) ? ndir : adir;   // movement() turns the agent even if the move fails
+                    rew_bits = lane == a ? __float_as_uint((float)val) : rew_bits;
+                    tot += val * (double)(p.total_factor - 1);   // the extra add inside act() (agents.py:172) ...
+                    tot += val;                                  // ... and Agent.transition's own (agent.py:172)
+                    gsync<1>();
+                    continue;
+                }
+            }
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[valid ? s_t : (uint32_t)s_o]);
+            const bool tok = valid && t < (uint32_t)p.T;
+            const uint32_t tl = t & 31u;
+            const uint32_t v_lo = (uint32_t)__builtin_amdgcn_readlane((int)vt_lo, (int)tl);
+            const uint32_t v_hi = (uint32_t)__builtin_amdgcn_readlane((int)vt_hi, (int)tl);
+            const uint32_t v_f = (uint32_t)__builtin_amdgcn_readlane((int)vt_f32, (int)tl);
+            const bool pass = tok && ((p.pass_mask >> tl) & 1u);
+            if (pass && lane == 0) {
+                lg[s_t] = (uint8_t)my_type;
+                lg[s_o] = (uint8_t)p.default_type;
+            }
+            moved = lane == a ? (pass ? 1u : 0u) : moved;
+            if constexpr (!TAG) {
+                if (tok) tot += __longlong_as_double(((long long)v_hi << 32) | v_lo);   // reward BEFORE the move; float64, agent order
+                rew_bits = lane == a ? (tok ? v_f : 0u) : rew_bits;
+            } else {
+                // ---- TagAgent.act (sorrel/examples/tag/agents.py:84-106), scalar: the four neighbours of the
+                // cell the agent now stands on, in Location.adjacent order (up, right, down, left; off-map
+                // skipped); an agent that is "it" hands the flag to the first NotIt neighbour.
+                gsync<1>();
+                pov_type = lane == a ? my_type : pov_type;
+                const uint32_t np_a = (uint32_t)__builtin_amdgcn_readlane((int)npos, a);
+                const int cy = pass ? (int)(np_a & 0xFFu) : (int)(((uint32_t)s_o - (uint32_t)zoff) / (uint32_t)W);
+                const int cx = pass ? (int)((np_a >> 8) & 0xFFu) : (int)(((uint32_t)s_o - (uint32_t)zoff) % (uint32_t)W);
+                const int own = zoff + cy * W + cx;
+                uint32_t nt[4];
+                bool ain[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0), ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                    ain[d] = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                    nt[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[ain[d] ? zoff + ay * W + ax : own]);
+                }
+                int dstar = -1;
+#pragma unroll
+                for (int d = 3; d >= 0; --d)
+                    if (ain[d] && nt[d] == p.tag_notit) dstar = d;
+                uint32_t mine_now = my_type;
+                if (my_type == p.tag_it && dstar >= 0) {
+                    const int ay = cy + (dstar == 0 ? -1 : dstar == 2 ? 1 : 0), ax = cx + (dstar == 1 ? 1 : dstar == 3 ? -1 : 0);
+                    if (lane == 0) {
+                        lg[own] = (uint8_t)p.tag_notit;
+                        lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
+                    }
+                    // who stands there: lane b's current position is its start position or, if it moved, its target
+                    const uint32_t curpos = moved ? npos : yx;
+                    const uint32_t key = (uint32_t)ay | ((uint32_t)ax << 8);
+                    atype = (lane < p.A && lane != a && curpos == key) ? p.tag_it : atype;
+                    atype = lane == a ? p.tag_notit : atype;
+                    mine_now = p.tag_notit;
+                }
+                const double val = mine_now != p.tag_it ? p.tag_reward : 0.0;
+                tot += val;
+                rew_bits = lane == a ? __float_as_uint((float)val) : rew_bits;
+            }
+            if (valid && !tok) st_lane |= SGW_STATUS_BAD_TYPE;
+            gsync<1>();
+        }
+
+        STAMP(4);   // agent loop done
+        if constexpr (kStageAlways) {
+            if (write_obs) emit_chunk(ch_a0, p.a1);
+        } else if (stage && write_obs) {
+            gsync<1>();
+            const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
+            const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
+            if (!p.obs_u8) {
+                // Non-temporal (streaming) stores: every wave instruction here writes eight whole 128-byte lines that
+                // nothing reads again in this launch; keeping them out of the caches leaves those to the grids (134 MB,
+                // re-read next turn) and takes config 3 from 167 to 125-132 us.  (The same hint on the per-agent dword
+                // stores of the unstaged path, which write partial lines, was measured SLOWER.)
+                typedef float vfloat4 __attribute__((ext_vector_type(4)));
+                vfloat4* o4 = reinterpret_cast<vfloat4*>(p.obs + turn_obs + env * (int64_t)(p.A * C * VV));
+                for (int i = lane; i < nd; i += 64) {
+                    const uint32_t b = ob4[i];
+                    vfloat4 v;
+                    v.x = (float)(b & 0xFFu);
+                    v.y = (float)((b >> 8) & 0xFFu);
+                    v.z = (float)((b >> 16) & 0xFFu);
+                    v.w = (float)(b >> 24);
+                    __builtin_nontemporal_store(v, &o4[i]);
+                }
+            } else {
+                uint32_t* o1 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.obs) + turn_obs + env * (int64_t)(p.A * C * VV));
+                for (int i = lane; i < nd; i += 64) __builtin_nontemporal_store(ob4[i], &o1[i]);   // two whole lines per wave instruction
+            }
+        }
+        if (p.do_move && mine) {      // this turn's rewards (and what TagAgent.pov appends)
+            p.rewards[tix * p.ts_rew + env * p.A + lane] = __uint_as_float(rew_bits);
+            if (p.state_at_pov) p.state_at_pov[env * p.A + lane] = (uint8_t)pov_type;
+        }
+        if (tix + 1 < nturns) yx = moved ? npos : yx;   // the next turn starts where this one ended
+        }   // turns
+        if (dirty) {
+            if (!TAG && !RULES && !do_sweep) {
+                // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
+                // not the whole grid (two movers touching one cell both write its FINAL content: no race)
+                if (mine && moved) {
+                    uint8_t* g = p.grid + env * p.env_stride;
+                    g[oaddr_v] = lg[oaddr_v];
+                    g[taddr_v] = lg[taddr_v];
+                }
+            } else {
+                uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
+            }
+        }
+        if (p.do_move) {
+            if (mine) {
+                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)(moved ? npos : yx);
+                if (st_lane) atomicOr(p.status, st_lane);
+            }
+            if (TAG && p.agent_state && lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)atype;   // a tag can flip any agent
+            if (RULES && p.agent_dir && lane < p.A) p.agent_dir[env * p.A + lane] = (uint8_t)adir;
+            if (lane == 0) p.total[env] = tot;
+        }
+        STAMP(5);   // all stores issued
+#ifdef SGW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(6);   // all stores acknowledged
+    }
+}
+

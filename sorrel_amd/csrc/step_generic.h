@@ -1,0 +1,341 @@
+// step_generic.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
+// step_kernel<G, ONEHOT, L, C, RULE>: every shape and rule; 256 / 64 / 32 / 16 lanes per env (small envs share a wave).
+#pragma once
+
+// ---------------------------------------------------------------- step kernel
+// Per-env LDS slice: [grid cells_pad][pos 2*64][act 64][rew f32 x64]
+constexpr int kPosOff = 0;
+constexpr int kActOff = 2 * SGW_MAX_AGENTS;
+constexpr int kRewOff = kActOff + SGW_MAX_AGENTS;
+constexpr int kTypeOff = kRewOff + 4 * SGW_MAX_AGENTS;   // current type of each agent
+constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it observed
+constexpr int kDirOff = kPovOff + SGW_MAX_AGENTS;       // its facing (Cleanup)
+constexpr int kAgentLds = kDirOff + SGW_MAX_AGENTS;     // 640 bytes, multiple of 16
+
+#ifndef SGW_GENERIC_WAVES
+#define SGW_GENERIC_WAVES 6
+#endif
+// G = threads per environment: 256 (a workgroup per env, worlds above 4 KiB), 64 (a wave per env) or, for small worlds,
+// 32 / 16 lanes of a wave -- two or four envs share a wave and its instruction stream.  The kernel keeps every piece of
+// per-env state in the group's LDS slice and uses no cross-lane instruction, so a sub-wave group needs nothing but the
+// wave-level ordering of DS instructions; what it buys is that the per-env instruction count, which bounds small worlds
+// (a 21x21x2 world keeps 29 of 64 lanes busy in the sweep and 25 in the window gather), is shared by 2 or 4 envs.
+template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE>
+__global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
+    constexpr int EPB = kBlock / G;    // envs per workgroup
+    const int tid = threadIdx.x;
+    const int sub = tid / G;
+    const int gtid = tid - sub * G;
+
+    // constant tables -> LDS (once per workgroup)
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(p.tab);
+        uint4* d = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < (p.tab_bytes >> 4); i += kBlock) d[i] = s[i];
+    }
+    __syncthreads();
+    const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
+    uint8_t* slice = smem + p.tab_bytes + sub * p.env_lds;
+    uint8_t* lg = slice;                              // grid
+    uint8_t* s_pos = slice + p.cells_pad + kPosOff;   // [A][2]
+    uint8_t* s_act = slice + p.cells_pad + kActOff;   // [A]
+    float* s_rew = reinterpret_cast<float*>(slice + p.cells_pad + kRewOff);
+    uint8_t* s_type = slice + p.cells_pad + kTypeOff;   // [A] current entity type of each agent
+    uint8_t* s_pov = slice + p.cells_pad + kPovOff;     // [A] its type when it observed
+    uint8_t* s_dir = slice + p.cells_pad + kDirOff;     // [A] its facing
+
+    // window cell(s) this thread renders: fixed for the whole kernel
+    int wi[kMaxPass], wj[kMaxPass];
+#pragma unroll
+    for (int k = 0; k < kMaxPass; ++k) {
+        const int w = gtid + k * G;
+        wi[k] = w / p.V;
+        wj[k] = w - wi[k] * p.V;
+    }
+    const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
+    const bool dirty = (p.flags & SGW_STEP_SWEEP) || (p.do_move && p.a1 > p.a0);
+    const int zoff = p.zA * p.H * p.W;
+    const int HW = p.H * p.W;
+
+    // one env per group and launch (no persistent loop: nothing stays live from one env to the next, and the
+    // dispatcher balances the workgroups)
+    const int64_t env = (int64_t)blockIdx.x * EPB + sub;
+    if (env < p.E) {
+        const uint32_t env_id = p.first_env + (uint32_t)env;
+        uint8_t* ggrid = p.grid + env * p.env_stride;
+        load_grid<G>(p, ggrid, lg, gtid);
+        double tot = 0.0;
+        if (gtid == 0 && p.do_move) tot = p.total[env];
+        uint32_t yx0 = 0;                     // this thread's agent: position at the start of the call
+        if (gtid < p.A) {
+            uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
+            if ((yx & 0xFF) >= p.H || (yx >> 8) >= p.W) {   // garbage in: stay inside this env's LDS slice, and say so
+                yx = 0;
+                atomicOr(p.status, SGW_STATUS_BAD_POS);
+            }
+            yx0 = yx;
+            reinterpret_cast<uint16_t*>(s_pos)[gtid] = yx;
+            s_type[gtid] = p.agent_state ? p.agent_state[env * p.A + gtid] : tab->agent_type[gtid];
+            s_dir[gtid] = p.agent_dir ? p.agent_dir[env * p.A + gtid] : (uint8_t)2;
+        }
+        int st_bits = 0;
+        // sgw_rollout: nturns whole turns on the LDS-resident env (nturns == 1: an ordinary sgw_step / sgw_observe)
+        for (uint32_t tix = 0; tix < p.nturns; ++tix) {
+        const uint32_t turn = p.turn + tix;
+        if (gtid < p.A && p.do_move && gtid >= p.a0 && gtid < p.a1) {
+            uint8_t* acts = p.actions + tix * p.ts_act;
+            uint32_t act;
+            if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
+                const U4 w = philox4x32_10((uint32_t)gtid >> 2, turn, env_id,
+                                           (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+                act = (uint32_t)(((uint64_t)word_of(w, gtid & 3) * (uint32_t)p.nact) >> 32);
+                acts[env * p.A + gtid] = (uint8_t)act;
+            } else {
+                act = acts[env * p.A + gtid];
+            }
+            s_act[gtid] = (uint8_t)act;
+        }
+        gsync<WPE>();
+        if (p.flags & SGW_STEP_SWEEP) {
+            if (p.has_become) {
+                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid, turn);
+            } else {
+                if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid, turn);
+                else sweep<G>(p, tab, lg, env_id, gtid, turn);
+                gsync<WPE>();
+            }
+        }
+
+        const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;   // OBS_NEXT: one extra, observe-only iteration
+        for (int a = p.a0; a < a_end; ++a) {
+            const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
+            // ---- pov: egocentric window (visual_field.py:9-101)
+            if (p.obs_next ? a == p.a1 : write_obs) {
+                float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * p.VV;
+                auto render = [&](const int w, const int i, const int j) {
+                    const int gy = y - p.r + i, gx = x - p.r + j;
+                    const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                    const int off = gy * p.W + gx;
+                    float* o = obase + w;
+                    if constexpr (ONEHOT) {
+                        constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
+                        const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
+                        uint32_t cnt[NWq];
+#pragma unroll
+                        for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
+                        const int nw = (Cn + 3) >> 2;
+                        if (inb) {
+#pragma unroll
+                            for (int z = 0; z < (TL ? TL : 1); ++z) {
+                                const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                for (int q = 0; q < NWq; ++q)
+                                    if (q < nw) cnt[q] += tab->delta[q][t];
+                            }
+                            if constexpr (TL == 0) {
+                                for (int z = 1; z < Ln; ++z) {
+                                    const uint32_t t = lg[z * HW + off] & 31u;
+#pragma unroll
+                                    for (int q = 0; q < NWq; ++q)
+                                        if (q < nw) cnt[q] += tab->delta[q][t];
+                                }
+                            }
+                        } else {   // fill entity's appearance, once (visual_field.py:89-94)
+#pragma unroll
+                            for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NWq; ++q) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int c = 4 * q + b;
+                                if (c < Cn) {
+                                    const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                                    if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * p.VV] = (uint8_t)v;
+                                    else o[c * p.VV] = (float)v;
+                                }
+                            }
+                        }
+                    } else {
+                        for (int c = 0; c < p.C; ++c) {
+                            double acc;
+                            if (inb) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
+                                acc = tab->appearance[lg[off] & 31u][c];
+                                for (int z = 1; z < p.L; ++z) acc += tab->appearance[lg[z * HW + off] & 31u][c];
+                            } else {
+                                acc = tab->appearance[p.fill_type][c];
+                            }
+                            o[c * p.VV] = obs_finish(acc, p.obs_post);
+                        }
+                    }
+                };
+#pragma unroll
+                for (int k = 0; k < kMaxPass; ++k) {
+                    const int w = gtid + k * G;
+                    if (w < p.VV) render(w, wi[k], wj[k]);
+                }
+                {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
+                    int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
+                    for (int w = gtid + kMaxPass * G; w < p.VV; w += G) {
+                        j += G;
+                        while (j >= p.V) { j -= p.V; ++i; }
+                        render(w, i, j);
+                    }
+                }
+            }
+            if (!p.do_move || a >= p.a1) continue;
+            if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
+                // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
+                // same LDS bytes, so all control flow here is uniform; single threads do the writes.
+                const uint32_t act = s_act[a];
+                const uint32_t my_type = s_type[a];
+                const bool act_ok = act < (uint32_t)p.nact;
+                const uint32_t kind = act_ok ? (p.kind_pack >> (2 * act)) & 3u : 0u;
+                const int dy = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
+                const int dx = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
+                const int ny = y + dy, nx = x + dx;
+                const uint32_t facing = s_dir[a] & 3u;
+                gsync<WPE>();
+                if (act_ok && kind != SGW_ACTION_MOVE && p.zA + 1 < p.L && gtid < 3 * p.beam_radius) {
+                    // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
+                    const int arm = gtid / p.beam_radius, i = gtid - arm * p.beam_radius;
+                    const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
+                    const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
+                    const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                    const int by = y + side * ry + step * fy, bx = x + side * rx + step * fx;
+                    if ((unsigned)by < (unsigned)p.H && (unsigned)bx < (unsigned)p.W) {
+                        const int boff = (p.zA + 1) * HW + by * p.W + bx;
+                        if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
+                            lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
+                    }
+                }
+                gsync<WPE>();
+                const bool inb = act_ok && (unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W;
+                double val = 0.0;
+                uint32_t t = 0xFFu;
+                if (inb) {
+                    for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * p.W + nx] & 31u];   // all layers, BEFORE the move
+                    t = lg[zoff + ny * p.W + nx];
+                }
+                const bool pass = inb && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                gsync<WPE>();
+                if (gtid == 0) {
+                    s_pov[a] = (uint8_t)my_type;
+                    if (act_ok && kind == SGW_ACTION_MOVE) {            // movement() turns the agent even if the move fails
+                        if (dy == -1 && dx == 0) s_dir[a] = 0;
+                        else if (dy == 1 && dx == 0) s_dir[a] = 2;
+                        else if (dy == 0 && dx == -1) s_dir[a] = 3;
+                        else if (dy == 0 && dx == 1) s_dir[a] = 1;
+                    }
+                    if (pass) {
+                        lg[zoff + ny * p.W + nx] = (uint8_t)my_type;
+                        lg[zoff + y * p.W + x] = (uint8_t)p.default_type;
+                        s_pos[2 * a] = (uint8_t)ny;
+                        s_pos[2 * a + 1] = (uint8_t)nx;
+                    }
+                    s_rew[a] = (float)val;
+                    tot += val * (double)(p.total_factor - 1);       // the extra add inside act() (agents.py:172) ...
+                    tot += val;                                      // ... and Agent.transition's own (agent.py:172)
+                    st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0);
+                }
+                gsync<WPE>();
+                continue;
+            }
+            // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
+            const uint32_t act = s_act[a];
+            const uint32_t my_type = s_type[a];
+            const bool act_ok = act < (uint32_t)p.nact;
+            const int dy = act_ok ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
+            const int dx = act_ok ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
+            const int ty = y + dy, tx = x + dx;
+            const bool inb = act_ok && (unsigned)ty < (unsigned)p.H && (unsigned)tx < (unsigned)p.W;
+            const int taddr = zoff + ty * p.W + tx;
+            const int oaddr = zoff + y * p.W + x;
+            const uint32_t t = inb ? lg[taddr] : 0xFFu;
+            const bool tok = t < (uint32_t)p.T;
+            double val = (inb && tok && RULE == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
+            const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
+            const int cy = pass ? ty : y, cx = pass ? tx : x;   // where the agent stands after the move
+            gsync<WPE>();   // every thread has read s_type / the target before thread 0 rewrites them
+            if (gtid == 0) {
+                s_pov[a] = (uint8_t)my_type;
+                if (pass) {
+                    lg[taddr] = (uint8_t)my_type;
+                    lg[oaddr] = (uint8_t)p.default_type;
+                    s_pos[2 * a] = (uint8_t)ty;
+                    s_pos[2 * a + 1] = (uint8_t)tx;
+                }
+                st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
+                           ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
+            }
+            if constexpr (RULE == SGW_AGENT_RULE_TAG) {
+                // TagAgent.act (sorrel/examples/tag/agents.py:84-106): look at the four neighbours in
+                // Location.adjacent order (up, right, down, left; off-map skipped); an agent that is
+                // "it" hands the flag to the FIRST neighbour that is a NotIt agent.  Every thread
+                // evaluates the same LDS bytes, so `mine_now` stays uniform.
+                gsync<WPE>();
+                uint32_t mine_now = my_type;
+                const int own = zoff + cy * p.W + cx;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
+                    const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                    const bool ain = (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
+                    const uint32_t nt = ain ? lg[zoff + ay * p.W + ax] : 0xFFu;
+                    if (mine_now == p.tag_it && nt == p.tag_notit) {
+                        mine_now = p.tag_notit;
+                        if (gtid == 0) {
+                            lg[own] = (uint8_t)p.tag_notit;
+                            lg[zoff + ay * p.W + ax] = (uint8_t)p.tag_it;
+                            s_type[a] = (uint8_t)p.tag_notit;
+                        }
+                        // the neighbour's slot: the agent standing on (ay, ax)
+                        if (gtid < p.A && gtid != a && s_pos[2 * gtid] == ay && s_pos[2 * gtid + 1] == ax)
+                            s_type[gtid] = (uint8_t)p.tag_it;
+                    }
+                }
+                val = mine_now != p.tag_it ? p.tag_reward : 0.0;
+            }
+            if (gtid == 0) {
+                s_rew[a] = (float)val;
+                tot += val;   // world.total_reward += reward, float64, agent order (agent.py:172)
+            }
+            gsync<WPE>();
+        }
+        if (p.do_move && gtid >= p.a0 && gtid < p.a1) {      // this turn's rewards (and what TagAgent.pov appends)
+            p.rewards[tix * p.ts_rew + env * p.A + gtid] = s_rew[gtid];
+            if (p.state_at_pov) p.state_at_pov[env * p.A + gtid] = s_pov[gtid];
+        }
+        }   // turns
+
+        if (dirty) {
+            if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP)) {
+                // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
+                // not the whole grid (with agents i < j both touching a cell, both write its FINAL content: no race)
+                if (gtid >= p.a0 && gtid < p.a1) {
+                    const uint32_t now = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
+                    if (now != yx0) {
+                        const int o0 = zoff + (int)(yx0 & 0xFFu) * p.W + (int)(yx0 >> 8), o1 = zoff + (int)(now & 0xFFu) * p.W + (int)(now >> 8);
+                        ggrid[o0] = lg[o0];
+                        ggrid[o1] = lg[o1];
+                    }
+                }
+            } else {
+                store_grid<G>(p, ggrid, lg, gtid);
+            }
+        }
+        if (p.do_move) {
+            if (gtid >= p.a0 && gtid < p.a1)
+                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
+            if (gtid < p.A && p.agent_state) p.agent_state[env * p.A + gtid] = s_type[gtid];   // a tag can flip any agent
+            if (gtid < p.A && p.agent_dir) p.agent_dir[env * p.A + gtid] = s_dir[gtid];
+            if (gtid == 0) {
+                p.total[env] = tot;
+                if (st_bits) atomicOr(p.status, st_bits);
+            }
+        }
+    }
+}
+

@@ -1,7 +1,7 @@
 """GridEngine: owns the state tensors of E environments and drives the HIP kernels.
 
 PyTorch is plumbing here (device memory, streams); all step/observe/reset
-arithmetic runs in ``sorrel_amd/csrc/sgw.hip`` through the C ABI of
+arithmetic runs in ``sorrel_amd/csrc/`` (``sgw.hip`` + the kernel headers it includes) through the C ABI of
 ``include/sgw.h``.  There is no CPU path: constructing an engine on a non-GPU
 device raises.
 """

@@ -846,6 +846,8 @@ def main() -> int:
     assert (ref["grid"] == 7).any() and (ref["grid"] == 9).any() and (ref["grid"] == 4).any(), "beams / pollution never appeared"
     save("cleanup_15x16", spec, ids, ref)
 
+    make_round2_fixtures(R)
+
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)
     spec = O.treasurehunt_spec(10, 10, 2, 2, spawn_prob=0.05, seed=0)
@@ -860,6 +862,32 @@ def main() -> int:
     print(f"done in {time.time() - t0:.1f}s")
     return 0
 
+
+
+def make_round2_fixtures(R):
+    """More reference-generated pins for the widened rule sets (round 2): Cleanup at the example's own shape and at a
+    small odd one with another beam radius, Tag at the example's own shape."""
+    print("cleanup_21x31_default: examples/cleanup at its configured shape (21x31x3, 10 agents, 11x11 window)")
+    spec = cleanup_spec(21, 31, 10, 5, seed=43, beam_radius=3, pollution_p=0.05, apple_p=0.03)
+    ids = [3]
+    ref = run_reference_cleanup(R, spec, ids, 14, initial_apples=20)
+    check_against_oracle(spec, ids, 14, ref, injected=True)
+    save("cleanup_21x31_default", spec, ids, ref)
+
+    print("cleanup_13x12_r2: small odd-sized Cleanup world, beam radius 2, 3 agents")
+    spec = cleanup_spec(13, 12, 3, 2, seed=44, beam_radius=2, pollution_p=0.08, apple_p=0.05)
+    ids = [1, 6]
+    ref = run_reference_cleanup(R, spec, ids, 30, initial_apples=4)
+    check_against_oracle(spec, ids, 30, ref, injected=True)
+    assert (ref["grid"] == 7).any() or (ref["grid"] == 9).any(), "no beam was ever fired"
+    save("cleanup_13x12_r2", spec, ids, ref)
+
+    print("tag_11x11_default: examples/tag at its configured shape (11x11, 5 agents, 9x9 window)")
+    spec = tag_spec(11, 11, 5, 4, seed=45)
+    ids = [2, 5]
+    ref = run_reference_tag(R, spec, ids, 25)
+    check_against_oracle(spec, ids, 25, ref)
+    save("tag_11x11_default", spec, ids, ref)
 
 
 def make_buffer_fixture():
@@ -923,5 +951,8 @@ def make_buffer_fixture():
 if __name__ == "__main__":
     if sys.argv[1:] == ["buffers"]:      # only the replay-buffer fixtures
         make_buffer_fixture()
+        sys.exit(0)
+    if sys.argv[1:] == ["round2"]:       # only the fixtures added in round 2
+        make_round2_fixtures(_import_reference())
         sys.exit(0)
     sys.exit(main())

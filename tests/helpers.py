@@ -21,7 +21,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 NON_WORLD_FIXTURES = {"buffer_ring", "buffer_saved_by_reference", "savedgames_by_reference"}   # fixtures that are not step-loop traces
-INJECTED_FIXTURES = {"cleanup_15x16"}  # worlds populated by host code: runs start from the stored grid0 / pos0
+INJECTED_FIXTURES = {"cleanup_15x16", "cleanup_21x31_default", "cleanup_13x12_r2"}  # worlds populated by host code: runs start from the stored grid0 / pos0
 
 
 def golden_names():

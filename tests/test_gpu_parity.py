@@ -192,7 +192,7 @@ def test_tag_rule_batch_vs_oracle(torch_cuda):
 
 
 @pytest.mark.parametrize("name", ["c2_treasurehunt_16x16", "crowded_6x6", "tag_9x9", "tag_crowded_6x7", "rgb_treasurehunt",
-                                  "c5_small_dense", "basic_doublewall", "cleanup_15x16"])
+                                  "c5_small_dense", "basic_doublewall", "cleanup_15x16", "tag_11x11_default", "cleanup_21x31_default"])
 def test_generic_kernel_matches_reference_golden(torch_cuda, name, monkeypatch):
     """The fallback kernel (any shape, every rule) on fixtures the specialised kernels would take."""
     monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
@@ -220,7 +220,8 @@ def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
 @pytest.mark.parametrize("group", ["16", "32"])
 @pytest.mark.parametrize("name", ["c1_treasurehunt_10x10", "c2_treasurehunt_16x16", "crowded_6x6", "tag_9x9", "tag_crowded_6x7",
                                   "rgb_treasurehunt", "basic_doublewall", "float_appearance_3layer", "ragged_9x13_rmax",
-                                  "scripted_noop", "cleanup_15x16", "basic_1layer", "c3_treasurehunt_32x32"])
+                                  "scripted_noop", "cleanup_15x16", "basic_1layer", "c3_treasurehunt_32x32", "tag_11x11_default",
+                                  "cleanup_13x12_r2", "cleanup_21x31_default"])
 def test_packed_kernels_match_reference_golden(torch_cuda, name, group, monkeypatch):
     """Two / four envs per wave (step_kernel<32> / <16>): every fixture small enough, bit for bit."""
     monkeypatch.setenv("SGW_GROUP", group)

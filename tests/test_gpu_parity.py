@@ -688,3 +688,35 @@ def test_config5_per_gpu_size_properties(torch_cuda):
     eng = make_engine(ws, 2048)
     eng.reset(0)
     check_properties(torch, eng, ws, 3)
+
+
+@pytest.mark.parametrize("which", ["config3_rank0", "config4_last_rank", "config5_rank0", "config5_last_rank"])
+def test_full_size_batches_full_tensor_vs_oracle(torch_cuda, which):
+    """BASELINE configs 3 / 4 / 5 at their FULL per-GPU sizes, every element of every tensor against the C oracle (its
+    OpenMP rollout over all host cores does a 65 536-env turn in well under a second): observations (617 MB per turn at
+    config 3), actions, rewards, grid, positions, total_reward.  "config4_last_rank" / "config5_last_rank" are the shards
+    the eighth GPU of configs 4 / 5 owns (global env ids 458 752 ... and 14 336 ...): the RNG is keyed by the GLOBAL env
+    id, so this is what the 8-rank run computes there."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    if which.startswith("config5"):
+        ws, E, T = treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=0, dense_prob=0.25), 2048, 3
+    else:
+        ws, E, T = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=0), 65536, 3
+    first = 7 * E if which.endswith("last_rank") else 0
+    eng = make_engine(ws, E, first=first)
+    co = H.COracle(ws, E, first_env_id=first, threads=0)
+    eng.reset(0)
+    co.reset(0)
+    assert_same(eng, co, ("grid", "pos", "total"), ctx=f"{which} reset")
+    for t in range(1, T + 1):
+        eng.step(random_actions=True)
+        assert co.step(0, t, random_actions=True) == 0
+        assert_same(eng, co, ctx=f"{which} turn {t}")
+    # and the same turns once more through sgw_rollout on a second engine: identical final state and last-turn tensors
+    ro = make_engine(ws, E, first=first)
+    ro.reset(0)
+    ro.rollout(T)
+    assert_same(ro, co, ctx=f"{which} rollout")
+    assert eng.status() == 0 and ro.status() == 0

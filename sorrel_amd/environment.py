@@ -326,6 +326,21 @@ class Environment:
             for agent in self.agents:
                 agent.transition(self.world)
 
+    def rollout(self, turns: int) -> None:
+        """``turns`` fused ``take_turn``s with ONE engine call (``sgw_rollout``: one launch with every env's grid resident
+        in LDS where the kernel supports it) -- for agents whose actions are drawn on device (``RandomModel``).  The
+        step outputs (``obs`` / ``rewards`` / ``actions``) hold the last turn afterwards, as after ``turns`` calls of
+        ``take_turn``."""
+        if not all(getattr(a.model, "device_random", False) for a in self.agents):
+            raise ValueError("rollout() needs device-random models; policy-driven agents step turn by turn (take_turn)")
+        if turns <= 0:
+            return
+        eng = self._ensure_engine()
+        eng.epoch, eng.turn = self.epoch, self.turn
+        self._fresh_obs = None
+        eng.rollout(int(turns))
+        self.turn += int(turns)
+
     def raise_on_status(self) -> None:
         """Synchronising poll of the device status word: raises what the reference would have raised
         (``IndexError`` for a move off an un-walled border, ``KeyError`` for an action index outside the
@@ -508,6 +523,8 @@ class Environment:
             self.reset()
             for agent in self.agents:
                 agent.model.start_epoch_action(epoch=epoch)
+            if all(getattr(a.model, "device_random", False) for a in self.agents) and not self.stop_if_done:
+                self.rollout(max_turns - self.turn)        # the whole epoch in one engine call
             while self.turn < max_turns:
                 self.take_turn()
                 if self.world.is_done and self.stop_if_done:

@@ -501,3 +501,41 @@ def test_rollout_on_the_widened_rule_sets(torch_cuda, which, monkeypatch):
         if a is not None:
             assert torch.equal(a, b), (which, name)
     assert one.status() == 0 and many.status() == 0
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "24"))))
+def test_rollout_soak_random_worlds(torch_cuda, case, monkeypatch):
+    """Soak: sgw_rollout against turn-by-turn stepping on random worlds (plain, Tag, Cleanup, layered rules), random
+    kernel choices (dispatcher's own, packed 16 / 32, generic), random turn counts and ring strides."""
+    torch = torch_cuda
+    rng = np.random.default_rng(9000 + case)
+    ws, g, pos = H.random_rule_world(rng)
+    pick = case % 4
+    if pick == 1 and ws.num_agents <= 16 and (ws.agent_rule != 2 or 3 * ws.beam_radius <= 16):
+        monkeypatch.setenv("SGW_GROUP", "16")
+    elif pick == 2 and ws.num_agents <= 32 and (ws.agent_rule != 2 or 3 * ws.beam_radius <= 32):
+        monkeypatch.setenv("SGW_GROUP", "32")
+    elif pick == 3:
+        monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    E, T = int(rng.integers(2, 40)), int(rng.integers(2, 9))
+    first = int(rng.integers(0, 2**31))
+    one, many = make_engine(ws, E, first=first), make_engine(ws, E, first=first)
+    for e in (one, many):
+        e.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+        e.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+        e.total_reward.zero_()
+        e.epoch = 3
+    ring = torch.full((T, E) + tuple(ws.obs_shape), -1.0, device="cuda:0")
+    rew = torch.zeros((T, E, ws.num_agents), device="cuda:0")
+    act = torch.zeros((T, E, ws.num_agents), dtype=torch.uint8, device="cuda:0")
+    many.rollout(T, obs_out=ring, rewards_out=rew, actions_out=act)
+    for t in range(T):
+        one.step(random_actions=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ring[t], one.obs), (case, t, "obs")
+        assert torch.equal(rew[t], one.rewards) and torch.equal(act[t], one.actions), (case, t)
+    for name in ("grid", "agent_pos", "total_reward", "agent_state", "agent_dir"):
+        a, b = getattr(one, name, None), getattr(many, name, None)
+        if a is not None:
+            assert torch.equal(a, b), (case, name)
+    assert one.status() == many.status()

@@ -720,3 +720,35 @@ def test_full_size_batches_full_tensor_vs_oracle(torch_cuda, which):
     ro.rollout(T)
     assert_same(ro, co, ctx=f"{which} rollout")
     assert eng.status() == 0 and ro.status() == 0
+
+
+@pytest.mark.parametrize("group", ["16", "32"])
+def test_packed_kernels_edge_shapes(torch_cuda, group, monkeypatch):
+    """Packed kernels at their limits: as many agents as lanes per env, the widest window a small world allows (many
+    render passes per agent), 13 channels (second counter word), five layers, a world of exactly 4 096 bytes, batches of
+    one env and of 64 / G + 1 envs (one group of the last wave), general float appearance."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_GROUP", group)
+    G = int(group)
+    rollout_vs_oracle(treasurehunt_spec(12, 12, G, 2, spawn_prob=0.1, seed=1, dense_prob=0.2), 37, 5)          # A == G
+    rollout_vs_oracle(treasurehunt_spec(27, 23, 3, 11, spawn_prob=0.05, seed=2), 19, 4)                          # 23x23 window: 529 cells
+    rollout_vs_oracle(treasurehunt_spec(64, 32, 5, 4, spawn_prob=0.02, seed=3), 9, 4)                            # 4 096 bytes
+    rollout_vs_oracle(treasurehunt_spec(9, 9, 2, 3, spawn_prob=0.2, seed=4), 1, 6)                               # one env
+    rollout_vs_oracle(treasurehunt_spec(9, 9, 2, 3, spawn_prob=0.2, seed=4), 64 // G + 1, 6, first=123456789)
+    ws = treasurehunt_spec(14, 14, 3, 3, spawn_prob=0.1, seed=5)
+    ws.num_channels = 13
+    app = np.zeros((7, 13))
+    for t, ch in enumerate([0, 0, 12, 9, 3, 8, 11]):
+        if t >= 2:
+            app[t, ch] = 1.0
+    ws.appearance = app
+    rollout_vs_oracle(ws, 21, 5)
+    ws = treasurehunt_spec(10, 11, 4, 2, spawn_prob=0.1, seed=6)
+    ws.layers = 5
+    ws.layer_fill_type = ws.layer_fill_type + [0, 0, 0]
+    ws.layer_border_type = ws.layer_border_type + [255, 2, 255]
+    rollout_vs_oracle(ws, 30, 5)
+    ws = treasurehunt_spec(11, 13, 3, 2, spawn_prob=0.1, seed=7)
+    ws.appearance = np.asarray(ws.appearance) * np.array([[0.5], [1.0], [2.0], [1.5], [3.0], [0.25], [1.0]])     # not one-hot: float64 path
+    rollout_vs_oracle(ws, 25, 5)

@@ -229,54 +229,40 @@ class GridEngine:
         if T <= 0:
             return
         E, A = self.num_envs, self.spec.num_agents
-        flags = (N.STEP_SWEEP if sweep else 0)
-        if actions is not None:
-            if tuple(actions.shape) != (T, E, A) or actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
-                raise ValueError(f"actions must be contiguous uint8 [{T}, {E}, {A}] on {self.device}")
-            act, ts_act = actions, E * A
+
+        def per_turn(t, name, dtype, tail):
+            """A caller-owned ``[T, *tail]`` tensor the kernels fill turn by turn through a raw pointer."""
+            want = (T,) + tuple(tail)
+            if not torch.is_tensor(t) or tuple(t.shape) != want or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous {dtype} tensor of shape {want} on {self.device}")
+            return t, t[0].numel()
+
+        flags = N.STEP_SWEEP if sweep else 0
+        if actions is not None:                                  # scripted
+            act, ts_act = per_turn(actions, "actions", torch.uint8, (E, A))
+        elif not random_actions:
+            raise ValueError("rollout needs random_actions=True or an actions tensor")
         else:
-            if not random_actions:
-                raise ValueError("rollout needs random_actions=True or an actions tensor")
             flags |= N.STEP_RANDOM_ACTIONS
-            act, ts_act = self.actions, 0
-            if actions_out is not None:
-                if tuple(actions_out.shape) != (T, E, A) or actions_out.dtype != torch.uint8 or actions_out.device != self.device \
-                        or not actions_out.is_contiguous():
-                    raise ValueError(f"actions_out must be contiguous uint8 [{T}, {E}, {A}] on {self.device}")
-                act, ts_act = actions_out, E * A
-        rew, ts_rew = self.rewards, 0
-        if rewards_out is not None:
-            if tuple(rewards_out.shape) != (T, E, A) or rewards_out.dtype != torch.float32 or rewards_out.device != self.device \
-                    or not rewards_out.is_contiguous():
-                raise ValueError(f"rewards_out must be contiguous float32 [{T}, {E}, {A}] on {self.device}")
-            rew, ts_rew = rewards_out, E * A
-        obs, ts_obs = self.obs, 0
-        if obs_out is not None:
-            want = (T, E) + tuple(self.spec.obs_shape)
-            if tuple(obs_out.shape) != want or obs_out.dtype != self.obs_dtype or obs_out.device != self.device or not obs_out.is_contiguous():
-                raise ValueError(f"obs_out must be contiguous {self.obs_dtype} {want} on {self.device}")
-            obs, ts_obs = obs_out, obs_out[0].numel()
+            act, ts_act = (self.actions, 0) if actions_out is None else per_turn(actions_out, "actions_out", torch.uint8, (E, A))
+        rew, ts_rew = (self.rewards, 0) if rewards_out is None else per_turn(rewards_out, "rewards_out", torch.float32, (E, A))
+        obs, ts_obs = (self.obs, 0) if obs_out is None else per_turn(obs_out, "obs_out", self.obs_dtype, (E,) + tuple(self.spec.obs_shape))
         if not write_obs or obs is None:
             flags |= N.STEP_NO_OBS
             obs = None
-        first = self.turn + 1
         with torch.cuda.device(self.device):
             N.check(self._lib.sgw_rollout(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(act), self._ptr(obs),
-                                          self._ptr(rew), self._ptr(self.total_reward), self.epoch, first, T, ts_obs, ts_act, ts_rew,
-                                          flags, self._stream()))
-        if actions is not None and T > 0:
-            self.actions.copy_(actions[-1])
-        elif actions_out is not None:
-            self.actions.copy_(actions_out[-1])
-        if rewards_out is not None:
-            self.rewards.copy_(rewards_out[-1])
-        if obs_out is not None and self.obs is not None and write_obs:
-            pass   # self.obs is not touched when every turn goes to obs_out
+                                          self._ptr(rew), self._ptr(self.total_reward), self.epoch, self.turn + 1, T,
+                                          ts_obs, ts_act, ts_rew, flags, self._stream()))
+        # the engine's own per-turn tensors hold the LAST turn, as after T calls of step()
+        if act is not self.actions:
+            self.actions.copy_(act[-1])
+        if rew is not self.rewards:
+            self.rewards.copy_(rew[-1])
         self.turn += T
-        if self.max_turns:                       # the library reset the batch at every epoch boundary it crossed
-            while self.turn >= self.max_turns and self.max_turns:
-                self.turn -= self.max_turns
-                self.epoch += 1
+        while self.max_turns and self.turn >= self.max_turns:    # the library reset the batch at every epoch boundary it crossed
+            self.turn -= self.max_turns
+            self.epoch += 1
 
     def set_auto_reset(self, max_turns: int):
         """Arm (``max_turns > 0``) or disarm the in-stream reset at the end of turn ``max_turns``;

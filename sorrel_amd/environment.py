@@ -657,4 +657,4 @@ class Environment:
         torch.save(self.state_dict(), path)
 
     def load_checkpoint(self, path) -> None:
-        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))   # tensors and plain values only

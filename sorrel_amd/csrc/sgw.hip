@@ -695,7 +695,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // kernel, which does not stage the env (SGW_NO_PHASE_KERNEL=1: A/B and test hook).
     if (e->phase_ok && p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1)) {
         Params q = p;
-        q.env_lds = e->onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
+        q.env_lds = (e->onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8) + SGW_MAX_TYPES * 8;   // + the value table
         hipLaunchKernelGGL(e->onehot ? phase_kernel<true> : phase_kernel<false>, dim3((unsigned)ceil_div(p.E, 4)), dim3(kBlock),
                            (size_t)4 * q.env_lds, s, q);
         HIP_TRY(hipGetLastError());

@@ -79,6 +79,7 @@ struct Params {
     float* rewards;
     double* total;
     const DevTables* tab;
+    const uint8_t* tmpl;   // reset: the fill + border image of one env (cells_pad bytes, pad = 0xFF)
     int* status;
     int obs_stage;    // step_fast: bytes of the per-wave LDS observation staging area (0: observations go straight to HBM)
     int stage_agents; // step_fast<..., STAGE>: agents whose observations are staged together and leave in one burst

@@ -76,6 +76,7 @@ struct sgw_engine {
     sgw_config cfg;
     Params base;          // everything except per-call fields
     DevTables* d_tab = nullptr;
+    uint8_t* d_tmpl = nullptr;   // fill + border image of one env (reset)
     int* d_status = nullptr;
     double* d_part = nullptr;
     int obs_format = SGW_OBS_F32;
@@ -575,6 +576,18 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
 
     hipError_t err = hipMalloc(&e->d_tab, sizeof(DevTables));
     if (err == hipSuccess) err = hipMemcpy(e->d_tab, &h, sizeof(DevTables), hipMemcpyHostToDevice);
+    {   // the reset image: per layer the fill type, the border type around it; bytes past the last cell are not cells
+        std::vector<uint8_t> img((size_t)p.cells_pad, (uint8_t)0xFF);
+        for (int z = 0; z < c.layers; ++z)
+            for (int y = 0; y < c.height; ++y)
+                for (int x = 0; x < c.width; ++x) {
+                    const bool edge = y == 0 || y == c.height - 1 || x == 0 || x == c.width - 1;
+                    const uint8_t b = c.layer_border_type[z];
+                    img[((size_t)z * c.height + y) * c.width + x] = (b != SGW_NO_BORDER && edge) ? b : c.layer_fill_type[z];
+                }
+        if (err == hipSuccess) err = hipMalloc(&e->d_tmpl, img.size());
+        if (err == hipSuccess) err = hipMemcpy(e->d_tmpl, img.data(), img.size(), hipMemcpyHostToDevice);
+    }
     if (err == hipSuccess) err = hipMalloc(&e->d_status, 4 * sizeof(int));
     if (err == hipSuccess) err = hipMemset(e->d_status, 0, 4 * sizeof(int));
     if (err == hipSuccess) err = hipMalloc(&e->d_part, 2 * kRedBlocks * sizeof(double));
@@ -583,6 +596,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         return fail(SGW_EHIP, "device allocation failed: %s", hipGetErrorString(err));
     }
     p.tab = e->d_tab;
+    p.tmpl = e->d_tmpl;
     p.status = e->d_status;
 
     if (e->fast) e->step_fn_plain = pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, false, &e->kernel_name_plain);
@@ -623,7 +637,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     (void)nb;
     e->grid_blocks = (int)ceil_div(p.E, (e->fast || e->big) ? epb : epb_step);   // every step kernel: one env per group, the dispatcher balances
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
-    e->reset_blocks = (int)std::min<int64_t>(ceil_div(p.E, epb), nb);
+    e->reset_blocks = (int)ceil_div(p.E, epb);   // one env per group and launch
     *out = e;
     return SGW_OK;
 }
@@ -633,6 +647,7 @@ void sgw_destroy(sgw_engine* e) {
     for (hipEvent_t ev : e->ev0) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev1) (void)hipEventDestroy(ev);
     if (e->d_tab) (void)hipFree(e->d_tab);
+    if (e->d_tmpl) (void)hipFree(e->d_tmpl);
     if (e->d_status) (void)hipFree(e->d_status);
     if (e->d_part) (void)hipFree(e->d_part);
     delete e;

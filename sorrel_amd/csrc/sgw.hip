@@ -251,7 +251,8 @@ StepFn pick_step(int group, bool onehot, int L, int C, int rule, const char** na
 // the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
 // a loop of single-turn launches
 StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
-    if (onehot && rules && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true>);    // layered rule sets (Cleanup)
+    if (onehot && rules && stage && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, true>);   // Cleanup
+    if (onehot && rules && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true>);    // layered rule sets
     if (!onehot || tag || rules || L != 2 || C != 6) return nullptr;
     if (r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32, false, false, false, true>);
     if (r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16, false, false, false, true>);
@@ -279,6 +280,8 @@ StepFn pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
 
 StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
     if (rules) {
+        if (onehot && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true>);   // Cleanup's tables (3 layers, 9 kinds)
+        if (onehot && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true>);
         if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true>);
         PICK(step_fast<false, 0, 0, 0, 0, 0, false, true>);

@@ -482,6 +482,16 @@ class Environment:
     def total_reward(self):
         return self.world.total_reward
 
+    # ------------------------------------------------------------------ model hooks (overridable, environment.py:95-105)
+    def _model_start_epoch_action(self, agent: Agent, epoch: int):
+        agent.model.start_epoch_action(epoch=epoch)
+
+    def _model_end_epoch_action(self, agent: Agent, epoch: int):
+        agent.model.end_epoch_action(epoch=epoch)
+
+    def _model_train_step(self, agent: Agent):
+        return agent.model.train_step()
+
     # ------------------------------------------------------------------ epoch loops (environment.py:108-300)
     def _output_dir(self, output_dir) -> Path:
         if output_dir is None:
@@ -522,7 +532,7 @@ class Environment:
         for epoch in range(epochs + 1):
             self.reset()
             for agent in self.agents:
-                agent.model.start_epoch_action(epoch=epoch)
+                self._model_start_epoch_action(agent, epoch)
             if all(getattr(a.model, "device_random", False) for a in self.agents) and not self.stop_if_done:
                 self.rollout(max_turns - self.turn)        # the whole epoch in one engine call
             while self.turn < max_turns:
@@ -533,10 +543,10 @@ class Environment:
             self.raise_on_status()
             m = D.rollout_metrics(self._ensure_engine(), all_reduce=all_reduce)
             for agent in self.agents:
-                agent.model.end_epoch_action(epoch=epoch)
+                self._model_end_epoch_action(agent, epoch)
             total_loss = 0
             for agent in self.agents:
-                total_loss = agent.model.train_step()
+                total_loss = self._model_train_step(agent)
             m["loss"] = float(total_loss) if total_loss is not None else 0.0
             m["epsilon"] = float(getattr(self.agents[0].model, "epsilon", 0.0))
             history.append(m)
@@ -585,7 +595,7 @@ class Environment:
         for game in range(num_games):
             self.reset()
             for agent in self.agents:
-                agent.model.start_epoch_action(epoch=game)
+                self._model_start_epoch_action(agent, game)
             eng = self._ensure_engine()
             if fused:
                 if ring is None:
@@ -603,7 +613,7 @@ class Environment:
             self.world.is_done = True
             self.raise_on_status()
             for agent, sg in zip(self.agents, saved):
-                agent.model.end_epoch_action(epoch=game)
+                self._model_end_epoch_action(agent, game)
                 if not fused:
                     sg.add_from_buffer(agent.model.memory)
         os.makedirs(out_dir / "memories", exist_ok=True)

@@ -94,6 +94,9 @@ class MovingAgent(Agent):
     """Agent that moves up / down / left / right (``agent.py:176-225``)."""
 
     direction = 2
+    #: sprites of the four headings in the reference (PNG paths under ``sorrel/agents/assets``); sprite rendering is outside
+    #: this engine, the attribute exists so that subclasses that index it keep importing
+    sprite_directions = [None, None, None, None]
 
     def movement(self, action):
         """New location for an action: an int gives the env-0 tuple (reference call shape),

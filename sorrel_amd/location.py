@@ -116,3 +116,7 @@ class Vector:
         a = self.forward * f[0] + self.right * r[0] + self.backward * b[0] + self.left * l[0]
         c = self.forward * f[1] + self.right * r[1] + self.backward * b[1] + self.left * l[1]
         return Location(a, c, self.layer)
+
+    def to_tuple(self):
+        """The computed offset as a plain tuple (``sorrel/location.py:317-318``)."""
+        return self.compute().to_tuple()

@@ -31,6 +31,10 @@ class BaseModel:
     def reset(self):
         pass
 
+    def save(self, file_path) -> None:
+        """Abstract in the reference too (``base_model.py:89-99``): a subclass that has weights writes them here;
+        ``run_experiment`` calls it every ``record_period`` epochs when ``config.model.save_weights`` is set."""
+
     def set_epsilon(self, new_epsilon: float) -> None:
         self.epsilon = new_epsilon
 

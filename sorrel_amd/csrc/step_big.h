@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     }   // turns
 
     // ---- write-back
-    if (dirty && !do_sweep) {
+    if (dirty && !do_sweep && nturns == 1) {   // (a rollout's earlier turns moved other cells too)
         // a policy-driven phase (no sweep): only the movers' two cells changed -- write those bytes, not the whole grid
         if (wv == 0 && mine && (jr & 0x200u)) {
             uint8_t* g = p.grid + env * p.env_stride + p.zA * H * W;

@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kBlock, 8) void step_fast(const Params p) {
         if (tix + 1 < nturns) yx = moved ? npos : yx;   // the next turn starts where this one ended
         }   // turns
         if (dirty) {
-            if (!TAG && !RULES && !do_sweep) {
+            if (!TAG && !RULES && !do_sweep && nturns == 1) {   // (a rollout's earlier turns moved other cells too)
                 // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
                 // not the whole grid (two movers touching one cell both write its FINAL content: no race)
                 if (mine && moved) {

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         }   // turns
 
         if (dirty) {
-            if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP)) {
+            if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP) && p.nturns == 1) {   // (a rollout's earlier turns moved other cells too)
                 // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
                 // not the whole grid (with agents i < j both touching a cell, both write its FINAL content: no race)
                 if (gtid >= p.a0 && gtid < p.a1) {

@@ -539,3 +539,32 @@ def test_rollout_soak_random_worlds(torch_cuda, case, monkeypatch):
         if a is not None:
             assert torch.equal(a, b), (case, name)
     assert one.status() == many.status()
+
+
+@pytest.mark.parametrize("case", [("fast_static", (32, 32, 8, 3, 40), {}), ("fast_stage", (24, 24, 4, 3, 30), {}), ("big", (64, 64, 10, 4, 5), {}),
+                                  ("packed", (21, 21, 2, 2, 60), {"SGW_GROUP": "16"}), ("generic", (18, 14, 4, 3, 21), {"SGW_FORCE_GENERIC": "1"})],
+                         ids=lambda c: c[0])
+def test_rollout_without_a_sweep_writes_every_turns_moves_back(torch_cuda, case, monkeypatch):
+    """A world in which nothing transitions (spawn_prob = 0: the library drops the sweep flag) takes the sparse write-back
+    in single-turn phases; a multi-turn rollout must write the whole grid back -- the moves of ALL its turns, not only the
+    last one's (found by the rollout soak, case 1071)."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    _, (h, w, a, r, E), env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.0, seed=3, dense_prob=0.3)
+    one, many = make_engine(ws, E), make_engine(ws, E)
+    co = H.COracle(ws, E)
+    for e in (one, many):
+        e.reset(0)
+    co.reset(0)
+    many.rollout(6)
+    for t in range(6):
+        one.step(random_actions=True)
+        co.step(0, t + 1, random_actions=True)
+    torch.cuda.synchronize()
+    for name in ("grid", "agent_pos", "total_reward", "obs", "rewards", "actions"):
+        assert torch.equal(getattr(one, name), getattr(many, name)), name
+    assert np.array_equal(many.grid.cpu().numpy(), co.grid) and np.array_equal(many.total_reward.cpu().numpy(), co.total)

@@ -395,6 +395,8 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
         monkeypatch.setenv("SGW_NO_FAST_RULES", "1")
     rng = np.random.default_rng(7000 + case)
     ws, g, pos = H.random_rule_world(rng)
+    if ws.agent_rule == 0 and case % 2:      # plain movers: the policy-driven phases on phase_kernel (default only above 4 KiB)
+        monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0")
     E, T = int(rng.integers(2, 30)), int(rng.integers(3, 12))
     first = int(rng.integers(0, 2**31))
     eng = make_engine(ws, E, first=first)
@@ -408,6 +410,7 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     epoch = int(rng.integers(0, 9))
     eng.epoch = epoch
     phased = case % 3 == 1          # a third of the cases: sweep-only call, then one call per agent (policy path)
+    phased_next = case % 6 == 2     # a sixth: the 1 + A launch form (SGW_STEP_OBS_NEXT: each launch renders the NEXT agent)
     for t in range(1, T + 1):
         assert co.step(epoch, t, random_actions=True) == 0
         if phased:
@@ -415,9 +418,16 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
             eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t, advance_turn=False)
             for a in range(ws.num_agents):
                 eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t, advance_turn=False)
+        elif phased_next:
+            acts = torch.from_numpy(co.actions.copy())
+            eng.obs.fill_(-5.0)
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for a in range(ws.num_agents):
+                eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, obs_next=a + 1 < ws.num_agents, write_obs=False, turn=t,
+                         advance_turn=False)
         else:
             eng.step(random_actions=True, turn=t, advance_turn=False)
-        assert_same(eng, co, ctx=f"case {case} turn {t}{' (phased)' if phased else ''}")
+        assert_same(eng, co, ctx=f"case {case} turn {t}{' (phased)' if phased else ' (obs_next)' if phased_next else ''}")
         if eng.agent_dir is not None:
             assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), f"case {case} turn {t}: agent_dir"
         if eng.agent_state is not None:

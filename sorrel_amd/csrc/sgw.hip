@@ -18,10 +18,12 @@
 //                                        observations staged as bytes in LDS and emitted as one burst of streaming
 //                                        16-byte stores (fixed shapes: whole env; STAGE: chunks of agents, any alignment);
 //                                        MULTI = the turn loop of sgw_rollout
-//   step_big<ONEHOT, L, C, r, MULTI>     a 512-thread workgroup per env, worlds above 4 KiB (config 5): padded LDS row
+//   step_big<ONEHOT, L, C, r, MULTI, WALK>
+//                                        a 512-thread workgroup per env, worlds above 4 KiB (config 5): padded LDS row
 //                                        pitch, moves resolved in registers by wave 0 (only interfering agents are walked),
 //                                        observations rendered by all waves from the post-move grid with later moves
-//                                        undone in registers
+//                                        undone in registers; WALK = resident workgroups walking the batch, the next
+//                                        env's loads issued ahead of this env's observation stores
 //   phase_kernel<ONEHOT>                 one policy-driven phase of a world above 4 KiB without staging the env
 //   reset_kernel, random_actions_kernel, init_agent_state_kernel, reduce_stage1/2
 // then the host side: validation, table building, kernel selection (sgw_create), the launchers.
@@ -92,6 +94,10 @@ struct sgw_engine {
     void (*step_fn_plain)(const Params) = nullptr;   // run-time-shape STAGE kernels: the direct-store variant for calls that cannot be staged
     void (*step_fn_multi)(const Params) = nullptr;   // step_fast<..., MULTI>: sgw_rollout's turns in one launch
     const char* kernel_name_multi = "-";
+    void (*step_fn_walk)(const Params) = nullptr;   // step_big<..., WALK>: resident workgroups walking the batch
+    const char* kernel_name_walk = "-";
+    int walk_blocks = 0;                            // how many workgroups of it the chip holds at once
+    int64_t walk_min_envs = 0, walk_max_envs = 0;  // batches above min and up to max take it (multiples of what the plain kernel holds at once)
     const char* kernel_name_plain = "?";
     int stage_agents = 0;      // agents per staged chunk (STAGE kernels)
     bool phase_ok = false;     // the phase kernel applies (plain moves)
@@ -276,6 +282,12 @@ StepFn pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
     if (!onehot) PICK(step_big<false, 0, 0, 0, true>);
     if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, true>);
     PICK(step_big<true, 0, 0, 0, true>);
+}
+
+StepFn pick_big_walk(bool onehot, int L, int C, int r, const char** name) {
+    if (!onehot) PICK(step_big<false, 0, 0, 0, false, true>);
+    if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, true>);
+    PICK(step_big<true, 0, 0, 0, false, true>);
 }
 
 StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
@@ -621,12 +633,17 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
                                            c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name_multi);
     if (e->big) e->step_fn_multi = pick_big_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_multi);
     e->multi_turn = (e->fast || e->big) ? e->step_fn_multi != nullptr : true;   // kernels with sgw_rollout's turn loop
+    if (e->big && ((p.cells + 15) >> 4) <= 4 * kBigThreads)   // the prefetch holds one 4-unit round per thread
+        e->step_fn_walk = pick_big_walk(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_walk);
+    if (const char* f = getenv("SGW_BIG_NO_WALK")) { if (f[0] == '1') e->step_fn_walk = nullptr; }   // A/B hook
     if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess && e->step_fn_plain && e->step_fn_plain != sk)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess && e->step_fn_multi)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+        if (err == hipSuccess && e->step_fn_walk)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err != hipSuccess) {
@@ -640,6 +657,31 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     (void)nb;
     e->grid_blocks = (int)ceil_div(p.E, (e->fast || e->big) ? epb : epb_step);   // every step kernel: one env per group, the dispatcher balances
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
+    if (e->step_fn_walk) {
+        int per_cu = 0;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_fn_walk, kBigThreads, e->step_lds_bytes);
+        int plain_per_cu = 0;
+        if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain_per_cu, sk, kBigThreads, e->step_lds_bytes);
+        if (oe != hipSuccess || per_cu < 1 || plain_per_cu < 1) e->step_fn_walk = nullptr;
+        else {
+            // Engaged for batches of 1.5x to 3x what the plain kernel holds at once (one env per workgroup, four
+            // workgroups per CU at config 5 = 1 024 envs), measured on config 5's shape, same box, us per launch, walking
+            // against plain: 1 280 envs 53 / 55, 1 536 74-77 / 70-72, 2 048 88-96 / 109-118, 3 072 161-183 / 174-178,
+            // 4 096 206 / 224, 8 192 511 / 436.  Fewer walking workgroups are resident (76 VGPRs: three per CU), they
+            // run in lockstep and each env's prefetch waits for the previous env's stores, so over many rounds the
+            // dispatcher's four per CU win; over two or three rounds the hidden drain does.  Also measured at 2 048 envs:
+            // 683 workgroups (three envs each, evenly) 100 us, 512 100 us, 1 024 / 1 365 (oversubscribed) 93-107 us, a
+            // 64-VGPR build (four per CU, six spilled registers) 95-98 us, staggered starts 96-101 us.
+            e->walk_blocks = per_cu * e->num_cus;
+            e->walk_min_envs = (int64_t)plain_per_cu * e->num_cus * 3 / 2;
+            e->walk_max_envs = (int64_t)plain_per_cu * e->num_cus * 3;
+        }
+        if (const char* f = getenv("SGW_BIG_WALK_BLOCKS")) {   // tuning / test hook: this many workgroups, whatever the batch
+            e->walk_blocks = std::max(1, atoi(f));
+            e->walk_min_envs = e->walk_blocks;
+            e->walk_max_envs = INT64_MAX;
+        }
+    }
     e->reset_blocks = (int)ceil_div(p.E, epb);   // one env per group and launch
     *out = e;
     return SGW_OK;
@@ -725,7 +767,12 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS)))
         fn = e->step_fn_plain;
     if (p.nturns > 1 && (e->fast || e->big)) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
-    hipLaunchKernelGGL(fn, dim3(e->grid_blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
+    int blocks = e->grid_blocks;
+    if (e->big && p.nturns == 1 && e->step_fn_walk && p.E > e->walk_min_envs && p.E <= e->walk_max_envs) {   // two to three rounds of the plain kernel
+        fn = e->step_fn_walk;
+        blocks = e->walk_blocks;
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
 }
@@ -931,9 +978,12 @@ int sgw_set_wg_per_cu(sgw_engine* e, int wg_per_cu) {
 
 int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     if (!e || !buf || capacity < 1) return fail(SGW_EINVAL, "sgw_launch_info: NULL argument");
-    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%s%d", e->kernel_name,
+    const bool walk = e->step_fn_walk && e->base.E > e->walk_min_envs && e->base.E <= e->walk_max_envs;   // what a whole-batch sgw_step launches
+    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%s%d",
+             walk ? e->kernel_name_walk : e->kernel_name,
              (e->fast || e->big) ? e->wpe * kWave * (e->big ? kBigWaves / 4 : 1) : e->group,
-             e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->stage_agents, e->grid_blocks,
+             e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->stage_agents,
+             walk ? e->walk_blocks : e->grid_blocks,
              e->wg_per_cu == 0 ? "auto:" : "", e->wg_per_cu == 0 ? e->fast_wg_cap : e->wg_per_cu);
     return SGW_OK;
 }

@@ -25,19 +25,27 @@
 #define SGW_BIG_THREADS 512
 #endif
 constexpr int kBigThreads = SGW_BIG_THREADS;
+#ifndef SGW_WALK_WAVES
+#define SGW_WALK_WAVES 6   // waves per SIMD the WALK variant is compiled for (8 = 64 VGPRs: spills the prefetched units)
+#endif
 constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
 
 // MULTI: sgw_rollout's variant -- a turn loop around sweep / moves / observations with the env's 32 KiB resident in LDS
 // (later turns sweep the units read back from LDS; only the last turn is followed by the write-back).
-template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false>
-__global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
+// WALK: the single-turn variant for batches larger than the chip holds at once -- as many workgroups as are resident,
+// each walking envs blockIdx.x, + gridDim.x, ...  A wave cannot end before its stores are acknowledged, so with one env
+// per workgroup the second round of workgroups (whose first 17 us are the sweep: pure VALU) only starts once the first
+// round's 190 MB of observation stores have drained; a workgroup that carries on with its next env sweeps while they
+// drain.  vmcnt counts loads and stores together on gfx9, so the next env's grid (64 B per thread), positions, actions
+// and total are loaded during phase M of the current env -- before this env's stores are issued -- and waited for
+// there; the loop then contains no load that would have to wait behind the observation stores.
+template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false>
+__global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_WAVES : 6) : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
+    static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t env = blockIdx.x;
-    const uint32_t env_id = p.first_env + (uint32_t)env;
+    const int tid0 = threadIdx.x;
+    int64_t env = blockIdx.x;
 #ifdef SGW_STAMPS
     unsigned long long tprev_ = 0;
 #define STAMPB(i)                                                                                            \
@@ -46,11 +54,11 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
         unsigned long long t_;                                                                               \
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (tid == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;                 \
+        if (threadIdx.x == 0 && (i) > 0 && env < kStampEnvs) g_stamps[env * 8 + (i)-1] = t_ - tprev_;         \
         tprev_ = t_;                                                                                         \
     } while (0)
     STAMPB(0);
-    if (tid == 0 && env < kStampEnvs) {
+    if (threadIdx.x == 0 && env < kStampEnvs) {
         g_stamps[env * 8 + 6] = tprev_;
         g_stamps[env * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
     }
@@ -99,30 +107,61 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     // ---- tables -> LDS
     if constexpr (ONEHOT) {
         uint32_t* wd = reinterpret_cast<uint32_t*>(smem);
-        if (tid < 4 * SGW_MAX_TYPES) wd[tid] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid];
+        if (tid0 < 4 * SGW_MAX_TYPES) wd[tid0] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid0];
     } else {
         double* wa = reinterpret_cast<double*>(smem);
-        for (int i = tid; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBigThreads) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
+        for (int i = tid0; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBigThreads) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
     }
-    if (tid < 32) s_vtab[tid] = gtab->value[tid];
-    if (tid >= 64 && tid < 128) s_atype[tid - 64] = gtab->agent_type[tid - 64];
+    if (tid0 < 32) s_vtab[tid0] = gtab->value[tid0];
+    if (tid0 >= 64 && tid0 < 128) s_atype[tid0 - 64] = gtab->agent_type[tid0 - 64];
     const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(smem);
     const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(smem);
 
     // per-agent state of wave 0 (lane a = agent a), carried from turn to turn of a rollout
     uint32_t yx = 0;
     int st_lane = 0;
-    const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
     uint32_t ta_v = 0xFFFFFFFFu, npos_v = 0, oaddr_v = 0, jr = 0;
+    const uint32_t nturns = MULTI ? p.nturns : 1u;
+    // WALK: what an env needs from global memory is loaded one env ahead (the first env's: here)
+    uint4 nu[4] = {};
+    uint32_t nyx = 0, nact = 0;
+    double ntot = 0.0;
+    auto prefetch = [&](const int64_t e, const int t) {
+        if (e >= p.E) return;
+        const uint4* nsrc = reinterpret_cast<const uint4*>(p.grid + e * p.env_stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = k * kBigThreads + t;
+            if (idx < nunits) nu[k] = nsrc[idx];
+        }
+        if (t < p.A) {
+            nyx = reinterpret_cast<const uint16_t*>(p.pos)[e * p.A + t];
+            if (!rnd && p.do_move && t >= p.a0 && t < p.a1) nact = p.actions[e * p.A + t];
+        }
+        if (t == 0 && p.do_move) ntot = p.total[e];
+    };
+    if constexpr (WALK) prefetch(env, tid0);
+    do {
+    // WALK: the thread index is re-derived per env behind an opaque copy, so that nothing computed from it is hoisted
+    // out of the env loop and kept in registers across it (the hoisted version needed 80 VGPRs + 27 spilled)
+    const int tid = WALK ? (int)opaque((uint32_t)tid0) : tid0;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mine = tid >= p.a0 && tid < p.a1 && tid < p.A;
+    const uint32_t env_id = p.first_env + (uint32_t)env;
     if (wv == 0 && tid < p.A) {
-        yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
+        if constexpr (WALK) yx = nyx;
+        else yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + tid];
         if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) {   // garbage in: stay inside the LDS grid, and say so
             yx = 0;
-            atomicOr(p.status, SGW_STATUS_BAD_POS);
+            st_lane |= SGW_STATUS_BAD_POS;
         }
     }
-    double tot = (tid == 0 && p.do_move) ? p.total[env] : 0.0;
-    const uint32_t nturns = MULTI ? p.nturns : 1u;
+    double tot = 0.0;
+    if (tid == 0 && p.do_move) {
+        if constexpr (WALK) tot = ntot;
+        else tot = p.total[env];
+    }
     for (uint32_t tix = 0; tix < nturns; ++tix) {
     const uint32_t turn = p.turn + tix;
     // ---- grid -> LDS (first turn), sweep on the registers, 4 units per thread per round
@@ -134,7 +173,8 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = base + k * kBigThreads + tid;
-                if (idx < nunits) u[k] = (MULTI && tix > 0) ? lg16[lunit(idx)] : src[idx];
+                if constexpr (WALK) u[k] = nu[k];   // (nunits <= 4 * kBigThreads: host)
+                else if (idx < nunits) u[k] = (MULTI && tix > 0) ? lg16[lunit(idx)] : src[idx];
                 if ((cells & 15) && idx == nunits - 1) {   // ragged world: mask the bytes past the last cell
                     const int tail = cells & 15;
                     uint32_t d[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
@@ -198,7 +238,8 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
                     act = __umulhi(word_of(w, tid & 3), (uint32_t)p.nact);
                     p.actions[tix * p.ts_act + env * p.A + tid] = (uint8_t)act;
                 } else {
-                    act = p.actions[tix * p.ts_act + env * p.A + tid];
+                    if constexpr (WALK) act = nact;
+                    else act = p.actions[tix * p.ts_act + env * p.A + tid];
                 }
                 const bool act_ok = act < (uint32_t)p.nact;
                 const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1;
@@ -218,6 +259,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     }
     __syncthreads();             // grid (+ sweep patches) and tables visible to every wave
     STAMPB(1);                   // load + sweep done
+    if constexpr (WALK) prefetch(env + gridDim.x, tid);   // the next env's inputs: issued now, complete by the end of phase M (before any observation store)
 
     // ---- phase M: the strictly sequential part, by wave 0 alone, entirely in registers.
     // All targets are read from the pre-move grid in ONE LDS round trip (lane a = agent a).  What
@@ -291,6 +333,11 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     }
     __syncthreads();
     STAMPB(2);                   // phase M done
+    if constexpr (WALK) {       // a use of every prefetched register: the compiler waits for those loads HERE
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(nu[k].x), "v"(nu[k].y), "v"(nu[k].z), "v"(nu[k].w));
+        asm volatile("" ::"v"(nyx), "v"(nact), "v"(ntot));
+    }
 
     // ---- phase R: observations, all waves in parallel (agent a -> wave (a - a0) mod waves).
     // LDS now holds the grid AFTER all moves of this call; agent a must see it after the moves of
@@ -442,11 +489,14 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? 6 : (kBigThreads 
     STAMPB(5);                   // wave 0's stores acknowledged
     STAMPB(6);
     if (p.do_move) {
-        if (wv == 0 && mine) {
-            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)((jr & 0x200u) ? npos_v : yx);
-            if (st_lane) atomicOr(p.status, st_lane);
-        }
+        if (wv == 0 && mine) reinterpret_cast<uint16_t*>(p.pos)[env * p.A + tid] = (uint16_t)((jr & 0x200u) ? npos_v : yx);
         if (tid == 0) p.total[env] = tot;
     }
+    if constexpr (!WALK) break;
+    env += gridDim.x;
+    if (env >= p.E) break;
+    __syncthreads();             // the write-back has read this env's LDS image: the next env may overwrite it
+    } while (true);
+    if (tid0 < 64 && st_lane) atomicOr(p.status, st_lane);
 }
 

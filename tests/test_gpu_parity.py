@@ -339,6 +339,57 @@ def test_big_kernel_crowded_vs_oracle(torch_cuda):
     rollout_vs_oracle(treasurehunt_spec(80, 64, 64, 2, spawn_prob=0.02, seed=13), 24, 6, first=3)     # 10 KiB env, one window pass
 
 
+@pytest.mark.parametrize("blocks", ["1", "5", "16"])
+@pytest.mark.parametrize("variant", ["config5_shape", "general_tables", "float_appearance", "scripted_actions", "no_sweep"])
+def test_big_kernel_walking_workgroups_vs_oracle(torch_cuda, monkeypatch, blocks, variant):
+    """step_big<..., WALK>: fewer workgroups than envs, each walking envs b, b + blocks, ... with the next env's grid,
+    positions, actions and total loaded one env ahead (SGW_BIG_WALK_BLOCKS forces the workgroup count; the full-size
+    config-5 tests take this path on their own).  Uneven walks (23 envs over 5 or 16 workgroups), one workgroup doing
+    everything, the run-time-shape and the float-appearance instantiations, actions given by the caller, no sweep."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_BIG_WALK_BLOCKS", blocks)
+    if variant == "config5_shape":
+        ws = treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=21, dense_prob=0.25)
+    elif variant == "float_appearance":
+        ws = treasurehunt_spec(64, 80, 24, 4, spawn_prob=0.05, seed=23, dense_prob=0.2)
+        app = np.asarray(ws.appearance, dtype=np.float64).copy()
+        app[app != 0] = 0.375
+        ws.appearance = app
+    else:
+        ws = treasurehunt_spec(80, 64, 40, 3, spawn_prob=0.0 if variant == "no_sweep" else 0.04, seed=22, dense_prob=0.3)
+    E, T = 23, 5
+    eng = make_engine(ws, E, first=3)
+    assert "step_big" in eng.launch_info()
+    co = H.COracle(ws, E, first_env_id=3)
+    eng.reset(epoch=1)
+    co.reset(1)
+    rng = np.random.default_rng(5)
+    for t in range(1, T + 1):
+        if variant == "scripted_actions":
+            acts = rng.integers(0, len(ws.action_dy), size=(E, ws.num_agents), dtype=np.uint8)
+            eng.step(torch.from_numpy(acts).cuda())
+            assert co.step(1, t, actions=acts) == 0
+        else:
+            eng.step(random_actions=True)
+            assert co.step(1, t, random_actions=True) == 0
+        assert_same(eng, co, ctx=f"{variant} blocks={blocks} turn {t}")
+    # the other calls that reach the same kernel: sgw_observe, a sweep-only launch, an agent range with SGW_STEP_OBS_NEXT
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    assert_same(eng, co, ("obs",), ctx=f"{variant} blocks={blocks} observe")
+    a = ws.num_agents // 2
+    eng.step(random_actions=True, agent_begin=0, agent_end=a, write_obs=False, obs_next=True, advance_turn=False, turn=T + 1)
+    assert co.step(1, T + 1, random_actions=True, write_obs=False, a0=0, a1=a) == 0
+    co.observe(a, a + 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs[:, a].cpu().numpy(), co.obs[:, a]), f"{variant} blocks={blocks}: OBS_NEXT window"
+    assert_same(eng, co, ("grid", "pos", "total"), ctx=f"{variant} blocks={blocks} agent range")
+    assert eng.status() == 0
+
+
 @pytest.mark.parametrize("shape", [(9, 13, 3, 4), (7, 7, 5, 3), (33, 21, 9, 2), (64, 64, 16, 4), (66, 70, 7, 6), (5, 5, 2, 2)])
 def test_ragged_shapes_vs_oracle(torch_cuda, shape):
     """Grid byte counts that are not multiples of 16 / 4, odd sizes, maximum radius."""

@@ -390,8 +390,21 @@ class Environment:
     # ------------------------------------------------------------------ kernels behind the agent hooks
     @staticmethod
     def _ospec_key(ospec):
-        return (type(ospec).__name__, int(ospec.vision_radius), ospec.fill_entity_kind, int(getattr(ospec, "obs_post", 0)),
-                tuple((k, np.asarray(v, dtype=np.float64).tobytes()) for k, v in ospec.entity_map.items()))
+        """What an observation spec compiles to, as a hashable key.  Computed once per (spec object, entity-map object,
+        scalar settings) and kept on the spec: every agent's ``pov`` asks for it every turn, and serialising the
+        appearance vectors each time cost ~7 us per agent phase.  Replace ``entity_map`` (or change radius / fill kind) to
+        have a spec recompiled; editing an appearance vector in place after first use is not seen."""
+        sig = (id(ospec.entity_map), len(ospec.entity_map), ospec.vision_radius, ospec.fill_entity_kind, getattr(ospec, "obs_post", 0))
+        cached = ospec.__dict__.get("_sgw_key")
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        key = (type(ospec).__name__, int(ospec.vision_radius), ospec.fill_entity_kind, int(getattr(ospec, "obs_post", 0)),
+               tuple((k, np.asarray(v, dtype=np.float64).tobytes()) for k, v in ospec.entity_map.items()))
+        try:
+            ospec.__dict__["_sgw_key"] = (sig, key, ospec.entity_map)   # (the map is kept alive so that its id cannot be reused)
+        except (AttributeError, TypeError):      # a spec class with __slots__: just recompute
+            pass
+        return key
 
     def _engine_for(self, ospec):
         """The engine whose tables were compiled from ``ospec``: the step engine when it is (equal to) the
@@ -453,7 +466,7 @@ class Environment:
         a = agent.slot
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
-        eng.actions[:, a] = action.to(torch.uint8)
+        eng.actions[:, a].copy_(action)          # one strided copy that also narrows int64 -> uint8
         nxt = a + 1 < len(self.agents) and eng.obs is not None
         eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn, obs_next=nxt)
         self._fresh_obs = (a + 1, self.world.mutations) if nxt else None

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""What a user who switches from the reference feels: wall time of ``Environment.take_turn()`` through the Python API
+(run on the GPU box).  Treasurehunt example defaults (21x21, 2 agents, 5x5 window) and the headline shape, batches of
+1 ... 65 536 envs; the device-random model (one launch per turn) and a small torch policy (1 + A launches + A forward
+passes per turn, memories appended).  The reference's own step loop does one env at ~3 ms per turn on one core."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
+import torch
+from sorrel_amd.examples.treasurehunt.entities import EmptyEntity
+from sorrel_amd.examples.treasurehunt.env import TreasurehuntEnv
+from sorrel_amd.examples.treasurehunt.main import make_config
+from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
+from sorrel_amd.models import BaseModel
+
+
+def policy_factory(E):
+    class LinearPolicy(BaseModel):
+        """obs [E, F] -> argmax of one linear layer: the cheapest model that really reads the observation."""
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=64, num_envs=E, device="cuda:0")
+            g = torch.Generator(device="cpu").manual_seed(1)
+            self.w = torch.randn(int(input_size[0]), action_space, generator=g).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.w).argmax(dim=1)
+
+    return LinearPolicy
+
+
+def time_turns(env, turns):
+    for _ in range(20):
+        env.take_turn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(turns):
+        env.take_turn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / turns * 1e6
+
+
+def run(h, w, a, r, E, policy):
+    cfg = make_config(h, w, a, r, spawn_prob=0.005)
+    world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0)
+    env = TreasurehuntEnv(world, cfg, model_factory=policy_factory(E) if policy else None)
+    turns = 2000 if E <= 4096 else 300
+    us = time_turns(env, turns)
+    print(f"{h}x{w} A{a} r{r} E={E:6d} {'policy (1+A launches)' if policy else 'device-random (1 launch)':26s} "
+          f"{us:9.1f} us/turn  {E * a / us * 1e6:.3e} agent-steps/s")
+
+
+def main():
+    for shape in ((21, 21, 2, 2), (32, 32, 8, 3)):
+        for E in (1, 64, 1024, 16384, 65536):
+            for policy in (False, True):
+                run(*shape, E, policy)
+
+
+if __name__ == "__main__":
+    main()

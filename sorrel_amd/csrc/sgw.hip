@@ -232,27 +232,42 @@ using StepFn = void (*)(const Params);
         return __VA_ARGS__;       \
     } while (0)
 
+// The examples as shipped get a compile-time vision radius (window size constant: channel planes become immediate store
+// offsets, no division in the cell -> (i, j) split): Tag 11x11 / 9x9 windows 116-119 -> 107-108 us, Treasurehunt 5x5
+// windows 51.0 -> 46.2 us (65 536 envs, same box).  A compile-time world size on top: Tag 2 % (and 72 VGPRs = a seventh
+// wave per SIMD), Treasurehunt 21x21 nothing (46.2 both: not instantiated); Cleanup's wave-per-env kernel with r = 5:
+// nothing (699 against 704 us: not instantiated).
 template <int G>
-StepFn pick_step_g(bool onehot, int L, int C, int rule, const char** name) {
+StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, const char** name) {
     if (rule == SGW_AGENT_RULE_CLEANUP) {
         if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>);
         PICK(step_kernel<G, false, 0, 0, SGW_AGENT_RULE_CLEANUP>);
     }
     if (rule == SGW_AGENT_RULE_TAG) {
+        if constexpr (G == 32) {
+            if (onehot && L == 1 && C == 4 && r == 4 && H == 11 && W == 11) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4, 11, 11>);   // the Tag example as shipped
+            if (onehot && L == 1 && C == 4 && r == 4) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>);
+        }
         if (onehot && L == 1 && C == 4) PICK(step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>);   // the Tag example's tables
         if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>);
         PICK(step_kernel<G, false, 0, 0, SGW_AGENT_RULE_TAG>);
     }
+    if constexpr (G == 16)
+        if (onehot && L == 2 && C == 6 && r == 2) PICK(step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>);   // the Treasurehunt example's 5x5 windows
     if (onehot && L == 2 && C == 6) PICK(step_kernel<G, true, 2, 6>);                             // Treasurehunt-shaped tables
     if (onehot) PICK(step_kernel<G, true>);
     PICK(step_kernel<G, false>);
 }
 
-StepFn pick_step(int group, bool onehot, int L, int C, int rule, const char** name) {
-    if (group == 16) return pick_step_g<16>(onehot, L, C, rule, name);
-    if (group == 32) return pick_step_g<32>(onehot, L, C, rule, name);
-    if (group == 64) return pick_step_g<64>(onehot, L, C, rule, name);
-    return pick_step_g<256>(onehot, L, C, rule, name);
+StepFn pick_step(int group, bool onehot, int L, int C, int rule, int r, int H, int W, const char** name) {
+    if (const char* f = getenv("SGW_NO_STATIC_RADIUS")) {   // A/B hook: 1 = the run-time-shape instances, 2 = static radius but run-time world size
+        if (f[0] == '1') r = -1;
+        if (f[0] == '2') H = W = -1;
+    }
+    if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, name);
+    if (group == 32) return pick_step_g<32>(onehot, L, C, rule, r, H, W, name);
+    if (group == 64) return pick_step_g<64>(onehot, L, C, rule, r, H, W, name);
+    return pick_step_g<256>(onehot, L, C, rule, r, H, W, name);
 }
 // the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
 // a loop of single-turn launches
@@ -623,7 +638,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.stage_agents = e->stage_agents;
     StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name)
-                         : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, &e->kernel_name);
+                         : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
     e->step_fn = sk;

@@ -20,7 +20,10 @@ constexpr int kAgentLds = kDirOff + SGW_MAX_AGENTS;     // 640 bytes, multiple o
 // per-env state in the group's LDS slice and uses no cross-lane instruction, so a sub-wave group needs nothing but the
 // wave-level ordering of DS instructions; what it buys is that the per-env instruction count, which bounds small worlds
 // (a 21x21x2 world keeps 29 of 64 lanes busy in the sweep and 25 in the window gather), is shared by 2 or 4 envs.
-template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE>
+// TR: compile-time vision radius (0 = run-time) for the example defaults: the window size becomes a constant, so the
+// channel planes of an observation are immediate store offsets and the cell -> (i, j) split needs no division.
+// TH, TW: compile-time world size on top of that (the examples' own maps).
+template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0>
 __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
@@ -46,18 +49,20 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     uint8_t* s_pov = slice + p.cells_pad + kPovOff;     // [A] its type when it observed
     uint8_t* s_dir = slice + p.cells_pad + kDirOff;     // [A] its facing
 
+    const int r = TR ? TR : p.r, V = TR ? 2 * TR + 1 : p.V, VV = TR ? (2 * TR + 1) * (2 * TR + 1) : p.VV;
+    const int H = TH ? TH : p.H, W = TW ? TW : p.W;
     // window cell(s) this thread renders: fixed for the whole kernel
     int wi[kMaxPass], wj[kMaxPass];
 #pragma unroll
     for (int k = 0; k < kMaxPass; ++k) {
         const int w = gtid + k * G;
-        wi[k] = w / p.V;
-        wj[k] = w - wi[k] * p.V;
+        wi[k] = w / V;
+        wj[k] = w - wi[k] * V;
     }
     const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
     const bool dirty = (p.flags & SGW_STEP_SWEEP) || (p.do_move && p.a1 > p.a0);
-    const int zoff = p.zA * p.H * p.W;
-    const int HW = p.H * p.W;
+    const int zoff = p.zA * H * W;
+    const int HW = H * W;
 
     // one env per group and launch (no persistent loop: nothing stays live from one env to the next, and the
     // dispatcher balances the workgroups)
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         uint32_t yx0 = 0;                     // this thread's agent: position at the start of the call
         if (gtid < p.A) {
             uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
-            if ((yx & 0xFF) >= p.H || (yx >> 8) >= p.W) {   // garbage in: stay inside this env's LDS slice, and say so
+            if ((yx & 0xFF) >= H || (yx >> 8) >= W) {   // garbage in: stay inside this env's LDS slice, and say so
                 yx = 0;
                 atomicOr(p.status, SGW_STATUS_BAD_POS);
             }
@@ -113,11 +118,11 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
             // ---- pov: egocentric window (visual_field.py:9-101)
             if (p.obs_next ? a == p.a1 : write_obs) {
-                float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * p.VV;
+                float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * VV;
                 auto render = [&](const int w, const int i, const int j) {
-                    const int gy = y - p.r + i, gx = x - p.r + j;
-                    const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                    const int off = gy * p.W + gx;
+                    const int gy = y - r + i, gx = x - r + j;
+                    const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    const int off = gy * W + gx;
                     float* o = obase + w;
                     if constexpr (ONEHOT) {
                         constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
@@ -153,8 +158,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                                 const int c = 4 * q + b;
                                 if (c < Cn) {
                                     const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
-                                    if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * p.VV] = (uint8_t)v;
-                                    else o[c * p.VV] = (float)v;
+                                    if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
+                                    else o[c * VV] = (float)v;
                                 }
                             }
                         }
@@ -167,20 +172,20 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                             } else {
                                 acc = tab->appearance[p.fill_type][c];
                             }
-                            o[c * p.VV] = obs_finish(acc, p.obs_post);
+                            o[c * VV] = obs_finish(acc, p.obs_post);
                         }
                     }
                 };
 #pragma unroll
                 for (int k = 0; k < kMaxPass; ++k) {
                     const int w = gtid + k * G;
-                    if (w < p.VV) render(w, wi[k], wj[k]);
+                    if (w < VV) render(w, wi[k], wj[k]);
                 }
                 {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
                     int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
-                    for (int w = gtid + kMaxPass * G; w < p.VV; w += G) {
+                    for (int w = gtid + kMaxPass * G; w < VV; w += G) {
                         j += G;
-                        while (j >= p.V) { j -= p.V; ++i; }
+                        while (j >= V) { j -= V; ++i; }
                         render(w, i, j);
                     }
                 }
@@ -205,19 +210,19 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
                     const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
                     const int by = y + side * ry + step * fy, bx = x + side * rx + step * fx;
-                    if ((unsigned)by < (unsigned)p.H && (unsigned)bx < (unsigned)p.W) {
-                        const int boff = (p.zA + 1) * HW + by * p.W + bx;
+                    if ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) {
+                        const int boff = (p.zA + 1) * HW + by * W + bx;
                         if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
                             lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
                     }
                 }
                 gsync<WPE>();
-                const bool inb = act_ok && (unsigned)ny < (unsigned)p.H && (unsigned)nx < (unsigned)p.W;
+                const bool inb = act_ok && (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
                 double val = 0.0;
                 uint32_t t = 0xFFu;
                 if (inb) {
-                    for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * p.W + nx] & 31u];   // all layers, BEFORE the move
-                    t = lg[zoff + ny * p.W + nx];
+                    for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * W + nx] & 31u];   // all layers, BEFORE the move
+                    t = lg[zoff + ny * W + nx];
                 }
                 const bool pass = inb && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
                 gsync<WPE>();
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                         else if (dy == 0 && dx == 1) s_dir[a] = 1;
                     }
                     if (pass) {
-                        lg[zoff + ny * p.W + nx] = (uint8_t)my_type;
-                        lg[zoff + y * p.W + x] = (uint8_t)p.default_type;
+                        lg[zoff + ny * W + nx] = (uint8_t)my_type;
+                        lg[zoff + y * W + x] = (uint8_t)p.default_type;
                         s_pos[2 * a] = (uint8_t)ny;
                         s_pos[2 * a + 1] = (uint8_t)nx;
                     }
@@ -250,9 +255,9 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             const int dy = act_ok ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
             const int dx = act_ok ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
             const int ty = y + dy, tx = x + dx;
-            const bool inb = act_ok && (unsigned)ty < (unsigned)p.H && (unsigned)tx < (unsigned)p.W;
-            const int taddr = zoff + ty * p.W + tx;
-            const int oaddr = zoff + y * p.W + x;
+            const bool inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+            const int taddr = zoff + ty * W + tx;
+            const int oaddr = zoff + y * W + x;
             const uint32_t t = inb ? lg[taddr] : 0xFFu;
             const bool tok = t < (uint32_t)p.T;
             double val = (inb && tok && RULE == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
@@ -277,18 +282,18 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                 // evaluates the same LDS bytes, so `mine_now` stays uniform.
                 gsync<WPE>();
                 uint32_t mine_now = my_type;
-                const int own = zoff + cy * p.W + cx;
+                const int own = zoff + cy * W + cx;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
                     const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
-                    const bool ain = (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
-                    const uint32_t nt = ain ? lg[zoff + ay * p.W + ax] : 0xFFu;
+                    const bool ain = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                    const uint32_t nt = ain ? lg[zoff + ay * W + ax] : 0xFFu;
                     if (mine_now == p.tag_it && nt == p.tag_notit) {
                         mine_now = p.tag_notit;
                         if (gtid == 0) {
                             lg[own] = (uint8_t)p.tag_notit;
-                            lg[zoff + ay * p.W + ax] = (uint8_t)p.tag_it;
+                            lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
                             s_type[a] = (uint8_t)p.tag_notit;
                         }
                         // the neighbour's slot: the agent standing on (ay, ax)
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                 if (gtid >= p.a0 && gtid < p.a1) {
                     const uint32_t now = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
                     if (now != yx0) {
-                        const int o0 = zoff + (int)(yx0 & 0xFFu) * p.W + (int)(yx0 >> 8), o1 = zoff + (int)(now & 0xFFu) * p.W + (int)(now >> 8);
+                        const int o0 = zoff + (int)(yx0 & 0xFFu) * W + (int)(yx0 >> 8), o1 = zoff + (int)(now & 0xFFu) * W + (int)(now >> 8);
                         ggrid[o0] = lg[o0];
                         ggrid[o1] = lg[o1];
                     }

@@ -239,16 +239,17 @@ def test_packed_kernels_batches_vs_oracle(torch_cuda, group, monkeypatch):
     for (h, w, a, r, E) in ((21, 21, 2, 2, 1003), (10, 10, 2, 2, 517), (16, 16, 4, 2, 64), (13, 9, 5, 4, 77), (32, 32, 8, 3, 130)):
         eng, co = rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=31, dense_prob=0.1), E, 5, first=11)
         assert "step_kernel<" in eng.launch_info() and f"group={group} " in eng.launch_info()
-    d, spec = H.load_golden("tag_9x9")
-    ws = H.world_spec(spec)
-    eng, co = make_engine(ws, 333, first=9), H.COracle(ws, 333, first_env_id=9)
-    eng.reset(0)
-    co.reset(0)
-    for t in range(1, 12):
-        eng.step(random_actions=True)
-        co.step(0, t, random_actions=True)
-        assert_same(eng, co, ctx=f"packed tag turn {t}")
-        assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
+    for fixture in ("tag_9x9", "tag_11x11_default"):      # the second is the shape with its own static instance (G = 32)
+        d, spec = H.load_golden(fixture)
+        ws = H.world_spec(spec)
+        eng, co = make_engine(ws, 333, first=9), H.COracle(ws, 333, first_env_id=9)
+        eng.reset(0)
+        co.reset(0)
+        for t in range(1, 12):
+            eng.step(random_actions=True)
+            co.step(0, t, random_actions=True)
+            assert_same(eng, co, ctx=f"packed {fixture} turn {t}")
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
     # compact uint8 observations
     ws = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=5)
     e8, e32 = make_engine(ws, 200, obs_dtype=torch.uint8), make_engine(ws, 200)
@@ -270,7 +271,8 @@ def test_dispatch_rule_packs_small_worlds_of_large_batches(torch_cuda):
 
     ws = treasurehunt_spec(21, 21, 2, 2, spawn_prob=0.02, seed=77)
     big = make_engine(ws, 65536, first=100)
-    assert "step_kernel<" in big.launch_info() and "group=16 " in big.launch_info()
+    assert "step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>" in big.launch_info() and "group=16 " in big.launch_info()   # the static 5x5 window
+    assert "step_kernel<G, true, 2, 6> group=16 " in make_engine(treasurehunt_spec(21, 21, 2, 1), 65536).launch_info()                  # another radius: run-time shape
     assert "step_fast" in make_engine(ws, 512).launch_info()
     assert "step_fast<true, 2, 6, 3, 32, 32>" in make_engine(treasurehunt_spec(32, 32, 8, 3), 65536).launch_info()
     big.reset(0)

@@ -435,6 +435,8 @@ def test_random_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     ws = _random_world(rng)
     if case % 3 and ws.num_agents <= 16 and ws.layers * ws.height * ws.width <= 4096:     # two thirds of the small cases: packed kernels
         monkeypatch.setenv("SGW_GROUP", "16" if case % 3 == 1 else "32")
+    if case % 2:          # half of the cases: worlds that reach step_big take its walking-workgroups instance, 1 / 2 / 5 workgroups
+        monkeypatch.setenv("SGW_BIG_WALK_BLOCKS", str((1, 2, 5)[case % 3]))
     rollout_vs_oracle(ws, int(rng.integers(3, 40)), int(rng.integers(2, 7)), first=int(rng.integers(0, 2**31)),
                       epoch=int(rng.integers(0, 50)))
 

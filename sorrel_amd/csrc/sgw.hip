@@ -7,11 +7,14 @@
 // bandwidth for the big shapes (observation stores dominate) and instruction issue for the small ones.
 //
 // Kernels, in file order:
-//   step_kernel<G, ONEHOT, L, C, RULE>   every shape and rule; G = lanes per env: 256 (a workgroup per env, worlds above
-//                                        4 KiB), 64 (a wave per env), or 32 / 16 -- two / four SMALL envs share a wave and
-//                                        its instruction stream (what 10x10 ... 24x24 worlds of large batches run on);
-//                                        all per-env state in the group's LDS slice, no cross-lane instruction; turn loop
-//                                        for sgw_rollout built in
+//   step_kernel<G, ONEHOT, L, C, RULE, r, H, W>
+//                                        every shape and rule; G = lanes per env: 256 (a workgroup per env, worlds above
+//                                        4 KiB: the four waves take the agents in turn behind an LDS ticket, window bytes
+//                                        captured before the act and stored after it), 64 (a wave per env), or 32 / 16 --
+//                                        two / four SMALL envs share a wave and its instruction stream (what 10x10 ...
+//                                        24x24 worlds of large batches run on; compile-time window for the examples as
+//                                        shipped); all per-env state in the group's LDS slice; turn loop for sgw_rollout
+//                                        built in
 //   step_fast<ONEHOT, L, C, r, H, W, TAG, RULES, STAGE, MULTI>
 //                                        a wave per env, worlds <= 4 KiB: register sweep, per-lane move inputs + scalar
 //                                        move resolution, compile-time window geometry for the BASELINE shapes; one-hot

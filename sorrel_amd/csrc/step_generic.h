@@ -1,5 +1,6 @@
 // step_generic.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
-// step_kernel<G, ONEHOT, L, C, RULE>: every shape and rule; 256 / 64 / 32 / 16 lanes per env (small envs share a wave).
+// step_kernel<G, ONEHOT, L, C, RULE, r, H, W>: every shape and rule; 256 / 64 / 32 / 16 lanes per env (small envs share a
+// wave; a workgroup per env runs its agent phases wave by wave behind a ticket).
 #pragma once
 
 // ---------------------------------------------------------------- step kernel
@@ -10,7 +11,8 @@ constexpr int kRewOff = kActOff + SGW_MAX_AGENTS;
 constexpr int kTypeOff = kRewOff + 4 * SGW_MAX_AGENTS;   // current type of each agent
 constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it observed
 constexpr int kDirOff = kPovOff + SGW_MAX_AGENTS;       // its facing (Cleanup)
-constexpr int kAgentLds = kDirOff + SGW_MAX_AGENTS;     // 640 bytes, multiple of 16
+constexpr int kTicketOff = kDirOff + SGW_MAX_AGENTS;    // G = 256: whose turn it is (u32), the env's running total (f64 at + 8)
+constexpr int kAgentLds = kTicketOff + 16;              // 656 bytes, multiple of 16
 
 #ifndef SGW_GENERIC_WAVES
 #define SGW_GENERIC_WAVES 6
@@ -48,6 +50,18 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     uint8_t* s_type = slice + p.cells_pad + kTypeOff;   // [A] current entity type of each agent
     uint8_t* s_pov = slice + p.cells_pad + kPovOff;     // [A] its type when it observed
     uint8_t* s_dir = slice + p.cells_pad + kDirOff;     // [A] its facing
+    // G = 256 (worlds above 4 KiB): the load, the sweep and the write-back use the whole workgroup, but an AGENT PHASE is the
+    // work of one wave, and the four waves take the agents in turn behind a ticket in LDS: wave (a - a0) mod 4 waits
+    // until agent a - 1 has acted, captures agent a's window bytes in registers, acts (Tag / Cleanup / move: the same code
+    // as below, its synchronisation now wave-level), passes the ticket on and only then turns the captured bytes into
+    // stores -- so the sequential chain is capture + act, and the observation work of four agents overlaps.  Before,
+    // all 256 threads rendered one agent (121 cells: half of them idle) and met at ~5 workgroup barriers per agent.
+    constexpr bool kTicket = G == 256;
+    constexpr int GA = kTicket ? kWave : G;            // threads that cooperate on one agent
+    constexpr int WPA = kTicket ? 1 : WPE;             // waves that synchronise inside an agent phase
+    const int atid = kTicket ? (tid & 63) : gtid;      // index inside that group
+    volatile uint32_t* s_ticket = reinterpret_cast<volatile uint32_t*>(slice + p.cells_pad + kTicketOff);
+    double* s_tot = reinterpret_cast<double*>(slice + p.cells_pad + kTicketOff + 8);
 
     const int r = TR ? TR : p.r, V = TR ? 2 * TR + 1 : p.V, VV = TR ? (2 * TR + 1) * (2 * TR + 1) : p.VV;
     const int H = TH ? TH : p.H, W = TW ? TW : p.W;
@@ -55,7 +69,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     int wi[kMaxPass], wj[kMaxPass];
 #pragma unroll
     for (int k = 0; k < kMaxPass; ++k) {
-        const int w = gtid + k * G;
+        const int w = atid + k * GA;
         wi[k] = w / V;
         wj[k] = w - wi[k] * V;
     }
@@ -72,7 +86,10 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         uint8_t* ggrid = p.grid + env * p.env_stride;
         load_grid<G>(p, ggrid, lg, gtid);
         double tot = 0.0;
-        if (gtid == 0 && p.do_move) tot = p.total[env];
+        if (gtid == 0 && p.do_move) {
+            tot = p.total[env];
+            if constexpr (kTicket) *s_tot = tot;
+        }
         uint32_t yx0 = 0;                     // this thread's agent: position at the start of the call
         if (gtid < p.A) {
             uint16_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + gtid];
@@ -102,6 +119,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             }
             s_act[gtid] = (uint8_t)act;
         }
+        if constexpr (kTicket)
+            if (gtid == 0) s_ticket[0] = s_ticket[1] = (uint32_t)p.a0;
         gsync<WPE>();
         if (p.flags & SGW_STEP_SWEEP) {
             if (p.has_become) {
@@ -114,200 +133,521 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         }
 
         const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;   // OBS_NEXT: one extra, observe-only iteration
-        for (int a = p.a0; a < a_end; ++a) {
-            const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
-            // ---- pov: egocentric window (visual_field.py:9-101)
-            if (p.obs_next ? a == p.a1 : write_obs) {
-                float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * VV;
-                auto render = [&](const int w, const int i, const int j) {
-                    const int gy = y - r + i, gx = x - r + j;
-                    const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                    const int off = gy * W + gx;
-                    float* o = obase + w;
-                    if constexpr (ONEHOT) {
-                        constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
-                        const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
-                        uint32_t cnt[NWq];
-#pragma unroll
-                        for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
-                        const int nw = (Cn + 3) >> 2;
-                        if (inb) {
-#pragma unroll
-                            for (int z = 0; z < (TL ? TL : 1); ++z) {
-                                const uint32_t t = lg[z * HW + off] & 31u;
-#pragma unroll
-                                for (int q = 0; q < NWq; ++q)
-                                    if (q < nw) cnt[q] += tab->delta[q][t];
-                            }
-                            if constexpr (TL == 0) {
-                                for (int z = 1; z < Ln; ++z) {
+        if constexpr (!kTicket) {
+        // ---- a wave (or part of one) per env: the agents one after the other, the whole group on each
+            for (int a = p.a0; a < a_end; ++a) {
+                const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
+                // ---- pov: egocentric window (visual_field.py:9-101)
+                if (p.obs_next ? a == p.a1 : write_obs) {
+                    float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * VV;
+                    auto render = [&](const int w, const int i, const int j) {
+                        const int gy = y - r + i, gx = x - r + j;
+                        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                        const int off = gy * W + gx;
+                        float* o = obase + w;
+                        if constexpr (ONEHOT) {
+                            constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
+                            const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
+                            uint32_t cnt[NWq];
+    #pragma unroll
+                            for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
+                            const int nw = (Cn + 3) >> 2;
+                            if (inb) {
+    #pragma unroll
+                                for (int z = 0; z < (TL ? TL : 1); ++z) {
                                     const uint32_t t = lg[z * HW + off] & 31u;
-#pragma unroll
+    #pragma unroll
                                     for (int q = 0; q < NWq; ++q)
                                         if (q < nw) cnt[q] += tab->delta[q][t];
                                 }
+                                if constexpr (TL == 0) {
+                                    for (int z = 1; z < Ln; ++z) {
+                                        const uint32_t t = lg[z * HW + off] & 31u;
+    #pragma unroll
+                                        for (int q = 0; q < NWq; ++q)
+                                            if (q < nw) cnt[q] += tab->delta[q][t];
+                                    }
+                                }
+                            } else {   // fill entity's appearance, once (visual_field.py:89-94)
+    #pragma unroll
+                                for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
                             }
-                        } else {   // fill entity's appearance, once (visual_field.py:89-94)
-#pragma unroll
-                            for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
-                        }
-#pragma unroll
-                        for (int q = 0; q < NWq; ++q) {
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int c = 4 * q + b;
-                                if (c < Cn) {
-                                    const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
-                                    if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
-                                    else o[c * VV] = (float)v;
+    #pragma unroll
+                            for (int q = 0; q < NWq; ++q) {
+    #pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < Cn) {
+                                        const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                                        if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
+                                        else o[c * VV] = (float)v;
+                                    }
                                 }
                             }
-                        }
-                    } else {
-                        for (int c = 0; c < p.C; ++c) {
-                            double acc;
-                            if (inb) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
-                                acc = tab->appearance[lg[off] & 31u][c];
-                                for (int z = 1; z < p.L; ++z) acc += tab->appearance[lg[z * HW + off] & 31u][c];
-                            } else {
-                                acc = tab->appearance[p.fill_type][c];
+                        } else {
+                            for (int c = 0; c < p.C; ++c) {
+                                double acc;
+                                if (inb) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
+                                    acc = tab->appearance[lg[off] & 31u][c];
+                                    for (int z = 1; z < p.L; ++z) acc += tab->appearance[lg[z * HW + off] & 31u][c];
+                                } else {
+                                    acc = tab->appearance[p.fill_type][c];
+                                }
+                                o[c * VV] = obs_finish(acc, p.obs_post);
                             }
-                            o[c * VV] = obs_finish(acc, p.obs_post);
+                        }
+                    };
+    #pragma unroll
+                    for (int k = 0; k < kMaxPass; ++k) {
+                        const int w = gtid + k * G;
+                        if (w < VV) render(w, wi[k], wj[k]);
+                    }
+                    {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
+                        int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
+                        for (int w = gtid + kMaxPass * G; w < VV; w += G) {
+                            j += G;
+                            while (j >= V) { j -= V; ++i; }
+                            render(w, i, j);
                         }
                     }
-                };
-#pragma unroll
-                for (int k = 0; k < kMaxPass; ++k) {
-                    const int w = gtid + k * G;
-                    if (w < VV) render(w, wi[k], wj[k]);
                 }
-                {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
-                    int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
-                    for (int w = gtid + kMaxPass * G; w < VV; w += G) {
-                        j += G;
-                        while (j >= V) { j -= V; ++i; }
-                        render(w, i, j);
+                if (!p.do_move || a >= p.a1) continue;
+                if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
+                    // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
+                    // same LDS bytes, so all control flow here is uniform; single threads do the writes.
+                    const uint32_t act = s_act[a];
+                    const uint32_t my_type = s_type[a];
+                    const bool act_ok = act < (uint32_t)p.nact;
+                    const uint32_t kind = act_ok ? (p.kind_pack >> (2 * act)) & 3u : 0u;
+                    const int dy = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
+                    const int dx = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
+                    const int ny = y + dy, nx = x + dx;
+                    const uint32_t facing = s_dir[a] & 3u;
+                    gsync<WPE>();
+                    if (act_ok && kind != SGW_ACTION_MOVE && p.zA + 1 < p.L && gtid < 3 * p.beam_radius) {
+                        // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
+                        const int arm = gtid / p.beam_radius, i = gtid - arm * p.beam_radius;
+                        const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
+                        const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
+                        const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                        const int by = y + side * ry + step * fy, bx = x + side * rx + step * fx;
+                        if ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) {
+                            const int boff = (p.zA + 1) * HW + by * W + bx;
+                            if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
+                                lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
+                        }
                     }
+                    gsync<WPE>();
+                    const bool inb = act_ok && (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
+                    double val = 0.0;
+                    uint32_t t = 0xFFu;
+                    if (inb) {
+                        for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * W + nx] & 31u];   // all layers, BEFORE the move
+                        t = lg[zoff + ny * W + nx];
+                    }
+                    const bool pass = inb && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                    gsync<WPE>();
+                    if (gtid == 0) {
+                        s_pov[a] = (uint8_t)my_type;
+                        if (act_ok && kind == SGW_ACTION_MOVE) {            // movement() turns the agent even if the move fails
+                            if (dy == -1 && dx == 0) s_dir[a] = 0;
+                            else if (dy == 1 && dx == 0) s_dir[a] = 2;
+                            else if (dy == 0 && dx == -1) s_dir[a] = 3;
+                            else if (dy == 0 && dx == 1) s_dir[a] = 1;
+                        }
+                        if (pass) {
+                            lg[zoff + ny * W + nx] = (uint8_t)my_type;
+                            lg[zoff + y * W + x] = (uint8_t)p.default_type;
+                            s_pos[2 * a] = (uint8_t)ny;
+                            s_pos[2 * a + 1] = (uint8_t)nx;
+                        }
+                        s_rew[a] = (float)val;
+                        tot += val * (double)(p.total_factor - 1);       // the extra add inside act() (agents.py:172) ...
+                        tot += val;                                      // ... and Agent.transition's own (agent.py:172)
+                        st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0);
+                    }
+                    gsync<WPE>();
+                    continue;
                 }
-            }
-            if (!p.do_move || a >= p.a1) continue;
-            if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
-                // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
-                // same LDS bytes, so all control flow here is uniform; single threads do the writes.
+                // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
                 const uint32_t act = s_act[a];
                 const uint32_t my_type = s_type[a];
                 const bool act_ok = act < (uint32_t)p.nact;
-                const uint32_t kind = act_ok ? (p.kind_pack >> (2 * act)) & 3u : 0u;
-                const int dy = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
-                const int dx = (act_ok && kind == SGW_ACTION_MOVE) ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
-                const int ny = y + dy, nx = x + dx;
-                const uint32_t facing = s_dir[a] & 3u;
-                gsync<WPE>();
-                if (act_ok && kind != SGW_ACTION_MOVE && p.zA + 1 < p.L && gtid < 3 * p.beam_radius) {
-                    // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
-                    const int arm = gtid / p.beam_radius, i = gtid - arm * p.beam_radius;
-                    const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
-                    const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
-                    const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
-                    const int by = y + side * ry + step * fy, bx = x + side * rx + step * fx;
-                    if ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) {
-                        const int boff = (p.zA + 1) * HW + by * W + bx;
-                        if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
-                            lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
-                    }
-                }
-                gsync<WPE>();
-                const bool inb = act_ok && (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
-                double val = 0.0;
-                uint32_t t = 0xFFu;
-                if (inb) {
-                    for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * W + nx] & 31u];   // all layers, BEFORE the move
-                    t = lg[zoff + ny * W + nx];
-                }
-                const bool pass = inb && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
-                gsync<WPE>();
+                const int dy = act_ok ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
+                const int dx = act_ok ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
+                const int ty = y + dy, tx = x + dx;
+                const bool inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+                const int taddr = zoff + ty * W + tx;
+                const int oaddr = zoff + y * W + x;
+                const uint32_t t = inb ? lg[taddr] : 0xFFu;
+                const bool tok = t < (uint32_t)p.T;
+                double val = (inb && tok && RULE == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
+                const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
+                const int cy = pass ? ty : y, cx = pass ? tx : x;   // where the agent stands after the move
+                gsync<WPE>();   // every thread has read s_type / the target before thread 0 rewrites them
                 if (gtid == 0) {
                     s_pov[a] = (uint8_t)my_type;
-                    if (act_ok && kind == SGW_ACTION_MOVE) {            // movement() turns the agent even if the move fails
-                        if (dy == -1 && dx == 0) s_dir[a] = 0;
-                        else if (dy == 1 && dx == 0) s_dir[a] = 2;
-                        else if (dy == 0 && dx == -1) s_dir[a] = 3;
-                        else if (dy == 0 && dx == 1) s_dir[a] = 1;
-                    }
                     if (pass) {
-                        lg[zoff + ny * W + nx] = (uint8_t)my_type;
-                        lg[zoff + y * W + x] = (uint8_t)p.default_type;
-                        s_pos[2 * a] = (uint8_t)ny;
-                        s_pos[2 * a + 1] = (uint8_t)nx;
+                        lg[taddr] = (uint8_t)my_type;
+                        lg[oaddr] = (uint8_t)p.default_type;
+                        s_pos[2 * a] = (uint8_t)ty;
+                        s_pos[2 * a + 1] = (uint8_t)tx;
                     }
-                    s_rew[a] = (float)val;
-                    tot += val * (double)(p.total_factor - 1);       // the extra add inside act() (agents.py:172) ...
-                    tot += val;                                      // ... and Agent.transition's own (agent.py:172)
-                    st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0);
+                    st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
+                               ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
                 }
-                gsync<WPE>();
-                continue;
-            }
-            // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
-            const uint32_t act = s_act[a];
-            const uint32_t my_type = s_type[a];
-            const bool act_ok = act < (uint32_t)p.nact;
-            const int dy = act_ok ? (int)((p.dy_pack >> (2 * act)) & 3u) - 1 : 0;
-            const int dx = act_ok ? (int)((p.dx_pack >> (2 * act)) & 3u) - 1 : 0;
-            const int ty = y + dy, tx = x + dx;
-            const bool inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
-            const int taddr = zoff + ty * W + tx;
-            const int oaddr = zoff + y * W + x;
-            const uint32_t t = inb ? lg[taddr] : 0xFFu;
-            const bool tok = t < (uint32_t)p.T;
-            double val = (inb && tok && RULE == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
-            const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
-            const int cy = pass ? ty : y, cx = pass ? tx : x;   // where the agent stands after the move
-            gsync<WPE>();   // every thread has read s_type / the target before thread 0 rewrites them
-            if (gtid == 0) {
-                s_pov[a] = (uint8_t)my_type;
-                if (pass) {
-                    lg[taddr] = (uint8_t)my_type;
-                    lg[oaddr] = (uint8_t)p.default_type;
-                    s_pos[2 * a] = (uint8_t)ty;
-                    s_pos[2 * a + 1] = (uint8_t)tx;
-                }
-                st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
-                           ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
-            }
-            if constexpr (RULE == SGW_AGENT_RULE_TAG) {
-                // TagAgent.act (sorrel/examples/tag/agents.py:84-106): look at the four neighbours in
-                // Location.adjacent order (up, right, down, left; off-map skipped); an agent that is
-                // "it" hands the flag to the FIRST neighbour that is a NotIt agent.  Every thread
-                // evaluates the same LDS bytes, so `mine_now` stays uniform.
-                gsync<WPE>();
-                uint32_t mine_now = my_type;
-                const int own = zoff + cy * W + cx;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
-                    const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
-                    const bool ain = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
-                    const uint32_t nt = ain ? lg[zoff + ay * W + ax] : 0xFFu;
-                    if (mine_now == p.tag_it && nt == p.tag_notit) {
-                        mine_now = p.tag_notit;
-                        if (gtid == 0) {
-                            lg[own] = (uint8_t)p.tag_notit;
-                            lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
-                            s_type[a] = (uint8_t)p.tag_notit;
+                if constexpr (RULE == SGW_AGENT_RULE_TAG) {
+                    // TagAgent.act (sorrel/examples/tag/agents.py:84-106): look at the four neighbours in
+                    // Location.adjacent order (up, right, down, left; off-map skipped); an agent that is
+                    // "it" hands the flag to the FIRST neighbour that is a NotIt agent.  Every thread
+                    // evaluates the same LDS bytes, so `mine_now` stays uniform.
+                    gsync<WPE>();
+                    uint32_t mine_now = my_type;
+                    const int own = zoff + cy * W + cx;
+    #pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
+                        const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                        const bool ain = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                        const uint32_t nt = ain ? lg[zoff + ay * W + ax] : 0xFFu;
+                        if (mine_now == p.tag_it && nt == p.tag_notit) {
+                            mine_now = p.tag_notit;
+                            if (gtid == 0) {
+                                lg[own] = (uint8_t)p.tag_notit;
+                                lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
+                                s_type[a] = (uint8_t)p.tag_notit;
+                            }
+                            // the neighbour's slot: the agent standing on (ay, ax)
+                            if (gtid < p.A && gtid != a && s_pos[2 * gtid] == ay && s_pos[2 * gtid + 1] == ax)
+                                s_type[gtid] = (uint8_t)p.tag_it;
                         }
-                        // the neighbour's slot: the agent standing on (ay, ax)
-                        if (gtid < p.A && gtid != a && s_pos[2 * gtid] == ay && s_pos[2 * gtid + 1] == ax)
-                            s_type[gtid] = (uint8_t)p.tag_it;
+                    }
+                    val = mine_now != p.tag_it ? p.tag_reward : 0.0;
+                }
+                if (gtid == 0) {
+                    s_rew[a] = (float)val;
+                    tot += val;   // world.total_reward += reward, float64, agent order (agent.py:172)
+                }
+                gsync<WPE>();
+            }
+        } else {
+        // ---- G = 256: an agent phase is the work of ONE wave; the waves take the agents in turn (see kTicket above)
+            auto agent_phase = [&](const int a) {
+                // what does not depend on the other agents is read BEFORE the wait for the ticket: an agent's position only
+                // changes by its own act, its action is fixed for the turn
+                const uint32_t yx_a = reinterpret_cast<const uint16_t*>(s_pos)[a];
+                const int y = (int)(yx_a & 0xFFu), x = (int)(yx_a >> 8);
+                const uint32_t act_a = (p.do_move && a < p.a1) ? (uint32_t)s_act[a] : 0u;
+                double pend[2];                              // G = 256: this agent's additions to total_reward, applied in agent order below
+                int npend = 0;
+                auto add_total = [&](const double v) {       // world.total_reward += reward, float64, agent order (agent.py:172)
+                    if constexpr (kTicket) pend[npend++] = v;
+                    else tot += v;
+                };
+                const bool observe = p.obs_next ? a == p.a1 : write_obs;
+                float* const obase0 = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * VV;
+                uint32_t clo[kMaxPass], chi[kMaxPass];      // G = 256: the captured window bytes (layers 0-3 | 4-6, five bits each)
+                bool cin[kMaxPass];
+                int coff[kMaxPass];
+                // the geometry of the move (agent.py:187-225; Cleanup: only a move action moves): pure arithmetic on this
+                // agent's own position and action.  G = 256 does it -- and the window's -- before the wait; the packed kernels
+                // where they always did, after the observation (earlier costs them registers: Tag's static instance 72 -> 76)
+                bool act_ok = false, inb = false;
+                uint32_t kind = SGW_ACTION_MOVE;
+                int dy = 0, dx = 0, ty = y, tx = x, taddr = 0, oaddr = 0;
+                auto move_geometry = [&]() {
+                    act_ok = act_a < (uint32_t)p.nact;
+                    if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) kind = act_ok ? (p.kind_pack >> (2 * act_a)) & 3u : 0u;
+                    const bool moves = act_ok && kind == SGW_ACTION_MOVE;
+                    dy = moves ? (int)((p.dy_pack >> (2 * act_a)) & 3u) - 1 : 0;
+                    dx = moves ? (int)((p.dx_pack >> (2 * act_a)) & 3u) - 1 : 0;
+                    ty = y + dy;
+                    tx = x + dx;
+                    inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+                    taddr = zoff + ty * W + tx;
+                    oaddr = zoff + y * W + x;
+                };
+                if constexpr (kTicket) {
+                    move_geometry();
+                    if (observe) {
+    #pragma unroll
+                        for (int k = 0; k < kMaxPass; ++k) {
+                            const int w = atid + k * GA;
+                            const int gy = y - r + wi[k], gx = x - r + wj[k];
+                            cin[k] = w < VV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                            coff[k] = cin[k] ? gy * W + gx : 0;
+                        }
+                    }
+                    if (p.do_move) {                         // (sgw_observe: nothing changes the grid, no order to keep)
+                        while (s_ticket[0] != (uint32_t)a) {}      // (s_sleep 1 / 2 / 4 between looks: 125.3 / 126.2 / 127.4 us against 125.5)
+                        asm volatile("" ::: "memory");
                     }
                 }
-                val = mine_now != p.tag_it ? p.tag_reward : 0.0;
-            }
-            if (gtid == 0) {
-                s_rew[a] = (float)val;
-                tot += val;   // world.total_reward += reward, float64, agent order (agent.py:172)
-            }
-            gsync<WPE>();
+                // G = 256: pass the ticket on, then turn the captured bytes into stores (visual_field.py:41-55, 89-94)
+                auto after_act = [&]() {
+                    if constexpr (kTicket) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes have landed (LDS only: no wait for stores)
+                        if (atid == 0) s_ticket[0] = (uint32_t)(a + 1);
+                        // the float64 total: same agent order, its own ticket, so that the read-modify-write in LDS is not part
+                        // of the act chain (the two chains run side by side)
+                        if (atid == 0 && p.do_move && a < p.a1) {
+                            while (s_ticket[1] != (uint32_t)a) {}
+                            asm volatile("" ::: "memory");
+                            double t = *s_tot;
+                            for (int i = 0; i < npend; ++i) t += pend[i];
+                            *s_tot = t;
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            s_ticket[1] = (uint32_t)(a + 1);
+                        }
+                        if (!observe) return;
+    #pragma unroll
+                        for (int k = 0; k < kMaxPass; ++k) {
+                            const int w = atid + k * GA;
+                            if (w >= VV) continue;
+                            float* o = obase0 + w;
+                            const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
+                            if constexpr (ONEHOT) {
+                                constexpr int NWq = TC ? (TC + 3) / 4 : 4;
+                                uint32_t cnt[NWq];
+    #pragma unroll
+                                for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
+                                const int nw = (Cn + 3) >> 2;
+                                if (cin[k]) {
+                                    for (int z = 0; z < Ln; ++z) {
+                                        const uint32_t t = z < 4 ? (clo[k] >> (8 * z)) & 31u : (chi[k] >> (8 * (z - 4))) & 31u;
+    #pragma unroll
+                                        for (int q = 0; q < NWq; ++q)
+                                            if (q < nw) cnt[q] += tab->delta[q][t];
+                                    }
+                                } else {
+    #pragma unroll
+                                    for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
+                                }
+    #pragma unroll
+                                for (int q = 0; q < NWq; ++q) {
+    #pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < Cn) {
+                                            const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                                            if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
+                                            else o[c * VV] = (float)v;
+                                        }
+                                    }
+                                }
+                            } else {
+                                for (int c = 0; c < Cn; ++c) {
+                                    double acc;
+                                    if (cin[k]) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
+                                        acc = tab->appearance[clo[k] & 31u][c];
+                                        for (int z = 1; z < Ln; ++z)
+                                            acc += tab->appearance[z < 4 ? (clo[k] >> (8 * z)) & 31u : (chi[k] >> (8 * (z - 4))) & 31u][c];
+                                    } else {
+                                        acc = tab->appearance[p.fill_type][c];
+                                    }
+                                    o[c * VV] = obs_finish(acc, p.obs_post);
+                                }
+                            }
+                        }
+                    }
+                };
+                // ---- pov: egocentric window (visual_field.py:9-101)
+                if (observe) {
+                    float* obase = obase0;
+                    auto render = [&](const int w, const int i, const int j) {
+                        const int gy = y - r + i, gx = x - r + j;
+                        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                        const int off = gy * W + gx;
+                        float* o = obase + w;
+                        if constexpr (ONEHOT) {
+                            constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
+                            const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
+                            uint32_t cnt[NWq];
+    #pragma unroll
+                            for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
+                            const int nw = (Cn + 3) >> 2;
+                            if (inb) {
+    #pragma unroll
+                                for (int z = 0; z < (TL ? TL : 1); ++z) {
+                                    const uint32_t t = lg[z * HW + off] & 31u;
+    #pragma unroll
+                                    for (int q = 0; q < NWq; ++q)
+                                        if (q < nw) cnt[q] += tab->delta[q][t];
+                                }
+                                if constexpr (TL == 0) {
+                                    for (int z = 1; z < Ln; ++z) {
+                                        const uint32_t t = lg[z * HW + off] & 31u;
+    #pragma unroll
+                                        for (int q = 0; q < NWq; ++q)
+                                            if (q < nw) cnt[q] += tab->delta[q][t];
+                                    }
+                                }
+                            } else {   // fill entity's appearance, once (visual_field.py:89-94)
+    #pragma unroll
+                                for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
+                            }
+    #pragma unroll
+                            for (int q = 0; q < NWq; ++q) {
+    #pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < Cn) {
+                                        const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                                        if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
+                                        else o[c * VV] = (float)v;
+                                    }
+                                }
+                            }
+                        } else {
+                            for (int c = 0; c < p.C; ++c) {
+                                double acc;
+                                if (inb) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
+                                    acc = tab->appearance[lg[off] & 31u][c];
+                                    for (int z = 1; z < p.L; ++z) acc += tab->appearance[lg[z * HW + off] & 31u][c];
+                                } else {
+                                    acc = tab->appearance[p.fill_type][c];
+                                }
+                                o[c * VV] = obs_finish(acc, p.obs_post);
+                            }
+                        }
+                    };
+                    if constexpr (kTicket) {   // the first kMaxPass cells of this lane: bytes now, stores after the act
+    #pragma unroll
+                        for (int k = 0; k < kMaxPass; ++k) {
+                            clo[k] = chi[k] = 0;
+                            for (int z = 0; z < (TL ? TL : p.L); ++z) {      // (out-of-window lanes read cell 0 and ignore it)
+                                const uint32_t t = lg[z * HW + coff[k]] & 31u;
+                                if (z < 4) clo[k] |= t << (8 * z);
+                                else chi[k] |= t << (8 * (z - 4));
+                            }
+                        }
+                    } else {
+    #pragma unroll
+                        for (int k = 0; k < kMaxPass; ++k) {
+                            const int w = atid + k * GA;
+                            if (w < VV) render(w, wi[k], wj[k]);
+                        }
+                    }
+                    {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
+                        int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
+                        for (int w = atid + kMaxPass * GA; w < VV; w += GA) {
+                            j += GA;
+                            while (j >= V) { j -= V; ++i; }
+                            render(w, i, j);
+                        }
+                    }
+                }
+                if (!p.do_move || a >= p.a1) { after_act(); return; }
+                if constexpr (!kTicket) move_geometry();
+                if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
+                    // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
+                    // same LDS bytes, so all control flow here is uniform; single threads do the writes.
+                    const uint32_t my_type = s_type[a];
+                    const int ny = ty, nx = tx;
+                    const uint32_t facing = s_dir[a] & 3u;
+                    gsync<WPA>();
+                    if (act_ok && kind != SGW_ACTION_MOVE && p.zA + 1 < p.L)
+                      for (int bc = atid; bc < 3 * p.beam_radius; bc += GA) {
+                        // beam cells on the layer above: 1..R ahead; 0..R-1 ahead of the right / left neighbours
+                        const int arm = bc / p.beam_radius, i = bc - arm * p.beam_radius;
+                        const int fy = facing == 0 ? -1 : facing == 2 ? 1 : 0, fx = facing == 1 ? 1 : facing == 3 ? -1 : 0;
+                        const int ry = facing == 1 ? 1 : facing == 3 ? -1 : 0, rx = facing == 0 ? 1 : facing == 2 ? -1 : 0;
+                        const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                        const int by = y + side * ry + step * fy, bx = x + side * rx + step * fx;
+                        if ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) {
+                            const int boff = (p.zA + 1) * HW + by * W + bx;
+                            if (!((p.beam_block_mask >> (lg[boff] & 31u)) & 1u))
+                                lg[boff] = (uint8_t)(kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam);
+                        }
+                    }
+                    gsync<WPA>();
+                    double val = 0.0;
+                    uint32_t t = 0xFFu;
+                    if (inb) {
+                        for (int zl = 0; zl < p.L; ++zl) val += tab->value[lg[zl * HW + ny * W + nx] & 31u];   // all layers, BEFORE the move
+                        t = lg[zoff + ny * W + nx];
+                    }
+                    const bool pass = inb && t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                    gsync<WPA>();
+                    if (atid == 0) {
+                        s_pov[a] = (uint8_t)my_type;
+                        if (act_ok && kind == SGW_ACTION_MOVE) {            // movement() turns the agent even if the move fails
+                            if (dy == -1 && dx == 0) s_dir[a] = 0;
+                            else if (dy == 1 && dx == 0) s_dir[a] = 2;
+                            else if (dy == 0 && dx == -1) s_dir[a] = 3;
+                            else if (dy == 0 && dx == 1) s_dir[a] = 1;
+                        }
+                        if (pass) {
+                            lg[zoff + ny * W + nx] = (uint8_t)my_type;
+                            lg[zoff + y * W + x] = (uint8_t)p.default_type;
+                            s_pos[2 * a] = (uint8_t)ny;
+                            s_pos[2 * a + 1] = (uint8_t)nx;
+                        }
+                        s_rew[a] = (float)val;
+                        add_total(val * (double)(p.total_factor - 1));       // the extra add inside act() (agents.py:172) ...
+                        add_total(val);                                  // ... and Agent.transition's own (agent.py:172)
+                        st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0);
+                    }
+                    gsync<WPA>();
+                    after_act();
+                    return;
+                }
+                // ---- act: MovingAgent.movement / act, Gridworld.move (agent.py:187-225, gridworld.py:95-122)
+                const uint32_t my_type = s_type[a];
+                const uint32_t t = inb ? lg[taddr] : 0xFFu;
+                const bool tok = t < (uint32_t)p.T;
+                double val = (inb && tok && RULE == SGW_AGENT_RULE_MOVE) ? tab->value[t & 31u] : 0.0;   // reward read BEFORE the move
+                const bool pass = inb && tok && ((p.pass_mask >> (t & 31u)) & 1u);
+                const int cy = pass ? ty : y, cx = pass ? tx : x;   // where the agent stands after the move
+                gsync<WPA>();   // every thread has read s_type / the target before thread 0 rewrites them
+                if (atid == 0) {
+                    s_pov[a] = (uint8_t)my_type;
+                    if (pass) {
+                        lg[taddr] = (uint8_t)my_type;
+                        lg[oaddr] = (uint8_t)p.default_type;
+                        s_pos[2 * a] = (uint8_t)ty;
+                        s_pos[2 * a + 1] = (uint8_t)tx;
+                    }
+                    st_bits |= (!act_ok ? SGW_STATUS_BAD_ACTION : 0) | ((act_ok && !inb) ? SGW_STATUS_OOB_MOVE : 0) |
+                               ((inb && !tok) ? SGW_STATUS_BAD_TYPE : 0);
+                }
+                if constexpr (RULE == SGW_AGENT_RULE_TAG) {
+                    // TagAgent.act (sorrel/examples/tag/agents.py:84-106): look at the four neighbours in
+                    // Location.adjacent order (up, right, down, left; off-map skipped); an agent that is
+                    // "it" hands the flag to the FIRST neighbour that is a NotIt agent.  Every thread
+                    // evaluates the same LDS bytes, so `mine_now` stays uniform.
+                    gsync<WPA>();
+                    uint32_t mine_now = my_type;
+                    const int own = zoff + cy * W + cx;
+    #pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
+                        const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                        const bool ain = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                        const uint32_t nt = ain ? lg[zoff + ay * W + ax] : 0xFFu;
+                        if (mine_now == p.tag_it && nt == p.tag_notit) {
+                            mine_now = p.tag_notit;
+                            if (atid == 0) {
+                                lg[own] = (uint8_t)p.tag_notit;
+                                lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
+                                s_type[a] = (uint8_t)p.tag_notit;
+                            }
+                            // the neighbour's slot: the agent standing on (ay, ax)
+                            if (atid < p.A && atid != a && s_pos[2 * atid] == ay && s_pos[2 * atid + 1] == ax)
+                                s_type[atid] = (uint8_t)p.tag_it;
+                        }
+                    }
+                    val = mine_now != p.tag_it ? p.tag_reward : 0.0;
+                }
+                if (atid == 0) {
+                    s_rew[a] = (float)val;
+                    add_total(val);
+                }
+                gsync<WPA>();
+                after_act();
+            };
+            for (int a = p.a0 + (tid >> 6); a < a_end; a += kBlock / kWave) agent_phase(a);
+            __syncthreads();            // every agent has acted: rewards / positions / the grid are final
         }
         if (p.do_move && gtid >= p.a0 && gtid < p.a1) {      // this turn's rewards (and what TagAgent.pov appends)
             p.rewards[tix * p.ts_rew + env * p.A + gtid] = s_rew[gtid];
@@ -336,10 +676,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                 reinterpret_cast<uint16_t*>(p.pos)[env * p.A + gtid] = reinterpret_cast<const uint16_t*>(s_pos)[gtid];
             if (gtid < p.A && p.agent_state) p.agent_state[env * p.A + gtid] = s_type[gtid];   // a tag can flip any agent
             if (gtid < p.A && p.agent_dir) p.agent_dir[env * p.A + gtid] = s_dir[gtid];
-            if (gtid == 0) {
-                p.total[env] = tot;
-                if (st_bits) atomicOr(p.status, st_bits);
-            }
+            if (gtid == 0) p.total[env] = kTicket ? *s_tot : tot;
+            if (atid == 0 && st_bits) atomicOr(p.status, st_bits);      // (G = 256: lane 0 of every wave kept its own bits)
         }
     }
 }

@@ -217,6 +217,97 @@ def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
         assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
 
 
+@pytest.mark.parametrize("case", ["tag_70x80", "tag_crowded_66x64", "cleanup_40x48", "cleanup_wide_beam", "move_phased", "move_wide_window",
+                                  "observe_only", "u8_obs"])
+def test_workgroup_per_env_generic_kernel_ticket_order(torch_cuda, case, monkeypatch):
+    """Worlds above 4 KiB on the generic kernel (step_kernel<256>: what Tag / Cleanup worlds of that size run on): the
+    four waves of a workgroup take the agents in turn behind an LDS ticket, window bytes captured before the act and
+    stored after it.  Tag (flags handed from wave to wave, crowded so that many tags happen), Cleanup (beams, ordered
+    sweep; the widest beam the library takes, 3R = 63 cells), plain moves stepped agent by agent with OBS_NEXT, a 13x13
+    window (more cells than the registers hold: the rest is rendered before the act), sgw_observe, uint8 observations."""
+    torch = torch_cuda
+    import dataclasses
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    kw = {}
+    grid0 = pos0 = None
+    if case.startswith("tag"):
+        d, spec = H.load_golden("tag_11x11_default")
+        ws = H.world_spec(spec)
+        h, w, a = (70, 80, 12) if case == "tag_70x80" else (66, 64, 64)
+        ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a)
+        E, T = (13, 25) if case == "tag_70x80" else (7, 12)
+    elif case.startswith("cleanup"):
+        d, spec = H.load_golden("cleanup_15x16")
+        ws = H.world_spec(spec)
+        h, w, a = 40, 48, 10
+        ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a,
+                                 beam_radius=21 if case == "cleanup_wide_beam" else ws.beam_radius)
+        # the reference's map at this size (type ids as in oracle/make_golden.py: 1 sand, 2 wall, 3 river, 5 apple tree, 11 agent)
+        g = np.zeros((3, h, w), np.uint8)
+        g[:, 0, :] = g[:, -1, :] = 2
+        g[:, :, 0] = g[:, :, -1] = 2
+        g[0, 1:12, 1:-1] = 3
+        g[0, 12:28, 1:-1] = 1
+        g[0, 28:39, 1:-1] = 5
+        pos = np.array([[14 + (i // 5) * 6, 4 + (i % 5) * 9] for i in range(a)], np.uint8)
+        for (y, x) in pos:
+            g[1, y, x] = 11
+        grid0, pos0 = g, pos
+        E, T = 9, 14
+    else:
+        r = 6 if case == "move_wide_window" else 4
+        ws = treasurehunt_spec(72, 64, 23, r, spawn_prob=0.05, seed=41, dense_prob=0.25)
+        E, T = 11, 5
+        if case == "u8_obs":
+            kw["obs_dtype"] = torch.uint8
+    eng = make_engine(ws, E, first=17, **kw)
+    assert "step_kernel<" in eng.launch_info() and "group=256 " in eng.launch_info()
+    co = H.COracle(ws, E, first_env_id=17)
+    if grid0 is not None:
+        eng.grid.copy_(torch.from_numpy(np.broadcast_to(grid0, (E,) + grid0.shape).copy()))
+        eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos0, (E,) + pos0.shape).copy()))
+        eng.total_reward.zero_()
+        co.grid[...] = grid0
+        co.pos[...] = pos0
+        co.total[...] = 0
+    else:
+        eng.reset(0)
+        co.reset(0)
+    what = ("grid", "pos", "actions", "rewards", "total") if case == "u8_obs" else ("grid", "pos", "actions", "obs", "rewards", "total")
+    for t in range(1, T + 1):
+        if case == "move_phased":       # 1 + A launches, each rendering the NEXT agent's window after its own agent's move
+            assert co.step(0, t, random_actions=True) == 0
+            acts = torch.from_numpy(co.actions.copy()).cuda()
+            eng.obs.fill_(-3.0)
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for a in range(ws.num_agents):
+                eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, obs_next=a + 1 < ws.num_agents, write_obs=False, turn=t, advance_turn=False)
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+            assert co.step(0, t, random_actions=True) == 0
+        assert_same(eng, co, what, ctx=f"{case} turn {t}")
+        if case == "u8_obs":
+            torch.cuda.synchronize()
+            assert np.array_equal(eng.obs.cpu().numpy().astype(np.float32), co.obs), f"{case} turn {t}: uint8 observations"
+        if case.startswith("tag"):
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state) and np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov)
+        if case.startswith("cleanup"):
+            assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir)
+    if case == "observe_only":
+        eng.obs.zero_()
+        eng.observe()
+        co.observe()
+        assert_same(eng, co, ("obs",), ctx="observe")
+        eng.observe(5, 9)
+        co.observe(5, 9)
+        assert_same(eng, co, ("obs",), ctx="observe range")
+    if case.startswith("tag"):
+        assert len(np.unique(eng.agent_state.cpu().numpy(), axis=0)) > 1        # the flag really moved around
+    assert eng.status() == 0
+
+
 @pytest.mark.parametrize("group", ["16", "32"])
 @pytest.mark.parametrize("name", ["c1_treasurehunt_10x10", "c2_treasurehunt_16x16", "crowded_6x6", "tag_9x9", "tag_crowded_6x7",
                                   "rgb_treasurehunt", "basic_doublewall", "float_appearance_3layer", "ragged_9x13_rmax",

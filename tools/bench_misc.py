@@ -102,3 +102,44 @@ def run_cleanup(E=16384, K=50):
 
 
 run_cleanup(int(os.environ.get('CLEANUP_E', '16384')))
+
+
+def run_big_rule_worlds():
+    """Tag and Cleanup worlds above 4 KiB (step_kernel<256>): only with MISC_ONLY=big."""
+    if "big" not in ONLY:
+        return
+    for name, spec, E in (("big tag 72x72x1 A16 r4", tag_spec(72, 72, 16, 4), 8192),
+                          ("big tag 128x128x1 A64 r4", tag_spec(128, 128, 64, 4), 2048)):
+        eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
+        for _ in range(100): eng.step(random_actions=True)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(100): eng.step(random_actions=True)
+        b.record(); torch.cuda.synchronize()
+        us = a.elapsed_time(b) / 100 * 1000
+        byt = spec.algorithmic_bytes_per_env_step() * E
+        print(f"{name:34s} E={E:7d} {us:8.1f} us/step  {E*spec.num_agents/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)  [{eng.launch_info().split(' group')[0]}]")
+    spec = cleanup_spec(48, 48, 10, 5)
+    E = 4096
+    eng = GridEngine(spec, E, device="cuda:0")
+    g = np.zeros((3, 48, 48), np.uint8)
+    g[:, 0, :] = g[:, -1, :] = 2; g[:, :, 0] = g[:, :, -1] = 2
+    g[0, 1:14, 1:-1] = 3; g[0, 34:47, 1:-1] = 5; g[0, 14:34, 1:-1] = 1
+    pos = np.array([[18 + (i // 5) * 8, 5 + (i % 5) * 9] for i in range(10)], np.uint8)
+    for (y, x) in pos: g[1, y, x] = 11
+    eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+    eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+    for _ in range(100): eng.step(random_actions=True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(100): eng.step(random_actions=True)
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) / 100 * 1000
+    byt = spec.algorithmic_bytes_per_env_step() * E
+    print(f"{'big cleanup 48x48x3 A10 r5':34s} E={E:7d} {us:8.1f} us/step  {E*10/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)  [{eng.launch_info().split(' group')[0]}]")
+    assert eng.status() == 0
+
+
+run_big_rule_worlds()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""sgw_rollout on the Cleanup example's shape (21x31x3, 10 agents, 11x11 windows): us per turn at 50 turns per call
+against turn-by-turn sgw_step (run on the GPU box).  usage: tools/cleanup_rollout_bench.py [E]"""
+import os, sys
+os.environ["MISC_ONLY"] = "none"          # bench_misc runs nothing at import then
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch
+import bench_misc as BM
+from sorrel_amd.engine import GridEngine
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+spec = BM.cleanup_spec(21, 31, 10, 5)
+eng = GridEngine(spec, E, device="cuda:0")
+g = np.zeros((3, 21, 31), np.uint8)
+g[:, 0, :] = g[:, -1, :] = 2; g[:, :, 0] = g[:, :, -1] = 2
+g[0, 1:7, 1:-1] = 3; g[0, 14:20, 1:-1] = 5; g[0, 7:14, 1:-1] = 1
+pos = np.array([[8 + (i // 5) * 2, 3 + (i % 5) * 5] for i in range(10)], np.uint8)
+for (y, x) in pos: g[1, y, x] = 11
+eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+
+
+def timed(fn, reps):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1000
+
+
+for _ in range(100): eng.step(random_actions=True)
+print(f"cleanup 21x31x3 A10 r5 E={E}  {eng.launch_info().split(' threads')[0]}")
+print(f"  turn by turn (sgw_step)   {timed(lambda: [eng.step(random_actions=True) for _ in range(50)], 3) / 50:8.1f} us/turn")
+print(f"  sgw_rollout, 50 turns     {timed(lambda: eng.rollout(50), 3) / 50:8.1f} us/turn")
+assert eng.status() == 0

@@ -90,13 +90,17 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // MULTI: the variant sgw_rollout launches for nturns > 1 (a turn loop around sweep / agents / emit, the grid staying in
 // LDS).  It is a separate instantiation because the loop costs registers (config 3's kernel: 39 -> 64 VGPRs), which the
 // single-turn kernel must not pay.
+#ifndef SGW_FAST_RULES_PLAIN_WAVES
+#define SGW_FAST_RULES_PLAIN_WAVES 6   // the direct-store RULES instances (agent ranges, OBS_NEXT: the policy path of Cleanup): at 8 the
+                                      // 3-layer / 9-channel one spilled 19 registers; Cleanup policy turn 495 -> 346 us (16 384 envs)
+#endif
 #ifndef SGW_FAST_MULTI_WAVES
 #define SGW_FAST_MULTI_WAVES 6   // waves per SIMD the MULTI (sgw_rollout) instances are compiled for: at 8 (64 VGPRs) the config-3
                                  // instance spills two registers, and a scratch reload waits on vmcnt -- behind the observation
                                  // stores in flight; 8 / 7 / 6 / 5 / 4: 112.4 / 107.6 / 102.2 / 103.2 / 103.2 us per turn (config 3, 50 turns)
 #endif
 template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false>
-__global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : 8) void step_fast(const Params p) {
+__global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (STAGE ? 7 : SGW_FAST_RULES_PLAIN_WAVES) : 8)) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
     // wave-private LDS (grid slice + the table words this wave reads), no s_barrier.

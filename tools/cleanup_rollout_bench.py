@@ -34,4 +34,14 @@ for _ in range(100): eng.step(random_actions=True)
 print(f"cleanup 21x31x3 A10 r5 E={E}  {eng.launch_info().split(' threads')[0]}")
 print(f"  turn by turn (sgw_step)   {timed(lambda: [eng.step(random_actions=True) for _ in range(50)], 3) / 50:8.1f} us/turn")
 print(f"  sgw_rollout, 50 turns     {timed(lambda: eng.rollout(50), 3) / 50:8.1f} us/turn")
+
+
+def phased_turn():          # what a policy-driven Environment.take_turn launches: sweep + pov of agent 0, then one launch per agent
+    eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, obs_next=True, advance_turn=False)
+    for a in range(10):
+        eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, obs_next=a < 9, advance_turn=False)
+    eng.turn += 1
+
+
+print(f"  policy-driven, 1 + A launches {timed(lambda: [phased_turn() for _ in range(20)], 3) / 20:8.1f} us/turn")
 assert eng.status() == 0

@@ -117,6 +117,11 @@ extern "C" {
                                      * the grid AFTER the moves of [agent_begin, agent_end) -- exactly what that agent's
                                      * pov() sees next (sorrel/agents/agent.py:167), so a policy turn costs 1 + A
                                      * launches instead of 1 + 2A */
+#define SGW_STEP_OBS_NEXT_PACKED 16u /* with SGW_STEP_OBS_NEXT: `obs` is NOT the [E][A][C][V][V] tensor but one window per env,
+                                     * [E][C][V][V] contiguous, which receives agent `agent_end`'s observation -- e.g. the
+                                     * slot of that agent's replay buffer its pov() is about to be stored in
+                                     * (sorrel/agents/agent.py:155-173: state = pov(); ...; add_memory(state, ...)), so the
+                                     * observation is written once, where it will live */
 #define SGW_STEP_DEFAULT (SGW_STEP_SWEEP)
 
 /* error codes */

@@ -11,7 +11,7 @@ import os
 MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
 RULE_NONE, RULE_SPAWN, RULE_BECOME_IF = 0, 1, 2
 NO_BORDER = 255
-STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT = 1, 2, 4, 8
+STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT, STEP_OBS_NEXT_PACKED = 1, 2, 4, 8, 16
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
 ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2

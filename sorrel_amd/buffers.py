@@ -40,7 +40,10 @@ class Buffer:
     def add(self, obs, action, reward, done, **extra):
         """Append one turn: ``obs [E, *obs_shape]``, ``action [E]``, ``reward [E]``, ``done`` scalar or ``[E]``."""
         i = self.idx
-        self.states[i].copy_(obs.reshape(self.states[i].shape))
+        row = self.states[i]
+        src = obs.reshape(row.shape)
+        if src.data_ptr() != row.data_ptr():       # (the step kernel may have written the state straight into this row)
+            row.copy_(src)
         self.actions[i].copy_(action)
         self.rewards[i].copy_(reward)
         self.dones[i] = done

@@ -84,6 +84,8 @@ struct Params {
     int obs_stage;    // step_fast: bytes of the per-wave LDS observation staging area (0: observations go straight to HBM)
     int stage_agents; // step_fast<..., STAGE>: agents whose observations are staged together and leave in one burst
     int obs_next;     // SGW_STEP_OBS_NEXT: write only the observation of agent a1, after the moves of [a0, a1)
+    int obs_A, obs_a0; // where agent a's window goes: obs + ((env * obs_A + (a - obs_a0)) * C) * V * V.  (A, 0): the [E][A][C][V][V]
+                      // tensor; (1, a1) with SGW_STEP_OBS_NEXT_PACKED: one window per env, [E][C][V][V] (an agent's replay slot)
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
     // sgw_rollout: `nturns` whole turns in ONE launch (the env's grid stays in LDS from turn to turn); turn t of the call

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock, 8) void phase_kernel(const Params p) {
     }
 
     // ---- the window of agent `ra` (visual_field.py:9-101): lane = window cell
-    const int64_t obase = ((env * p.A + ra) * (int64_t)C) * VV;
+    const int64_t obase = ((env * p.obs_A + (ra - p.obs_a0)) * (int64_t)C) * VV;
     constexpr int NW = 4;
     const int nw = (C + 3) >> 2;
     const int zsh = 8 * (p.zA & 3);

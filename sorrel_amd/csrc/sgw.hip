@@ -481,6 +481,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     }
     p.single_spawner = nspawn <= 1 ? 1 : 0;
     p.nturns = 1;
+    p.obs_A = c.num_agents;      // observations go to the [E][A][C][V][V] tensor unless a call says otherwise
+    p.obs_a0 = 0;
     p.seed_lo = (uint32_t)c.seed;
     p.seed_hi = (uint32_t)(c.seed >> 32);
     p.first_env = (uint32_t)c.first_env_id;
@@ -822,6 +824,12 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
     if (flags & SGW_STEP_OBS_NEXT) {   // the stepped agents' own observations are not written
         p.obs_next = 1;
         p.flags |= SGW_STEP_NO_OBS;
+        if (flags & SGW_STEP_OBS_NEXT_PACKED) {   // `obs` holds one window per env: agent_end's
+            p.obs_A = 1;
+            p.obs_a0 = agent_end;
+        }
+    } else if (flags & SGW_STEP_OBS_NEXT_PACKED) {
+        return fail(SGW_EINVAL, "sgw_step: SGW_STEP_OBS_NEXT_PACKED qualifies SGW_STEP_OBS_NEXT");
     }
     if (int rc = launch_step(e, p, static_cast<hipStream_t>(stream))) return rc;
     if (e->auto_max_turns && turn == e->auto_max_turns && agent_end == e->cfg.num_agents) {

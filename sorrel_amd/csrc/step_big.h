@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
                     }
                 }
             }
-            float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)C) * VV;
+            float* obase = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int w = lane + 64 * k;

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                 const int y = __builtin_amdgcn_readlane((int)py, a);
                 const int x = __builtin_amdgcn_readlane((int)px, a);
                 const int cbase = s_o - zoff;
-                float* obase = p.obs + turn_obs + ((env * p.A + a) * (int64_t)C) * VV;
+                float* obase = p.obs + turn_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (64 * k >= VV) break;

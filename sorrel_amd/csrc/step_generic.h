@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                 const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
                 // ---- pov: egocentric window (visual_field.py:9-101)
                 if (p.obs_next ? a == p.a1 : write_obs) {
-                    float* obase = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * VV;
+                    float* obase = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
                     auto render = [&](const int w, const int i, const int j) {
                         const int gy = y - r + i, gx = x - r + j;
                         const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     else tot += v;
                 };
                 const bool observe = p.obs_next ? a == p.a1 : write_obs;
-                float* const obase0 = p.obs + tix * p.ts_obs + ((env * p.A + a) * (int64_t)p.C) * VV;
+                float* const obase0 = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
                 uint32_t clo[kMaxPass], chi[kMaxPass];      // G = 256: the captured window bytes (layers 0-3 | 4-6, five bits each)
                 bool cin[kMaxPass];
                 int coff[kMaxPass];

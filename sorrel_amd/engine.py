@@ -152,6 +152,19 @@ class GridEngine:
                              f"(got {got}); the step kernel writes exactly that many bytes")
         return t
 
+    def _check_window(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        """One window per env (``SGW_STEP_OBS_NEXT_PACKED``): exactly ``E * C * V * V`` contiguous elements of the engine's
+        observation dtype on its device, whatever the trailing shape (``[E, C, V, V]`` or a replay row ``[E, C*V*V]``)."""
+        per_env = 1
+        for d in self.spec.obs_shape[1:]:
+            per_env *= int(d)
+        if not torch.is_tensor(t) or t.dtype != self.obs_dtype or t.device != self.device or not t.is_contiguous() \
+                or t.dim() < 2 or t.shape[0] != self.num_envs or t.numel() != self.num_envs * per_env:
+            got = (tuple(t.shape), t.dtype, t.device) if torch.is_tensor(t) else type(t)
+            raise ValueError(f"{name} must be a contiguous {self.obs_dtype} tensor with {self.num_envs} rows of {per_env} "
+                             f"elements on {self.device} (got {got}); the step kernel writes exactly that many bytes")
+        return t
+
     def _check_pos(self, t: torch.Tensor) -> torch.Tensor:
         want = (self.num_envs, self.spec.num_agents, 2)
         if not torch.is_tensor(t) or t.dtype != torch.uint8 or tuple(t.shape) != want or t.device != self.device \
@@ -202,14 +215,17 @@ class GridEngine:
     def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,
              write_obs: bool = True, agent_begin: int = 0, agent_end: Optional[int] = None,
              turn: Optional[int] = None, advance_turn: bool = True, obs_out: Optional[torch.Tensor] = None,
-             obs_next: bool = False):
+             obs_next: bool = False, obs_next_out: Optional[torch.Tensor] = None):
         """One ``Environment.take_turn`` for every env (K2).
 
         ``actions``: uint8 ``[E, A]`` chosen by a policy; or ``random_actions=True``
         to draw them on device from the counter RNG (they are stored to
         ``self.actions``).  ``obs_next=True`` (policy-driven stepping): instead of the stepped
         agents' own observations, write the observation of agent ``agent_end`` as it stands
-        after their moves.  With ``set_auto_reset`` armed, the call that completes turn
+        after their moves -- into slot ``agent_end`` of the observation tensor, or, with
+        ``obs_next_out`` (contiguous, the engine's observation dtype, ``E * C * V * V`` elements:
+        e.g. a row of that agent's replay buffer), straight into that one-window-per-env tensor.
+        With ``set_auto_reset`` armed, the call that completes turn
         ``max_turns`` also resets every env for the next epoch (``self.epoch`` / ``self.turn``
         follow when the engine keeps the counters, i.e. ``turn`` is not passed)."""
         if advance_turn and turn is None:
@@ -221,7 +237,12 @@ class GridEngine:
         actions = self.actions
         flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
         obs = self.obs if obs_out is None else self._check_obs(obs_out, "obs_out")
-        if obs_next:
+        if obs_next_out is not None:
+            if not obs_next:
+                raise ValueError("obs_next_out is the destination of obs_next=True")
+            obs = self._check_window(obs_next_out, "obs_next_out")
+            flags |= N.STEP_OBS_NEXT | N.STEP_OBS_NEXT_PACKED
+        elif obs_next:
             if obs is None:
                 raise ValueError("obs_next needs an observation tensor")
             flags |= N.STEP_OBS_NEXT

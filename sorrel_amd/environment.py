@@ -321,8 +321,9 @@ class Environment:
             eng.step(random_actions=True, turn=self.turn)
         else:
             # entity sweep; the same launch renders agent 0's observation (nothing intervenes before its pov)
-            eng.step(sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=self.turn)
-            self._fresh_obs = (0, self.world.mutations)
+            slot = self._replay_slot(0, None)
+            eng.step(sweep=True, agent_begin=0, agent_end=0, obs_next=True, obs_next_out=slot, turn=self.turn)
+            self._fresh_obs = (0, self.world.mutations, slot)
             for agent in self.agents:
                 agent.transition(self.world)
 
@@ -437,8 +438,11 @@ class Environment:
         if isinstance(who, Agent):
             who = who.slot
         if isinstance(who, int):
-            if own and self._fresh_obs == (who, self.world.mutations):
-                return eng.obs[:, who]          # rendered by the launch that moved the previous agent (SGW_STEP_OBS_NEXT)
+            if own and self._fresh_obs is not None and self._fresh_obs[:2] == (who, self.world.mutations):
+                # rendered by the launch that moved the previous agent (SGW_STEP_OBS_NEXT) -- into the observation tensor,
+                # or straight into the row of this agent's replay buffer that add_memory is about to fill
+                slot = self._fresh_obs[2]
+                return eng.obs[:, who] if slot is None else slot.view((eng.num_envs,) + tuple(eng.spec.obs_shape[1:]))
             out = eng.obs if own else eng.scratch_obs()
             eng.observe(who, who + 1, out=out)
             return out[:, who]
@@ -461,6 +465,34 @@ class Environment:
             out = out.clamp(0, 255) / 255
         return out
 
+    #: policy-driven turns render each agent's window straight into its replay row where that is possible (see below);
+    #: False = always through the observation tensor + a copy in ``Buffer.add`` (A/B and test switch)
+    write_obs_into_replay = True
+
+    def _replay_slot(self, a: int, acting: Optional[int]):
+        """The row of agent ``a``'s replay buffer that its next ``add_memory`` will fill, if the step kernel can write
+        the agent's window straight into it (``SGW_STEP_OBS_NEXT_PACKED``): a ``sorrel_amd.buffers.Buffer`` of the engine's
+        dtype and device whose rows hold exactly one window (a ``pov`` that appends to the window, like Cleanup's
+        positional code, does not qualify), not shared with the agent that acts in between (its ``add_memory`` would
+        land on the same row first).  ``Buffer.add`` then finds the state already in place and copies nothing -- at
+        65 536 envs of config 3 that copy is 77 MB per agent and turn."""
+        from sorrel_amd.buffers import Buffer
+
+        eng = self._engine
+        mem = getattr(self.agents[a].model, "memory", None)
+        if not self.write_obs_into_replay or not isinstance(mem, Buffer) or eng is None or eng.obs is None:
+            return None
+        if acting is not None and mem is getattr(self.agents[acting].model, "memory", None):
+            return None
+        row = mem.states[mem.idx]
+        per_env = 1
+        for d in eng.spec.obs_shape[1:]:
+            per_env *= int(d)
+        if row.dtype != eng.obs_dtype or row.device != eng.device or not row.is_contiguous() or row.dim() < 2 \
+                or row.shape[0] != eng.num_envs or row.numel() != eng.num_envs * per_env:
+            return None
+        return row
+
     def _act(self, agent: Agent, action) -> torch.Tensor:
         eng = self._ensure_engine()
         a = agent.slot
@@ -468,8 +500,10 @@ class Environment:
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
         eng.actions[:, a].copy_(action)          # one strided copy that also narrows int64 -> uint8
         nxt = a + 1 < len(self.agents) and eng.obs is not None
-        eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn, obs_next=nxt)
-        self._fresh_obs = (a + 1, self.world.mutations) if nxt else None
+        slot = self._replay_slot(a + 1, a) if nxt else None
+        eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn, obs_next=nxt,
+                 obs_next_out=slot)
+        self._fresh_obs = (a + 1, self.world.mutations, slot) if nxt else None
         return eng.rewards[:, a]
 
     # ------------------------------------------------------------------ step outputs (batched additions)

@@ -568,3 +568,120 @@ def test_rollout_without_a_sweep_writes_every_turns_moves_back(torch_cuda, case,
     for name in ("grid", "agent_pos", "total_reward", "obs", "rewards", "actions"):
         assert torch.equal(getattr(one, name), getattr(many, name)), name
     assert np.array_equal(many.grid.cpu().numpy(), co.grid) and np.array_equal(many.total_reward.cpu().numpy(), co.total)
+
+
+# ------------------------------------------------------------------ SGW_STEP_OBS_NEXT_PACKED: the next agent's window, one per env
+@pytest.mark.parametrize("case", ["fast_32x32", "packed_21x21", "phase_kernel_128", "step_big_128", "generic_256_128", "rules_cleanup", "u8"])
+def test_obs_next_packed_destination_equals_the_tensor_slot(torch_cuda, case, monkeypatch):
+    """``obs_next_out`` (one window per env, e.g. a replay row) receives exactly what slot ``agent_end`` of the observation
+    tensor receives without it, on every kernel family that serves policy-driven phases; nothing else is written."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    kw = {}
+    if case == "fast_32x32":
+        ws, E = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.05, seed=3, dense_prob=0.2), 70
+    elif case == "packed_21x21":
+        monkeypatch.setenv("SGW_GROUP", "16")
+        ws, E = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=4, dense_prob=0.2), 203
+    elif case == "rules_cleanup":
+        d, spec = H.load_golden("cleanup_15x16")
+        ws, E = H.world_spec(spec), 33
+    elif case == "u8":
+        ws, E = treasurehunt_spec(20, 24, 5, 2, spawn_prob=0.05, seed=6, dense_prob=0.2), 41
+        kw["obs_dtype"] = torch.uint8
+    else:
+        if case == "step_big_128":
+            monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "1")
+        if case == "generic_256_128":
+            monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+        ws, E = treasurehunt_spec(128, 128, 24, 5, spawn_prob=0.05, seed=5, dense_prob=0.25), 9
+    A = ws.num_agents
+    a, b = make_engine(ws, E, first=5, **kw), make_engine(ws, E, first=5, **kw)
+    if case == "rules_cleanup":
+        for e in (a, b):
+            e.grid.copy_(torch.from_numpy(np.broadcast_to(d["grid0"][0], (E,) + d["grid0"][0].shape).copy()))
+            e.agent_pos.copy_(torch.from_numpy(np.broadcast_to(d["pos0"][0], (E,) + d["pos0"][0].shape).copy()))
+            e.total_reward.zero_()
+    else:
+        a.reset(0)
+        b.reset(0)
+    per_env = int(np.prod(ws.obs_shape[1:]))
+    rng = np.random.default_rng(2)
+    for t in range(1, 4):
+        acts = torch.from_numpy(rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)).cuda()
+        rows = [torch.full((E, per_env), 7, dtype=a.obs_dtype, device="cuda:0") for _ in range(A)]
+        a.obs.fill_(9)
+        b.obs.fill_(9)
+        a.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+        b.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, obs_next_out=rows[0], turn=t, advance_turn=False)
+        for i in range(A):
+            nxt = i + 1 < A
+            a.step(acts, sweep=False, write_obs=False, agent_begin=i, agent_end=i + 1, obs_next=nxt, turn=t, advance_turn=False)
+            b.step(acts, sweep=False, write_obs=False, agent_begin=i, agent_end=i + 1, obs_next=nxt,
+                   obs_next_out=rows[i + 1] if nxt else None, turn=t, advance_turn=False)
+        torch.cuda.synchronize()
+        for i in range(A):
+            assert torch.equal(rows[i].view(E, *ws.obs_shape[1:]), a.obs[:, i]), f"{case} turn {t}: window of agent {i}"
+        assert bool((b.obs == 9).all()), f"{case}: the packed calls must not touch the observation tensor"
+        assert torch.equal(a.grid, b.grid) and torch.equal(a.agent_pos, b.agent_pos) and torch.equal(a.total_reward, b.total_reward)
+    assert a.status() == 0 and b.status() == 0
+    with pytest.raises(ValueError):
+        b.step(acts, obs_next=False, obs_next_out=rows[0])
+    with pytest.raises(ValueError):
+        b.step(acts, agent_begin=0, agent_end=1, obs_next=True, obs_next_out=torch.zeros((E, per_env + 1), dtype=a.obs_dtype, device="cuda:0"))
+
+
+def test_policy_turn_writes_windows_straight_into_replay_rows(torch_cuda):
+    """Environment.take_turn with policy models: each agent's window is rendered into the row of its replay buffer that
+    add_memory fills (no copy), a model shared by all agents and a pov that appends to the window fall back to the
+    observation tensor -- and all of it stores exactly what the copy path stores."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+    from sorrel_amd.environment import Environment
+    from tests.test_gpu_api import make_env
+
+    E, T = 19, 7
+
+    def factory(shared):
+        made = []
+
+        class Policy(BaseModel):
+            def __init__(self, input_size, action_space):
+                super().__init__(input_size, action_space, memory_size=5, num_envs=E, device="cuda:0")
+                self.seen = []
+
+            def take_action(self, state):
+                self.seen.append(state.data_ptr())
+                return (state.reshape(state.shape[0], -1).sum(dim=1).long() * 5 + 1) % 4
+
+        def make(input_size, action_space):
+            if shared and made:
+                return made[0]
+            made.append(Policy(input_size, action_space))
+            return made[-1]
+
+        return make
+
+    for shared in (False, True):
+        runs = []
+        for direct in (True, False):
+            env = make_env(15, 17, 3, 2, E, p=0.05, model_factory=factory(shared))
+            env.write_obs_into_replay = direct
+            for _ in range(T):
+                env.take_turn()
+            torch.cuda.synchronize()
+            runs.append(env)
+        d, c = runs
+        for ad, ac in zip(d.agents, c.agents):
+            md, mc = ad.model.memory, ac.model.memory
+            assert md.idx == mc.idx and md.size == mc.size
+            assert torch.equal(md.states, mc.states) and torch.equal(md.actions, mc.actions) and torch.equal(md.rewards, mc.rewards)
+        assert torch.equal(d.world.grid, c.world.grid) and torch.equal(d.world.total_reward, c.world.total_reward)
+        rows = {d.agents[0].model.memory.states[i].data_ptr() for i in range(5)}
+        in_rows = [p in rows for p in d.agents[0].model.seen]
+        if shared:      # only agent 0's window (rendered by the sweep launch, nobody adds in between) can go straight in
+            assert any(in_rows) and not all(in_rows)
+        else:
+            assert all(in_rows), "every state the policy saw was already sitting in its replay row"
+        assert not any(p in {c.agents[0].model.memory.states[i].data_ptr() for i in range(5)} for p in c.agents[0].model.seen)

@@ -45,6 +45,7 @@ def run(h, w, a, r, E, policy):
     cfg = make_config(h, w, a, r, spawn_prob=0.005)
     world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0)
     env = TreasurehuntEnv(world, cfg, model_factory=policy_factory(E) if policy else None)
+    env.write_obs_into_replay = os.environ.get("LAT_NO_DIRECT") != "1"      # A/B: windows through the observation tensor + a copy
     turns = 2000 if E <= 4096 else 300
     us = time_turns(env, turns)
     print(f"{h}x{w} A{a} r{r} E={E:6d} {'policy (1+A launches)' if policy else 'device-random (1 launch)':26s} "

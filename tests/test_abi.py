@@ -24,6 +24,16 @@ def test_header_declares_what_binding_expects():
     assert set(declared_symbols()) == set(N.EXPORTS)
 
 
+def test_flag_constants_match_the_header():
+    """The ctypes binding's flag / rule constants are the header's macros (the header is the interface)."""
+    text = open(HEADER).read()
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(SGW_[A-Z_0-9]+)\s+(\d+)u?\b", text)}
+    for name in ("STEP_SWEEP", "STEP_RANDOM_ACTIONS", "STEP_NO_OBS", "STEP_OBS_NEXT", "STEP_OBS_NEXT_PACKED"):
+        assert getattr(N, name) == macros["SGW_" + name], name
+    flags = [macros[k] for k in macros if k.startswith("SGW_STEP_") and k != "SGW_STEP_DEFAULT"]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)      # distinct single bits
+
+
 def test_library_exports_every_declared_symbol(built):
     lib = N.load()   # dlopen only (after torch, so one HIP runtime is mapped): no HIP call, works without a GPU
     for name in declared_symbols():

@@ -341,112 +341,100 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                 double pend[2];                              // G = 256: this agent's additions to total_reward, applied in agent order below
                 int npend = 0;
                 auto add_total = [&](const double v) {       // world.total_reward += reward, float64, agent order (agent.py:172)
-                    if constexpr (kTicket) pend[npend++] = v;
-                    else tot += v;
+                    pend[npend++] = v;
                 };
                 const bool observe = p.obs_next ? a == p.a1 : write_obs;
                 float* const obase0 = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
                 uint32_t clo[kMaxPass], chi[kMaxPass];      // G = 256: the captured window bytes (layers 0-3 | 4-6, five bits each)
                 bool cin[kMaxPass];
                 int coff[kMaxPass];
-                // the geometry of the move (agent.py:187-225; Cleanup: only a move action moves): pure arithmetic on this
-                // agent's own position and action.  G = 256 does it -- and the window's -- before the wait; the packed kernels
-                // where they always did, after the observation (earlier costs them registers: Tag's static instance 72 -> 76)
-                bool act_ok = false, inb = false;
+                // the geometry of the move (agent.py:187-225; Cleanup: only a move action moves) and of the window: pure
+                // arithmetic on this agent's own position and action, so it is done before the wait as well
+                const bool act_ok = act_a < (uint32_t)p.nact;
                 uint32_t kind = SGW_ACTION_MOVE;
-                int dy = 0, dx = 0, ty = y, tx = x, taddr = 0, oaddr = 0;
-                auto move_geometry = [&]() {
-                    act_ok = act_a < (uint32_t)p.nact;
-                    if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) kind = act_ok ? (p.kind_pack >> (2 * act_a)) & 3u : 0u;
-                    const bool moves = act_ok && kind == SGW_ACTION_MOVE;
-                    dy = moves ? (int)((p.dy_pack >> (2 * act_a)) & 3u) - 1 : 0;
-                    dx = moves ? (int)((p.dx_pack >> (2 * act_a)) & 3u) - 1 : 0;
-                    ty = y + dy;
-                    tx = x + dx;
-                    inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
-                    taddr = zoff + ty * W + tx;
-                    oaddr = zoff + y * W + x;
-                };
-                if constexpr (kTicket) {
-                    move_geometry();
-                    if (observe) {
-    #pragma unroll
-                        for (int k = 0; k < kMaxPass; ++k) {
-                            const int w = atid + k * GA;
-                            const int gy = y - r + wi[k], gx = x - r + wj[k];
-                            cin[k] = w < VV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                            coff[k] = cin[k] ? gy * W + gx : 0;
-                        }
+                if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) kind = act_ok ? (p.kind_pack >> (2 * act_a)) & 3u : 0u;
+                const bool moves = act_ok && kind == SGW_ACTION_MOVE;
+                const int dy = moves ? (int)((p.dy_pack >> (2 * act_a)) & 3u) - 1 : 0;
+                const int dx = moves ? (int)((p.dx_pack >> (2 * act_a)) & 3u) - 1 : 0;
+                const int ty = y + dy, tx = x + dx;
+                const bool inb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+                const int taddr = zoff + ty * W + tx;
+                const int oaddr = zoff + y * W + x;
+                if (observe) {
+#pragma unroll
+                    for (int k = 0; k < kMaxPass; ++k) {
+                        const int w = atid + k * GA;
+                        const int gy = y - r + wi[k], gx = x - r + wj[k];
+                        cin[k] = w < VV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                        coff[k] = cin[k] ? gy * W + gx : 0;
                     }
-                    if (p.do_move) {                         // (sgw_observe: nothing changes the grid, no order to keep)
-                        while (s_ticket[0] != (uint32_t)a) {}      // (s_sleep 1 / 2 / 4 between looks: 125.3 / 126.2 / 127.4 us against 125.5)
-                        asm volatile("" ::: "memory");
-                    }
+                }
+                if (p.do_move) {                             // (sgw_observe: nothing changes the grid, no order to keep)
+                    while (s_ticket[0] != (uint32_t)a) {}    // (s_sleep 1 / 2 / 4 between looks: 125.3 / 126.2 / 127.4 us against 125.5)
+                    asm volatile("" ::: "memory");
                 }
                 // G = 256: pass the ticket on, then turn the captured bytes into stores (visual_field.py:41-55, 89-94)
                 auto after_act = [&]() {
-                    if constexpr (kTicket) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes have landed (LDS only: no wait for stores)
-                        if (atid == 0) s_ticket[0] = (uint32_t)(a + 1);
-                        // the float64 total: same agent order, its own ticket, so that the read-modify-write in LDS is not part
-                        // of the act chain (the two chains run side by side)
-                        if (atid == 0 && p.do_move && a < p.a1) {
-                            while (s_ticket[1] != (uint32_t)a) {}
-                            asm volatile("" ::: "memory");
-                            double t = *s_tot;
-                            for (int i = 0; i < npend; ++i) t += pend[i];
-                            *s_tot = t;
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            s_ticket[1] = (uint32_t)(a + 1);
-                        }
-                        if (!observe) return;
-    #pragma unroll
-                        for (int k = 0; k < kMaxPass; ++k) {
-                            const int w = atid + k * GA;
-                            if (w >= VV) continue;
-                            float* o = obase0 + w;
-                            const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
-                            if constexpr (ONEHOT) {
-                                constexpr int NWq = TC ? (TC + 3) / 4 : 4;
-                                uint32_t cnt[NWq];
-    #pragma unroll
-                                for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
-                                const int nw = (Cn + 3) >> 2;
-                                if (cin[k]) {
-                                    for (int z = 0; z < Ln; ++z) {
-                                        const uint32_t t = z < 4 ? (clo[k] >> (8 * z)) & 31u : (chi[k] >> (8 * (z - 4))) & 31u;
-    #pragma unroll
-                                        for (int q = 0; q < NWq; ++q)
-                                            if (q < nw) cnt[q] += tab->delta[q][t];
-                                    }
-                                } else {
-    #pragma unroll
-                                    for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
-                                }
-    #pragma unroll
-                                for (int q = 0; q < NWq; ++q) {
-    #pragma unroll
-                                    for (int b = 0; b < 4; ++b) {
-                                        const int c = 4 * q + b;
-                                        if (c < Cn) {
-                                            const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
-                                            if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
-                                            else o[c * VV] = (float)v;
-                                        }
-                                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes have landed (LDS only: no wait for stores)
+                    if (atid == 0) s_ticket[0] = (uint32_t)(a + 1);
+                    // the float64 total: same agent order, its own ticket, so that the read-modify-write in LDS is not part
+                    // of the act chain (the two chains run side by side)
+                    if (atid == 0 && p.do_move && a < p.a1) {
+                        while (s_ticket[1] != (uint32_t)a) {}
+                        asm volatile("" ::: "memory");
+                        double t = *s_tot;
+                        for (int i = 0; i < npend; ++i) t += pend[i];
+                        *s_tot = t;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        s_ticket[1] = (uint32_t)(a + 1);
+                    }
+                    if (!observe) return;
+#pragma unroll
+                    for (int k = 0; k < kMaxPass; ++k) {
+                        const int w = atid + k * GA;
+                        if (w >= VV) continue;
+                        float* o = obase0 + w;
+                        const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
+                        if constexpr (ONEHOT) {
+                            constexpr int NWq = TC ? (TC + 3) / 4 : 4;
+                            uint32_t cnt[NWq];
+#pragma unroll
+                            for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
+                            const int nw = (Cn + 3) >> 2;
+                            if (cin[k]) {
+                                for (int z = 0; z < Ln; ++z) {
+                                    const uint32_t t = z < 4 ? (clo[k] >> (8 * z)) & 31u : (chi[k] >> (8 * (z - 4))) & 31u;
+#pragma unroll
+                                    for (int q = 0; q < NWq; ++q)
+                                        if (q < nw) cnt[q] += tab->delta[q][t];
                                 }
                             } else {
-                                for (int c = 0; c < Cn; ++c) {
-                                    double acc;
-                                    if (cin[k]) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
-                                        acc = tab->appearance[clo[k] & 31u][c];
-                                        for (int z = 1; z < Ln; ++z)
-                                            acc += tab->appearance[z < 4 ? (clo[k] >> (8 * z)) & 31u : (chi[k] >> (8 * (z - 4))) & 31u][c];
-                                    } else {
-                                        acc = tab->appearance[p.fill_type][c];
+#pragma unroll
+                                for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
+                            }
+#pragma unroll
+                            for (int q = 0; q < NWq; ++q) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const int c = 4 * q + b;
+                                    if (c < Cn) {
+                                        const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                                        if (p.obs_u8) reinterpret_cast<uint8_t*>(p.obs)[(o - p.obs) + c * VV] = (uint8_t)v;
+                                        else o[c * VV] = (float)v;
                                     }
-                                    o[c * VV] = obs_finish(acc, p.obs_post);
                                 }
+                            }
+                        } else {
+                            for (int c = 0; c < Cn; ++c) {
+                                double acc;
+                                if (cin[k]) {   // np.sum over layers: left to right, float64 (visual_field.py:51)
+                                    acc = tab->appearance[clo[k] & 31u][c];
+                                    for (int z = 1; z < Ln; ++z)
+                                        acc += tab->appearance[z < 4 ? (clo[k] >> (8 * z)) & 31u : (chi[k] >> (8 * (z - 4))) & 31u][c];
+                                } else {
+                                    acc = tab->appearance[p.fill_type][c];
+                                }
+                                o[c * VV] = obs_finish(acc, p.obs_post);
                             }
                         }
                     }
@@ -463,32 +451,32 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                             constexpr int NWq = TC ? (TC + 3) / 4 : 4;     // counter words (static for the common channel counts)
                             const int Cn = TC ? TC : p.C, Ln = TL ? TL : p.L;
                             uint32_t cnt[NWq];
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < NWq; ++q) cnt[q] = 0u;
                             const int nw = (Cn + 3) >> 2;
                             if (inb) {
-    #pragma unroll
+#pragma unroll
                                 for (int z = 0; z < (TL ? TL : 1); ++z) {
                                     const uint32_t t = lg[z * HW + off] & 31u;
-    #pragma unroll
+#pragma unroll
                                     for (int q = 0; q < NWq; ++q)
                                         if (q < nw) cnt[q] += tab->delta[q][t];
                                 }
                                 if constexpr (TL == 0) {
                                     for (int z = 1; z < Ln; ++z) {
                                         const uint32_t t = lg[z * HW + off] & 31u;
-    #pragma unroll
+#pragma unroll
                                         for (int q = 0; q < NWq; ++q)
                                             if (q < nw) cnt[q] += tab->delta[q][t];
                                     }
                                 }
                             } else {   // fill entity's appearance, once (visual_field.py:89-94)
-    #pragma unroll
+#pragma unroll
                                 for (int q = 0; q < NWq; ++q) cnt[q] = p.fill_delta[q];
                             }
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < NWq; ++q) {
-    #pragma unroll
+#pragma unroll
                                 for (int b = 0; b < 4; ++b) {
                                     const int c = 4 * q + b;
                                     if (c < Cn) {
@@ -511,24 +499,17 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                             }
                         }
                     };
-                    if constexpr (kTicket) {   // the first kMaxPass cells of this lane: bytes now, stores after the act
-    #pragma unroll
-                        for (int k = 0; k < kMaxPass; ++k) {
-                            clo[k] = chi[k] = 0;
-                            for (int z = 0; z < (TL ? TL : p.L); ++z) {      // (out-of-window lanes read cell 0 and ignore it)
-                                const uint32_t t = lg[z * HW + coff[k]] & 31u;
-                                if (z < 4) clo[k] |= t << (8 * z);
-                                else chi[k] |= t << (8 * (z - 4));
-                            }
-                        }
-                    } else {
-    #pragma unroll
-                        for (int k = 0; k < kMaxPass; ++k) {
-                            const int w = atid + k * GA;
-                            if (w < VV) render(w, wi[k], wj[k]);
+                    // the first kMaxPass cells of this lane: bytes now, stores after the act
+#pragma unroll
+                    for (int k = 0; k < kMaxPass; ++k) {
+                        clo[k] = chi[k] = 0;
+                        for (int z = 0; z < (TL ? TL : p.L); ++z) {      // (out-of-window lanes read cell 0 and ignore it)
+                            const uint32_t t = lg[z * HW + coff[k]] & 31u;
+                            if (z < 4) clo[k] |= t << (8 * z);
+                            else chi[k] |= t << (8 * (z - 4));
                         }
                     }
-                    {   // further passes (small groups, wide windows): (i, j) advance by G cells, no division
+                    {   // windows wider than that (more than 128 cells): the rest is rendered here, before the act
                         int i = wi[kMaxPass - 1], j = wj[kMaxPass - 1];
                         for (int w = atid + kMaxPass * GA; w < VV; w += GA) {
                             j += GA;
@@ -538,7 +519,6 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     }
                 }
                 if (!p.do_move || a >= p.a1) { after_act(); return; }
-                if constexpr (!kTicket) move_geometry();
                 if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
                     // ---- CleanupAgent.act (sorrel/examples/cleanup/agents.py:146-177).  Every thread evaluates the
                     // same LDS bytes, so all control flow here is uniform; single threads do the writes.
@@ -619,7 +599,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     gsync<WPA>();
                     uint32_t mine_now = my_type;
                     const int own = zoff + cy * W + cx;
-    #pragma unroll
+#pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
                         const int ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);

@@ -480,6 +480,14 @@ def test_big_kernel_walking_workgroups_vs_oracle(torch_cuda, monkeypatch, blocks
     torch.cuda.synchronize()
     assert np.array_equal(eng.obs[:, a].cpu().numpy(), co.obs[:, a]), f"{variant} blocks={blocks}: OBS_NEXT window"
     assert_same(eng, co, ("grid", "pos", "total"), ctx=f"{variant} blocks={blocks} agent range")
+    # the first launch of a policy-driven turn: sweep only, plus agent 0's window, into a one-window-per-env tensor
+    row = torch.zeros((E,) + tuple(ws.obs_shape[1:]), dtype=eng.obs_dtype, device="cuda:0")
+    eng.step(sweep=True, agent_begin=0, agent_end=0, obs_next=True, obs_next_out=row, advance_turn=False, turn=T + 2)
+    assert co.step(1, T + 2, sweep=True, write_obs=False, a0=0, a1=0) == 0
+    co.observe(0, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(row.cpu().numpy(), co.obs[:, 0]), f"{variant} blocks={blocks}: sweep-only launch, packed window"
+    assert_same(eng, co, ("grid", "pos", "total"), ctx=f"{variant} blocks={blocks} sweep only")
     assert eng.status() == 0
 
 

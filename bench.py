@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_COPY_GBS = 6290.0   # measured float4-copy ceiling (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
-CACHE_RESIDENT_GRID_BYTES = 384 << 20   # = kCacheResidentGrid in csrc/step_fast.h: grids of a batch up to this size are re-read
+CACHE_RESIDENT_GRID_BYTES = 288 << 20   # = kCacheResidentGrid in csrc/step_fast.h: grids of a batch up to this size are re-read
                                         # from the 256 MiB Infinity Cache + 32 MiB of L2 on the next turn, not from HBM
 
 CONFIGS = {

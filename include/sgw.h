@@ -25,6 +25,8 @@
  *                   -> Agent.transition (pov, act, reward)    sorrel/agents/agent.py:155-173
  *                   -> MovingAgent.act -> Gridworld.move      sorrel/agents/agent.py:215-225,
  *                                                             sorrel/worlds/gridworld.py:95-122
+ *   sgw_observe_rows / sgw_act   Agent.transition of a policy-driven agent: pov, then act
+ *                                                             sorrel/agents/agent.py:155-173, 215-225
  *   sgw_rollout     the turn loop of run_experiment           sorrel/environment.py:160-166
  *   sgw_reduce_metrics  world.total_reward read-out           sorrel/environment.py:193-199
  *
@@ -208,6 +210,29 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
              float* rewards, double* total_reward, uint32_t epoch, uint32_t turn,
              int32_t agent_begin, int32_t agent_end, uint32_t flags, void* stream);
 
+/* ---- Policy-driven turns without re-rendering (round 3) ----------------------------------------------------------
+ * The reference's agent loop is pov -> get_action -> act, one agent after another (sorrel/agents/agent.py:155-173), and
+ * agent j's pov shows the moves of agents < j.  A move changes at most two cells of the agent layer, so instead of
+ * rendering a window per agent and launch:
+ *   1. sgw_step(agent_begin = agent_end = 0, SGW_STEP_SWEEP | SGW_STEP_NO_OBS)      the entity sweep alone
+ *   2. sgw_observe_rows(...)  (or sgw_observe into the [E][A][C][V][V] tensor)       EVERY agent's window, once
+ *   3. per agent a, in order: policy(window a) -> actions[:, a];  sgw_act(a)         move agent a AND rewrite, in the
+ *      windows of the agents after a that contain them, the <= 2 cells its move changed
+ * gives every agent exactly the window the reference's pov() would build, at the cost of one fused turn plus A tiny
+ * launches.  `rows[a]` (a HOST array of num_agents DEVICE pointers) is where agent a's window lives: element
+ * rows[a][e * env_stride + (c * V + i) * V + j] for env e -- a row of that agent's replay buffer (env_stride = C*V*V) or
+ * slot a of the observation tensor (rows[a] = obs + a*C*V*V, env_stride = A*C*V*V); element type = sgw_set_obs_format's.
+ * sgw_observe_rows needs SGW_CAP_OBSERVE_ROWS (one-hot float32 windows of an instantiated layers / channels / radius),
+ * sgw_act needs SGW_CAP_ACT (SGW_AGENT_RULE_MOVE; any appearance table, float32 or uint8 windows); rows entries of agents
+ * <= `agent` are ignored by sgw_act, NULL entries (or rows == NULL) are skipped. */
+#define SGW_CAP_OBSERVE_ROWS 1
+#define SGW_CAP_ACT 2
+int sgw_capabilities(sgw_engine* eng);
+int sgw_observe_rows(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
+                     int32_t agent_begin, int32_t agent_end, void* stream);
+int sgw_act(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, const uint8_t* actions, void* const* rows, int64_t env_stride,
+            float* rewards, double* total_reward, int32_t agent, void* stream);
+
 /* `num_turns` whole take_turns (all agents, in order) with one call -- Environment.run_experiment's inner loop
  * `while turn < max_turns: take_turn()` (sorrel/environment.py:160-166) for actions that need no host in between: drawn
  * on device (SGW_STEP_RANDOM_ACTIONS) or given up front.  Turn t of the call (t = 0 .. num_turns-1, Environment.turn =
@@ -261,8 +286,9 @@ int64_t sgw_algorithmic_bytes_per_env_step(const sgw_config* cfg);
 /* Launch timing: with sgw_set_timing(eng, 1) every sgw_step / sgw_observe launch is bracketed by a pair of
  * HIP events on its stream.  sgw_get_step_time_ms returns (and clears) the sum and the number of launches since
  * the last read; sgw_get_step_times_ms copies the per-launch durations since the last read (oldest first, at most
- * `capacity`; *count = how many were written) to the HOST array `out_ms` and clears them.  Both wait for the
- * events they read. */
+ * `capacity`; *count = how many were written) to the HOST array `out_ms` and clears them; it returns 1 (not an error:
+ * the durations written are valid) when launches were left out because `capacity` or the internal cap of 2^20 samples was
+ * exceeded.  Both wait for the events they read. */
 int sgw_set_timing(sgw_engine* eng, int enable);
 int sgw_get_step_time_ms(sgw_engine* eng, double* total_ms, int64_t* launches);
 int sgw_get_step_times_ms(sgw_engine* eng, float* out_ms, int64_t capacity, int64_t* count);
@@ -279,8 +305,10 @@ int sgw_set_auto_reset(sgw_engine* eng, uint32_t max_turns, double* episode_retu
  * DESIGN.md section 6); the only launch-time lever for that is the dynamic-LDS request, which bounds the workgroups
  * a CU admits.  wg_per_cu = 0 selects the documented automatic rule (a cap of 5 for whole-turn float32 observation
  * writes of >= 8 KiB per env when the batch's grids outgrow the caches or the emit is unstaged), 1..8 forces that
- * many workgroups per CU, -1 never caps.  sgw_launch_info writes a one-line description of what sgw_step launches
- * (kernel variant, threads, LDS bytes, workgroups per CU) into buf. */
+ * many workgroups per CU, -1 never caps.  sgw_launch_info writes a one-line description of what a whole-batch, whole-turn
+ * sgw_step launches into buf: kernel variant, lanes per env, threads, `lds` = the dynamic-LDS bytes REQUESTED (the cap is
+ * part of the request), `wg_per_cu` = the workgroups per CU the runtime admits for that request (occupancy query),
+ * `cap` = policy and the cap in force (0 = none), `phase` = the kernel a policy-driven phase (one agent) takes. */
 int sgw_set_wg_per_cu(sgw_engine* eng, int wg_per_cu);
 int sgw_launch_info(sgw_engine* eng, char* buf, int64_t capacity);
 

@@ -176,3 +176,370 @@ __global__ __launch_bounds__(kBlock, 8) void phase_kernel(const Params p) {
     }
     commit();
 }
+
+// ---------------------------------------------------------------- row-load window kernels (round 3)
+// Windows of one-hot worlds WITHOUT staging the env, for worlds of ANY size, small ones included (where phase_kernel's
+// byte gather -- 49 of 64 lanes, a byte load per cell and layer -- lost to staging the whole env):
+//   * a LANE owns a window ROW: G = 4 / 8 / 16 lanes per window (V <= 4 / 8 / 16), so a wave carries 16 / 8 / 4 windows and
+//     the instruction stream is shared by that many (a small world's phase is bound by issue and by the number of waves
+//     in flight, not by bytes);
+//   * a row of a layer arrives with ONE unaligned 8-byte load per 8 columns (global_load_dwordx2 at a byte address; the
+//     start is clamped into the env and the value shifted, so that no load ever leaves the env's bytes); columns outside
+//     the map are replaced by the fill entity through a byte mask -- no per-cell bounds test;
+//   * a lane emits its V consecutive floats per channel with 16-byte stores at 4-byte-aligned addresses.
+// L and the number of counter words NW = ceil(C / 4) are compile-time (loops over cells / layers / words fully unrolled:
+// everything stays in registers); C, H, W are run-time.
+// Two kernels share the pieces below:
+//   phase_rows<L, NW, R>     one policy-driven phase: MovingAgent.act of agent a0 and / or ONE window per env (the 1 + A launch
+//                            protocol of sgw_step with SGW_STEP_OBS_NEXT; sorrel/agents/agent.py:155-173)
+//   observe_rows<L, NW, R>   the windows of a RANGE of agents of every env into per-agent destinations (sgw_observe_rows)
+typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float vf2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// per-agent window destinations (sgw_observe_rows / sgw_act): agent a's window of env e starts at p[a] + e * stride elements
+struct RowPtrs {
+    void* p[SGW_MAX_AGENTS];
+    int64_t stride;
+};
+
+__device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* q) {
+    uint64_t v;
+    __builtin_memcpy(&v, q, 8);
+    return v;
+}
+
+template <int NW>
+struct RowsTab {
+    static constexpr int kTabW = 34;                     // counter words per q: 32 types + [32] the fill entity + [33] zero
+    static constexpr int kBytes = NW * kTabW * 4;
+    // one wave's copy of the counter words (wave-private: no workgroup barrier)
+    static __device__ __forceinline__ void fill(uint32_t* wd, const DevTables* gtab, const Params& p, int lane) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            if (lane < 32) wd[q * kTabW + lane] = gtab->delta[q][lane];
+            if (lane == 32) wd[q * kTabW + 32] = p.fill_delta[q];
+            if (lane == 33) wd[q * kTabW + 33] = 0u;
+        }
+    }
+};
+
+// the window row `gy` of an agent at column x: L x NCH 64-bit values, byte j of chunk ch = type id at column x - R + 8 ch + j
+template <int L, int R>
+__device__ __forceinline__ void rows_load(uint64_t (&row)[L][(2 * R + 1 + 7) / 8], const uint8_t* g, const bool rowinb, const int gy,
+                                          const int x, const int W, const int HW, const int cells) {
+    constexpr int NCH = (2 * R + 1 + 7) / 8;
+#pragma unroll
+    for (int z = 0; z < L; ++z)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            row[z][ch] = 0;
+            if (rowinb) {
+                const int s = z * HW + gy * W + (x - R) + 8 * ch;             // first byte wanted (may lie outside the env)
+                const int sc = min(max(s, 0), cells - 8);                     // first byte loaded
+                const uint64_t raw = load8_unaligned(g + sc);
+                const int d = min(max(s - sc, -7), 7);                        // |d| > 7: nothing of this chunk is on the map
+                row[z][ch] = d >= 0 ? raw >> (8 * d) : raw << (8 * -d);
+            }
+        }
+}
+
+// rows -> per cell (table index) << 2: cells off the map look up the fill entity once (layer 0) and zeros (other layers)
+template <int L, int R>
+__device__ __forceinline__ void rows_index(uint64_t (&row)[L][(2 * R + 1 + 7) / 8], const bool rowinb, const int x, const int W) {
+    constexpr int V = 2 * R + 1, NCH = (V + 7) / 8;
+    const int jlo = max(0, R - x), jhi = min(V, W + R - x);                   // columns on the map: j in [jlo, jhi)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int blo = min(max(jlo - 8 * ch, 0), 8), bhi = min(max(jhi - 8 * ch, 0), 8);
+        const int n = bhi - blo;
+        const uint64_t mask = (rowinb && n > 0) ? ((~0ull >> (64 - 8 * n)) << (8 * blo)) : 0ull;
+#pragma unroll
+        for (int z = 0; z < L; ++z) {
+            const uint64_t off = z == 0 ? 0x2020202020202020ull : 0x2121212121212121ull;
+            row[z][ch] = (((row[z][ch] & 0x1F1F1F1F1F1F1F1Full) & mask) | (off & ~mask)) << 2;
+        }
+    }
+}
+
+// Table look-ups and layer sums of the lane's row, then the wave's windows leave TOGETHER: the one-hot counts are staged
+// as bytes in the wave's LDS area in each window's final [C][V][V] order and streamed out window by window with
+// consecutive lanes on consecutive elements (float2 units where every destination is 8-byte aligned and C*V*V is even,
+// else single floats): whole 512-byte runs per store instruction instead of 16-byte pieces scattered 28 bytes apart
+// (observe_rows at config 3: 188 -> ... us for the 617 MB of a turn's windows).
+//   idx     this lane's row (rows_index)          o       the window's destination (the same in every lane of a group)
+//   wd      the wave's counter words              stage   the wave's staging area, WPW * npad bytes
+//   act     this lane renders a row of a live window
+template <int L, int NW, int R>
+__device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 7) / 8], const uint32_t* wd, uint8_t* stage, float* o,
+                                          const int C, const int lane, const bool act, const int unit) {
+    constexpr int V = 2 * R + 1, VV = V * V, kTabW = RowsTab<NW>::kTabW;
+    constexpr int G = V <= 4 ? 4 : (V <= 8 ? 8 : 16), WPW = 64 / G;
+    const int N = C * VV, npad = (N + 3) & ~3;
+    const uint8_t* wdb = reinterpret_cast<const uint8_t*>(wd);
+    const int gl = lane & (G - 1);
+    uint8_t* mine = stage + (lane / G) * npad + gl * V;
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            uint32_t cnt[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) cnt[q] = 0;
+#pragma unroll
+            for (int z = 0; z < L; ++z) {
+                const uint32_t half = (j & 7) < 4 ? (uint32_t)idx[z][j >> 3] : (uint32_t)(idx[z][j >> 3] >> 32);
+                const uint32_t t4 = (half >> (8 * (j & 3))) & 0xFFu;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) cnt[q] += *reinterpret_cast<const uint32_t*>(wdb + q * kTabW * 4 + t4);
+            }
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = 4 * q + b;
+                    if (c < C) mine[c * VV + j] = (uint8_t)(cnt[q] >> (8 * b));
+                }
+        }
+    }
+    gsync<1>();
+    const uint32_t o_lo = (uint32_t)reinterpret_cast<uintptr_t>(o), o_hi = (uint32_t)(reinterpret_cast<uintptr_t>(o) >> 32);
+    const uint64_t livemask = __ballot(act);
+#pragma unroll
+    for (int w = 0; w < WPW; ++w) {
+        if (!((livemask >> (w * G)) & 1ull)) continue;                        // (lane 0 of a group always renders row 0 of a live window)
+        float* ow = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)o_hi, w * G) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)o_lo, w * G));
+        const uint8_t* sw = stage + w * npad;
+        if (unit == 2) {
+            for (int k = lane; 2 * k < N; k += 64) {
+                const uint32_t b2 = *reinterpret_cast<const uint16_t*>(sw + 2 * k);
+                vf2u v2 = {(float)(b2 & 0xFFu), (float)(b2 >> 8)};
+                *reinterpret_cast<vf2u*>(ow + 2 * k) = v2;
+            }
+        } else {
+            for (int k = lane; k < N; k += 64) ow[k] = (float)sw[k];
+        }
+    }
+}
+
+// MovingAgent.act of agent `a` of env `env` (agent.py:215-225, gridworld.py:95-122), computed by every lane that calls it
+// (same-address loads; vector instructions cost the same for 1 or 64 lanes); `writer` lanes store.  Returns the status
+// bits; (old_y, old_x) -> default type and (new_y, new_x) -> my_type are the changed cells of the agent layer if it moved
+// (old_y = -1 otherwise).  The stores are issued behind an s_waitcnt vmcnt(0): every load this wave issued before has
+// returned, so a window row loaded earlier shows the grid BEFORE this move.
+struct MoveOut {
+    int old_y, old_x, new_y, new_x;
+    uint32_t my_type;
+};
+__device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, uint8_t* g, const int64_t env, const int a,
+                                        const double* wval, const bool writer, MoveOut& mo) {
+    const int H = p.H, W = p.W, HW = H * W;
+    int st = 0;
+    uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
+    const uint32_t act = p.actions[env * p.A + a];
+    const uint32_t my_type = p.agent_state ? p.agent_state[env * p.A + a] : gtab->agent_type[a];
+    const double tot = p.total[env];
+    if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
+    const int my = (int)(yx & 0xFFu), mx = (int)(yx >> 8);
+    const bool act_ok = act < (uint32_t)p.nact;
+    const int dy = act_ok ? (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1 : 0;
+    const int dx = act_ok ? (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1 : 0;
+    const int ty = my + dy, tx = mx + dx;
+    const bool tinb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
+    const uint32_t t = tinb ? (uint32_t)g[p.zA * HW + ty * W + tx] : 0xFFu;
+    const bool tok = tinb && t < (uint32_t)p.T;
+    const double val = tok ? (wval ? wval[t & 31u] : gtab->value[t & 31u]) : 0.0;   // reward read BEFORE the move
+    const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
+    st |= !act_ok ? SGW_STATUS_BAD_ACTION : (!tinb ? SGW_STATUS_OOB_MOVE : (!tok ? SGW_STATUS_BAD_TYPE : 0));
+    mo.old_y = -1; mo.old_x = 0; mo.new_y = -1; mo.new_x = 0; mo.my_type = my_type;
+    if (pass) { mo.old_y = my; mo.old_x = mx; mo.new_y = ty; mo.new_x = tx; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (writer) {
+        if (pass) {
+            g[p.zA * HW + ty * W + tx] = (uint8_t)my_type;
+            g[p.zA * HW + my * W + mx] = (uint8_t)p.default_type;
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + a] = (uint16_t)((uint32_t)ty | ((uint32_t)tx << 8));
+        }
+        p.rewards[env * p.A + a] = (float)val;
+        p.total[env] = tot + val;                                              // float64, agent order (agent.py:172)
+    }
+    return st;
+}
+
+template <int L, int NW, int R>
+__global__ __launch_bounds__(kBlock, 8) void phase_rows(const Params p) {
+    constexpr int V = 2 * R + 1, VV = V * V;
+    constexpr int G = V <= 4 ? 4 : (V <= 8 ? 8 : 16);   // lanes per env; lane gl < V owns window row gl
+    constexpr int EPW = 64 / G;                          // envs per wave
+    constexpr int NCH = (V + 7) / 8;                     // 8-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kWaveLds = RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8 + EPW * ((p.C * VV + 3) & ~3);   // = rows_wave_lds() on the host
+    const int64_t env0 = ((int64_t)blockIdx.x * 4 + sub) * EPW;
+    if (env0 >= p.E) return;                             // whole wave
+    const int gl = lane & (G - 1);
+    int64_t env = env0 + (lane / G);
+    const bool live = env < p.E;
+    if (!live) env = p.E - 1;                            // addresses stay valid; nothing is stored
+    const DevTables* gtab = p.tab;
+    const int H = p.H, W = p.W, HW = H * W, C = p.C, cells = p.cells;
+    uint8_t* g = p.grid + env * p.env_stride;
+    const bool mover = p.do_move && p.a0 < p.a1;
+    const int ra = p.obs_next ? p.a1 : p.a0;
+    const bool render = p.obs_next ? p.a1 < p.A : (!(p.flags & SGW_STEP_NO_OBS) && p.a0 < p.a1);
+    const bool after = p.obs_next != 0;
+
+    // wave-private tables: [NW][34] counter words, value f64 x 32
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + sub * kWaveLds);
+    double* wval = reinterpret_cast<double*>(smem + sub * kWaveLds + RowsTab<NW>::kBytes);
+    RowsTab<NW>::fill(wd, gtab, p, lane);
+    if (lane < SGW_MAX_TYPES) wval[lane] = gtab->value[lane];
+
+    // ---- this lane's window row (issued before the move decision: the loads overlap)
+    int st = 0;
+    uint32_t pyx = 0;
+    if (render) pyx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + ra];   // ra is not the mover when `after` (ra = a1 > a0)
+    if (render && ((pyx & 0xFFu) >= (uint32_t)H || (pyx >> 8) >= (uint32_t)W)) { pyx = 0; st |= SGW_STATUS_BAD_POS; }
+    const int y = (int)(pyx & 0xFFu), x = (int)(pyx >> 8);
+    const int gy = y - R + gl;                           // the map row this lane renders
+    const bool rowinb = render && gl < V && (unsigned)gy < (unsigned)H;
+    uint64_t row[L][NCH];
+    rows_load<L, R>(row, g, rowinb, gy, x, W, HW, cells);
+
+    // ---- the move: decided from reads only; its stores wait for every row load of this wave
+    gsync<1>();                                                                // table words visible to every lane
+    MoveOut mo{-1, 0, -1, 0, 0u};
+    if (mover) st |= move_one(p, gtab, g, env, p.a0, wval, live && gl == 0, mo);
+    if (st && live && gl == 0) atomicOr(p.status, st);
+    if (!render) return;
+
+    // ---- the window of agent `ra` (visual_field.py:9-101)
+    if (after && mo.old_y >= 0) {                                              // the move, applied to the loaded rows
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int z = 0; z < L; ++z)
+                if (z == p.zA) {
+                    uint64_t v = row[z][ch];
+                    if (mo.old_y == gy) {
+                        const int j = mo.old_x - (x - R) - 8 * ch;
+                        if ((unsigned)j < 8u) v = (v & ~(0xFFull << (8 * j))) | ((uint64_t)(p.default_type & 31u) << (8 * j));
+                    }
+                    if (mo.new_y == gy) {
+                        const int j = mo.new_x - (x - R) - 8 * ch;
+                        if ((unsigned)j < 8u) v = (v & ~(0xFFull << (8 * j))) | ((uint64_t)(mo.my_type & 31u) << (8 * j));
+                    }
+                    row[z][ch] = v;
+                }
+    }
+    rows_index<L, R>(row, rowinb, x, W);
+    float* o = p.obs + ((env * p.obs_A + (ra - p.obs_a0)) * (int64_t)C) * VV;
+    rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, C, lane, live && gl < V, p.rows_unit);
+}
+
+// The windows of agents [a0, a1) of every env, each into its own destination (rp.p[a] + env * rp.stride): what every
+// agent's pov() reads at the start of a policy-driven turn (sorrel/agents/agent.py:167), rendered once; sgw_act then
+// repairs the cells that earlier agents' moves change.  Consecutive groups of a wave render consecutive agents of one
+// env (their rows share cache lines).
+template <int L, int NW, int R>
+__global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const RowPtrs rp) {
+    constexpr int V = 2 * R + 1, VV = V * V;
+    constexpr int G = V <= 4 ? 4 : (V <= 8 ? 8 : 16);
+    constexpr int WPW = 64 / G;                          // windows per wave
+    constexpr int NCH = (V + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kWaveLds = RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8 + WPW * ((p.C * VV + 3) & ~3);   // the same layout as phase_rows
+    const int nA = p.a1 - p.a0;
+    const int64_t nwin = p.E * nA;
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + sub) * WPW;
+    if (w0 >= nwin) return;
+    const int gl = lane & (G - 1);
+    int64_t wi = w0 + (lane / G);
+    const bool live = wi < nwin;
+    if (!live) wi = nwin - 1;
+    const int64_t env = wi / nA;
+    const int a = p.a0 + (int)(wi - env * nA);
+    const int H = p.H, W = p.W, HW = H * W;
+    const uint8_t* g = p.grid + env * p.env_stride;
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + sub * kWaveLds);
+    RowsTab<NW>::fill(wd, p.tab, p, lane);
+    uint32_t pyx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
+    if ((pyx & 0xFFu) >= (uint32_t)H || (pyx >> 8) >= (uint32_t)W) {
+        pyx = 0;
+        if (live && gl == 0) atomicOr(p.status, SGW_STATUS_BAD_POS);
+    }
+    const int y = (int)(pyx & 0xFFu), x = (int)(pyx >> 8);
+    const int gy = y - R + gl;
+    const bool rowinb = gl < V && (unsigned)gy < (unsigned)H;
+    uint64_t row[L][NCH];
+    rows_load<L, R>(row, g, rowinb, gy, x, W, HW, p.cells);
+    gsync<1>();
+    rows_index<L, R>(row, rowinb, x, W);
+    float* o = reinterpret_cast<float*>(rp.p[a]) + env * rp.stride;
+    rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, p.C, lane, live && gl < V, p.rows_unit);
+}
+
+// ---------------------------------------------------------------- sgw_act: one agent moves, later agents' windows are repaired
+// MovingAgent.act of agent a (= p.a0) of every env, and -- instead of rendering the next agent's window again -- the at
+// most two cells the move changed are rewritten in the window of every LATER agent that sees them (the windows of a turn
+// were rendered once, after the sweep: sgw_observe_rows / sgw_observe).  Agent j's window then shows the grid after the
+// moves of agents < j: exactly what its pov() reads in the reference (agent.py:155-173).  Any appearance
+// table, float32 or uint8 windows.  G lanes per env (a power of two >= A), lane j = agent j.
+template <int G>
+__global__ __launch_bounds__(kBlock, 8) void act_patch(const Params p, const RowPtrs rp) {
+    constexpr int EPW = 64 / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t env0 = ((int64_t)blockIdx.x * 4 + sub) * EPW;
+    if (env0 >= p.E) return;
+    const int j = lane & (G - 1);
+    int64_t env = env0 + (lane / G);
+    const bool live = env < p.E;
+    if (!live) env = p.E - 1;
+    const DevTables* gtab = p.tab;
+    const int H = p.H, W = p.W, HW = H * W, C = p.C, V = p.V, VV = p.VV, r = p.r, L = p.L, a = p.a0;
+    uint8_t* g = p.grid + env * p.env_stride;
+    uint32_t pj = 0;
+    const bool later = live && j > a && j < p.A;
+    if (later) pj = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + j];
+    MoveOut mo;
+    const int st = move_one(p, gtab, g, env, a, nullptr, live && j == 0, mo);
+    if (st && live && j == 0) atomicOr(p.status, st);
+    if (!later || mo.old_y < 0 || rp.p[j] == nullptr) return;
+    const int yj = (int)(pj & 0xFFu), xj = (int)(pj >> 8);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int cy = k ? mo.new_y : mo.old_y, cx = k ? mo.new_x : mo.old_x;
+        const uint32_t nt = k ? mo.my_type : p.default_type;
+        const int di = cy - yj + r, dj = cx - xj + r;
+        if ((unsigned)di >= (unsigned)V || (unsigned)dj >= (unsigned)V) continue;
+        const int64_t o = env * rp.stride + di * V + dj;
+        if (p.onehot) {                                   // one-hot tables: byte counters
+            uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+            for (int z = 0; z < L; ++z) {
+                const uint32_t tz = (z == p.zA ? nt : (uint32_t)g[z * HW + cy * W + cx]) & 31u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cnt[q] += gtab->delta[q][tz];
+            }
+            for (int c = 0; c < C; ++c) {
+                const uint32_t v = (cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+                if (p.obs_u8) reinterpret_cast<uint8_t*>(rp.p[j])[o + (int64_t)c * VV] = (uint8_t)v;
+                else reinterpret_cast<float*>(rp.p[j])[o + (int64_t)c * VV] = (float)v;
+            }
+        } else {                                          // np.sum over layers: left to right, float64 (visual_field.py:51)
+            for (int c = 0; c < C; ++c) {
+                double acc = 0.0;
+                for (int z = 0; z < L; ++z) {
+                    const uint32_t tz = (z == p.zA ? nt : (uint32_t)g[z * HW + cy * W + cx]) & 31u;
+                    acc = z == 0 ? gtab->appearance[tz][c] : acc + gtab->appearance[tz][c];
+                }
+                reinterpret_cast<float*>(rp.p[j])[o + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
+            }
+        }
+    }
+}

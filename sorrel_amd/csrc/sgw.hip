@@ -104,6 +104,13 @@ struct sgw_engine {
     const char* kernel_name_plain = "?";
     int stage_agents = 0;      // agents per staged chunk (STAGE kernels)
     bool phase_ok = false;     // the phase kernel applies (plain moves)
+    void (*rows_fn)(const Params) = nullptr;   // phase_rows<L, NW, R>: a policy-driven phase with a lane per window row (one-hot, plain moves)
+    void (*obs_rows_fn)(const Params, const RowPtrs) = nullptr;   // observe_rows<L, NW, R>: a range of agents, per-agent destinations
+    const char* kernel_name_rows = "-";
+    const char* kernel_name_obs_rows = "-";
+    int rows_wpb = 0;          // windows per 256-thread workgroup of observe_rows
+    int rows_epb = 0;          // envs per 256-thread workgroup of it
+    size_t rows_lds = 0;
     bool multi_turn = false;   // the step kernel in use runs sgw_rollout's turns in one launch
     void (*reset_fn)(const Params) = nullptr;
     size_t lds_bytes = 0;       // reset / generic step
@@ -127,6 +134,7 @@ struct sgw_engine {
     double ms_acc = 0.0;
     int64_t launches = 0;
     std::vector<float> series;   // per-launch durations since the last sgw_get_step_times_ms
+    int64_t series_dropped = 0;  // launches beyond kSeriesCap since the last read: in the sum, not in the series
 };
 
 namespace {
@@ -308,6 +316,28 @@ StepFn pick_big_walk(bool onehot, int L, int C, int r, const char** name) {
     PICK(step_big<true, 0, 0, 0, false, true>);
 }
 
+// phase_rows instances: layers x counter words (channels / 4) x vision radius.  Shapes outside the table keep the
+// staging kernels (worlds <= 4 KiB) or phase_kernel (above).
+using RowsFn = void (*)(const Params, const RowPtrs);
+StepFn pick_rows(int L, int NW, int r, const char** name, RowsFn* obs_fn, const char** obs_name) {
+#define ROWS_CASE(l, n, rr)                           \
+    if (L == l && NW == n && r == rr) {               \
+        *obs_fn = observe_rows<l, n, rr>;             \
+        *obs_name = "observe_rows<" #l ", " #n ", " #rr ">"; \
+        PICK(phase_rows<l, n, rr>);                   \
+    }
+    ROWS_CASE(2, 2, 3);   // BASELINE configs 3 / 4
+    ROWS_CASE(2, 2, 2);   // BASELINE config 2, the Treasurehunt example
+    ROWS_CASE(2, 2, 5);   // BASELINE config 5
+    ROWS_CASE(2, 2, 1); ROWS_CASE(2, 2, 4);
+    ROWS_CASE(1, 1, 1); ROWS_CASE(1, 1, 2); ROWS_CASE(1, 1, 3); ROWS_CASE(1, 1, 4); ROWS_CASE(1, 1, 5);
+    ROWS_CASE(1, 2, 2); ROWS_CASE(1, 2, 3);
+    ROWS_CASE(2, 1, 1); ROWS_CASE(2, 1, 2); ROWS_CASE(2, 1, 3);
+    ROWS_CASE(3, 2, 2); ROWS_CASE(3, 2, 3);
+#undef ROWS_CASE
+    return nullptr;
+}
+
 StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
     if (rules) {
         if (onehot && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true>);   // Cleanup's tables (3 layers, 9 kinds)
@@ -339,12 +369,13 @@ constexpr size_t kSeriesCap = (size_t)1 << 20;
 // Waits for the recorded event pairs and folds them into the running sum and the per-launch series.
 int time_drain(sgw_engine* e) {
     if (e->ev_used == 0) return SGW_OK;
-    HIP_TRY(hipEventSynchronize(e->ev1[e->ev_used - 1]));
     for (int i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(e->ev1[i]));   // each pair on its own: timed launches may have gone to different streams
         HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
         e->ms_acc += ms;
         if (e->series.size() < kSeriesCap) e->series.push_back(ms);
+        else e->series_dropped++;
     }
     e->ev_used = 0;
     return SGW_OK;
@@ -480,6 +511,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         }
     }
     p.single_spawner = nspawn <= 1 ? 1 : 0;
+    p.onehot = onehot ? 1 : 0;
     p.nturns = 1;
     p.obs_A = c.num_agents;      // observations go to the [E][A][C][V][V] tensor unless a call says otherwise
     p.obs_a0 = 0;
@@ -640,6 +672,14 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     // byte gather from global is the slower way (config 3: 62.9 against 46.1 us).  SGW_NO_PHASE_KERNEL = 1 / 0 forces.
     e->phase_ok = c.agent_rule == SGW_AGENT_RULE_MOVE && e->wpe == 4;
     if (const char* f = getenv("SGW_NO_PHASE_KERNEL")) e->phase_ok = c.agent_rule == SGW_AGENT_RULE_MOVE && f[0] == '0';
+    if (e->onehot && c.agent_rule == SGW_AGENT_RULE_MOVE && p.cells >= 8) {
+        e->rows_fn = pick_rows(c.layers, (c.num_channels + 3) / 4, c.vision_radius, &e->kernel_name_rows, &e->obs_rows_fn, &e->kernel_name_obs_rows);
+        const int V = 2 * c.vision_radius + 1;
+        e->rows_epb = e->rows_wpb = 4 * (64 / (V <= 4 ? 4 : (V <= 8 ? 8 : 16)));
+        // per wave: counter words, the value table, the staging bytes of the windows it carries
+        e->rows_lds = (size_t)4 * (((c.num_channels + 3) / 4) * 34 * 4 + SGW_MAX_TYPES * 8 + (e->rows_epb / 4) * ((c.num_channels * V * V + 3) & ~3));
+    }
+    if (const char* f = getenv("SGW_PHASE_ROWS")) { if (f[0] == '0') e->rows_fn = nullptr; }   // A/B and test hook: the older phase paths (sgw_step's phases only)
     p.stage_agents = e->stage_agents;
     StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name)
@@ -738,6 +778,29 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
     return launch_reset(e, grid, agent_pos, total_reward, epoch, stream);
 }
 
+// The dynamic-LDS request of a step launch, and the workgroup-per-CU cap it encodes (0 = none).  The cap is the one
+// launch-time lever on occupancy; the policy (sgw_set_wg_per_cu: 0 = the automatic rule, 1..8 forced, -1 never):
+// five workgroups per CU for whole-turn float32 observation writes of 8 KiB or more per env in large batches, where fewer
+// concurrent waves mean fewer half-written lines open in HBM --
+//  - the unstaged path (Cleanup, 21x31x3 at 65 536 envs: 893 -> 801 us);
+//  - the staged path only when the grids of the batch no longer fit the caches (262 144 envs of config 3: 662 -> 578 us,
+//    524 288: 1375 -> 1146 us).  While they do fit (configs 3/4: 65 536 envs, 134 MB) the staged emit with its streaming
+//    full-line stores is fastest at full occupancy (124 us at 8 and 7 per CU, 126 at 6, 131 at 5; 131 072 envs: 248 vs 281).
+// The uint8 format, small batches and the shapes with small windows, which are latency-bound (Tag 11x11, 6.5 KB per env:
+// 164 us at full occupancy, 192 us capped), are not capped.
+static size_t step_lds_request(const sgw_engine* e, const Params& p, int* cap_out) {
+    size_t lds = e->step_lds_bytes;
+    int cap = 0;
+    if (e->fast && e->wg_per_cu > 0) cap = e->wg_per_cu;
+    else if (e->fast && e->wg_per_cu == 0 && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 &&
+             (!p.obs_stage || (size_t)p.E * (size_t)p.env_stride > kCacheResidentGrid) && p.a1 == p.A && p.a0 == 0 &&
+             (size_t)p.A * p.C * p.VV * 4 >= 8192 && p.E >= (int64_t)e->num_cus * 32 * 2)
+        cap = e->fast_wg_cap;
+    if (cap > 0) lds = std::max(lds, (size_t)(kLdsPerCu / cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
+    if (cap_out) *cap_out = cap;
+    return lds;
+}
+
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (int rc = time_begin(e, s)) return rc;
     p.agent_state = e->agent_state;
@@ -752,27 +815,19 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
-    // Occupancy cap (an LDS request that fits 5 workgroups per CU = 5 waves per SIMD) for whole-turn float32
-    // observation writes of 8 KiB or more per env in large batches, where fewer concurrent waves mean fewer
-    // half-written lines open in HBM:
-    //  - the unstaged path (Cleanup, 21x31x3 at 65 536 envs: 893 -> 801 us);
-    //  - the staged path only when the grids of the batch no longer fit the caches (262 144 envs of config 3:
-    //    662 -> 578 us, 524 288: 1375 -> 1146 us).  While they do fit (configs 3/4: 65 536 envs, 134 MB) the staged
-    //    emit with its streaming full-line stores is fastest at full occupancy (124 us at 8 and 7 per CU, 126 at 6,
-    //    131 at 5; 131 072 envs: 248 vs 281 us).
-    // The uint8 format, small batches and the shapes with small windows, which are latency-bound (Tag 11x11, 6.5 KB
-    // per env: 164 us at full occupancy, 192 us capped), are not capped.
-    // The policy is explicit (sgw_set_wg_per_cu, include/sgw.h): 0 = this automatic rule, 1..8 = forced, -1 = never.
-    size_t lds = e->step_lds_bytes;
     int cap = 0;
-    if (e->fast && e->wg_per_cu > 0) cap = e->wg_per_cu;
-    else if (e->fast && e->wg_per_cu == 0 && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 &&
-             (!p.obs_stage || (size_t)p.E * (size_t)p.env_stride > kCacheResidentGrid) && p.a1 == p.A && p.a0 == 0 &&
-             (size_t)p.A * p.C * p.VV * 4 >= 8192 && p.E >= (int64_t)e->num_cus * 32 * 2)
-        cap = e->fast_wg_cap;
-    if (cap > 0) lds = std::max(lds, (size_t)(kLdsPerCu / cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
-    // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves): the phase
-    // kernel, which does not stage the env (SGW_NO_PHASE_KERNEL=1: A/B and test hook).
+    const size_t lds = step_lds_request(e, p, &cap);
+    // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
+    // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
+    const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
+    if (e->rows_fn && one_phase && !p.obs_u8) {
+        const int64_t N = (int64_t)p.C * p.VV;
+        p.rows_unit = (p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 7) == 0 && (N & 1) == 0) ? 2 : 1;
+        hipLaunchKernelGGL(e->rows_fn, dim3((unsigned)ceil_div(p.E, e->rows_epb)), dim3(kBlock), e->rows_lds, s, p);
+        HIP_TRY(hipGetLastError());
+        return time_end(e, s);
+    }
+    // ... otherwise, for worlds above 4 KiB: the byte-gather phase kernel (SGW_NO_PHASE_KERNEL=1: A/B and test hook).
     if (e->phase_ok && p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1)) {
         Params q = p;
         q.env_lds = (e->onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8) + SGW_MAX_TYPES * 8;   // + the value table
@@ -886,6 +941,80 @@ int sgw_rollout(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actio
     return SGW_OK;
 }
 
+int sgw_capabilities(sgw_engine* e) {
+    if (!e) return 0;
+    int caps = 0;
+    if (e->obs_rows_fn && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_OBSERVE_ROWS;
+    if (e->cfg.agent_rule == SGW_AGENT_RULE_MOVE) caps |= SGW_CAP_ACT;
+    return caps;
+}
+
+static int fill_rows(const sgw_engine* e, void* const* rows, int64_t env_stride, int a0, int a1, bool need_all, RowPtrs* rp, const char* who) {
+    const sgw_config& c = e->cfg;
+    const int64_t V = 2 * c.vision_radius + 1;
+    if (!rows) return fail(SGW_EINVAL, "%s: rows is NULL", who);
+    if (env_stride < (int64_t)c.num_channels * V * V) return fail(SGW_EINVAL, "%s: env_stride is smaller than one window", who);
+    memset(rp, 0, sizeof(*rp));
+    for (int a = a0; a < a1; ++a) {
+        if (!rows[a] && need_all) return fail(SGW_EINVAL, "%s: rows[%d] is NULL", who, a);
+        if (e->obs_format == SGW_OBS_F32 && (reinterpret_cast<uintptr_t>(rows[a]) & 3u))
+            return fail(SGW_EINVAL, "%s: rows[%d] is not 4-byte aligned", who, a);
+        rp->p[a] = rows[a];
+    }
+    rp->stride = env_stride;
+    return SGW_OK;
+}
+
+int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
+                     int32_t agent_begin, int32_t agent_end, void* stream) {
+    if (!e || !grid || !agent_pos) return fail(SGW_EINVAL, "sgw_observe_rows: NULL argument");
+    if (agent_begin < 0 || agent_end > e->cfg.num_agents || agent_begin >= agent_end)
+        return fail(SGW_EINVAL, "sgw_observe_rows: agent range [%d, %d) invalid", agent_begin, agent_end);
+    if (!(sgw_capabilities(e) & SGW_CAP_OBSERVE_ROWS))
+        return fail(SGW_EINVAL, "sgw_observe_rows: no row-load instance for this world (one-hot float32 windows of an instantiated "
+                                "layers / channels / radius only; see sgw_capabilities) -- use sgw_observe");
+    RowPtrs rp;
+    if (int rc = fill_rows(e, rows, env_stride, agent_begin, agent_end, true, &rp, "sgw_observe_rows")) return rc;
+    Params p = e->base;
+    p.grid = const_cast<uint8_t*>(grid); p.pos = const_cast<uint8_t*>(agent_pos);
+    p.a0 = agent_begin; p.a1 = agent_end; p.flags = 0; p.do_move = 0;
+    p.rows_unit = (((int64_t)p.C * p.VV) & 1) == 0 && (env_stride & 1) == 0 ? 2 : 1;
+    for (int a = agent_begin; a < agent_end; ++a)
+        if (reinterpret_cast<uintptr_t>(rows[a]) & 7) p.rows_unit = 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = time_begin(e, s)) return rc;
+    const int64_t nwin = p.E * (agent_end - agent_begin);
+    hipLaunchKernelGGL(e->obs_rows_fn, dim3((unsigned)ceil_div(nwin, e->rows_wpb)), dim3(kBlock), e->rows_lds, s, p, rp);
+    HIP_TRY(hipGetLastError());
+    return time_end(e, s);
+}
+
+int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, const uint8_t* actions, void* const* rows, int64_t env_stride,
+            float* rewards, double* total_reward, int32_t agent, void* stream) {
+    if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_act: NULL argument");
+    if (agent < 0 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_act: agent %d out of range", agent);
+    if (!(sgw_capabilities(e) & SGW_CAP_ACT))
+        return fail(SGW_EINVAL, "sgw_act: only MovingAgent.act (SGW_AGENT_RULE_MOVE) is served; other agent rules step through sgw_step");
+    RowPtrs rp;
+    memset(&rp, 0, sizeof(rp));
+    if (rows)
+        if (int rc = fill_rows(e, rows, env_stride, agent + 1, e->cfg.num_agents, false, &rp, "sgw_act")) return rc;
+    Params p = e->base;
+    p.grid = grid; p.pos = agent_pos; p.actions = const_cast<uint8_t*>(actions); p.rewards = rewards; p.total = total_reward;
+    p.a0 = agent; p.a1 = agent + 1; p.flags = SGW_STEP_NO_OBS; p.do_move = 1;
+    p.agent_state = e->agent_state;
+    p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = time_begin(e, s)) return rc;
+    const int A = e->cfg.num_agents;
+    const int G = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
+    const unsigned blocks = (unsigned)ceil_div(p.E, 4 * (64 / G));
+    RowsFn fn = G == 8 ? act_patch<8> : (G == 16 ? act_patch<16> : (G == 32 ? act_patch<32> : act_patch<64>));
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, s, p, rp);
+    HIP_TRY(hipGetLastError());
+    return time_end(e, s);
+}
+
 int sgw_set_obs_format(sgw_engine* e, int format) {
     if (!e) return fail(SGW_EINVAL, "sgw_set_obs_format: NULL engine");
     if (format != SGW_OBS_F32 && format != SGW_OBS_U8) return fail(SGW_EINVAL, "unknown observation format %d", format);
@@ -965,6 +1094,7 @@ int sgw_set_timing(sgw_engine* e, int enable) {
     e->ms_acc = 0.0;
     e->launches = 0;
     e->series.clear();
+    e->series_dropped = 0;
     return SGW_OK;
 }
 
@@ -983,8 +1113,15 @@ int sgw_get_step_times_ms(sgw_engine* e, float* out_ms, int64_t capacity, int64_
     if (int rc = time_drain(e)) return rc;
     const int64_t n = std::min<int64_t>((int64_t)e->series.size(), std::max<int64_t>(capacity, 0));
     for (int64_t i = 0; i < n; ++i) out_ms[i] = e->series[(size_t)i];
+    const int64_t lost = (int64_t)e->series.size() - n + e->series_dropped;
     *count = n;
     e->series.clear();
+    e->series_dropped = 0;
+    if (lost > 0) {   // the durations read are right; the caller learns that the series is not complete
+        fail(SGW_OK, "sgw_get_step_times_ms: %lld launches not returned (capacity %lld, series cap %lld)", (long long)lost,
+             (long long)capacity, (long long)kSeriesCap);
+        return 1;
+    }
     return SGW_OK;
 }
 
@@ -1004,13 +1141,26 @@ int sgw_set_wg_per_cu(sgw_engine* e, int wg_per_cu) {
 
 int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     if (!e || !buf || capacity < 1) return fail(SGW_EINVAL, "sgw_launch_info: NULL argument");
-    const bool walk = e->step_fn_walk && e->base.E > e->walk_min_envs && e->base.E <= e->walk_max_envs;   // what a whole-batch sgw_step launches
-    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%s%d",
+    // what a whole-batch, whole-turn sgw_step with 16-byte-aligned observations launches: the kernel, the LDS bytes it
+    // REQUESTS (a workgroup-per-CU cap is part of that request) and the workgroups per CU the runtime then admits
+    const bool walk = e->step_fn_walk && e->base.E > e->walk_min_envs && e->base.E <= e->walk_max_envs;
+    Params p = e->base;
+    p.a0 = 0; p.a1 = p.A; p.flags = SGW_STEP_SWEEP | SGW_STEP_RANDOM_ACTIONS; p.do_move = 1;
+    p.obs = reinterpret_cast<float*>(16); p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
+    p.obs_stage = e->fast ? e->obs_stage : 0;
+    int cap = 0;
+    const size_t lds = step_lds_request(e, p, &cap);
+    const int threads = e->big ? kBigThreads : kBlock;
+    StepFn fn = walk ? e->step_fn_walk : e->step_fn;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
+    const char* phase = e->rows_fn ? e->kernel_name_rows : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
+    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s",
              walk ? e->kernel_name_walk : e->kernel_name,
              (e->fast || e->big) ? e->wpe * kWave * (e->big ? kBigWaves / 4 : 1) : e->group,
-             e->big ? kBigThreads : kBlock, e->step_lds_bytes, e->step_env_lds, e->obs_stage, e->stage_agents,
-             walk ? e->walk_blocks : e->grid_blocks,
-             e->wg_per_cu == 0 ? "auto:" : "", e->wg_per_cu == 0 ? e->fast_wg_cap : e->wg_per_cu);
+             threads, lds, e->step_env_lds, e->obs_stage, e->stage_agents,
+             walk ? e->walk_blocks : e->grid_blocks, per_cu,
+             e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase);
     return SGW_OK;
 }
 

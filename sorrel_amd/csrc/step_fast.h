@@ -18,7 +18,8 @@
 //     so gather/emit is branch-free: v_cvt_f32_ubyteN + global_store_dword.
 constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kCacheResidentGrid = (size_t)384 << 20;   // grids of a batch up to about this size stay in the 256 MB Infinity Cache + L2 from turn to turn
+constexpr size_t kCacheResidentGrid = (size_t)288 << 20;   // on-die capacity: 256 MiB Infinity Cache + 8 x 4 MiB L2; grids of a batch up to this size can stay
+                                                            // resident from turn to turn (measured: 256 MiB of grids still do, 512 MiB do not)
 
 // (non-temporal observation stores were measured: slower)
 #define OBS_STORE(ptr, val) (*(ptr) = (val))

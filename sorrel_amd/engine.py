@@ -207,6 +207,54 @@ class GridEngine:
                                           agent_begin, agent_end, self._stream()))
         return out
 
+    # ------------------------------------------------------------------ policy-driven turns without re-rendering
+    def capabilities(self) -> int:
+        """``N.CAP_OBSERVE_ROWS`` | ``N.CAP_ACT`` (include/sgw.h)."""
+        return int(self._lib.sgw_capabilities(self._h))
+
+    def window_rows(self, dests=None):
+        """The per-agent window destinations ``sgw_observe_rows`` / ``sgw_act`` take: ``(ctypes pointer array, env stride in
+        elements, the tensors)``.  ``dests`` = one tensor per agent, each ``num_envs`` contiguous rows of exactly one window
+        (``C*V*V`` elements of the engine's observation dtype, e.g. a row of that agent's replay buffer); default = the
+        slots of the observation tensor ``self.obs[:, a]``."""
+        A = self.spec.num_agents
+        per_env = 1
+        for d in self.spec.obs_shape[1:]:
+            per_env *= int(d)
+        arr = (C.c_void_p * A)()
+        if dests is None:
+            if self.obs is None:
+                raise ValueError("engine was built with allocate_obs=False; pass per-agent destinations")
+            base, esz = self.obs.data_ptr(), self.obs.element_size()
+            for a in range(A):
+                arr[a] = base + a * per_env * esz
+            return arr, A * per_env, None
+        if len(dests) != A:
+            raise ValueError(f"need one destination per agent ({A}), got {len(dests)}")
+        for a, t in enumerate(dests):
+            arr[a] = self._check_window(t, f"dests[{a}]").data_ptr()
+        return arr, per_env, list(dests)
+
+    def observe_rows(self, rows, agent_begin: int = 0, agent_end: Optional[int] = None):
+        """Every agent's window, once, into its own destination (``rows`` from ``window_rows``): step 2 of a policy-driven
+        turn.  Needs ``CAP_OBSERVE_ROWS``; otherwise ``observe()`` into the observation tensor does the same job."""
+        arr, stride, _ = rows
+        agent_end = self.spec.num_agents if agent_end is None else agent_end
+        with self._on_device():
+            N.check(self._lib.sgw_observe_rows(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), arr, stride,
+                                               agent_begin, agent_end, self._stream()))
+
+    def act(self, agent: int, rows=None):
+        """``MovingAgent.act`` of ONE agent (its action is ``self.actions[:, agent]``) for every env; the at most two
+        cells the move changes are rewritten in the windows (``rows``) of the agents after it that contain them, so that
+        each later agent's window shows the grid after the moves of all agents before it, without being rendered again.
+        Rewards land in ``self.rewards[:, agent]``."""
+        arr, stride = (None, 0) if rows is None else rows[:2]
+        with self._on_device():
+            N.check(self._lib.sgw_act(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(self.actions), arr, stride,
+                                      self._ptr(self.rewards), self._ptr(self.total_reward), int(agent), self._stream()))
+        return self.rewards[:, agent]
+
     def scratch_obs(self) -> torch.Tensor:
         if self._scratch_obs is None:
             self._scratch_obs = torch.zeros((self.num_envs,) + self.spec.obs_shape, dtype=self.obs_dtype, device=self.device)
@@ -364,7 +412,10 @@ class GridEngine:
         """Per-launch durations (ms, HIP events on the launch stream) since the last read, oldest first."""
         buf = (C.c_float * capacity)()
         n = C.c_int64(0)
-        N.check(self._lib.sgw_get_step_times_ms(self._h, buf, capacity, C.byref(n)))
+        rc = self._lib.sgw_get_step_times_ms(self._h, buf, capacity, C.byref(n))
+        if rc < 0:
+            N.check(rc)
+        self.series_truncated = rc == 1          # launches beyond `capacity` / the library's sample cap were left out
         return [float(buf[i]) for i in range(int(n.value))]
 
     def set_wg_per_cu(self, n: int):

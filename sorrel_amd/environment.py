@@ -6,11 +6,14 @@ Subclass it exactly like the reference: implement ``setup_agents`` (assign
 
 * fused (one kernel launch): every agent's model is a ``RandomModel`` (actions drawn
   on device) or an ``actions [E, A]`` tensor is passed;
-* phased (1 + A launches): policy-driven agents -- the entity sweep, then for each
-  agent in list order ``agent.transition(world)`` = observe -> policy -> act, so
-  agent i+1 observes agent i's move exactly as in the reference.  The launch that
-  moves agent i also renders agent i+1's observation (``SGW_STEP_OBS_NEXT``): nothing
-  intervenes between the two in the reference either (``sorrel/agents/agent.py:167-169``).
+* policy-driven (2 + A launches): the entity sweep, EVERY agent's window rendered once, then
+  for each agent in list order ``agent.transition(world)`` = observe -> policy -> act, where
+  the act launch (``sgw_act``) moves the agent and rewrites, in the windows of the agents
+  after it, the at most two cells its move changed -- so agent i+1 observes agent i's move
+  exactly as in the reference (``sorrel/agents/agent.py:155-173``) without a window being
+  rendered per launch.  Where that protocol does not apply (Tag / Cleanup agents) the older
+  1 + A form runs: the launch that moves agent i also renders agent i+1's observation
+  (``SGW_STEP_OBS_NEXT``).
 
 The device status word (off-grid move, bad action index, unregistered type id -- where the
 reference raises ``IndexError`` / ``KeyError``) is polled once per epoch by ``run_experiment`` /
@@ -115,6 +118,7 @@ class Environment:
         self.turn = 0
         self.epoch = 0
         self._fresh_obs = None       # (slot, world mutation count): eng.obs[:, slot] was rendered by the last launch
+        self._turn_windows = None    # (world mutation count, rows, first agent whose window is still current): this turn's windows
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
@@ -302,6 +306,7 @@ class Environment:
         self.turn = 0
         self.epoch += 1
         self._fresh_obs = None
+        self._turn_windows = None
         self.world.is_done = False
         self.world.create_world()
         self.populate_environment()
@@ -319,6 +324,10 @@ class Environment:
             eng.step(actions, turn=self.turn)
         elif all(getattr(a.model, "device_random", False) for a in self.agents):
             eng.step(random_actions=True, turn=self.turn)
+        elif self._begin_policy_turn(eng):
+            for agent in self.agents:
+                agent.transition(self.world)
+            self._turn_windows = None
         else:
             # entity sweep; the same launch renders agent 0's observation (nothing intervenes before its pov)
             slot = self._replay_slot(0, None)
@@ -326,6 +335,67 @@ class Environment:
             self._fresh_obs = (0, self.world.mutations, slot)
             for agent in self.agents:
                 agent.transition(self.world)
+
+    #: policy-driven turns render every agent's window once and let each act launch repair the cells its move changed
+    #: (``sgw_observe_rows`` / ``sgw_act``); False = the older 1 + A protocol, a window rendered per launch (A/B and test switch)
+    patch_windows = True
+
+    def _begin_policy_turn(self, eng) -> bool:
+        """Steps 1 and 2 of the patched-window protocol (``include/sgw.h``): the entity sweep alone, then EVERY agent's
+        window, once, from the grid after the sweep -- into the row of each agent's replay buffer that its ``add_memory``
+        is about to fill where that is possible (``_replay_rows``), else into the observation tensor.  Step 3 is
+        ``_act``.  Applies to ``MovingAgent.act`` agents; returns False where it does not (Tag / Cleanup)."""
+        from sorrel_amd import _native as N
+
+        self._turn_windows = None
+        caps = eng.capabilities()
+        if not self.patch_windows or not (caps & N.CAP_ACT) or eng.obs is None:
+            return False
+        eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
+        if caps & N.CAP_OBSERVE_ROWS:
+            rows = eng.window_rows(self._replay_rows())
+            eng.observe_rows(rows)
+        else:                                   # any appearance table, uint8 windows: the step kernels render the tensor
+            rows = eng.window_rows(None)
+            eng.observe()
+        self._turn_windows = [self.world.mutations, rows, 0]
+        return True
+
+    def _replay_rows(self):
+        """One destination per agent -- the row of its replay buffer that its next ``add_memory`` fills -- if EVERY agent
+        has one: a ``sorrel_amd.buffers.Buffer`` of the engine's dtype and device whose rows hold exactly one window (a
+        ``pov`` that appends to the window, like Cleanup's positional code, does not qualify); agents that share one
+        buffer get consecutive rows, in the order their ``add_memory`` calls will arrive.  ``Buffer.add`` then finds the
+        state in place and copies nothing (config 3 at 65 536 envs: 77 MB per agent and turn).
+
+        Invariant this relies on: a ``pov`` is followed by the same agent's ``add_memory`` within the turn, which is what
+        ``Agent.transition`` does; an agent class that overrides ``transition`` or ``add_memory`` could leave a
+        pre-written row behind in a full ring, so such agents (and ``write_obs_into_replay = False``) get the
+        observation tensor and ``Buffer.add`` copies."""
+        from sorrel_amd.buffers import Buffer
+
+        eng = self._engine
+        if not self.write_obs_into_replay:
+            return None
+        per_env = 1
+        for d in eng.spec.obs_shape[1:]:
+            per_env *= int(d)
+        taken, rows = {}, []
+        for agent in self.agents:
+            mem = getattr(agent.model, "memory", None)
+            if not isinstance(mem, Buffer) or type(agent).transition is not Agent.transition \
+                    or type(agent).add_memory is not Agent.add_memory:
+                return None
+            k = taken.get(id(mem), 0)
+            taken[id(mem)] = k + 1
+            if k >= mem.capacity:
+                return None
+            row = mem.states[(mem.idx + k) % mem.capacity]
+            if row.dtype != eng.obs_dtype or row.device != eng.device or not row.is_contiguous() or row.dim() < 2 \
+                    or row.shape[0] != eng.num_envs or row.numel() != eng.num_envs * per_env:
+                return None
+            rows.append(row)
+        return rows
 
     def rollout(self, turns: int) -> None:
         """``turns`` fused ``take_turn``s with ONE engine call (``sgw_rollout``: one launch with every env's grid resident
@@ -438,6 +508,12 @@ class Environment:
         if isinstance(who, Agent):
             who = who.slot
         if isinstance(who, int):
+            tw = self._turn_windows
+            if own and tw is not None and tw[0] == self.world.mutations and who >= tw[2]:
+                # this turn's window of an agent that has not acted yet: rendered after the sweep, kept current by the act
+                # launches of the agents before it
+                dests = tw[1][2]
+                return eng.obs[:, who] if dests is None else dests[who].view((eng.num_envs,) + tuple(eng.spec.obs_shape[1:]))
             if own and self._fresh_obs is not None and self._fresh_obs[:2] == (who, self.world.mutations):
                 # rendered by the launch that moved the previous agent (SGW_STEP_OBS_NEXT) -- into the observation tensor,
                 # or straight into the row of this agent's replay buffer that add_memory is about to fill
@@ -499,6 +575,12 @@ class Environment:
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
         eng.actions[:, a].copy_(action)          # one strided copy that also narrows int64 -> uint8
+        tw = self._turn_windows
+        if tw is not None:
+            if tw[0] == self.world.mutations and a >= tw[2]:
+                tw[2] = a + 1                    # the windows of the agents after a stay current: sgw_act repairs them
+                return eng.act(a, tw[1])
+            self._turn_windows = None            # host code changed the world mid-turn: render on demand from here on
         nxt = a + 1 < len(self.agents) and eng.obs is not None
         slot = self._replay_slot(a + 1, a) if nxt else None
         eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn, obs_next=nxt,
@@ -580,8 +662,10 @@ class Environment:
             self.reset()
             for agent in self.agents:
                 self._model_start_epoch_action(agent, epoch)
-            if all(getattr(a.model, "device_random", False) for a in self.agents) and not self.stop_if_done:
-                self.rollout(max_turns - self.turn)        # the whole epoch in one engine call
+            if all(getattr(a.model, "device_random", False) for a in self.agents) and not self.stop_if_done \
+                    and type(self).take_turn is Environment.take_turn:
+                self.rollout(max_turns - self.turn)        # the whole epoch in one engine call (a subclass that overrides
+                                                           # take_turn gets its per-turn loop below, as in the reference)
             while self.turn < max_turns:
                 self.take_turn()
                 if self.world.is_done and self.stop_if_done:
@@ -637,21 +721,35 @@ class Environment:
                                     device="cpu", positions=(2,)))
             if hasattr(agent.model, "eval"):
                 agent.model.eval()
-        fused = all(getattr(a.model, "device_random", False) for a in self.agents)
+        device_random = all(getattr(a.model, "device_random", False) for a in self.agents)
+        # one engine call per game -- unless a subclass overrides take_turn: the reference's loop goes through take_turn
+        # every turn (sorrel/environment.py:266-282), so an override (per-turn logging, extra world logic) must be called
+        one_call = device_random and type(self).take_turn is Environment.take_turn
         ring = None
         for game in range(num_games):
             self.reset()
             for agent in self.agents:
                 self._model_start_epoch_action(agent, game)
             eng = self._ensure_engine()
-            if fused:
+            if device_random:
                 if ring is None:
                     ring = TurnBuffer(T, E, eng.spec.obs_shape, device=eng.device, obs_dtype=eng.obs_dtype,
                                       positions=record_positions)
                 ring.clear()
-                self.collect(T, ring)
+                if one_call:
+                    self.collect(T, ring)
+                else:
+                    while self.turn < T:
+                        self.take_turn()
+                        eng = self._ensure_engine()
+                        ring.obs[ring.slot()].copy_(eng.obs)
+                        ring.commit(eng.actions, eng.rewards, eng.agent_pos)
+                        if self.world.is_done and self.stop_if_done:
+                            break
+                n = len(ring)
                 for a, sg in enumerate(saved):
-                    sg.add_turns(*ring.agent_view(a), positions=None if ring.positions is None else ring.positions[:, :, a])
+                    st, ac, rw, dn = ring.agent_view(a)
+                    sg.add_turns(st[:n], ac[:n], rw[:n], dn[:n], positions=None if ring.positions is None else ring.positions[:n, :, a])
             else:
                 while self.turn < T:
                     self.take_turn()
@@ -661,7 +759,7 @@ class Environment:
             self.raise_on_status()
             for agent, sg in zip(self.agents, saved):
                 self._model_end_epoch_action(agent, game)
-                if not fused:
+                if not device_random:
                     sg.add_from_buffer(agent.model.memory)
         os.makedirs(out_dir / "memories", exist_ok=True)
         paths = []

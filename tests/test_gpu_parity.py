@@ -549,7 +549,8 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
         monkeypatch.setenv("SGW_NO_FAST_RULES", "1")
     rng = np.random.default_rng(7000 + case)
     ws, g, pos = H.random_rule_world(rng)
-    if ws.agent_rule == 0 and case % 2:      # plain movers: the policy-driven phases on phase_kernel (default only above 4 KiB)
+    if ws.agent_rule == 0 and case % 4 == 1:  # plain movers: the policy-driven phases on the byte-gather phase_kernel; the other
+        monkeypatch.setenv("SGW_PHASE_ROWS", "0")        # cases take the row-load phase kernel wherever an instance exists
         monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0")
     E, T = int(rng.integers(2, 30)), int(rng.integers(3, 12))
     first = int(rng.integers(0, 2**31))
@@ -637,14 +638,19 @@ def test_observe_kernel_vs_oracle(torch_cuda):
 
 
 @pytest.mark.parametrize("shape", [(16, 16, 4, 2, 200), (32, 32, 8, 3, 70), (21, 21, 3, 2, 33), (13, 9, 5, 4, 50), (64, 64, 9, 5, 5)])
-@pytest.mark.parametrize("phase_kernel", ["1", "0"])
+@pytest.mark.parametrize("phase_kernel", ["1", "0", "rows"])
 def test_policy_phase_stepping_equals_fused(torch_cuda, shape, phase_kernel, monkeypatch):
     """sweep once, then per agent sgw_observe + sgw_step (round 1's 1 + 2A launches) == one fused take_turn; and the plain
-    per-agent step that writes the mover's own pre-move observation.  With and without the phase kernel."""
+    per-agent step that writes the mover's own pre-move observation.  On the row-load phase kernel (the default where an
+    instance exists), the byte-gather phase kernel and the staging kernels."""
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0" if phase_kernel == "1" else "1")
+    if phase_kernel == "rows":
+        monkeypatch.setenv("SGW_PHASE_ROWS", "1")
+    else:
+        monkeypatch.setenv("SGW_PHASE_ROWS", "0")
+        monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0" if phase_kernel == "1" else "1")
     h, w, a_, r_, E = shape
     ws = treasurehunt_spec(h, w, a_, r_, spawn_prob=0.05, seed=6, dense_prob=0.1)
     fused, phased = make_engine(ws, E), make_engine(ws, E)

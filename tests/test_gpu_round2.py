@@ -52,7 +52,7 @@ KERNEL_CASES = [
 ]
 
 
-@pytest.mark.parametrize("phase_kernel", ["phase_kernel", "staging_kernels"])
+@pytest.mark.parametrize("phase_kernel", ["phase_rows", "phase_kernel", "staging_kernels"])
 @pytest.mark.parametrize("case", KERNEL_CASES, ids=[c[0] for c in KERNEL_CASES])
 def test_obs_next_phased_turn_equals_fused(torch_cuda, case, phase_kernel, monkeypatch):
     """Sweep + obs of agent 0 in one launch, then ONE launch per agent that moves it and renders the next agent's
@@ -62,6 +62,8 @@ def test_obs_next_phased_turn_equals_fused(torch_cuda, case, phase_kernel, monke
     _, mk, env, E = case
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    if phase_kernel != "phase_rows":           # (round 3's row-load phase kernel is the default where an instance exists)
+        monkeypatch.setenv("SGW_PHASE_ROWS", "0")
     if phase_kernel == "staging_kernels":      # the phases on the step kernels themselves (what Tag / Cleanup phases always use)
         monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "1")
     ws = mk()
@@ -571,7 +573,8 @@ def test_rollout_without_a_sweep_writes_every_turns_moves_back(torch_cuda, case,
 
 
 # ------------------------------------------------------------------ SGW_STEP_OBS_NEXT_PACKED: the next agent's window, one per env
-@pytest.mark.parametrize("case", ["fast_32x32", "packed_21x21", "phase_kernel_128", "step_big_128", "generic_256_128", "rules_cleanup", "u8"])
+@pytest.mark.parametrize("case", ["fast_32x32", "rows_32x32", "packed_21x21", "rows_128", "phase_kernel_128", "step_big_128", "generic_256_128",
+                                  "rules_cleanup", "u8"])
 def test_obs_next_packed_destination_equals_the_tensor_slot(torch_cuda, case, monkeypatch):
     """``obs_next_out`` (one window per env, e.g. a replay row) receives exactly what slot ``agent_end`` of the observation
     tensor receives without it, on every kernel family that serves policy-driven phases; nothing else is written."""
@@ -579,7 +582,9 @@ def test_obs_next_packed_destination_equals_the_tensor_slot(torch_cuda, case, mo
     from sorrel_amd.spec import treasurehunt_spec
 
     kw = {}
-    if case == "fast_32x32":
+    if not case.startswith("rows_"):           # the older phase paths; rows_*: the row-load phase kernel (the default)
+        monkeypatch.setenv("SGW_PHASE_ROWS", "0")
+    if case in ("fast_32x32", "rows_32x32"):
         ws, E = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.05, seed=3, dense_prob=0.2), 70
     elif case == "packed_21x21":
         monkeypatch.setenv("SGW_GROUP", "16")
@@ -664,24 +669,29 @@ def test_policy_turn_writes_windows_straight_into_replay_rows(torch_cuda):
         return make
 
     for shared in (False, True):
-        runs = []
-        for direct in (True, False):
-            env = make_env(15, 17, 3, 2, E, p=0.05, model_factory=factory(shared))
-            env.write_obs_into_replay = direct
-            for _ in range(T):
-                env.take_turn()
-            torch.cuda.synchronize()
-            runs.append(env)
-        d, c = runs
-        for ad, ac in zip(d.agents, c.agents):
-            md, mc = ad.model.memory, ac.model.memory
-            assert md.idx == mc.idx and md.size == mc.size
-            assert torch.equal(md.states, mc.states) and torch.equal(md.actions, mc.actions) and torch.equal(md.rewards, mc.rewards)
-        assert torch.equal(d.world.grid, c.world.grid) and torch.equal(d.world.total_reward, c.world.total_reward)
-        rows = {d.agents[0].model.memory.states[i].data_ptr() for i in range(5)}
-        in_rows = [p in rows for p in d.agents[0].model.seen]
-        if shared:      # only agent 0's window (rendered by the sweep launch, nobody adds in between) can go straight in
-            assert any(in_rows) and not all(in_rows)
-        else:
-            assert all(in_rows), "every state the policy saw was already sitting in its replay row"
+        ref = None
+        for patch in (True, False):     # round 3's protocol (all windows once + sgw_act repairs) and the 1 + A protocol
+            runs = []
+            for direct in (True, False):
+                env = make_env(15, 17, 3, 2, E, p=0.05, model_factory=factory(shared))
+                env.write_obs_into_replay = direct
+                env.patch_windows = patch
+                for _ in range(T):
+                    env.take_turn()
+                torch.cuda.synchronize()
+                runs.append(env)
+            d, c = runs
+            ref = ref or c
+            for other in (d, c):
+                for ad, ac in zip(other.agents, ref.agents):
+                    md, mc = ad.model.memory, ac.model.memory
+                    assert md.idx == mc.idx and md.size == mc.size
+                    assert torch.equal(md.states, mc.states) and torch.equal(md.actions, mc.actions) and torch.equal(md.rewards, mc.rewards)
+                assert torch.equal(other.world.grid, ref.world.grid) and torch.equal(other.world.total_reward, ref.world.total_reward)
+            rows = {d.agents[0].model.memory.states[i].data_ptr() for i in range(5)}
+            in_rows = [p in rows for p in d.agents[0].model.seen]
+            if shared and not patch:      # 1 + A protocol: only agent 0's window (rendered by the sweep launch, nobody adds in between) can go straight in
+                assert any(in_rows) and not all(in_rows)
+            else:                         # own buffers; or all windows rendered up front into consecutive rows of the shared one
+                assert all(in_rows), "every state the policy saw was already sitting in its replay row"
         assert not any(p in {c.agents[0].model.memory.states[i].data_ptr() for i in range(5)} for p in c.agents[0].model.seen)

@@ -1,0 +1,316 @@
+"""Round-3 GPU tests: the row-load phase kernel (``phase_rows``) that serves policy-driven phases of one-hot plain-move
+worlds of any size; the long horizon at the benchmark's own shape; the whole-map (``full_view``) observation."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no silent CPU fallback)")
+    return torch
+
+
+def make_engine(ws, E, first=0, **kw):
+    from sorrel_amd.engine import GridEngine
+
+    return GridEngine(ws, E, device="cuda:0", first_env_id=first, **kw)
+
+
+def _move_world(h, w, layers, channels, a, r, seed, zA=None):
+    """A plain-mover world with `layers` layers and `channels` one-hot channels (every instance of phase_rows is keyed by
+    layers x ceil(channels / 4) x radius): walls around every layer, a spawner, a few pick-ups with values."""
+    from sorrel_amd.spec import WorldSpec, action_deltas
+
+    T = max(6, min(channels + 1, 12))
+    app = np.zeros((T, channels))
+    for t in range(1, T):
+        app[t, (t * 5 + 1) % channels] = 1.0
+    zA = layers - 1 if zA is None else zA
+    dy, dx = action_deltas(["up", "down", "left", "right", "stay"])
+    rule = [1] + [0] * (T - 1)
+    return WorldSpec(height=h, width=w, layers=layers, num_agents=a, vision_radius=r, num_channels=channels, agent_layer=zA,
+                     default_type=0, fill_type=1, action_dy=dy, action_dx=dx, agent_type=[T - 1] * a,
+                     type_value=[0.0, -1.0, 10.0, 5.0, -10.0] + [1.0] * (T - 6) + [0.0],
+                     type_passable=[1, 0, 1, 1, 1] + [1] * (T - 6) + [0], type_rule=rule,
+                     spawn_prob=[0.05] + [0.0] * (T - 1), spawn_choices=[[2, 3, 4]] + [[] for _ in range(T - 1)],
+                     appearance=app, seed=seed, layer_fill_type=[0] * layers, layer_border_type=[1] * layers,
+                     dense_prob=0.3, dense_choices=[2, 3, 4])
+
+
+ROWS_CASES = [
+    # (h, w, layers, channels, agents, radius, envs)   -- envs deliberately not multiples of the envs a workgroup carries
+    (32, 32, 2, 6, 8, 3, 77),      # BASELINE configs 3 / 4
+    (16, 16, 2, 6, 4, 2, 201),     # BASELINE config 2
+    (128, 128, 2, 6, 24, 5, 7),    # BASELINE config 5's shape
+    (7, 7, 2, 6, 9, 3, 65),        # the smallest world a 7x7 window allows, crowded: every window hangs over every edge
+    (5, 6, 2, 6, 4, 2, 33),        # rows shorter than one 8-byte load
+    (9, 13, 1, 4, 6, 4, 50),       # one layer, one counter word, 9x9 windows (two 8-byte chunks per row)
+    (11, 11, 1, 3, 5, 5, 19),      # maximum radius for the size
+    (3, 3, 1, 2, 1, 1, 130),       # the smallest world there is (9 cells)
+    (12, 10, 3, 7, 5, 2, 41),      # three layers, agents on the middle one
+    (21, 31, 3, 8, 6, 3, 23),
+    (24, 20, 2, 3, 7, 1, 300),     # 3x3 windows: 16 envs per wave
+    (40, 36, 2, 8, 10, 4, 29),
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_C{c[3]}_A{c[4]}_r{c[5]}" for c in ROWS_CASES])
+def test_phase_rows_policy_turn_vs_oracle(torch_cuda, case, monkeypatch):
+    """A policy-driven turn in 1 + A launches (sweep + window of agent 0; then per agent: move it, render the next) on the
+    row-load phase kernel: every window an agent's policy would read, every reward, the grid, positions and totals against
+    the C oracle, turn after turn; the packed destination (a replay row) receives the same windows; a phase that renders
+    nothing, the plain per-agent step (own window BEFORE the move) and sgw_observe of one agent take the kernel too."""
+    torch = torch_cuda
+    h, w, layers, channels, a_, r_, E = case
+    ws = _move_world(h, w, layers, channels, a_, r_, seed=h * 100 + w, zA=1 if layers == 3 else None)
+    A = ws.num_agents
+    eng, co = make_engine(ws, E, first=11), H.COracle(ws, E, first_env_id=11)
+    assert "phase_rows<" in eng.launch_info(), eng.launch_info()
+    eng.reset(0)
+    co.reset(0)
+    per_env = int(np.prod(ws.obs_shape[1:]))
+    rng = np.random.default_rng(5)
+    for t in range(1, 7):
+        acts_np = rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)
+        acts = torch.from_numpy(acts_np).cuda()
+        assert co.step(0, t, actions=acts_np) == 0
+        seen = torch.zeros_like(eng.obs)
+        rew = torch.zeros_like(eng.rewards)
+        packed = t % 2 == 0
+        rows = [torch.full((E, per_env), -3.0, device="cuda:0") for _ in range(A)] if packed else None
+        eng.obs.fill_(-7.0)
+        eng.step(acts, sweep=True, agent_begin=0, agent_end=0, turn=t, obs_next=True, obs_next_out=rows[0] if packed else None)
+        for a in range(A):
+            seen[:, a] = rows[a].view(E, *ws.obs_shape[1:]) if packed else eng.obs[:, a]
+            nxt = a + 1 < A
+            eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t, obs_next=nxt, write_obs=False,
+                     obs_next_out=rows[a + 1] if (packed and nxt) else None)
+            rew[:, a] = eng.rewards[:, a]
+        torch.cuda.synchronize()
+        assert np.array_equal(seen.cpu().numpy(), co.obs), f"turn {t}: windows differ from the oracle"
+        assert np.array_equal(rew.cpu().numpy(), co.rewards), f"turn {t}: rewards"
+        assert np.array_equal(eng.grid.cpu().numpy(), co.grid), f"turn {t}: grid"
+        assert np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), f"turn {t}: positions"
+        assert np.array_equal(eng.total_reward.cpu().numpy(), co.total), f"turn {t}: total_reward"
+        if packed:
+            assert bool((eng.obs == -7.0).all()), "the packed calls must not touch the observation tensor"
+    # the plain per-agent step: ONE call writes the mover's own (pre-move) window and moves it; sgw_observe of one agent
+    for t in range(7, 10):
+        acts_np = rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)
+        assert co.step(0, t, actions=acts_np) == 0
+        acts = torch.from_numpy(acts_np).cuda()
+        eng.obs.fill_(-3.0)
+        eng.step(acts, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)
+        for a in range(A):
+            eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, turn=t)
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.obs.cpu().numpy(), co.obs) and np.array_equal(eng.grid.cpu().numpy(), co.grid), t
+        assert np.array_equal(eng.total_reward.cpu().numpy(), co.total) and np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), t
+    eng.obs.fill_(-1.0)
+    co.obs.fill(-1.0)
+    for a in (0, A - 1):
+        eng.observe(a, a + 1)
+        co.observe(a, a + 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy(), co.obs), "sgw_observe of one agent"
+    assert eng.status() == 0
+
+
+def test_phase_rows_flags_bad_input_like_the_other_kernels(torch_cuda):
+    """Bad action index, a move off an un-walled map edge and a garbage position raise the same status bits on the
+    row-load phase kernel; nothing is written outside the env."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.0, seed=1)
+    E = 50
+    eng = make_engine(ws, E)
+    eng.reset(0)
+    guard = eng.grid.clone()
+    acts = torch.full((E, 4), 9, dtype=torch.uint8, device="cuda:0")           # no such action
+    eng.step(acts, sweep=False, agent_begin=1, agent_end=2, obs_next=True, write_obs=False, turn=1)
+    assert eng.status() & N.STATUS_BAD_ACTION
+    assert torch.equal(eng.grid, guard)
+    eng.agent_pos[:, 2, 0] = 200                                               # garbage row
+    eng.step(torch.zeros_like(acts), sweep=False, agent_begin=1, agent_end=2, obs_next=True, write_obs=False, turn=1)
+    assert eng.status() & N.STATUS_BAD_POS
+    eng.reset(0)
+    eng.grid[:, 1, 0, :] = 0                                                   # open the top wall, put agent 0 on the edge row
+    eng.grid[:, 1][torch.arange(E), eng.agent_pos[:, 0, 0].long(), eng.agent_pos[:, 0, 1].long()] = 0
+    eng.agent_pos[:, 0, 0] = 0
+    eng.agent_pos[:, 0, 1] = 5
+    eng.grid[:, 1, 0, 5] = ws.agent_type[0]
+    eng.step(torch.zeros_like(acts), sweep=False, agent_begin=0, agent_end=1, obs_next=True, write_obs=False, turn=1)   # "up" off the map
+    assert eng.status() & N.STATUS_OOB_MOVE
+    assert bool((eng.agent_pos[:, 0, 0] == 0).all())
+
+
+# ------------------------------------------------------------------ sgw_observe_rows + sgw_act: windows rendered once, repaired by the movers
+PATCH_CASES = ROWS_CASES + [
+    (14, 18, 2, 5, 6, 3, 37, "float"),     # a non one-hot appearance table: sgw_observe renders, sgw_act repairs in float64
+    (20, 16, 2, 6, 7, 2, 45, "u8"),        # compact uint8 windows
+    (26, 22, 2, 6, 40, 2, 11, "plain"),    # 40 agents: a wave per env in sgw_act
+    (12, 30, 1, 4, 20, 3, 14, "plain"),    # 20 agents: 32 lanes per env
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_C{c[3]}_A{c[4]}_r{c[5]}{'_' + c[7] if len(c) > 7 else ''}" for c in PATCH_CASES])
+def test_windows_rendered_once_and_repaired_by_sgw_act_vs_oracle(torch_cuda, case):
+    """The policy-driven turn of round 3: the sweep alone, every agent's window once (sgw_observe_rows into replay-like rows
+    or tensor slots; sgw_observe where there is no row-load instance), then per agent sgw_act = move + repair of the later
+    agents' windows.  What each agent's policy would read (its window at the moment BEFORE its own act), every reward,
+    the grid, positions and totals equal the C oracle's sequential take_turn."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+
+    h, w, layers, channels, a_, r_, E = case[:7]
+    kind = case[7] if len(case) > 7 else "plain"
+    ws = _move_world(h, w, layers, channels, a_, r_, seed=7 * h + w, zA=1 if layers == 3 else None)
+    if kind == "float":
+        ws.appearance = ws.appearance * 1.0
+        ws.appearance[2, 0] = 2.5
+        ws.appearance[3, 1] = 0.25
+        ws.appearance[ws.num_types - 1, 2] = 3.0          # the agents themselves: every move changes float cells
+    A = ws.num_agents
+    kw = dict(obs_dtype=torch.uint8) if kind == "u8" else {}
+    eng, co = make_engine(ws, E, first=3, **kw), H.COracle(ws, E, first_env_id=3)
+    caps = eng.capabilities()
+    assert caps & N.CAP_ACT
+    assert bool(caps & N.CAP_OBSERVE_ROWS) == (kind == "plain"), (caps, eng.launch_info())
+    eng.reset(0)
+    co.reset(0)
+    per_env = int(np.prod(ws.obs_shape[1:]))
+    rng = np.random.default_rng(9)
+    for t in range(1, 8):
+        acts_np = rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)
+        assert co.step(0, t, actions=acts_np) == 0
+        eng.actions.copy_(torch.from_numpy(acts_np))
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)      # the sweep alone
+        own_rows = (caps & N.CAP_OBSERVE_ROWS) and t % 2 == 0
+        dests = [torch.full((E, per_env), -3.0, device="cuda:0") for _ in range(A)] if own_rows else None
+        eng.obs.fill_(99 if kind == "u8" else -7.0)
+        rows = eng.window_rows(dests)
+        if caps & N.CAP_OBSERVE_ROWS:
+            eng.observe_rows(rows)
+        else:
+            eng.observe()
+        seen = torch.zeros_like(eng.obs)
+        rew = torch.zeros_like(eng.rewards)
+        for a in range(A):
+            seen[:, a] = dests[a].view(E, *ws.obs_shape[1:]) if own_rows else eng.obs[:, a]      # what agent a's policy reads
+            eng.act(a, rows)
+            rew[:, a] = eng.rewards[:, a]
+        torch.cuda.synchronize()
+        assert np.array_equal(seen.cpu().numpy().astype(np.float32), co.obs), f"turn {t}: windows differ from the oracle"
+        assert np.array_equal(rew.cpu().numpy(), co.rewards), f"turn {t}: rewards"
+        assert np.array_equal(eng.grid.cpu().numpy(), co.grid), f"turn {t}: grid"
+        assert np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), f"turn {t}: positions"
+        assert np.array_equal(eng.total_reward.cpu().numpy(), co.total), f"turn {t}: total_reward"
+        if own_rows:
+            assert bool((eng.obs == -7.0).all()), "per-agent destinations: the observation tensor must stay untouched"
+    assert eng.status() == 0
+
+
+def test_sgw_act_and_observe_rows_reject_what_they_cannot_serve(torch_cuda):
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+
+    d, spec = H.load_golden("tag_9x9")
+    tag = make_engine(H.world_spec(spec), 8)
+    assert tag.capabilities() == 0
+    with pytest.raises(ValueError):
+        tag.act(0, tag.window_rows(None))
+    ws = _move_world(16, 16, 2, 6, 4, 2, seed=1)
+    eng = make_engine(ws, 8)
+    per_env = int(np.prod(ws.obs_shape[1:]))
+    with pytest.raises(ValueError):                       # a destination that is not exactly one window per env
+        eng.window_rows([torch.zeros((8, per_env + 1), device="cuda:0") for _ in range(4)])
+    with pytest.raises(ValueError):
+        eng.window_rows([torch.zeros((8, per_env), device="cuda:0")] * 3)
+    rows = eng.window_rows(None)
+    with pytest.raises(ValueError):
+        eng.act(4, rows)
+    with pytest.raises(ValueError):
+        eng.observe_rows(rows, 2, 2)
+
+
+def test_environment_policy_turn_protocols_agree_and_overridden_take_turn_is_called(torch_cuda, tmp_path):
+    """Environment.take_turn with policy models: the patched-window protocol == the 1 + A protocol, turn after turn; a
+    world mutated by host code in the middle of a turn falls back to rendering on demand; and a subclass that overrides
+    take_turn gets it called every turn by run_experiment / generate_memories even with device-random models (the
+    reference's loop always goes through take_turn, sorrel/environment.py:160-166)."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel, RandomModel
+    from tests.test_gpu_round2 import make_env
+
+    E = 21
+
+    class Policy(BaseModel):
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=6, num_envs=E, device="cuda:0")
+
+        def take_action(self, state):
+            s = state.reshape(state.shape[0], -1)
+            return (s.sum(dim=1).long() * 3 + (s[:, ::7].sum(dim=1).long())) % 4
+
+    a, b = (make_env(13, 15, 5, 2, E, p=0.05, model_factory=Policy) for _ in range(2))
+    b.patch_windows = False
+    for t in range(9):
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        assert torch.equal(a.world.grid, b.world.grid) and torch.equal(a.world.agent_pos, b.world.agent_pos), t
+        assert torch.equal(a.rewards, b.rewards) and torch.equal(a.actions, b.actions) and torch.equal(a.world.total_reward, b.world.total_reward), t
+        for x, y in zip(a.agents, b.agents):
+            assert torch.equal(x.model.memory.states, y.model.memory.states), t
+    a.raise_on_status()
+
+    # host code that edits the world between two agents' transitions: the remaining agents render on demand
+    class Meddler(type(a.agents[0])):
+        def act(self, world, action):
+            out = super().act(world, action)
+            if self.slot == 1:
+                world.mutations += 1           # what world.add / remove / move do
+            return out
+
+    c, d2 = (make_env(13, 15, 5, 2, E, p=0.05, model_factory=Policy) for _ in range(2))
+    c.agents[1].__class__ = Meddler
+    d2.patch_windows = False
+    for t in range(5):
+        c.take_turn()
+        d2.take_turn()
+        torch.cuda.synchronize()
+        assert torch.equal(c.world.grid, d2.world.grid) and torch.equal(c.rewards, d2.rewards), t
+        for x, y in zip(c.agents, d2.agents):
+            assert torch.equal(x.model.memory.states, y.model.memory.states), t
+
+    calls = []
+
+    def counting(env):
+        orig = type(env).take_turn
+
+        class Counting(type(env)):
+            def take_turn(self, actions=None):
+                calls.append(self.turn)
+                return orig(self, actions)
+
+        env.__class__ = Counting
+        return env
+
+    e1 = counting(make_env(12, 12, 2, 2, 16, max_turns=7))
+    assert all(isinstance(ag.model, RandomModel) for ag in e1.agents)
+    e1.run_experiment(epochs=1, logging=False)
+    assert len(calls) == 2 * 7, calls
+    calls.clear()
+    e1.generate_memories(num_games=2, output_dir=tmp_path)
+    assert len(calls) == 2 * 7, calls

@@ -14,14 +14,18 @@ shard with no data-path collective; the only collective is one all-reduce (RCCL)
 of the 4-double metric vector at the end of the rollout.
 
 Order of a run: build check (before anything touches the GPU) -> reset -> P untimed
-clock-ramp steps (``--prewarm-steps``, reported; the GPU's clocks take tens of
-milliseconds of load to settle and the driver's default ``--steps 20 --warmup 5`` is 3 ms
-of work) -> W untimed warm-up steps -> barrier + synchronize -> EXACTLY K timed steps
-(``value`` / ``ms_per_step`` / ``roofline.kernel_ms`` come from here; nothing but the K
-launches and two HIP events is in the region) -> barrier + synchronize -> the same K
-steps once more with a pair of HIP events around EVERY launch (``roofline.series``:
-per-launch median / p10 / p90 / mean of the first five) -> end-of-rollout metric
-all-reduce -> (rank 0, N=1) the CPU baseline.
+pre-warm steps (``--prewarm-steps``, reported, and each of them timed with its own pair of
+HIP events: ``roofline.prewarm_series`` shows the cold start -- a fresh process runs
+launches ~10-100 slower than the settled kernel and the driver's default ``--steps 20
+--warmup 5`` is 3 ms of work) -> W untimed warm-up steps -> barrier + synchronize ->
+EXACTLY K timed steps (``value`` / ``ms_per_step`` / ``roofline.kernel_ms`` come from here;
+nothing but the K launches and two HIP events is in the region) -> barrier + synchronize ->
+the same K steps once more with a pair of HIP events around EVERY launch
+(``roofline.series``) -> the same workload through ``sgw_rollout`` (``fused_rollout``) ->
+end-of-rollout metric all-reduce -> (rank 0, N=1) the other 1-GPU BASELINE shapes, briefly
+(``configs``: config 2, config 5's per-GPU share, config 3 at 524 288 envs) -> the CPU
+baseline -> the envs the CPU baseline played, replayed on the GPU and compared
+(``rollout.checked_vs_oracle``).
 
 Prints ONE JSON line on rank 0.
 """
@@ -123,12 +127,13 @@ def cpu_baseline(spec, config_name: str, seconds_target: float = 12.0):
         per_turn = rollout(cfg, arr, 2, 2, threads) / 2
         turns = max(2, min(5000, int(seconds / max(per_turn, 1e-7))))
         dt = rollout(cfg, arr, 4, turns, threads)
-        return E * A * turns / dt, turns, dt
+        arr["turns_played"] = 3 + turns                        # epoch 0, turns 1 .. 3 + turns, from the reset state
+        return E * A * turns / dt, turns, dt, arr
 
     E = 32768 if small else max(256, 16 * cores)               # >= 32 768 envs of the config-3 shape
-    value, turns, dt = measure(E, cores, seconds_target)
+    value, turns, dt, played = measure(E, cores, seconds_target)
     E1 = 512 if small else 16
-    single, turns1, dt1 = measure(E1, 1, 3.0)
+    single, turns1, dt1, _ = measure(E1, 1, 3.0)
     out = {
         "value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
         "per_core": value / cores, "single_core_value": single,
@@ -142,6 +147,73 @@ def cpu_baseline(spec, config_name: str, seconds_target: float = 12.0):
         out["reference_python_source"] = ("BASELINE.md section 2: the reference's own Environment.take_turn (sorrel/environment.py:81-93), "
                                           "one env of this shape, one Xeon 2.1 GHz core of the build container (the Python reference "
                                           "cannot travel to the GPU box)")
+    return out, played
+
+
+def check_against_oracle(spec, played, dev, obs_dtype):
+    """The self-check of the line: the envs the CPU baseline just played (the C oracle: E envs from reset through
+    `turns_played` turns of epoch 0, global env ids 0 .. E-1) are played again by the GPU engine -- a second, small
+    engine, outside every timed region -- and the final grid, positions, float64 totals and the last turn's
+    observations / rewards / actions are compared element by element.  Long horizon at the benchmark's own shape."""
+    import numpy as np
+    import torch
+
+    from sorrel_amd.engine import GridEngine
+
+    E, T = played["grid"].shape[0], int(played["turns_played"])
+    eng = GridEngine(spec, E, device=dev, first_env_id=0, obs_dtype=obs_dtype)
+    eng.reset(epoch=0)
+    eng.rollout(T)
+    torch.cuda.synchronize(dev)
+    pairs = dict(grid=(eng.grid, played["grid"]), agent_pos=(eng.agent_pos, played["pos"]), total_reward=(eng.total_reward, played["tot"]),
+                 actions=(eng.actions, played["act"]), rewards=(eng.rewards, played["rew"]), obs=(eng.obs, played["obs"]))
+    differ = [k for k, (mine, ref) in pairs.items() if not np.array_equal(mine.cpu().numpy().astype(ref.dtype), ref)]
+    status = eng.status()
+    sum_total = float(eng.total_reward.sum().item())
+    eng.close()
+    return {"envs": E, "turns": T, "equal": not differ and status == 0, "tensors_that_differ": differ, "status": status,
+            "sum_total_reward": sum_total, "oracle_sum_total_reward": float(played["tot"].sum()),
+            "what": "the envs the cpu_baseline leg played with oracle/gridstep_oracle.c, replayed by a second GridEngine (sgw_rollout) "
+                    "after the timed regions; grid, positions, float64 totals and the last turn's observations / rewards / actions "
+                    "compared with np.array_equal"}
+
+
+def side_config(name, dev, steps, prewarm, envs=0):
+    """One more BASELINE shape in the same line: a short pre-warm, then `steps` launches between two
+    HIP events on the launch stream.  Random actions, sweep on, float32 observations written, no reset in the region."""
+    import torch
+
+    from sorrel_amd.engine import GridEngine
+    from sorrel_amd.spec import treasurehunt_spec
+
+    H, W, A, r, E_cfg, p_spawn, p_dense = CONFIGS[name]
+    E = envs or E_cfg
+    spec = treasurehunt_spec(H, W, A, r, spawn_prob=p_spawn, seed=0, dense_prob=p_dense)
+    eng = GridEngine(spec, E, device=dev, first_env_id=0)
+    eng.reset(epoch=0)
+    for _ in range(prewarm):
+        eng.step(random_actions=True)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        eng.step(random_actions=True)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / steps
+    alg = spec.algorithmic_bytes_per_env_step() * E
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    out = {"workload": f"{H}x{W} grid x {spec.layers} layers, {A} agents, {spec.window}x{spec.window} window, {E} envs on one GPU",
+           "envs": E, "steps": steps, "prewarm_steps": prewarm, "kernel_ms": kernel_ms, "wall_ms_per_step": wall / steps * 1e3,
+           "value": E * A / (kernel_ms * 1e-3), "unit": "agent-steps/s",
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "frac_of_copy_ceiling": achieved / HBM_COPY_GBS, "algorithmic_bytes_per_launch": alg},
+           "kernel": eng.launch_info(), "status": eng.status()}
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
     return out
 
 
@@ -208,6 +280,12 @@ def main() -> int:
     ap.add_argument("--obs-dtype", default="f32", choices=["f32", "u8"],
                     help="u8 = compact one-hot counts (an extra, reported separately; the contract format is f32)")
     ap.add_argument("--no-sweep", action="store_true", help="diagnostic: skip the entity sweep (NOT a valid bench line)")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the short runs of the other 1-GPU BASELINE shapes (config 2, config 5's per-GPU share, config 3 at "
+                         "524 288 envs) that the headline run adds to the line as `configs`")
+    ap.add_argument("--side-steps", type=int, default=100, help="timed launches of each side config")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="skip replaying the CPU baseline's envs on the GPU and comparing the results (rollout.checked_vs_oracle)")
     args = ap.parse_args()
 
     ensure_built()
@@ -274,8 +352,25 @@ def main() -> int:
     def step():
         eng.step(random_actions=True, write_obs=write_obs, sweep=sweep)
 
-    for _ in range(max(0, args.prewarm_steps)):    # clock ramp: untimed, reported
-        step()
+    # the pre-warm pass: untimed for `value`, but every launch of it sits between its own pair of HIP events, so the line
+    # shows the cold start next to the settled kernel
+    prewarm_series = None
+    if args.prewarm_steps > 0:
+        eng.set_timing(True)
+        for _ in range(args.prewarm_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        pw = eng.step_times_ms()
+        eng.set_timing(False)
+
+        def mean(v):
+            return sum(v) / len(v) if v else None
+
+        prewarm_series = {"n": len(pw), "launches_0_10_mean_ms": mean(pw[:10]), "launches_10_100_mean_ms": mean(pw[10:100]),
+                          "launches_100_400_mean_ms": mean(pw[100:400]), "last_100_mean_ms": mean(pw[-100:]) if len(pw) >= 200 else None,
+                          "what": "the untimed pre-warm launches, first launch of the process onwards, each between its own pair of HIP "
+                                  "events: a fresh process runs launches ~10-100 slower than the settled kernel (profiles/r03_c3_launch_ramp.txt "
+                                  "has the clock / power samples taken alongside)"}
     for _ in range(args.warmup):
         step()
     barrier()
@@ -336,15 +431,21 @@ def main() -> int:
                          "is read once and written back once per call (it stays in LDS in between), so a step moves fewer bytes than "
                          "SURVEY 8d's per-turn-launch formula -- hence its own bytes_moved_per_step instead of roofline.frac"}
 
+    # what one barrier + synchronize costs on this job (it closes the timed region, so it is inside `value`): stated, not hidden
+    tb = time.perf_counter()
+    barrier()
+    barrier_ms = (time.perf_counter() - tb) * 1e3
+
     # end-of-rollout metrics: on-device reduction + the one collective
     metrics = eng.reduce_metrics().clone()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    kernel_ms_rank = kernel_ms
+    tmax = torch.tensor([dt, kernel_ms, barrier_ms], dtype=torch.float64, device=dev)
     if world > 1:
         if rehearsal:     # gloo reduces host tensors
             metrics, tmax = metrics.cpu(), tmax.cpu()
         dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, kernel_ms, barrier_ms = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())   # MAX over ranks: the slowest rank's kernel prices the roofline
     status = eng.status()
 
     if rank == 0:
@@ -404,17 +505,36 @@ def main() -> int:
                 "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,   # both denominators
                 "hbm_side_achieved": hbm_side, "hbm_side_frac": hbm_side / HBM_PEAK_GBS,
                 "hbm_side_frac_of_copy_ceiling": hbm_side / HBM_COPY_GBS, "cache_served_bytes_per_launch": cache_served,
-                "hbm_side_what": "algorithmic bytes minus the grid READ of a turn, which the Infinity Cache serves while the batch's grids "
+                "hbm_side_what": "MODELLED, not measured: algorithmic bytes minus the grid READ of a turn, which the Infinity Cache serves while the batch's grids "
                                  f"({grid_bytes / 1e6:.0f} MB here) stay resident (<= {CACHE_RESIDENT_GRID_BYTES >> 20} MiB); 0 subtracted otherwise",
-                "kernel": eng.launch_info(), "kernel_ms": kernel_ms, "series": series,
+                "kernel": eng.launch_info(), "kernel_ms": kernel_ms, "kernel_ms_what": "HIP events over the timed region / steps; MAX over ranks for N > 1",
+                "kernel_ms_rank0": kernel_ms_rank, "series": series, "prewarm_series": prewarm_series,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },
             "fused_rollout": fused,
-            "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status},
+            "timing": {"region": "barrier + synchronize | K launches | barrier + synchronize, MAX over ranks",
+                       "barrier_plus_synchronize_ms": barrier_ms,
+                       "barrier_what": "one more barrier + synchronize timed right after the region (MAX over ranks): the closing one is inside "
+                                       "`value`; kernel_ms is not affected by it"},
+            "rollout": {"sum_total_reward": float(metrics[0].item()), "envs": float(metrics[2].item()), "status": status,
+                        "first_env_id_rank0": 0, "first_env_id_last_rank": (world - 1) * E},
         }
+        valid_line = write_obs and sweep and args.diag_agents < 0 and args.obs_dtype == "f32"
+        if world == 1 and args.config == "c3" and valid_line and not args.no_side_configs:
+            # the other 1-GPU BASELINE shapes, briefly, AFTER the headline run (its numbers are not touched by them)
+            eng_obs, eng.obs = eng.obs, None                       # give the headline's 617 MB observation tensor back first
+            del eng_obs
+            torch.cuda.empty_cache()
+            out["configs"] = {
+                "c2": side_config("c2", dev, args.side_steps, 300),
+                "c5": side_config("c5", dev, args.side_steps, 300),
+                "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 40, envs=524288),
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, args.config, args.cpu_seconds)
+            out["cpu_baseline"], played = cpu_baseline(spec, args.config, args.cpu_seconds)
+            if valid_line and not args.no_self_check:
+                out["rollout"]["checked_vs_oracle"] = check_against_oracle(spec, played, dev, obs_dtype)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()

@@ -88,7 +88,8 @@ struct Params {
                       // tensor; (1, a1) with SGW_STEP_OBS_NEXT_PACKED: one window per env, [E][C][V][V] (an agent's replay slot)
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
-    int rows_unit;        // phase_rows / observe_rows: floats per store of the window stream (2: every destination 8-byte aligned and C*V*V even; else 1)
+    int rows_mode;        // phase_rows / observe_rows: how the staged windows leave (kRowsFlat / kRowsPair / kRowsSingle, phase.h)
+    int rows_by_agent;    // observe_rows: a wave carries consecutive envs of ONE agent (per-agent destinations) instead of consecutive agents of an env
     int onehot;           // every appearance row is a one-hot (or zero) vector and there is no post-processing: byte counters apply
     // sgw_rollout: `nturns` whole turns in ONE launch (the env's grid stays in LDS from turn to turn); turn t of the call
     // writes its observations / actions / rewards `t * ts_*` elements further on (0 = every turn overwrites the same tensors)

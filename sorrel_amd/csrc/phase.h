@@ -262,22 +262,28 @@ __device__ __forceinline__ void rows_index(uint64_t (&row)[L][(2 * R + 1 + 7) / 
 }
 
 // Table look-ups and layer sums of the lane's row, then the wave's windows leave TOGETHER: the one-hot counts are staged
-// as bytes in the wave's LDS area in each window's final [C][V][V] order and streamed out window by window with
-// consecutive lanes on consecutive elements (float2 units where every destination is 8-byte aligned and C*V*V is even,
-// else single floats): whole 512-byte runs per store instruction instead of 16-byte pieces scattered 28 bytes apart
-// (observe_rows at config 3: 188 -> ... us for the 617 MB of a turn's windows).
+// as bytes in the wave's LDS area, window after window in each window's final [C][V][V] order, and streamed out with
+// consecutive lanes on consecutive elements.  `mode` (host: rows_mode()):
+//   kRowsFlat     the wave's live windows are ONE contiguous, 16-byte aligned run in global memory starting at `o` of the
+//                 wave's first group (all agents of consecutive envs in the [E][A][C][V][V] tensor; or consecutive envs of
+//                 one agent in that agent's own [E][C][V][V] destination): streaming float4 stores of whole lines, as the
+//                 headline kernel's emit -- observe_rows at config 3: 188 us with per-lane 16-byte pieces, 145 with
+//                 per-window float2 runs, ... flat;
+//   kRowsPair     every destination 8-byte aligned and C*V*V even: per window, float2 runs;
+//   kRowsSingle   anything else: per window, single floats.
 //   idx     this lane's row (rows_index)          o       the window's destination (the same in every lane of a group)
-//   wd      the wave's counter words              stage   the wave's staging area, WPW * npad bytes
+//   wd      the wave's counter words              stage   the wave's staging area, WPW * C*V*V bytes (+ 3)
 //   act     this lane renders a row of a live window
+constexpr int kRowsSingle = 1, kRowsPair = 2, kRowsFlat = 4;
 template <int L, int NW, int R>
 __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 7) / 8], const uint32_t* wd, uint8_t* stage, float* o,
-                                          const int C, const int lane, const bool act, const int unit) {
+                                          const int C, const int lane, const bool act, const int mode) {
     constexpr int V = 2 * R + 1, VV = V * V, kTabW = RowsTab<NW>::kTabW;
     constexpr int G = V <= 4 ? 4 : (V <= 8 ? 8 : 16), WPW = 64 / G;
-    const int N = C * VV, npad = (N + 3) & ~3;
+    const int N = C * VV;
     const uint8_t* wdb = reinterpret_cast<const uint8_t*>(wd);
     const int gl = lane & (G - 1);
-    uint8_t* mine = stage + (lane / G) * npad + gl * V;
+    uint8_t* mine = stage + (lane / G) * N + gl * V;
     if (act) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -303,15 +309,36 @@ __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 
     gsync<1>();
     const uint32_t o_lo = (uint32_t)reinterpret_cast<uintptr_t>(o), o_hi = (uint32_t)(reinterpret_cast<uintptr_t>(o) >> 32);
     const uint64_t livemask = __ballot(act);
+    if (mode == kRowsFlat) {
+        // live windows are a prefix of the wave's groups; their bytes are contiguous in LDS and in global memory
+        const int nlive = __popcll(livemask & (G == 4 ? 0x1111111111111111ull : (G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull)));
+        const int total = nlive * N;
+        float* ow = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)o_hi) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)o_lo));
+        typedef float vfloat4 __attribute__((ext_vector_type(4)));
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(stage);
+        for (int k = lane; 4 * k + 3 < total; k += 64) {
+            const uint32_t b = s4[k];
+            vfloat4 v;
+            v.x = (float)(b & 0xFFu);
+            v.y = (float)((b >> 8) & 0xFFu);
+            v.z = (float)((b >> 16) & 0xFFu);
+            v.w = (float)(b >> 24);
+            __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(ow) + k);
+        }
+        const int rem = total & 3;                                            // a last, partial wave only
+        if (lane < rem) ow[(total & ~3) + lane] = (float)stage[(total & ~3) + lane];
+        return;
+    }
 #pragma unroll
     for (int w = 0; w < WPW; ++w) {
         if (!((livemask >> (w * G)) & 1ull)) continue;                        // (lane 0 of a group always renders row 0 of a live window)
         float* ow = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)o_hi, w * G) << 32) |
                                              (uint32_t)__builtin_amdgcn_readlane((int)o_lo, w * G));
-        const uint8_t* sw = stage + w * npad;
-        if (unit == 2) {
+        const uint8_t* sw = stage + w * N;
+        if (mode == kRowsPair) {
             for (int k = lane; 2 * k < N; k += 64) {
-                const uint32_t b2 = *reinterpret_cast<const uint16_t*>(sw + 2 * k);
+                const uint32_t b2 = (uint32_t)sw[2 * k] | ((uint32_t)sw[2 * k + 1] << 8);
                 vf2u v2 = {(float)(b2 & 0xFFu), (float)(b2 >> 8)};
                 *reinterpret_cast<vf2u*>(ow + 2 * k) = v2;
             }
@@ -375,7 +402,7 @@ __global__ __launch_bounds__(kBlock, 8) void phase_rows(const Params p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kWaveLds = RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8 + EPW * ((p.C * VV + 3) & ~3);   // = rows_wave_lds() on the host
+    const int kWaveLds = RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8 + ((EPW * p.C * VV + 15) & ~15);   // = what sgw_create reserves
     const int64_t env0 = ((int64_t)blockIdx.x * 4 + sub) * EPW;
     if (env0 >= p.E) return;                             // whole wave
     const int gl = lane & (G - 1);
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(kBlock, 8) void phase_rows(const Params p) {
     }
     rows_index<L, R>(row, rowinb, x, W);
     float* o = p.obs + ((env * p.obs_A + (ra - p.obs_a0)) * (int64_t)C) * VV;
-    rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, C, lane, live && gl < V, p.rows_unit);
+    rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, C, lane, live && gl < V, p.rows_mode);
 }
 
 // The windows of agents [a0, a1) of every env, each into its own destination (rp.p[a] + env * rp.stride): what every
@@ -452,17 +479,32 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kWaveLds = RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8 + WPW * ((p.C * VV + 3) & ~3);   // the same layout as phase_rows
+    const int kWaveLds = RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8 + ((WPW * p.C * VV + 15) & ~15);   // the same layout as phase_rows
     const int nA = p.a1 - p.a0;
-    const int64_t nwin = p.E * nA;
-    const int64_t w0 = ((int64_t)blockIdx.x * 4 + sub) * WPW;
-    if (w0 >= nwin) return;
     const int gl = lane & (G - 1);
-    int64_t wi = w0 + (lane / G);
-    const bool live = wi < nwin;
-    if (!live) wi = nwin - 1;
-    const int64_t env = wi / nA;
-    const int a = p.a0 + (int)(wi - env * nA);
+    int64_t env;
+    int a;
+    bool live;
+    const int64_t v = (int64_t)blockIdx.x * 4 + sub;                           // wave index
+    if (p.rows_by_agent) {
+        // per-agent destinations: a wave renders WPW consecutive envs of ONE agent (contiguous in that agent's destination)
+        const int64_t nchunk = (p.E + WPW - 1) / WPW;
+        if (v >= nchunk * nA) return;
+        a = p.a0 + (int)(v / nchunk);
+        env = (v % nchunk) * WPW + (lane / G);
+        live = env < p.E;
+        if (!live) env = p.E - 1;
+    } else {
+        // consecutive windows = consecutive agents of an env, env after env (contiguous in the [E][A][C][V][V] tensor)
+        const int64_t nwin = p.E * nA;
+        const int64_t w0 = v * WPW;
+        if (w0 >= nwin) return;
+        int64_t wi = w0 + (lane / G);
+        live = wi < nwin;
+        if (!live) wi = nwin - 1;
+        env = wi / nA;
+        a = p.a0 + (int)(wi - env * nA);
+    }
     const int H = p.H, W = p.W, HW = H * W;
     const uint8_t* g = p.grid + env * p.env_stride;
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem + sub * kWaveLds);
@@ -480,7 +522,7 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
     gsync<1>();
     rows_index<L, R>(row, rowinb, x, W);
     float* o = reinterpret_cast<float*>(rp.p[a]) + env * rp.stride;
-    rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, p.C, lane, live && gl < V, p.rows_unit);
+    rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, p.C, lane, live && gl < V, p.rows_mode);
 }
 
 // ---------------------------------------------------------------- sgw_act: one agent moves, later agents' windows are repaired

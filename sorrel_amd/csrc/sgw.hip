@@ -677,7 +677,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         const int V = 2 * c.vision_radius + 1;
         e->rows_epb = e->rows_wpb = 4 * (64 / (V <= 4 ? 4 : (V <= 8 ? 8 : 16)));
         // per wave: counter words, the value table, the staging bytes of the windows it carries
-        e->rows_lds = (size_t)4 * (((c.num_channels + 3) / 4) * 34 * 4 + SGW_MAX_TYPES * 8 + (e->rows_epb / 4) * ((c.num_channels * V * V + 3) & ~3));
+        e->rows_lds = (size_t)4 * (((c.num_channels + 3) / 4) * 34 * 4 + SGW_MAX_TYPES * 8 + (((e->rows_epb / 4) * c.num_channels * V * V + 15) & ~15));
     }
     if (const char* f = getenv("SGW_PHASE_ROWS")) { if (f[0] == '0') e->rows_fn = nullptr; }   // A/B and test hook: the older phase paths (sgw_step's phases only)
     p.stage_agents = e->stage_agents;
@@ -821,8 +821,10 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
     if (e->rows_fn && one_phase && !p.obs_u8) {
+        // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
         const int64_t N = (int64_t)p.C * p.VV;
-        p.rows_unit = (p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 7) == 0 && (N & 1) == 0) ? 2 : 1;
+        const uintptr_t dst = reinterpret_cast<uintptr_t>(p.obs);
+        p.rows_mode = (p.obs_A == 1 && (dst & 15) == 0) ? kRowsFlat : (((dst & 7) == 0 && (N & 1) == 0) ? kRowsPair : kRowsSingle);
         hipLaunchKernelGGL(e->rows_fn, dim3((unsigned)ceil_div(p.E, e->rows_epb)), dim3(kBlock), e->rows_lds, s, p);
         HIP_TRY(hipGetLastError());
         return time_end(e, s);
@@ -978,13 +980,31 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
     Params p = e->base;
     p.grid = const_cast<uint8_t*>(grid); p.pos = const_cast<uint8_t*>(agent_pos);
     p.a0 = agent_begin; p.a1 = agent_end; p.flags = 0; p.do_move = 0;
-    p.rows_unit = (((int64_t)p.C * p.VV) & 1) == 0 && (env_stride & 1) == 0 ? 2 : 1;
-    for (int a = agent_begin; a < agent_end; ++a)
-        if (reinterpret_cast<uintptr_t>(rows[a]) & 7) p.rows_unit = 1;
+    {   // how the windows leave (phase.h, rows_emit)
+        const int64_t N = (int64_t)p.C * p.VV;
+        const int nA = agent_end - agent_begin;
+        bool al16 = true, al8 = true, slots = env_stride == (int64_t)nA * N;     // slots: rows[a] = rows[a0] + (a - a0) * N, i.e. one [E][nA][N] tensor
+        for (int a = agent_begin; a < agent_end; ++a) {
+            const uintptr_t q = reinterpret_cast<uintptr_t>(rows[a]);
+            al16 = al16 && (q & 15) == 0;
+            al8 = al8 && (q & 7) == 0;
+            slots = slots && q == reinterpret_cast<uintptr_t>(rows[agent_begin]) + (uintptr_t)(a - agent_begin) * N * 4;
+        }
+        p.rows_by_agent = 0;
+        const bool pair_ok = al8 && (N & 1) == 0 && (env_stride & 1) == 0;
+        if (slots && (reinterpret_cast<uintptr_t>(rows[agent_begin]) & 15) == 0) p.rows_mode = kRowsFlat;
+        else if (env_stride == N && al16) { p.rows_mode = kRowsFlat; p.rows_by_agent = 1; }
+        else p.rows_mode = pair_ok ? kRowsPair : kRowsSingle;
+        if (const char* f = getenv("SGW_ROWS_MODE")) {   // test hook: force a slower emit (1 = single floats, 2 = float2 runs where legal)
+            const int m = atoi(f);
+            if (m == kRowsSingle || (m == kRowsPair && pair_ok)) { p.rows_mode = m; p.rows_by_agent = 0; }
+        }
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = time_begin(e, s)) return rc;
-    const int64_t nwin = p.E * (agent_end - agent_begin);
-    hipLaunchKernelGGL(e->obs_rows_fn, dim3((unsigned)ceil_div(nwin, e->rows_wpb)), dim3(kBlock), e->rows_lds, s, p, rp);
+    const int wpw = e->rows_wpb / 4;                                   // windows per wave
+    const int64_t waves = p.rows_by_agent ? ceil_div(p.E, wpw) * (agent_end - agent_begin) : ceil_div(p.E * (agent_end - agent_begin), wpw);
+    hipLaunchKernelGGL(e->obs_rows_fn, dim3((unsigned)ceil_div(waves, 4)), dim3(kBlock), e->rows_lds, s, p, rp);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
 }

@@ -366,6 +366,36 @@ def test_bench_two_ranks_run_the_product_and_agree_with_one_process(built):
     assert two["rollout"]["envs"] == one["rollout"]["envs"] == 8192.0
     assert two["rollout"]["sum_total_reward"] == one["rollout"]["sum_total_reward"]
     assert two["rollout"]["status"] == 0 and two["value"] > 0 and two["scaling"] == "weak"
+    # global env ids: rank r owns [r * 4096, (r + 1) * 4096)
+    assert two["rollout"]["first_env_id_rank0"] == 0 and two["rollout"]["first_env_id_last_rank"] == 4096
+    assert one["rollout"]["first_env_id_last_rank"] == 0
+    # N > 1 lines carry the roofline (priced on the slowest rank's kernel) and what the closing barrier costs
+    for line in (two, one):
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.0 < rf["frac"] < 1.5
+        assert rf["kernel_ms"] >= rf["kernel_ms_rank0"] > 0.0
+        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+        assert line["timing"]["barrier_plus_synchronize_ms"] >= 0.0
+    assert "configs" not in two and "cpu_baseline" not in two
+
+
+def test_bench_line_carries_side_configs_cold_start_and_the_oracle_self_check(built):
+    """The driver's line (N = 1, config 3) with short settings: `configs` holds config 2, config 5's per-GPU share and
+    config 3 at 524 288 envs, each with kernel_ms / roofline / kernel; `prewarm_series` shows the cold start; the envs the
+    CPU baseline played are replayed on the GPU and must be equal (rollout.checked_vs_oracle)."""
+    line = _run_bench(["--gpus", "1", "--steps", "10", "--warmup", "2", "--prewarm-steps", "120", "--side-steps", "10",
+                       "--cpu-seconds", "2", "--turns-per-launch", "0"], 1, {})
+    assert set(line["configs"]) == {"c2", "c5", "c3_524288"}
+    for name, c in line["configs"].items():
+        assert c["kernel_ms"] > 0 and 0.0 < c["roofline"]["frac"] < 1.5 and c["status"] == 0, name
+        assert "step_" in c["kernel"], name
+    assert line["configs"]["c3_524288"]["envs"] == 524288 and line["configs"]["c5"]["envs"] == 2048
+    pw = line["roofline"]["prewarm_series"]
+    assert pw["n"] == 120 and pw["launches_0_10_mean_ms"] > 0 and pw["launches_10_100_mean_ms"] > 0
+    chk = line["rollout"]["checked_vs_oracle"]
+    assert chk["equal"] is True and chk["tensors_that_differ"] == [] and chk["envs"] == 32768 and chk["turns"] >= 5
+    assert chk["sum_total_reward"] == chk["oracle_sum_total_reward"]
+    assert "wg_per_cu=8" in line["roofline"]["kernel"] and "cap=auto:0" in line["roofline"]["kernel"]     # what config 3 really launches
 
 
 ROLLOUT_CASES = [

@@ -314,3 +314,80 @@ def test_environment_policy_turn_protocols_agree_and_overridden_take_turn_is_cal
     calls.clear()
     e1.generate_memories(num_games=2, output_dir=tmp_path)
     assert len(calls) == 2 * 7, calls
+
+
+@pytest.mark.parametrize("mode", ["flat", "pairs", "singles", "offset_rows", "agent_range"])
+def test_observe_rows_emit_modes(torch_cuda, mode, monkeypatch):
+    """The staged windows leave as one contiguous aligned run per wave (tensor slots: agents of consecutive envs; per-agent
+    rows: consecutive envs of one agent), as float2 runs per window, or as single floats -- whatever the alignment of the
+    destinations allows; every form writes the same windows and nothing else."""
+    torch = torch_cuda
+    if mode == "pairs":
+        monkeypatch.setenv("SGW_ROWS_MODE", "2")
+    if mode == "singles":
+        monkeypatch.setenv("SGW_ROWS_MODE", "1")
+    for (h, w, layers, channels, a_, r_, E) in [(32, 32, 2, 6, 8, 3, 77), (16, 16, 2, 6, 4, 2, 201), (9, 13, 1, 3, 5, 1, 50), (40, 36, 2, 8, 3, 5, 13)]:
+        ws = _move_world(h, w, layers, channels, a_, r_, seed=3)
+        A = ws.num_agents
+        eng, co = make_engine(ws, E), H.COracle(ws, E)
+        eng.reset(0)
+        co.reset(0)
+        for t in range(1, 3):
+            eng.step(random_actions=True, turn=t)
+            co.step(0, t, random_actions=True)
+        co.obs.fill(-1.0)
+        co.observe()
+        per_env = int(np.prod(ws.obs_shape[1:]))
+        # tensor slots
+        eng.obs.fill_(-5.0)
+        if mode == "agent_range":
+            eng.observe_rows(eng.window_rows(None), 1, A - 1)
+            torch.cuda.synchronize()
+            got = eng.obs.cpu().numpy()
+            assert np.array_equal(got[:, 1:A - 1], co.obs[:, 1:A - 1]) and (got[:, 0] == -5.0).all() and (got[:, A - 1] == -5.0).all()
+            continue
+        eng.observe_rows(eng.window_rows(None))
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.obs.cpu().numpy(), co.obs), (mode, h, w)
+        # per-agent rows, with a guard element on either side of every destination
+        pad = 1 if mode == "offset_rows" else 4
+        store = [torch.full((E * per_env + 2 * pad,), -9.0, device="cuda:0") for _ in range(A)]
+        dests = [s[pad:pad + E * per_env].view(E, per_env) for s in store]
+        eng.observe_rows(eng.window_rows(dests))
+        torch.cuda.synchronize()
+        for a in range(A):
+            assert np.array_equal(dests[a].view(E, *ws.obs_shape[1:]).cpu().numpy(), co.obs[:, a]), (mode, h, w, a)
+            assert bool((store[a][:pad] == -9.0).all()) and bool((store[a][-pad:] == -9.0).all()), "wrote outside the destination"
+
+
+# ------------------------------------------------------------------ long horizon at the benchmark's own shape
+def test_config3_shape_long_horizon_vs_oracle(torch_cuda):
+    """bench.py times launches at turns ~1 500 of a saturated world; this plays 512 envs of the config-3 shape (32x32x2,
+    8 agents, 7x7 windows, spawn 0.005) for 1 600 turns: turn by turn against the C oracle at check points (every tensor,
+    observations included) and at the end, and once more as ONE sgw_rollout call."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=0)
+    E, T = 512, 1600
+    eng, co = make_engine(ws, E, first=1000), H.COracle(ws, E, first_env_id=1000)
+    one_call = make_engine(ws, E, first=1000)
+    for e in (eng, one_call):
+        e.reset(0)
+    co.reset(0)
+    for t in range(1, T + 1):
+        eng.step(random_actions=True, turn=t)
+        assert co.step(0, t, random_actions=True) == 0
+        if t % 200 == 0 or t in (1, 2, T - 1):
+            torch.cuda.synchronize()
+            for name, mine, ref in (("grid", eng.grid, co.grid), ("pos", eng.agent_pos, co.pos), ("actions", eng.actions, co.actions),
+                                    ("obs", eng.obs, co.obs), ("rewards", eng.rewards, co.rewards), ("total", eng.total_reward, co.total)):
+                assert np.array_equal(mine.cpu().numpy(), ref), f"turn {t}: {name} differs from the oracle"
+    one_call.rollout(T)
+    torch.cuda.synchronize()
+    for name in ("grid", "agent_pos", "total_reward", "obs", "rewards", "actions"):
+        assert torch.equal(getattr(eng, name), getattr(one_call, name)), f"sgw_rollout({T}) vs turn by turn: {name}"
+    # a world that has been running this long is saturated: most interior cells hold something
+    filled = float((eng.grid[:, 1, 1:-1, 1:-1] >= 3).float().mean())
+    assert filled > 0.25, filled
+    assert eng.status() == 0 and one_call.status() == 0

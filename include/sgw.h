@@ -124,6 +124,10 @@ extern "C" {
                                      * slot of that agent's replay buffer its pov() is about to be stored in
                                      * (sorrel/agents/agent.py:155-173: state = pov(); ...; add_memory(state, ...)), so the
                                      * observation is written once, where it will live */
+#define SGW_STEP_NO_MOVE 32u         /* nobody acts: the entity sweep (with SGW_STEP_SWEEP) and the windows of [agent_begin, agent_end)
+                                     * from the grid after it -- step 1 + 2 of a policy-driven turn in one launch when the windows
+                                     * live in the [E][A][C][V][V] tensor (see sgw_act).  No rewards, no totals, no auto-reset;
+                                     * SGW_STEP_RANDOM_ACTIONS / SGW_STEP_OBS_NEXT do not combine with it */
 #define SGW_STEP_DEFAULT (SGW_STEP_SWEEP)
 
 /* error codes */
@@ -216,6 +220,7 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
  * rendering a window per agent and launch:
  *   1. sgw_step(agent_begin = agent_end = 0, SGW_STEP_SWEEP | SGW_STEP_NO_OBS)      the entity sweep alone
  *   2. sgw_observe_rows(...)  (or sgw_observe into the [E][A][C][V][V] tensor)       EVERY agent's window, once
+ *      (1 + 2 in ONE launch when the windows live in the tensor: sgw_step(0, A, SGW_STEP_SWEEP | SGW_STEP_NO_MOVE))
  *   3. per agent a, in order: policy(window a) -> actions[:, a];  sgw_act(a)         move agent a AND rewrite, in the
  *      windows of the agents after a that contain them, the <= 2 cells its move changed
  * gives every agent exactly the window the reference's pov() would build, at the cost of one fused turn plus A tiny
@@ -224,14 +229,23 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
  * slot a of the observation tensor (rows[a] = obs + a*C*V*V, env_stride = A*C*V*V); element type = sgw_set_obs_format's.
  * sgw_observe_rows needs SGW_CAP_OBSERVE_ROWS (one-hot float32 windows of an instantiated layers / channels / radius),
  * sgw_act needs SGW_CAP_ACT (SGW_AGENT_RULE_MOVE; any appearance table, float32 or uint8 windows); rows entries of agents
- * <= `agent` are ignored by sgw_act, NULL entries (or rows == NULL) are skipped. */
+ * <= `agent` are ignored by sgw_act, NULL entries (or rows == NULL) are skipped.
+ * sgw_act's optional extras keep the host out of the agent loop: `agent_action` (device, [E], element type
+ * `action_kind`) is read INSTEAD of actions[:, agent] -- the policy's output tensor as it is, no narrowing copy; the
+ * uint8 record actions[:, agent] is still written -- and `reward_row` (float [E]) / `action_row` (int64 [E]) receive a
+ * second copy of the rewards / the actions: the rows of the agent's replay buffer (sorrel/buffers.py:46-63 stores
+ * int64 actions and float32 rewards), so add_memory has nothing left to copy.  All three may be NULL. */
 #define SGW_CAP_OBSERVE_ROWS 1
 #define SGW_CAP_ACT 2
+#define SGW_ACT_U8 0
+#define SGW_ACT_I32 1
+#define SGW_ACT_I64 2
 int sgw_capabilities(sgw_engine* eng);
 int sgw_observe_rows(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
                      int32_t agent_begin, int32_t agent_end, void* stream);
-int sgw_act(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, const uint8_t* actions, void* const* rows, int64_t env_stride,
-            float* rewards, double* total_reward, int32_t agent, void* stream);
+int sgw_act(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
+            float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
+            float* reward_row, int64_t* action_row, void* stream);
 
 /* `num_turns` whole take_turns (all agents, in order) with one call -- Environment.run_experiment's inner loop
  * `while turn < max_turns: take_turn()` (sorrel/environment.py:160-166) for actions that need no host in between: drawn

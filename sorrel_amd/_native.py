@@ -11,13 +11,14 @@ import os
 MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
 RULE_NONE, RULE_SPAWN, RULE_BECOME_IF = 0, 1, 2
 NO_BORDER = 255
-STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT, STEP_OBS_NEXT_PACKED = 1, 2, 4, 8, 16
+STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT, STEP_OBS_NEXT_PACKED, STEP_NO_MOVE = 1, 2, 4, 8, 16, 32
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
 ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2
 OBS_F32, OBS_U8 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE, STATUS_BAD_POS = 1, 2, 4, 8
 CAP_OBSERVE_ROWS, CAP_ACT = 1, 2
+ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
 
@@ -154,7 +155,7 @@ def load():
     lib.sgw_capabilities.restype = C.c_int
     lib.sgw_observe_rows.argtypes = [vp, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, vp]
     lib.sgw_observe_rows.restype = C.c_int
-    lib.sgw_act.argtypes = [vp, u8p, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, f32p, f64p, C.c_int32, vp]
+    lib.sgw_act.argtypes = [vp, u8p, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, f32p, f64p, C.c_int32, vp, C.c_int32, vp, vp, vp]
     lib.sgw_act.restype = C.c_int
     lib.sgw_last_error.argtypes = []
     lib.sgw_last_error.restype = C.c_char_p

@@ -32,21 +32,33 @@ class Buffer:
         self.dones = torch.zeros((capacity, E), dtype=torch.float32, device=self.device)
         self.idx = 0
         self.size = 0
+        self._prefilled = None        # (row, data_ptr of the action tensor): sgw_act already wrote that action into actions[row]
+        self._dones_dirty = False     # a non-zero `done` was ever stored: until then the dones rows are all zero already
         self.extra_data = {}
         for key, value in extra.items():
             shape = (capacity, E, *value) if isinstance(value, tuple) else (capacity, E)
             self.extra_data[key] = torch.zeros(shape, dtype=torch.int64, device=self.device)
 
     def add(self, obs, action, reward, done, **extra):
-        """Append one turn: ``obs [E, *obs_shape]``, ``action [E]``, ``reward [E]``, ``done`` scalar or ``[E]``."""
+        """Append one turn: ``obs [E, *obs_shape]``, ``action [E]``, ``reward [E]``, ``done`` scalar or ``[E]``.
+        Whatever the kernels have already written where it belongs is not copied again: the state (a window rendered
+        straight into this row), the reward (``sgw_act``'s ``reward_row``) and the action (``sgw_act``'s ``action_row``,
+        announced through ``_prefilled``)."""
         i = self.idx
         row = self.states[i]
         src = obs.reshape(row.shape)
         if src.data_ptr() != row.data_ptr():       # (the step kernel may have written the state straight into this row)
             row.copy_(src)
-        self.actions[i].copy_(action)
-        self.rewards[i].copy_(reward)
-        self.dones[i] = done
+        pre, self._prefilled = self._prefilled, None
+        if not (pre is not None and pre[0] == i and torch.is_tensor(action) and action.data_ptr() == pre[1]):
+            self.actions[i].copy_(action)
+        if not (torch.is_tensor(reward) and reward.data_ptr() == self.rewards[i].data_ptr() and reward.dtype == torch.float32):
+            self.rewards[i].copy_(reward)
+        if torch.is_tensor(done) or done:
+            self.dones[i] = done
+            self._dones_dirty = True
+        elif self._dones_dirty:
+            self.dones[i] = 0
         for key, value in extra.items():
             self.extra_data[key][i] = torch.as_tensor(value, device=self.device)
         self.idx = (self.idx + 1) % self.capacity

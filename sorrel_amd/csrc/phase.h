@@ -200,6 +200,11 @@ typedef float vf2u __attribute__((ext_vector_type(2), aligned(4)));
 struct RowPtrs {
     void* p[SGW_MAX_AGENTS];
     int64_t stride;
+    // sgw_act only: where the acting agent's action comes from and where else its outputs go (all optional)
+    const void* agent_action;   // [E] of the agent's own actions (the policy's output tensor as it is); NULL: actions[E][A]
+    int action_kind;            // SGW_ACT_U8 / _I32 / _I64
+    float* reward_row;          // [E]: a second copy of the rewards (the row of the agent's replay buffer)
+    int64_t* action_row;        // [E]: the actions as int64 (the row of the agent's replay buffer)
 };
 
 __device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* q) {
@@ -358,11 +363,21 @@ struct MoveOut {
     uint32_t my_type;
 };
 __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, uint8_t* g, const int64_t env, const int a,
-                                        const double* wval, const bool writer, MoveOut& mo) {
+                                        const double* wval, const bool writer, MoveOut& mo, const RowPtrs* io = nullptr) {
     const int H = p.H, W = p.W, HW = H * W;
     int st = 0;
     uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
-    const uint32_t act = p.actions[env * p.A + a];
+    uint32_t act;
+    int64_t act_raw;
+    if (io && io->agent_action) {                        // the policy's own output tensor: one action per env
+        act_raw = io->action_kind == SGW_ACT_I64 ? reinterpret_cast<const int64_t*>(io->agent_action)[env]
+                : io->action_kind == SGW_ACT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(io->agent_action)[env]
+                                                    : (int64_t)reinterpret_cast<const uint8_t*>(io->agent_action)[env];
+        act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;     // out of range either way: SGW_STATUS_BAD_ACTION
+    } else {
+        act = p.actions[env * p.A + a];
+        act_raw = act;
+    }
     const uint32_t my_type = p.agent_state ? p.agent_state[env * p.A + a] : gtab->agent_type[a];
     const double tot = p.total[env];
     if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
@@ -388,6 +403,11 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
         }
         p.rewards[env * p.A + a] = (float)val;
         p.total[env] = tot + val;                                              // float64, agent order (agent.py:172)
+        if (io) {
+            if (io->agent_action) p.actions[env * p.A + a] = (uint8_t)act;     // the record of what was taken
+            if (io->reward_row) io->reward_row[env] = (float)val;
+            if (io->action_row) io->action_row[env] = act_raw;
+        }
     }
     return st;
 }
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(kBlock, 8) void act_patch(const Params p, const Row
     const bool later = live && j > a && j < p.A;
     if (later) pj = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + j];
     MoveOut mo;
-    const int st = move_one(p, gtab, g, env, a, nullptr, live && j == 0, mo);
+    const int st = move_one(p, gtab, g, env, a, nullptr, live && j == 0, mo, &rp);
     if (st && live && j == 0) atomicOr(p.status, st);
     if (!later || mo.old_y < 0 || rp.p[j] == nullptr) return;
     const int yj = (int)(pj & 0xFFu), xj = (int)(pj >> 8);

@@ -878,6 +878,13 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
     p.epoch = epoch; p.turn = turn; p.a0 = agent_begin; p.a1 = agent_end; p.flags = flags; p.do_move = 1;
+    if (flags & SGW_STEP_NO_MOVE) {    // sweep + windows, nobody acts
+        if (flags & (SGW_STEP_RANDOM_ACTIONS | SGW_STEP_OBS_NEXT | SGW_STEP_OBS_NEXT_PACKED))
+            return fail(SGW_EINVAL, "sgw_step: SGW_STEP_NO_MOVE does not combine with RANDOM_ACTIONS / OBS_NEXT");
+        p.do_move = 0;
+        p.flags &= ~SGW_STEP_NO_MOVE;
+        return launch_step(e, p, static_cast<hipStream_t>(stream));
+    }
     if (flags & SGW_STEP_OBS_NEXT) {   // the stepped agents' own observations are not written
         p.obs_next = 1;
         p.flags |= SGW_STEP_NO_OBS;
@@ -1009,8 +1016,9 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
     return time_end(e, s);
 }
 
-int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, const uint8_t* actions, void* const* rows, int64_t env_stride,
-            float* rewards, double* total_reward, int32_t agent, void* stream) {
+int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
+            float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
+            float* reward_row, int64_t* action_row, void* stream) {
     if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_act: NULL argument");
     if (agent < 0 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_act: agent %d out of range", agent);
     if (!(sgw_capabilities(e) & SGW_CAP_ACT))
@@ -1019,8 +1027,11 @@ int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, const uint8_t* act
     memset(&rp, 0, sizeof(rp));
     if (rows)
         if (int rc = fill_rows(e, rows, env_stride, agent + 1, e->cfg.num_agents, false, &rp, "sgw_act")) return rc;
+    if (agent_action && action_kind != SGW_ACT_U8 && action_kind != SGW_ACT_I32 && action_kind != SGW_ACT_I64)
+        return fail(SGW_EINVAL, "sgw_act: unknown action_kind %d", action_kind);
+    rp.agent_action = agent_action; rp.action_kind = action_kind; rp.reward_row = reward_row; rp.action_row = action_row;
     Params p = e->base;
-    p.grid = grid; p.pos = agent_pos; p.actions = const_cast<uint8_t*>(actions); p.rewards = rewards; p.total = total_reward;
+    p.grid = grid; p.pos = agent_pos; p.actions = actions; p.rewards = rewards; p.total = total_reward;
     p.a0 = agent; p.a1 = agent + 1; p.flags = SGW_STEP_NO_OBS; p.do_move = 1;
     p.agent_state = e->agent_state;
     p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;

@@ -244,16 +244,32 @@ class GridEngine:
             N.check(self._lib.sgw_observe_rows(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), arr, stride,
                                                agent_begin, agent_end, self._stream()))
 
-    def act(self, agent: int, rows=None):
-        """``MovingAgent.act`` of ONE agent (its action is ``self.actions[:, agent]``) for every env; the at most two
-        cells the move changes are rewritten in the windows (``rows``) of the agents after it that contain them, so that
-        each later agent's window shows the grid after the moves of all agents before it, without being rendered again.
-        Rewards land in ``self.rewards[:, agent]``."""
+    _ACTION_KINDS = {torch.uint8: N.ACT_U8, torch.int32: N.ACT_I32, torch.int64: N.ACT_I64}
+
+    def act(self, agent: int, rows=None, action: Optional[torch.Tensor] = None, reward_row: Optional[torch.Tensor] = None,
+            action_row: Optional[torch.Tensor] = None):
+        """``MovingAgent.act`` of ONE agent for every env; the at most two cells the move changes are rewritten in the
+        windows (``rows``) of the agents after it that contain them, so that each later agent's window shows the grid after
+        the moves of all agents before it, without being rendered again.  The agent's actions are ``self.actions[:, agent]``
+        or, with ``action``, that ``[E]`` tensor as it is (uint8 / int32 / int64, contiguous, on the device: a policy's
+        output needs no narrowing copy; ``self.actions[:, agent]`` still records what was taken).  Rewards land in
+        ``self.rewards[:, agent]`` and, with ``reward_row`` (float32 ``[E]``) / ``action_row`` (int64 ``[E]``), a second
+        time in those rows -- e.g. the rows of the agent's replay buffer."""
         arr, stride = (None, 0) if rows is None else rows[:2]
+        E = self.num_envs
+        kind = 0
+        if action is not None:
+            kind = self._ACTION_KINDS.get(action.dtype)
+            if kind is None or action.device != self.device or action.numel() != E or not action.is_contiguous():
+                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {E} elements on {self.device}")
+        for t, dt, name in ((reward_row, torch.float32, "reward_row"), (action_row, torch.int64, "action_row")):
+            if t is not None and (t.dtype != dt or t.device != self.device or t.numel() != E or not t.is_contiguous()):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of {E} elements on {self.device}")
         with self._on_device():
             N.check(self._lib.sgw_act(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(self.actions), arr, stride,
-                                      self._ptr(self.rewards), self._ptr(self.total_reward), int(agent), self._stream()))
-        return self.rewards[:, agent]
+                                      self._ptr(self.rewards), self._ptr(self.total_reward), int(agent), self._ptr(action), kind,
+                                      self._ptr(reward_row), self._ptr(action_row), self._stream()))
+        return self.rewards[:, agent] if reward_row is None else reward_row
 
     def scratch_obs(self) -> torch.Tensor:
         if self._scratch_obs is None:
@@ -263,7 +279,7 @@ class GridEngine:
     def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,
              write_obs: bool = True, agent_begin: int = 0, agent_end: Optional[int] = None,
              turn: Optional[int] = None, advance_turn: bool = True, obs_out: Optional[torch.Tensor] = None,
-             obs_next: bool = False, obs_next_out: Optional[torch.Tensor] = None):
+             obs_next: bool = False, obs_next_out: Optional[torch.Tensor] = None, no_move: bool = False):
         """One ``Environment.take_turn`` for every env (K2).
 
         ``actions``: uint8 ``[E, A]`` chosen by a policy; or ``random_actions=True``
@@ -273,6 +289,8 @@ class GridEngine:
         after their moves -- into slot ``agent_end`` of the observation tensor, or, with
         ``obs_next_out`` (contiguous, the engine's observation dtype, ``E * C * V * V`` elements:
         e.g. a row of that agent's replay buffer), straight into that one-window-per-env tensor.
+        ``no_move=True``: nobody acts -- the sweep (if ``sweep``) and the windows of the agents from the grid after it
+        (steps 1 + 2 of a policy-driven turn in one launch; ``act`` then moves the agents one by one).
         With ``set_auto_reset`` armed, the call that completes turn
         ``max_turns`` also resets every env for the next epoch (``self.epoch`` / ``self.turn``
         follow when the engine keeps the counters, i.e. ``turn`` is not passed)."""
@@ -283,7 +301,7 @@ class GridEngine:
             # the step always consumes self.actions (so it also records what was taken)
             self.actions.copy_(actions.to(device=self.device, dtype=torch.uint8).reshape(self.actions.shape))
         actions = self.actions
-        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0)
+        flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0) | (N.STEP_NO_MOVE if no_move else 0)
         obs = self.obs if obs_out is None else self._check_obs(obs_out, "obs_out")
         if obs_next_out is not None:
             if not obs_next:
@@ -303,7 +321,7 @@ class GridEngine:
             N.check(self._lib.sgw_step(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(actions),
                                        self._ptr(obs), self._ptr(self.rewards), self._ptr(self.total_reward),
                                        epoch, t, agent_begin, agent_end, flags, self._stream()))
-        if self.max_turns and t == self.max_turns and agent_end == self.spec.num_agents:
+        if self.max_turns and t == self.max_turns and agent_end == self.spec.num_agents and not no_move:
             self.epoch = epoch + 1        # the library has reset every env for the next epoch (sgw_set_auto_reset)
             if turn is None:
                 self.turn = 0

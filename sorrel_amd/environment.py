@@ -118,7 +118,8 @@ class Environment:
         self.turn = 0
         self.epoch = 0
         self._fresh_obs = None       # (slot, world mutation count): eng.obs[:, slot] was rendered by the last launch
-        self._turn_windows = None    # (world mutation count, rows, first agent whose window is still current): this turn's windows
+        self._turn_windows = None    # [world mutation count, rows, first agent whose window is still current, replay slots]: this turn's windows
+        self._replay_slots = None
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
@@ -351,14 +352,15 @@ class Environment:
         caps = eng.capabilities()
         if not self.patch_windows or not (caps & N.CAP_ACT) or eng.obs is None:
             return False
-        eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
-        if caps & N.CAP_OBSERVE_ROWS:
-            rows = eng.window_rows(self._replay_rows())
+        dests = self._replay_rows() if caps & N.CAP_OBSERVE_ROWS else None
+        slots = self._replay_slots if dests is not None else None      # (buffer, row) per agent
+        rows = eng.window_rows(dests)
+        if dests is not None:                   # the sweep alone, then every window into its agent's replay row
+            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
             eng.observe_rows(rows)
-        else:                                   # any appearance table, uint8 windows: the step kernels render the tensor
-            rows = eng.window_rows(None)
-            eng.observe()
-        self._turn_windows = [self.world.mutations, rows, 0]
+        else:                                   # the windows live in the observation tensor: sweep + all of them in ONE launch
+            eng.step(sweep=True, no_move=True, turn=self.turn)
+        self._turn_windows = [self.world.mutations, rows, 0, slots]
         return True
 
     def _replay_rows(self):
@@ -380,7 +382,7 @@ class Environment:
         per_env = 1
         for d in eng.spec.obs_shape[1:]:
             per_env *= int(d)
-        taken, rows = {}, []
+        taken, rows, self._replay_slots = {}, [], []
         for agent in self.agents:
             mem = getattr(agent.model, "memory", None)
             if not isinstance(mem, Buffer) or type(agent).transition is not Agent.transition \
@@ -390,11 +392,13 @@ class Environment:
             taken[id(mem)] = k + 1
             if k >= mem.capacity:
                 return None
-            row = mem.states[(mem.idx + k) % mem.capacity]
+            i = (mem.idx + k) % mem.capacity
+            row = mem.states[i]
             if row.dtype != eng.obs_dtype or row.device != eng.device or not row.is_contiguous() or row.dim() < 2 \
                     or row.shape[0] != eng.num_envs or row.numel() != eng.num_envs * per_env:
                 return None
             rows.append(row)
+            self._replay_slots.append((mem, i))
         return rows
 
     def rollout(self, turns: int) -> None:
@@ -574,13 +578,25 @@ class Environment:
         a = agent.slot
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
-        eng.actions[:, a].copy_(action)          # one strided copy that also narrows int64 -> uint8
         tw = self._turn_windows
         if tw is not None:
             if tw[0] == self.world.mutations and a >= tw[2]:
                 tw[2] = a + 1                    # the windows of the agents after a stay current: sgw_act repairs them
-                return eng.act(a, tw[1])
+                # the policy's output goes to the kernel as it is (no narrowing copy); rewards and actions are also written
+                # where the agent's add_memory would copy them to
+                direct = action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1 \
+                    and action.shape[0] == eng.num_envs and action.is_contiguous()
+                if not direct:
+                    eng.actions[:, a].copy_(action)
+                rr = ar = None
+                if tw[3] is not None:
+                    mem, i = tw[3][a]
+                    if mem.idx == i:             # (still the row this agent's add_memory fills)
+                        rr, ar = mem.rewards[i], mem.actions[i]
+                        mem._prefilled = (i, action.data_ptr())
+                return eng.act(a, tw[1], action=action if direct else None, reward_row=rr, action_row=ar)
             self._turn_windows = None            # host code changed the world mid-turn: render on demand from here on
+        eng.actions[:, a].copy_(action)          # one strided copy that also narrows int64 -> uint8
         nxt = a + 1 < len(self.agents) and eng.obs is not None
         slot = self._replay_slot(a + 1, a) if nxt else None
         eng.step(eng.actions, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1, turn=self.turn, obs_next=nxt,

@@ -195,22 +195,35 @@ def test_windows_rendered_once_and_repaired_by_sgw_act_vs_oracle(torch_cuda, cas
         acts_np = rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)
         assert co.step(0, t, actions=acts_np) == 0
         eng.actions.copy_(torch.from_numpy(acts_np))
-        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)      # the sweep alone
         own_rows = (caps & N.CAP_OBSERVE_ROWS) and t % 2 == 0
         dests = [torch.full((E, per_env), -3.0, device="cuda:0") for _ in range(A)] if own_rows else None
         eng.obs.fill_(99 if kind == "u8" else -7.0)
         rows = eng.window_rows(dests)
-        if caps & N.CAP_OBSERVE_ROWS:
-            eng.observe_rows(rows)
+        if t % 3 == 0 and not own_rows:
+            eng.step(eng.actions, sweep=True, no_move=True, turn=t)                                 # sweep + every window in ONE launch (SGW_STEP_NO_MOVE)
         else:
-            eng.observe()
+            eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)  # the sweep alone
+            if caps & N.CAP_OBSERVE_ROWS:
+                eng.observe_rows(rows)
+            else:
+                eng.observe()
         seen = torch.zeros_like(eng.obs)
         rew = torch.zeros_like(eng.rewards)
+        want_actions = eng.actions.clone()
         for a in range(A):
             seen[:, a] = dests[a].view(E, *ws.obs_shape[1:]) if own_rows else eng.obs[:, a]      # what agent a's policy reads
-            eng.act(a, rows)
+            if a % 2:       # the policy's own output tensor (int64 / int32), rewards and actions also into replay-like rows
+                mine = want_actions[:, a].to(torch.int64 if a % 4 == 1 else torch.int32).contiguous()
+                eng.actions[:, a] = 77
+                rrow, arow = torch.full((E,), -1.0, device="cuda:0"), torch.full((E,), -1, dtype=torch.int64, device="cuda:0")
+                out = eng.act(a, rows, action=mine, reward_row=rrow, action_row=arow)
+                assert out.data_ptr() == rrow.data_ptr()
+                assert torch.equal(rrow, eng.rewards[:, a]) and torch.equal(arow, want_actions[:, a].long())
+            else:
+                eng.act(a, rows)
             rew[:, a] = eng.rewards[:, a]
         torch.cuda.synchronize()
+        assert torch.equal(eng.actions, want_actions), "actions[:, a] records what was taken"
         assert np.array_equal(seen.cpu().numpy().astype(np.float32), co.obs), f"turn {t}: windows differ from the oracle"
         assert np.array_equal(rew.cpu().numpy(), co.rewards), f"turn {t}: rewards"
         assert np.array_equal(eng.grid.cpu().numpy(), co.grid), f"turn {t}: grid"

@@ -66,7 +66,16 @@ def patched():
         eng.act(a, ROWS)
 
 
+def patched_tensor():
+    eng.turn += 1
+    eng.step(acts, sweep=True, no_move=True, turn=eng.turn)      # sweep + every window (into the tensor) in one launch
+    for a in range(A):
+        eng.act(a, ROWS)
+
+
 print(f"{h}x{w} A{A} r{r} E={E}  {eng.launch_info().split(' threads')[0]}")
+us = timed(patched_tensor)
+print(f"  {f'1 + A = {1 + A} launches (round 3, NO_MOVE + sgw_act)':40s} {us:9.1f} us/turn  {E * A / us * 1e6:.3e} agent-steps/s  ({us / (1 + A):6.1f} us per launch)")
 us = timed(patched)
 print(f"  {f'2 + A = {2 + A} launches (round 3, sgw_act)':40s} {us:9.1f} us/turn  {E * A / us * 1e6:.3e} agent-steps/s  ({us / (2 + A):6.1f} us per launch)")
 eng.set_timing(True)

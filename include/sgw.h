@@ -20,6 +20,8 @@
  *                                                             sorrel/observation/observation_spec.py:175-205,
  *                                                             sorrel/observation/visual_field.py:9-101,
  *                                                             sorrel/utils/helpers.py:48-77
+ *   sgw_observe_full  ObservationSpec(full_view=True).observe  sorrel/observation/observation_spec.py:197-203,
+ *                                                             sorrel/observation/visual_field.py:41-55
  *   sgw_step        Environment.take_turn                     sorrel/environment.py:81-93
  *                   -> Entity.transition sweep                sorrel/examples/treasurehunt/entities.py:69-85
  *                   -> Agent.transition (pov, act, reward)    sorrel/agents/agent.py:155-173
@@ -204,6 +206,12 @@ int sgw_reset(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, double* total_
  * grid; obs rows of other agents are left untouched. */
 int sgw_observe(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_pos, float* obs,
                 int32_t agent_begin, int32_t agent_end, void* stream);
+
+/* The whole map as an observation -- ObservationSpec(full_view=True).observe -> visual_field(location=None)
+ * (sorrel/observation/observation_spec.py:140-142,197-203, sorrel/observation/visual_field.py:41-55): `out`
+ * [E][C][H][W] (float, or uint8 with SGW_OBS_U8) receives every cell's appearance summed over the layers; no window, no
+ * fill entity, the same for every agent. */
+int sgw_observe_full(sgw_engine* eng, const uint8_t* grid, void* out, void* stream);
 
 /* One take_turn for every env.  `turn` is Environment.turn AFTER its increment
  * (1 for the first turn of an epoch).  Agents [agent_begin, agent_end) are

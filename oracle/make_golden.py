@@ -847,6 +847,7 @@ def main() -> int:
     save("cleanup_15x16", spec, ids, ref)
 
     make_round2_fixtures(R)
+    make_round3_fixtures(R)
 
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)
@@ -888,6 +889,50 @@ def make_round2_fixtures(R):
     ref = run_reference_tag(R, spec, ids, 25)
     check_against_oracle(spec, ids, 25, ref)
     save("tag_11x11_default", spec, ids, ref)
+
+
+def make_round3_fixtures(R):
+    """full_view observations (sorrel/observation/observation_spec.py:140-142, 197-203 -> visual_field.py:53-55: the whole
+    map, appearance summed over layers, no shift / crop / fill): the reference's OWN OneHotObservationSpec and
+    RGBObservationSpec with full_view=True observe the world of a running Treasurehunt harness after every turn."""
+    print("full_view_treasurehunt: 9x11x2, 3 agents, 7 turns, whole-map one-hot and RGB observations")
+    spec = O.treasurehunt_spec(9, 11, 3, 2, spawn_prob=0.08, seed=21, dense_prob=0.2)
+    ids = [0, 6]
+    turns = 7
+    entity_list = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+    dims = (spec.height, spec.width)
+    onehot = R["observation_spec"].OneHotObservationSpec(entity_list, full_view=True, env_dims=dims)
+    rgb = R["observation_spec"].RGBObservationSpec(entity_list, full_view=True, env_dims=dims)
+    assert tuple(onehot.input_size) == (6,) + dims and tuple(rgb.input_size) == (3,) + dims
+    E = len(ids)
+    full = dict(full_onehot0=np.zeros((E, 6) + dims), full_onehot=np.zeros((turns, E, 6) + dims),
+                full_rgb=np.zeros((turns, E, 3) + dims))
+    out = dict(grid0=np.zeros((E, spec.layers) + dims, np.uint8), pos0=np.zeros((E, spec.num_agents, 2), np.uint8),
+               grid=np.zeros((turns, E, spec.layers) + dims, np.uint8), pos=np.zeros((turns, E, spec.num_agents, 2), np.uint8))
+    for n, env_id in enumerate(ids):
+        Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec, Ctx.scripted = spec.seed, int(env_id), 0, 0, spec, None
+        env, CounterEmpty = make_treasurehunt_env(R, spec, turns)
+        out["grid0"][n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
+        out["pos0"][n] = [a.location[:2] for a in env.agents]
+        v = onehot.observe(env.world)                              # <- the reference's own full-view observe
+        assert v.dtype == np.float64 and v.shape == (6,) + dims
+        full["full_onehot0"][n] = v
+        for t in range(turns):
+            Ctx.turn = env.turn + 1
+            env.take_turn()
+            out["grid"][t, n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
+            out["pos"][t, n] = [a.location[:2] for a in env.agents]
+            full["full_onehot"][t, n] = onehot.observe(env.world, location=(1, 1, 1))    # (a location is ignored with full_view)
+            full["full_rgb"][t, n] = rgb.observe(env.world)
+    mine = O.rollout(spec, ids, turns)
+    assert np.array_equal(mine["grid"], out["grid"]) and np.array_equal(mine["grid0"], out["grid0"]), "restatement differs from the reference"
+    # the closed form the engine implements: appearance[type] summed over layers, channel-major
+    want = spec.appearance[out["grid"]].sum(axis=2).transpose(0, 1, 4, 2, 3)
+    assert np.array_equal(want, full["full_onehot"]), "closed form of the full view differs from the reference"
+    rgb_map = {k: np.asarray(val, dtype=np.float64) for k, val in rgb.entity_map.items()}
+    out.update(full)
+    out["rgb_table"] = np.stack([rgb_map[k] for k in entity_list])
+    save("full_view_treasurehunt", spec, ids, out)
 
 
 def make_buffer_fixture():
@@ -954,5 +999,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["round2"]:       # only the fixtures added in round 2
         make_round2_fixtures(_import_reference())
+        sys.exit(0)
+    if sys.argv[1:] == ["round3"]:       # only the fixtures added in round 3
+        make_round3_fixtures(_import_reference())
         sys.exit(0)
     sys.exit(main())

@@ -67,7 +67,7 @@ EXPORTS = (
     "sgw_create", "sgw_destroy", "sgw_reset", "sgw_observe", "sgw_step", "sgw_rollout", "sgw_reduce_metrics",
     "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
-    "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act",
+    "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
     "sgw_last_error", "sgw_version",
 )
 
@@ -151,6 +151,8 @@ def load():
     lib.sgw_set_wg_per_cu.restype = C.c_int
     lib.sgw_launch_info.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.sgw_launch_info.restype = C.c_int
+    lib.sgw_observe_full.argtypes = [vp, u8p, vp, vp]
+    lib.sgw_observe_full.restype = C.c_int
     lib.sgw_capabilities.argtypes = [vp]
     lib.sgw_capabilities.restype = C.c_int
     lib.sgw_observe_rows.argtypes = [vp, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, vp]

@@ -865,6 +865,20 @@ int sgw_observe(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, fl
     return launch_step(e, p, static_cast<hipStream_t>(stream));
 }
 
+int sgw_observe_full(sgw_engine* e, const uint8_t* grid, void* out, void* stream) {
+    if (!e || !grid || !out) return fail(SGW_EINVAL, "sgw_observe_full: NULL argument");
+    Params p = e->base;
+    p.grid = const_cast<uint8_t*>(grid);
+    p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
+    const int64_t n = p.E * (int64_t)p.H * p.W;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, kBlock), (int64_t)e->num_cus * 16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = time_begin(e, s)) return rc;
+    hipLaunchKernelGGL(observe_full_kernel, dim3(blocks), dim3(kBlock), 0, s, p, out);
+    HIP_TRY(hipGetLastError());
+    return time_end(e, s);
+}
+
 int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs, float* rewards,
              double* total_reward, uint32_t epoch, uint32_t turn, int32_t agent_begin, int32_t agent_end,
              uint32_t flags, void* stream) {

@@ -163,3 +163,40 @@ __global__ __launch_bounds__(kBlock) void reduce_stage2(const double* __restrict
 }
 static_assert(kRedBlocks == kBlock, "stage 2 assumes one partial per thread");
 
+
+// ---------------------------------------------------------------- whole-map observation (full_view)
+// ObservationSpec(full_view=True).observe -> visual_field(location=None) (observation_spec.py:140-142, 197-203;
+// visual_field.py:41-55): every cell's appearance summed over the layers, [C][H][W] per env, no shift / crop / fill.
+// Thread = cell; consecutive threads read consecutive bytes of each layer and write consecutive floats of each channel
+// plane.  One-hot tables use the packed byte counters, anything else the float64 layer sum (left to right, as np.sum
+// over <= 7 layers) with the spec's post-processing.
+__global__ __launch_bounds__(kBlock) void observe_full_kernel(const Params p, void* out) {
+    const int HW = p.H * p.W;
+    const int64_t n = p.E * (int64_t)HW;
+    const DevTables* tab = p.tab;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t env = i / HW;
+        const int cell = (int)(i - env * HW);
+        const uint8_t* g = p.grid + env * p.env_stride + cell;
+        const int64_t o = env * p.C * (int64_t)HW + cell;
+        if (p.onehot) {
+            uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+            for (int z = 0; z < p.L; ++z) {
+                const uint32_t t = g[z * HW] & 31u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cnt[q] += tab->delta[q][t];
+            }
+            for (int c = 0; c < p.C; ++c) {
+                const uint32_t v = (cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+                if (p.obs_u8) reinterpret_cast<uint8_t*>(out)[o + (int64_t)c * HW] = (uint8_t)v;
+                else reinterpret_cast<float*>(out)[o + (int64_t)c * HW] = (float)v;
+            }
+        } else {
+            for (int c = 0; c < p.C; ++c) {
+                double acc = tab->appearance[g[0] & 31u][c];
+                for (int z = 1; z < p.L; ++z) acc += tab->appearance[g[z * HW] & 31u][c];
+                reinterpret_cast<float*>(out)[o + (int64_t)c * HW] = obs_finish(acc, p.obs_post);
+            }
+        }
+    }
+}

@@ -271,6 +271,18 @@ class GridEngine:
                                       self._ptr(reward_row), self._ptr(action_row), self._stream()))
         return self.rewards[:, agent] if reward_row is None else reward_row
 
+    def observe_full(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The whole map as an observation, ``[E, C, H, W]`` (``ObservationSpec(full_view=True).observe``): every cell's
+        appearance summed over the layers."""
+        want = (self.num_envs, self.spec.num_channels, self.spec.height, self.spec.width)
+        if out is None:
+            out = torch.empty(want, dtype=self.obs_dtype, device=self.device)
+        elif tuple(out.shape) != want or out.dtype != self.obs_dtype or out.device != self.device or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous {self.obs_dtype} tensor of shape {want} on {self.device}")
+        with self._on_device():
+            N.check(self._lib.sgw_observe_full(self._h, self._ptr(self.grid), self._ptr(out), self._stream()))
+        return out
+
     def scratch_obs(self) -> torch.Tensor:
         if self._scratch_obs is None:
             self._scratch_obs = torch.zeros((self.num_envs,) + self.spec.obs_shape, dtype=self.obs_dtype, device=self.device)

@@ -533,17 +533,11 @@ class Environment:
         return eng.scratch_obs()[:, 0]
 
     def _full_view(self, ospec):
-        """Whole-map appearance summed over layers, ``[E, C, H, W]`` (``visual_field.py:41-55``).  Host-side
-        plumbing (a PyTorch table lookup), NOT the engine: ``full_view`` specs are rejected for the fused step
-        (``compile_spec``), no example on the path uses them, and this exists only so that an on-demand
-        ``observe`` / ``visual_field`` call with ``full_view=True`` answers as the reference does."""
-        w = self.world
-        spec = self.compile_spec(ospec)
-        app = torch.tensor(spec.appearance, dtype=torch.float64, device=w.device)        # [T, C]
-        out = app[w.grid.long()].sum(dim=1).permute(0, 3, 1, 2).contiguous()
-        if getattr(ospec, "obs_post", 0) == 1:
-            out = out.clamp(0, 255) / 255
-        return out
+        """Whole-map appearance summed over layers, ``[E, C, H, W]`` float32 (``visual_field.py:41-55``): the engine's
+        ``sgw_observe_full`` on the handle compiled from ``ospec``'s appearance table.  The same for every agent; a
+        ``full_view`` spec is still rejected as the agents' OWN spec of a fused step (it would mean A whole maps per env
+        and turn), it is an on-demand observation."""
+        return self._engine_for(ospec).observe_full()
 
     #: policy-driven turns render each agent's window straight into its replay row where that is possible (see below);
     #: False = always through the observation tensor + a copy in ``Buffer.add`` (A/B and test switch)

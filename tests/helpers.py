@@ -20,7 +20,8 @@ from sorrel_amd.spec import WorldSpec  # noqa: E402
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
-NON_WORLD_FIXTURES = {"buffer_ring", "buffer_saved_by_reference", "savedgames_by_reference"}   # fixtures that are not step-loop traces
+NON_WORLD_FIXTURES = {"buffer_ring", "buffer_saved_by_reference", "savedgames_by_reference",
+                      "full_view_treasurehunt"}   # fixtures that are not step-loop traces in the common format
 INJECTED_FIXTURES = {"cleanup_15x16", "cleanup_21x31_default", "cleanup_13x12_r2"}  # worlds populated by host code: runs start from the stored grid0 / pos0
 
 

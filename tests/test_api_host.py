@@ -389,3 +389,100 @@ def test_engine_rejects_observation_destinations_the_kernel_would_overrun():
     for bad in (pos.long(), pos[:, :3], pos.transpose(0, 1)):
         with pytest.raises(ValueError):
             eng._check_pos(bad)
+
+
+REFERENCE_STYLE_SCRIPT = '''
+# Written against the REFERENCE's import paths (the shape of sorrel/examples/treasurehunt/main.py + env.py), nothing from sorrel_amd:
+import numpy as np
+
+from sorrel.action.action_spec import ActionSpec
+from sorrel.agents import Agent, MovingAgent
+from sorrel.buffers import Buffer
+from sorrel.entities import EmptyEntity, Entity, Gem, Wall
+from sorrel.environment import Environment
+from sorrel.location import Location
+from sorrel.models.base_model import BaseModel, RandomModel
+from sorrel.observation.observation_spec import OneHotObservationSpec
+from sorrel.observation.visual_field import visual_field
+from sorrel.utils.helpers import one_hot_encode, shift
+from sorrel.worlds import Gridworld
+from sorrel.worlds.gridworld import Gridworld as G2
+
+
+class Walker(MovingAgent):
+    def reset(self):
+        pass
+
+    def pov(self, world):
+        return self.observation_spec.observe(world, self.location)
+
+    def get_action(self, state):
+        return self.model.take_action(state)
+
+    def is_done(self, world):
+        return world.is_done
+
+
+class Env(Environment):
+    def setup_agents(self):
+        spec = OneHotObservationSpec(["EmptyEntity", "Wall", "Gem", "Walker"], full_view=False, vision_radius=2)
+        actions = ActionSpec(["up", "down", "left", "right"])
+        self.agents = [Walker(spec, actions, RandomModel(spec.input_size, actions.n_actions)) for _ in range(2)]
+
+    def populate_environment(self):
+        w = self.world
+        for index in np.ndindex(w.height, w.width, w.layers):
+            y, x, z = index
+            if y in (0, w.height - 1) or x in (0, w.width - 1):
+                w.add(index, Wall())
+        w.add((3, 3, 0), Gem(5))
+        for agent, loc in zip(self.agents, [(1, 1, 0), (5, 5, 0)]):
+            w.add(loc, agent)
+
+
+world = Gridworld(8, 9, 1, EmptyEntity(), device="cpu")
+env = Env(world, {"experiment": {"epochs": 1, "max_turns": 5, "record_period": 1}})
+spec = env.compile_spec()
+assert G2 is Gridworld and issubclass(Walker, Agent) and issubclass(Gem, Entity)
+assert Location(1, 2, 3) + Location(2, 4, 8) == Location(3, 6, 11)
+print("OK", spec.height, spec.width, spec.layers, spec.num_agents, spec.num_channels, spec.vision_radius,
+      sorted(set(spec.type_names)), [float(v) for v in spec.type_value], world.observe((3, 3, 0)).kind, env.agents[1].location)
+import sorrel.environment, sorrel_amd.environment
+assert sorrel.environment.Environment is sorrel_amd.environment.Environment
+try:
+    import sorrel.utils.logging
+except ModuleNotFoundError as exc:
+    print("out of scope:", "outside the hot path" in str(exc))
+'''
+
+
+def test_reference_import_paths_resolve_to_the_mirror(tmp_path):
+    """SURVEY 8(b) "Import paths to mirror": a script written with the reference's own import lines builds a world and
+    compiles its spec -- through ``python -m sorrel_amd.compat script.py`` and through ``compat.install()`` -- and parts
+    of the reference outside the hot path fail with a message that says so.  (Subprocesses: the alias must not leak into
+    this test process, where other tests import the real reference under the same name.)"""
+    import subprocess
+    import sys
+
+    script = tmp_path / "experiment.py"
+    script.write_text(REFERENCE_STYLE_SCRIPT)
+    env = dict(__import__("os").environ, PYTHONPATH=H.ROOT, PYTHONDONTWRITEBYTECODE="1")
+    for cmd in ([sys.executable, "-m", "sorrel_amd.compat", str(script)],
+                [sys.executable, "-c", f"import sorrel_amd.compat as c, runpy; c.install(); c.install(); runpy.run_path({str(script)!r}, run_name='__main__')"]):
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("OK")][0]
+        assert line.startswith("OK 8 9 1 2 4 2 ['EmptyEntity', 'Gem', 'Walker', 'Wall']"), line
+        assert "Gem (5, 5, 0)" in line and "out of scope: True" in out.stdout
+    # without the alias the reference's names do not exist here (nothing is shadowed silently)
+    out = subprocess.run([sys.executable, "-c", "import sorrel.environment"], capture_output=True, text=True, cwd=str(tmp_path), env=env)
+    assert out.returncode != 0 and "No module named 'sorrel'" in out.stderr
+    # install() refuses to shadow a real `sorrel` distribution unless forced
+    (tmp_path / "sorrel").mkdir()
+    (tmp_path / "sorrel" / "__init__.py").write_text("REAL = True\n")
+    code = ("import sorrel_amd.compat as c\n"
+            "try:\n    c.install()\n    print('shadowed')\nexcept ImportError as e:\n    print('refused')\n"
+            "c.install(force=True)\nimport sorrel.worlds\nprint(sorrel.worlds.Gridworld.__module__)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path),
+                         env=dict(env, PYTHONPATH=H.ROOT + ":" + str(tmp_path)))
+    assert out.returncode == 0 and out.stdout.split() == ["refused", "sorrel_amd.worlds.gridworld"], out.stdout + out.stderr

@@ -404,3 +404,51 @@ def test_config3_shape_long_horizon_vs_oracle(torch_cuda):
     filled = float((eng.grid[:, 1, 1:-1, 1:-1] >= 3).float().mean())
     assert filled > 0.25, filled
     assert eng.status() == 0 and one_call.status() == 0
+
+
+# ------------------------------------------------------------------ full_view observations in the engine
+def test_full_view_kernel_vs_reference_fixture_and_oracle(torch_cuda):
+    """sgw_observe_full == what the reference's own OneHot / RGB specs with full_view=True observed (fixture generated by
+    running the reference), also as uint8; and through the API: ``OneHotObservationSpec(full_view=True).observe(world)``."""
+    torch = torch_cuda
+    import copy
+
+    d, spec = H.load_golden("full_view_treasurehunt")
+    E, T = d["grid0"].shape[0], d["grid"].shape[0]
+    ws = H.world_spec(spec)
+    for dtype in (torch.float32, torch.uint8):
+        eng = make_engine(ws, E, obs_dtype=dtype)
+        for t in range(T):
+            eng.grid.copy_(torch.from_numpy(d["grid"][t]))
+            got = eng.observe_full().cpu().numpy()
+            assert got.shape == d["full_onehot"][t].shape and np.array_equal(got.astype(np.float64), d["full_onehot"][t]), (dtype, t)
+    rgb = copy.deepcopy(spec)
+    rgb.appearance = d["rgb_table"][[0, 0, 1, 2, 3, 4, 5]].astype(np.float64)
+    rgb.num_channels, rgb.obs_post = 3, 1
+    eng = make_engine(H.world_spec(rgb), E)
+    for t in range(T):
+        eng.grid.copy_(torch.from_numpy(d["grid"][t]))
+        got = eng.observe_full().cpu().numpy()
+        assert np.array_equal(got, d["full_rgb"][t].astype(np.float32)), t
+    with pytest.raises(ValueError):
+        eng.observe_full(out=torch.zeros((E, 3, 9, 12), device="cuda:0"))
+    # a bigger batch against the oracle's restatement (ragged world: 21x21x2 = 882 bytes per env in a padded stride)
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws2 = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.1, seed=2, dense_prob=0.3)
+    eng2, co = make_engine(ws2, 300), H.COracle(ws2, 300)
+    eng2.reset(0)
+    co.reset(0)
+    for t in range(1, 4):
+        eng2.step(random_actions=True, turn=t)
+        co.step(0, t, random_actions=True)
+    got = eng2.observe_full().cpu().numpy()
+    osp = H.oracle_spec(ws2)
+    for e in (0, 1, 150, 299):
+        assert np.array_equal(got[e].astype(np.float64), O_full(osp, co.grid[e])), e
+
+
+def O_full(spec, grid):
+    from oracle import gridstep_oracle as O
+
+    return O.full_view(spec, grid)

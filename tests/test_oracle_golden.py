@@ -198,3 +198,26 @@ def test_rollout_entry_point_equals_turn_by_turn_steps():
     assert rc == 0
     for name in ("grid", "pos", "actions", "obs", "rewards", "total"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_full_view_restatement_matches_the_reference_fixture():
+    """``ObservationSpec(full_view=True).observe`` of the reference's own OneHot / RGB specs on a running Treasurehunt
+    world (``tests/golden/full_view_treasurehunt.npz``, written by ``oracle/make_golden.py round3``) == the oracle's
+    ``full_view`` on the same grids."""
+    import copy
+
+    d, spec = H.load_golden("full_view_treasurehunt")
+    E, T = d["grid0"].shape[0], d["grid"].shape[0]
+    for n in range(E):
+        assert np.array_equal(O.full_view(spec, d["grid0"][n]), d["full_onehot0"][n])
+        for t in range(T):
+            got = O.full_view(spec, d["grid"][t, n])
+            assert got.dtype == np.float64 and np.array_equal(got, d["full_onehot"][t, n]), (n, t)
+    # the RGB spec: the reference's colour per kind (fixture) on the same types, clip / 255
+    rgb = copy.deepcopy(spec)
+    kind_of_type = [0, 0, 1, 2, 3, 4, 5]           # Sand and EmptyEntity share the kind "EmptyEntity" (treasurehunt_spec)
+    rgb.appearance = d["rgb_table"][kind_of_type].astype(np.float64)
+    rgb.num_channels, rgb.obs_post = 3, 1
+    for n in range(E):
+        for t in range(T):
+            assert np.array_equal(O.full_view(rgb, d["grid"][t, n]), d["full_rgb"][t, n]), (n, t)

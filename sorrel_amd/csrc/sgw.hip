@@ -258,6 +258,8 @@ StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, con
         if constexpr (G == 32) {
             if (onehot && L == 1 && C == 4 && r == 4 && H == 11 && W == 11) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4, 11, 11>);   // the Tag example as shipped
             if (onehot && L == 1 && C == 4 && r == 4) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>);
+            if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3, 32, 32>);   // Tag at the headline's shape
+            if (onehot && L == 1 && C == 4 && r == 3) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>);
         }
         if (onehot && L == 1 && C == 4) PICK(step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>);   // the Tag example's tables
         if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>);
@@ -300,7 +302,8 @@ StepFn pick_big(bool onehot, int L, int C, int r, const char** name) {
     PICK(step_big<true, 0, 0, 0>);
 }
 
-bool fixed_fast_shape(int L, int C, int r, int H, int W) {
+bool fixed_fast_shape(int L, int C, int r, int H, int W, bool tag) {   // = the compile-time-shape instances of pick_fast
+    if (tag) return L == 1 && C == 4 && r == 3 && H == 32 && W == 32;
     return L == 2 && C == 6 && ((r == 3 && H == 32 && W == 32) || (r == 2 && H == 16 && W == 16));
 }
 
@@ -347,6 +350,7 @@ StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool 
         PICK(step_fast<false, 0, 0, 0, 0, 0, false, true>);
     }
     if (tag) {
+        if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK(step_fast<true, 1, 4, 3, 32, 32, true>);   // Tag on the headline's map
         if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, true, false, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, true>);
         PICK(step_fast<false, 0, 0, 0, 0, 0, true>);
@@ -565,8 +569,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     {   // LDS staging of one-hot observations
         const int ob_elems = c.num_agents * c.num_channels * p.VV;
         const int per_agent = c.num_channels * p.VV;
-        const bool fixed_shape = !e->fast_rules && c.agent_rule != SGW_AGENT_RULE_TAG &&
-                                 fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width);   // = pick_fast's fixed-shape kernels
+        const bool fixed_shape = !e->fast_rules && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width,
+                                                                    c.agent_rule == SGW_AGENT_RULE_TAG);   // = pick_fast's fixed-shape kernels
         e->obs_stage = 0;
         if (e->fast && onehot && fixed_shape) {
             // whole envs of a multiple of 4 elements, at most 4 KiB of byte counts
@@ -607,7 +611,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         const int64_t avv = (int64_t)c.num_agents * p.VV;
         auto enough = [&](int G) { return c.num_agents <= G && (int64_t)c.num_envs * G / kWave >= 12288; };
         int g = 0;
-        if (c.agent_rule == SGW_AGENT_RULE_TAG) g = enough(32) ? 32 : 0;
+        // (Tag on a map with a compile-time-shape wave-per-env instance stays there: 32x32 / 8 agents 117 us against 143 packed)
+        if (c.agent_rule == SGW_AGENT_RULE_TAG)
+            g = (enough(32) && !(e->fast && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, true))) ? 32 : 0;
         else if (c.agent_rule == SGW_AGENT_RULE_MOVE && !p.has_become) {
             if (avv <= 100 && p.cells_pad <= 1024 && enough(16)) g = 16;
             else if (avv <= 200 && enough(32)) g = 32;

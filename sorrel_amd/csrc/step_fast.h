@@ -570,18 +570,20 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                 const int cy = pass ? (int)(np_a & 0xFFu) : (int)(((uint32_t)s_o - (uint32_t)zoff) / (uint32_t)W);
                 const int cx = pass ? (int)((np_a >> 8) & 0xFFu) : (int)(((uint32_t)s_o - (uint32_t)zoff) % (uint32_t)W);
                 const int own = zoff + cy * W + cx;
-                uint32_t nt[4];
-                bool ain[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0), ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
-                    ain[d] = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
-                    nt[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[ain[d] ? zoff + ay * W + ax : own]);
-                }
                 int dstar = -1;
+                if (my_type == p.tag_it) {   // wave-uniform: only the agent that is "it" looks around (one in A; the others skip four LDS round trips)
+                    uint32_t nt[4];
+                    bool ain[4];
 #pragma unroll
-                for (int d = 3; d >= 0; --d)
-                    if (ain[d] && nt[d] == p.tag_notit) dstar = d;
+                    for (int d = 0; d < 4; ++d) {
+                        const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0), ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                        ain[d] = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                        nt[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg[ain[d] ? zoff + ay * W + ax : own]);
+                    }
+#pragma unroll
+                    for (int d = 3; d >= 0; --d)
+                        if (ain[d] && nt[d] == p.tag_notit) dstar = d;
+                }
                 uint32_t mine_now = my_type;
                 if (my_type == p.tag_it && dstar >= 0) {
                     const int ay = cy + (dstar == 0 ? -1 : dstar == 2 ? 1 : 0), ax = cx + (dstar == 1 ? 1 : dstar == 3 ? -1 : 0);

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     gsync<WPE>();
                     uint32_t mine_now = my_type;
                     const int own = zoff + cy * W + cx;
+                    if (my_type == p.tag_it)         // only the agent that is "it" looks around (one in A: the other agents skip four LDS round trips)
     #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     gsync<WPA>();
                     uint32_t mine_now = my_type;
                     const int own = zoff + cy * W + cx;
+                    if (my_type == p.tag_it)         // only the agent that is "it" looks around
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0);

@@ -452,3 +452,47 @@ def O_full(spec, grid):
     from oracle import gridstep_oracle as O
 
     return O.full_view(spec, grid)
+
+
+# ------------------------------------------------------------------ Tag on its compile-time-shape instances
+@pytest.mark.parametrize("shape", [(32, 32, 8, 3, 150, "step_fast<true, 1, 4, 3, 32, 32, true>"),     # wave per env, static 32x32 map
+                                   (32, 32, 8, 3, 65536, "step_fast<true, 1, 4, 3, 32, 32, true>"),   # ... also for big batches (not packed)
+                                   (20, 24, 6, 3, 40000, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>"),     # packed, static 7x7 window
+                                   (32, 32, 20, 3, 90, "step_fast<true, 1, 4, 3, 32, 32, true>")],    # crowded: many tags per turn
+                         ids=["static_32x32", "static_32x32_full_batch", "packed_static_radius", "static_32x32_crowded"])
+def test_tag_static_instances_vs_oracle(torch_cuda, shape):
+    """TagAgent.act on the instances round 3 added (only the agent that is "it" looks at its neighbours; compile-time
+    32x32 map on the wave-per-env kernel; compile-time 7x7 window on the packed kernel): every tensor, the agents' types
+    and what they were when they observed, against the C oracle; the 1 + A phased form too."""
+    torch = torch_cuda
+    h, w, a_, r_, E, kernel = shape
+    d, spec = H.load_golden("tag_9x9")
+    ws = H.world_spec(spec)
+    ws.height, ws.width, ws.num_agents, ws.vision_radius, ws.agent_type = h, w, a_, r_, [ws.agent_type[0]] * a_
+    eng = make_engine(ws, E, first=9)
+    assert kernel in eng.launch_info(), eng.launch_info()
+    Ec = min(E, 400)                                         # the oracle replays the first envs of the batch
+    co = H.COracle(ws, Ec, first_env_id=9)
+    eng.reset(0)
+    co.reset(0)
+    assert np.array_equal(eng.agent_state[:Ec].cpu().numpy(), co.agent_state)
+    for t in range(1, 13):
+        co.step(0, t, random_actions=True)
+        if t % 4 == 0 and E <= 400:                          # policy-driven form: sweep-less launches, one per agent, the next agent's window each
+            acts = torch.from_numpy(co.actions.copy())
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for a in range(a_):
+                eng.step(acts, sweep=False, agent_begin=a, agent_end=a + 1, obs_next=a + 1 < a_, write_obs=False, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            what = ("grid", "agent_pos", "total_reward", "rewards")
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            what = ("grid", "agent_pos", "total_reward", "rewards", "obs", "actions")
+            assert np.array_equal(eng.state_at_pov[:Ec].cpu().numpy(), co.state_at_pov), t
+        ref = dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions)
+        for k in what:
+            assert np.array_equal(getattr(eng, k)[:Ec].cpu().numpy(), ref[k]), f"turn {t}: {k}"
+        assert np.array_equal(eng.agent_state[:Ec].cpu().numpy(), co.agent_state), t
+    assert ((eng.agent_state == ws.tag_it_type).sum(dim=1) == 1).all()      # exactly one "it" per env, always
+    assert eng.status() == 0

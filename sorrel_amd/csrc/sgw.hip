@@ -296,7 +296,12 @@ StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag,
 
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
-StepFn pick_big(bool onehot, int L, int C, int r, const char** name) {
+StepFn pick_big(bool onehot, int L, int C, int r, bool tag, const char** name) {
+    if (tag) {   // TagAgent.act on the workgroup-per-env kernel (moves in registers, the "it" token walked by wave 0)
+        if (onehot && L == 1 && C == 4 && r == 4) PICK(step_big<true, 1, 4, 4, false, false, true>);   // the Tag example's tables and 9x9 window
+        if (onehot) PICK(step_big<true, 0, 0, 0, false, false, true>);
+        PICK(step_big<false, 0, 0, 0, false, false, true>);
+    }
     if (!onehot) PICK(step_big<false, 0, 0, 0>);
     if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5>);   // BASELINE config 5
     PICK(step_big<true, 0, 0, 0>);
@@ -532,6 +537,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tag_reward = c.tag_reward;
     p.agent_mask = 0;
     for (int a = 0; a < c.num_agents; ++a) p.agent_mask |= 1u << (c.agent_type[a] & 31u);
+    if (c.agent_rule == SGW_AGENT_RULE_TAG) p.agent_mask |= (1u << (c.tag_it_type & 31u)) | (1u << (c.tag_notit_type & 31u));
     p.has_become = 0;
     p.become_mask = 0;
     for (int t = 0; t < c.num_types; ++t)
@@ -564,7 +570,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
-    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && plain_move && simple_rules;
+    const bool tag_move = c.agent_rule == SGW_AGENT_RULE_TAG;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
+    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && (plain_move || tag_move) && simple_rules;
+    if (const char* f = getenv("SGW_NO_BIG_TAG")) { if (f[0] == '1' && tag_move) e->big = false; }   // A/B and test hook: the ticket-ordered generic kernel
     bool stage_kernel = false;   // a run-time-shape STAGE kernel applies
     {   // LDS staging of one-hot observations
         const int ob_elems = c.num_agents * c.num_channels * p.VV;
@@ -688,7 +696,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (const char* f = getenv("SGW_PHASE_ROWS")) { if (f[0] == '0') e->rows_fn = nullptr; }   // A/B and test hook: the older phase paths (sgw_step's phases only)
     p.stage_agents = e->stage_agents;
     StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
-                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name)
+                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, &e->kernel_name)
                          : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
@@ -697,9 +705,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (e->fast)
         e->step_fn_multi = pick_fast_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width,
                                            c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name_multi);
-    if (e->big) e->step_fn_multi = pick_big_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_multi);
+    if (e->big && !tag_move) e->step_fn_multi = pick_big_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_multi);
     e->multi_turn = (e->fast || e->big) ? e->step_fn_multi != nullptr : true;   // kernels with sgw_rollout's turn loop
-    if (e->big && ((p.cells + 15) >> 4) <= 4 * kBigThreads)   // the prefetch holds one 4-unit round per thread
+    if (e->big && !tag_move && ((p.cells + 15) >> 4) <= 4 * kBigThreads)   // the prefetch holds one 4-unit round per thread
         e->step_fn_walk = pick_big_walk(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_walk);
     if (const char* f = getenv("SGW_BIG_NO_WALK")) { if (f[0] == '1') e->step_fn_walk = nullptr; }   // A/B hook
     if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {

@@ -40,9 +40,17 @@ constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa
 // drain.  vmcnt counts loads and stores together on gfx9, so the next env's grid (64 B per thread), positions, actions
 // and total are loaded during phase M of the current env -- before this env's stores are issued -- and waited for
 // there; the loop then contains no load that would have to wait behind the observation stores.
-template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false>
+// TAG (round 3): TagAgent.act (sorrel/examples/tag/agents.py:76-106) on this kernel.  A Tag agent moves exactly like a plain
+// mover (agents are impassable), so phase M resolves the moves as before; what is sequential on top is the "it" token:
+// an agent that is "it" WHEN ITS TURN COMES (at the start of the turn, or tagged by an earlier agent of the same turn)
+// hands the flag to the first NotIt agent next to the cell it now stands on.  Wave 0 walks only those agents (typically
+// one per env and turn): lane b knows where agent b stands at that moment (its new cell if it has already acted, its old
+// one if not), four ballots find the neighbours in Location.adjacent order.  The journal of an agent then also says what
+// type it carried when it acted and whom it tagged, and phase R undoes tags along with moves, latest first.
+template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false>
 __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_WAVES : 6) : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
     static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
+    static_assert(!(TAG && (MULTI || WALK)), "Tag: single-turn, one env per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid0 = threadIdx.x;
     int64_t env = blockIdx.x;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
     uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // journal entry of each agent (phase M -> R)
     uint32_t* s_oa = s_ta + 64;                                             // packed (y, x) at the start of the turn
     uint32_t* s_np = s_oa + 64;                                             // packed (y, x) if the move succeeds
-    uint32_t* s_rm = s_np + 64;                                             // reward f32 bits
+    uint32_t* s_rm = s_np + 64;                                             // TAG: the tag journal -- victim's cell (y, x) | type the agent carried when it acted << 16 | tagged << 24
     double* s_val = reinterpret_cast<double*>(s_rm + 64);                   // reward f64 (for total, in agent order)
     double* s_vtab = s_val + 64 + 2;                                         // value[32] (keeps global loads out of the chain)
     uint8_t* s_atype = reinterpret_cast<uint8_t*>(s_vtab + 32);                       // agent_type[64]
@@ -269,7 +277,9 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
     // batches: every mover's old cell <- default, then every mover's new cell <- its type (a cell
     // can be left and then entered in one turn, never the other way round: an agent moves once).
     if (wv == 0 && p.do_move) {
-        const uint32_t atype_v = s_atype[lane];
+        uint32_t atype_v = s_atype[lane];
+        if constexpr (TAG)
+            if (lane < p.A) atype_v = p.agent_state[env * p.A + lane];   // the agent's CURRENT type: "it" or not (survives resets)
         const bool validv = ta_v != 0xFFFFFFFFu;
         const uint32_t t0_v = lg[validv ? ta_v : oaddr_v];
         uint32_t passed_v = 0;
@@ -318,12 +328,55 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
             jr = lane == a ? entry : jr;
             passed_v = lane == a ? (pass ? 1u : 0u) : passed_v;
         }
+        uint32_t type_v = atype_v;        // TAG: the agent's type as the turn proceeds (ends as its final type)
+        uint32_t pov_v = atype_v;         // TAG: its type when its own turn came (what TagAgent.pov appends; what its move carries)
+        uint32_t tagj = 0u;               // TAG: journal word of this agent's tag, 0 = tagged nobody
+        if constexpr (TAG) {
+            const uint32_t cur0 = passed_v ? npos_v : yx;                 // where this agent stands once it has acted
+            unsigned long long todo = ~0ull << p.a0;                      // agents whose turn is still to come
+            if (p.a1 < 64) todo &= (1ull << p.a1) - 1ull;
+            while (true) {
+                const unsigned long long its = __ballot(lane < p.A && type_v == p.tag_it) & todo;
+                if (!its) break;
+                const int i = __builtin_ctzll(its);                       // the next agent that acts as "it"
+                todo &= ~0ull << (i + 1);
+                const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cur0, i);
+                const int cy = (int)(ci & 0xFFu), cx = (int)(ci >> 8);
+                const uint32_t here = lane < i ? cur0 : yx;               // where agent `lane` stands at that moment (later agents have not moved yet)
+                const bool cand = lane < p.A && lane != i && type_v == p.tag_notit;
+                int victim = -1;
+#pragma unroll
+                for (int d = 3; d >= 0; --d) {                            // Location.adjacent order: up, right, down, left; the FIRST match wins
+                    const int ay = cy + (d == 0 ? -1 : d == 2 ? 1 : 0), ax = cx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                    const bool ain = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+                    const unsigned long long hit = __ballot(cand && ain && here == ((uint32_t)ay | ((uint32_t)ax << 8)));
+                    if (hit) victim = __builtin_ctzll(hit);
+                }
+                if (lane == i) pov_v = p.tag_it;
+                if (victim >= 0) {
+                    const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)here, victim);
+                    if (lane == i) { type_v = p.tag_notit; tagj = (cj & 0xFFFFu) | (1u << 24); }
+                    if (lane == victim) type_v = p.tag_it;
+                }
+            }
+        }
         if (passed_v) lg[oaddr_v] = (uint8_t)p.default_type;
         gsync<1>();
-        if (passed_v) lg[ta_v] = (uint8_t)atype_v;
-        const double val = (jr & 0x100u) ? s_vtab[jr & 31u] : 0.0;     // reward = value of the target BEFORE the move
+        if constexpr (TAG) {
+            if (lane < p.A) lg[passed_v ? ta_v : oaddr_v] = (uint8_t)type_v;   // every agent's cell: its FINAL type (a tag flips agents that did not move, too)
+        } else {
+            if (passed_v) lg[ta_v] = (uint8_t)atype_v;
+        }
+        double val = (jr & 0x100u) ? s_vtab[jr & 31u] : 0.0;           // reward = value of the target BEFORE the move
+        if constexpr (TAG) {
+            // TagAgent.act: reward_per_turn for not being "it" once its own act is over (agents.py:100-106)
+            const uint32_t after = tagj ? p.tag_notit : pov_v;
+            val = (mine && after != p.tag_it) ? p.tag_reward : 0.0;
+            s_rm[lane] = tagj | ((pov_v & 0xFFu) << 16);
+            if (lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)type_v;
+            if (mine && p.state_at_pov) p.state_at_pov[env * p.A + lane] = (uint8_t)pov_v;
+        }
         s_val[lane] = val;
-        s_rm[lane] = __float_as_uint((float)val);
         s_ta[lane] = jr;                                                // journal for the render phase
         if (jr & 0x400u) st_lane |= SGW_STATUS_BAD_TYPE;
         if (mine) p.rewards[tix * p.ts_rew + env * p.A + tid] = (float)val;   // this turn's rewards
@@ -355,8 +408,15 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
             woff[k] = wdi[k] * P + wdj[k];
         }
         // lane b: journal of agent b (where it was, where it went, what it found there)
-        const uint32_t jb = s_ta[lane], srcb = s_oa[lane], dstb = s_np[lane], atb = s_atype[lane];
+        const uint32_t jb = s_ta[lane], srcb = s_oa[lane], dstb = s_np[lane];
+        uint32_t atb = s_atype[lane];
+        [[maybe_unused]] uint32_t tgb = 0u;              // TAG: victim's cell | type carried << 16 | tagged << 24
+        if constexpr (TAG) {
+            tgb = p.do_move ? s_rm[lane] : 0u;
+            if (p.do_move) atb = (tgb >> 16) & 0xFFu;    // a move carries the type the agent had when its turn came
+        }
         const bool movedb = p.do_move && (jb & 0x200u) && lane >= p.a0 && lane < p.a1;
+        [[maybe_unused]] const bool taggedb = TAG && p.do_move && ((tgb >> 24) & 1u) && lane >= p.a0 && lane < p.a1;
         const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
         // SGW_STEP_OBS_NEXT: only agent a1, which sees the grid after ALL moves of this call (nothing to undo)
         const int r_lo = p.obs_next ? p.a1 : p.a0, r_hi = p.obs_next ? (p.a1 < p.A ? p.a1 + 1 : p.a1) : p.a1;
@@ -394,14 +454,41 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
             const int ey = (int)(dstb & 0xFFu), ex = (int)((dstb >> 8) & 0xFFu);
             const bool near_src = (unsigned)(sy - y + r) <= (unsigned)(2 * r) && (unsigned)(sx - x + r) <= (unsigned)(2 * r);
             const bool near_dst = (unsigned)(ey - y + r) <= (unsigned)(2 * r) && (unsigned)(ex - x + r) <= (unsigned)(2 * r);
-            unsigned long long undo = __ballot(movedb && lane >= a && (near_src || near_dst));
+            bool touches = movedb && (near_src || near_dst);
+            if constexpr (TAG) {
+                // a tag of agent b changes two cells: the one b stands on after its move, and its victim's
+                const int vy = (int)(tgb & 0xFFu), vx = (int)((tgb >> 8) & 0xFFu);
+                const bool near_vic = (unsigned)(vy - y + r) <= (unsigned)(2 * r) && (unsigned)(vx - x + r) <= (unsigned)(2 * r);
+                touches = touches || (taggedb && (near_vic || (movedb ? near_dst : near_src)));
+            }
+            unsigned long long undo = __ballot(touches && lane >= a);
             while (undo) {
-                const int b = 63 - __builtin_clzll(undo);            // latest move first
+                const int b = 63 - __builtin_clzll(undo);            // latest agent first
                 undo &= ~(1ull << b);
                 const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)srcb, b);
                 const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)dstb, b);
                 const uint32_t oldt = (uint32_t)__builtin_amdgcn_readlane((int)jb, b) & 31u;    // what the target held
-                const uint32_t agt = (uint32_t)__builtin_amdgcn_readlane((int)atb, b) & 31u;    // the mover itself
+                const uint32_t agt = (uint32_t)__builtin_amdgcn_readlane((int)atb, b) & 31u;    // the mover itself (TAG: as it was when it acted)
+                const bool mvb = ((uint32_t)__builtin_amdgcn_readlane((int)jb, b) & 0x200u) != 0;
+                if constexpr (TAG) {
+                    // agent b's turn was: move, then tag.  Undone in reverse: the tag first (b is "it" again where it stands
+                    // after its move, the victim is NotIt again), then the move
+                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)tgb, b);
+                    if ((tg >> 24) & 1u) {
+                        const uint32_t own = mvb ? dst : src, vic = tg & 0xFFFFu;
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+                            const uint32_t key = (uint32_t)((y + wdi[k]) & 0xFF) | ((uint32_t)((x + wdj[k]) & 0xFF) << 8);
+                            const bool at_own = inbk[k] && key == own, at_vic = inbk[k] && key == vic;
+                            if (at_own || at_vic) {
+                                const uint32_t nv = (at_own ? p.tag_it : p.tag_notit) & 31u;
+                                if (zw == 0) tb[k][0] = (tb[k][0] & ~(0xFFu << zsh)) | (nv << zsh);
+                                else tb[k][1] = (tb[k][1] & ~(0xFFu << zsh)) | (nv << zsh);
+                            }
+                        }
+                    }
+                    if (!mvb) continue;
+                }
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     const uint32_t key = (uint32_t)((y + wdi[k]) & 0xFF) | ((uint32_t)((x + wdj[k]) & 0xFF) << 8);
@@ -471,7 +558,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
     }   // turns
 
     // ---- write-back
-    if (dirty && !do_sweep && nturns == 1) {   // (a rollout's earlier turns moved other cells too)
+    if (dirty && !do_sweep && nturns == 1 && !TAG) {   // (a rollout's earlier turns moved other cells too; a tag flips cells of agents that did not move)
         // a policy-driven phase (no sweep): only the movers' two cells changed -- write those bytes, not the whole grid
         if (wv == 0 && mine && (jr & 0x200u)) {
             uint8_t* g = p.grid + env * p.env_stride + p.zA * H * W;

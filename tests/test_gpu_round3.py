@@ -496,3 +496,63 @@ def test_tag_static_instances_vs_oracle(torch_cuda, shape):
         assert np.array_equal(eng.agent_state[:Ec].cpu().numpy(), co.agent_state), t
     assert ((eng.agent_state == ws.tag_it_type).sum(dim=1) == 1).all()      # exactly one "it" per env, always
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ Tag worlds above 4 KiB on step_big<..., TAG>
+@pytest.mark.parametrize("case", ["tag_70x80", "tag_crowded_66x64", "tag_128x128", "tag_72x72_r3_float", "tag_phased", "tag_u8"])
+def test_big_tag_worlds_on_the_workgroup_per_env_kernel_vs_oracle(torch_cuda, case):
+    """TagAgent.act on step_big: moves resolved in registers, the "it" token walked by wave 0, tags undone along with moves
+    when the windows are rendered.  Sparse and crowded worlds (many tags per turn, flags handed on within a turn), the
+    Tag example's tables at 128x128 / 64 agents, a float appearance table, the phased 1 + A form, uint8 windows, and
+    sgw_observe; every tensor, the agents' types and their types at observation time against the C oracle."""
+    torch = torch_cuda
+    import dataclasses
+
+    d, spec = H.load_golden("tag_11x11_default")
+    ws = H.world_spec(spec)
+    kw = {}
+    h, w, a, r, E, T = {"tag_70x80": (70, 80, 12, 4, 13, 25), "tag_crowded_66x64": (66, 64, 64, 4, 7, 14), "tag_128x128": (128, 128, 64, 4, 9, 8),
+                        "tag_72x72_r3_float": (72, 72, 30, 3, 6, 10), "tag_phased": (80, 64, 9, 4, 5, 8), "tag_u8": (70, 70, 40, 2, 6, 8)}[case]
+    ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, vision_radius=r, agent_type=[ws.agent_type[0]] * a)
+    if case == "tag_72x72_r3_float":
+        ws.appearance = ws.appearance * 1.0
+        ws.appearance[ws.tag_it_type, 0] = 2.5           # not one-hot: the float64 layer-sum path
+    if case == "tag_u8":
+        kw["obs_dtype"] = torch.uint8
+    eng = make_engine(ws, E, first=17, **kw)
+    assert "step_big<" in eng.launch_info() and ", true>" in eng.launch_info().split(" group")[0], eng.launch_info()
+    co = H.COracle(ws, E, first_env_id=17)
+    eng.reset(0)
+    co.reset(0)
+    assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
+    ref = lambda: dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions)
+    for t in range(1, T + 1):
+        assert co.step(0, t, random_actions=True) == 0
+        if case == "tag_phased":
+            acts = torch.from_numpy(co.actions.copy()).cuda()
+            seen = torch.zeros_like(eng.obs)
+            eng.obs.fill_(-3.0)
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for i in range(a):
+                seen[:, i] = eng.obs[:, i]
+                eng.step(acts, sweep=False, agent_begin=i, agent_end=i + 1, obs_next=i + 1 < a, write_obs=False, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(seen.cpu().numpy(), co.obs), f"{case} turn {t}: phased windows"
+            what = ("grid", "agent_pos", "total_reward")
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            what = ("grid", "agent_pos", "total_reward", "rewards", "actions", "obs")
+            assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov), f"{case} turn {t}: state_at_pov"
+        for k in what:
+            assert np.array_equal(getattr(eng, k).cpu().numpy().astype(ref()[k].dtype), ref()[k]), f"{case} turn {t}: {k}"
+        assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), f"{case} turn {t}: agent_state"
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy().astype(np.float32), co.obs), "sgw_observe"
+    assert ((eng.agent_state == ws.tag_it_type).sum(dim=1) == 1).all()
+    if case == "tag_crowded_66x64":
+        assert len(np.unique(eng.agent_state.cpu().numpy(), axis=0)) > 1        # the flag really moved around
+    assert eng.status() == 0

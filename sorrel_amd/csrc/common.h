@@ -65,6 +65,7 @@ struct Params {
     uint8_t* agent_state;      // optional [E][A]: current type of every agent
     uint8_t* agent_dir;        // optional [E][A]: facing (SGW_AGENT_RULE_CLEANUP)
     int has_become;            // some type carries SGW_RULE_BECOME_IF: ordered, layer-by-layer sweep
+    uint32_t quiet0, quiet1;   // ordered sweep: dwords equal to one of these hold four cells of a rule-less layer-fill type (or pad bytes): skipped
     uint32_t kind_pack;        // 2 bits per action: SGW_ACTION_*
     int beam_radius;
     uint32_t clean_beam, zap_beam, beam_block_mask;
@@ -291,27 +292,52 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
 // Ordered sweep for rule sets with cross-layer conditions (SGW_RULE_BECOME_IF, e.g. Cleanup): the
 // reference visits cells in (y, x, z) order over a LIVE view, so within a column a lower layer has
 // already transitioned when a higher one is visited and a higher one has not when a lower one is.
-// Columns never read each other, so: one pass per layer, all cells of the layer in parallel.
-template <int WPE, int G>
-__device__ __forceinline__ void sweep_ordered(const Params& p, const DevTables* tab, uint8_t* lg, uint32_t env_id, int gtid, uint32_t turn) {
-    const int HW = p.H * p.W;
-    for (int z = 0; z < p.L; ++z) {
-        for (int cidx = gtid; cidx < HW; cidx += G) {
-            const int off = z * HW + cidx;
-            const uint32_t t = lg[off];
-            if (t >= SGW_MAX_TYPES) continue;
-            const uint32_t rule = tab->rule[t];
-            if (rule == SGW_RULE_BECOME_IF) {
-                const int zl = tab->rule_layer[t];
-                const bool fire = zl < 0 || ((tab->rule_mask[t] >> (lg[zl * HW + cidx] & 31u)) & 1u);
-                if (fire) lg[off] = tab->rule_become[t];
-            } else if (rule == SGW_RULE_SPAWN) {
-                const U4 w = philox4x32_10((uint32_t)off >> 2, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
-                if (((p.thr_full_mask >> t) & 1u) || word_of(w, off & 3) < tab->thr_lo[t]) {
-                    const U4 k = philox4x32_10((uint32_t)off >> 2, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
-                    lg[off] = tab->spawn_choice[t][__umulhi(word_of(k, off & 3), (uint32_t)tab->spawn_count[t])];
+// Columns never read each other and rules write their own cell only, so: one pass per layer, lower layers first, all
+// cells of the layer in parallel -- one dword (four cells = one Philox block) per lane and step.  `Tab` is DevTables
+// (generic kernels: the table block in LDS) or RuleLds (the RULES variant of step_fast: its wave-private copy).
+// (Round 3: the generic kernels walked this byte by byte with a Philox block per CELL; Cleanup 48x48x3: 30 of 101 us.)
+template <int WPE, int G, typename Tab>
+__device__ __forceinline__ void sweep_ordered(const Params& p, const Tab* rt, uint8_t* lg, const uint32_t env_id, const int gtid,
+                                              const uint32_t turn, const int L, const int HW) {
+    const uint32_t* lg32 = reinterpret_cast<const uint32_t*>(lg);
+    for (int z = 0; z < L; ++z) {
+        const int lo = z * HW, hi = lo + HW;
+        for (int d = (lo >> 2) + gtid; d < ((hi + 3) >> 2); d += G) {   // one dword = four cells = one Philox block
+            const uint32_t word = lg32[d];
+            if (word == p.quiet0 || word == p.quiet1) continue;       // four cells of a fill type without a rule (most of an agent / beam layer)
+            uint32_t tj[4];
+            bool spj[4], bcj[4];
+            bool any_sp = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int off = 4 * d + j;
+                tj[j] = (word >> (8 * j)) & 0xFFu;
+                const bool in = off >= lo && off < hi && tj[j] < (uint32_t)SGW_MAX_TYPES;   // (a dword may straddle two layers)
+                spj[j] = in && ((p.spawn_mask >> (tj[j] & 31u)) & 1u);
+                bcj[j] = in && ((p.become_mask >> (tj[j] & 31u)) & 1u);
+                any_sp = any_sp || spj[j];
+            }
+            if (any_sp) {
+                const U4 w = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                uint32_t hit = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (spj[j] && (((p.thr_full_mask >> tj[j]) & 1u) || word_of(w, j) < rt->thr_lo[tj[j]])) hit |= 1u << j;
+                if (hit) {   // rare: what spawns
+                    const U4 kw = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((hit >> j) & 1u)
+                            lg[4 * d + j] = rt->spawn_choice[tj[j]][__umulhi(word_of(kw, j), (uint32_t)rt->spawn_count[tj[j]])];
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (bcj[j]) {
+                    const int zl = rt->rule_layer[tj[j]];
+                    const bool fire = zl < 0 || ((rt->rule_mask[tj[j]] >> (lg[zl * HW + (4 * d + j - lo)] & 31u)) & 1u);
+                    if (fire) lg[4 * d + j] = rt->rule_become[tj[j]];
+                }
         }
         gsync<WPE>();
     }

@@ -545,6 +545,14 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             p.has_become = 1;
             p.become_mask |= 1u << t;
         }
+    p.quiet0 = p.quiet1 = 0xFFFFFFFFu;         // (four pad bytes: never cells)
+    for (int z = 0; z < c.layers; ++z) {
+        const uint32_t t = c.layer_fill_type[z];
+        if (t >= (uint32_t)c.num_types || c.type_rule[t] != SGW_RULE_NONE) continue;
+        const uint32_t w = 0x01010101u * t;
+        if (p.quiet0 == 0xFFFFFFFFu || p.quiet0 == w) p.quiet0 = w;
+        else if (p.quiet1 == 0xFFFFFFFFu || p.quiet1 == w) p.quiet1 = w;
+    }
     p.kind_pack = 0;
     for (int a = 0; a < c.num_actions; ++a) p.kind_pack |= (uint32_t)(c.action_kind[a] & 3u) << (2 * a);
     p.beam_radius = c.beam_radius;
@@ -587,7 +595,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             // run-time shapes: as many agents per burst as fit the wave's share of LDS at full occupancy (8 workgroups
             // of 4 waves per CU, 1 KiB granules: 5 120 bytes per wave); if not even one agent fits, at 5 workgroups per CU
             const int base = e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad;
-            int budget = (int)(kLdsPerCu / 8 / 4) - base - 16;
+            // The RULES kernels (layered rule sets: big windows over three layers) stage for FIVE workgroups per CU: longer bursts and
+            // fewer half-written observation streams open at once beat the extra waves, as for the occupancy cap of the plain
+            // kernels -- Cleanup 21x31x3 at 65 536 envs, agents per burst 1 / 2 / 3 / 4 / 5 / 10: 666 / 695 / 643-680 / 640 / 643 / 850 us
+            // (16 384 envs: 201 / 193 / 185-190 / 188 / 181 / 240).
+            int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16 : (int)(kLdsPerCu / 8 / 4) - base - 16;
             if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16;
             if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook
             int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;

@@ -250,50 +250,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         if constexpr (RULES) {
             gsync<1>();
             if (do_sweep) {
-                // Ordered sweep in LDS.  The reference visits cells in (y, x, z) order and a rule may read another
-                // layer of its own column (environment.py:88-91): going layer by layer, lower layers first, gives every
-                // cell the same view (lower layers already swept, higher ones not yet); rules write their own cell only.
-                const uint32_t* lg32 = reinterpret_cast<const uint32_t*>(lg);
-                for (int z = 0; z < L; ++z) {
-                    const int lo = z * HW, hi = lo + HW;
-                    for (int d = (lo >> 2) + lane; d < ((hi + 3) >> 2); d += 64) {   // one dword = four cells = one Philox block
-                        const uint32_t word = lg32[d];
-                        uint32_t tj[4];
-                        bool spj[4], bcj[4];
-                        bool any_sp = false;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int off = 4 * d + j;
-                            tj[j] = (word >> (8 * j)) & 0xFFu;
-                            const bool in = off >= lo && off < hi && tj[j] < (uint32_t)SGW_MAX_TYPES;
-                            spj[j] = in && ((p.spawn_mask >> (tj[j] & 31u)) & 1u);
-                            bcj[j] = in && ((p.become_mask >> (tj[j] & 31u)) & 1u);
-                            any_sp = any_sp || spj[j];
-                        }
-                        if (any_sp) {
-                            const U4 w = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
-                            uint32_t hit = 0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (spj[j] && (((p.thr_full_mask >> tj[j]) & 1u) || word_of(w, j) < rt->thr_lo[tj[j]])) hit |= 1u << j;
-                            if (hit) {   // rare: what spawns
-                                const U4 kw = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if ((hit >> j) & 1u)
-                                        lg[4 * d + j] = rt->spawn_choice[tj[j]][__umulhi(word_of(kw, j), (uint32_t)rt->spawn_count[tj[j]])];
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (bcj[j]) {
-                                const int zl = rt->rule_layer[tj[j]];
-                                const bool fire = zl < 0 || ((rt->rule_mask[tj[j]] >> (lg[zl * HW + (4 * d + j - lo)] & 31u)) & 1u);
-                                if (fire) lg[4 * d + j] = rt->rule_become[tj[j]];
-                            }
-                    }
-                    gsync<1>();
-                }
+                // Ordered sweep in LDS (common.h): layer by layer, lower layers first, a dword (four cells, one Philox block) per lane
+                sweep_ordered<1, 64>(p, rt, lg, env_id, lane, turn, L, HW);
             }
         } else {
             if (tix > 0) {   // later turns of a rollout: the units come back from LDS (moves and spawns of the turns before)
@@ -370,33 +328,38 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
             const int sh = (int)ch_shift;
             const int nd = (sh + N + 3) >> 2;
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
+            // dwords [i0, i1) lie wholly inside the chunk: unconditional 16-byte streaming stores; the (at most two) edge
+            // dwords leave element by element (round 3: the bounds test sat on every float4 of the loop)
+            const int i0 = sh > 0 ? 1 : 0, i1 = (sh + N) >> 2;
             if (!p.obs_u8) {
                 float* gb = p.obs + (e0 - sh);
-                for (int i = lane; i < nd; i += 64) {
+                for (int i = i0 + lane; i < i1; i += 64) {
                     const uint32_t b = ob4[i];
                     vfloat4 v;
                     v.x = (float)(b & 0xFFu);
                     v.y = (float)((b >> 8) & 0xFFu);
                     v.z = (float)((b >> 16) & 0xFFu);
                     v.w = (float)(b >> 24);
-                    const int lo = 4 * i - sh;       // chunk element held by byte 0 of this dword
-                    if (lo >= 0 && lo + 4 <= N) {
-                        __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
-                    } else {
-                        if (lo >= 0 && lo < N) gb[4 * i] = v.x;
-                        if (lo + 1 >= 0 && lo + 1 < N) gb[4 * i + 1] = v.y;
-                        if (lo + 2 >= 0 && lo + 2 < N) gb[4 * i + 2] = v.z;
-                        if (lo + 3 >= 0 && lo + 3 < N) gb[4 * i + 3] = v.w;
+                    __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
+                }
+                if (lane < 2) {
+                    const int i = lane == 0 ? 0 : i1;                     // the first and the last dword of the span
+                    if ((lane == 0 ? sh > 0 : (i1 < nd && (i1 > 0 || sh == 0)))) {
+                        const uint32_t b = ob4[i];
+                        const int lo = 4 * i - sh;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (lo + j >= 0 && lo + j < N) gb[4 * i + j] = (float)((b >> (8 * j)) & 0xFFu);
                     }
                 }
             } else {
                 uint8_t* gb = reinterpret_cast<uint8_t*>(p.obs) + (e0 - sh);
-                for (int i = lane; i < nd; i += 64) {
-                    const uint32_t b = ob4[i];
-                    const int lo = 4 * i - sh;
-                    if (lo >= 0 && lo + 4 <= N) {
-                        __builtin_nontemporal_store(b, reinterpret_cast<uint32_t*>(gb + 4 * i));
-                    } else {
+                for (int i = i0 + lane; i < i1; i += 64) __builtin_nontemporal_store(ob4[i], reinterpret_cast<uint32_t*>(gb + 4 * i));
+                if (lane < 2) {
+                    const int i = lane == 0 ? 0 : i1;
+                    if ((lane == 0 ? sh > 0 : (i1 < nd && (i1 > 0 || sh == 0)))) {
+                        const uint32_t b = ob4[i];
+                        const int lo = 4 * i - sh;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (lo + j >= 0 && lo + j < N) gb[4 * i + j] = (uint8_t)(b >> (8 * j));

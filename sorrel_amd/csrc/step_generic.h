@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         gsync<WPE>();
         if (p.flags & SGW_STEP_SWEEP) {
             if (p.has_become) {
-                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid, turn);
+                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid, turn, p.L, HW);
             } else {
                 if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid, turn);
                 else sweep<G>(p, tab, lg, env_id, gtid, turn);

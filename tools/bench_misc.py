@@ -111,11 +111,11 @@ def run_big_rule_worlds():
     for name, spec, E in (("big tag 72x72x1 A16 r4", tag_spec(72, 72, 16, 4), 8192),
                           ("big tag 128x128x1 A64 r4", tag_spec(128, 128, 64, 4), 2048)):
         eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
-        for _ in range(100): eng.step(random_actions=True)
+        for _ in range(100): eng.step(random_actions=True, **KW)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(100): eng.step(random_actions=True)
+        for _ in range(100): eng.step(random_actions=True, **KW)
         b.record(); torch.cuda.synchronize()
         us = a.elapsed_time(b) / 100 * 1000
         byt = spec.algorithmic_bytes_per_env_step() * E
@@ -130,11 +130,11 @@ def run_big_rule_worlds():
     for (y, x) in pos: g[1, y, x] = 11
     eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
     eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
-    for _ in range(100): eng.step(random_actions=True)
+    for _ in range(100): eng.step(random_actions=True, **KW)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(100): eng.step(random_actions=True)
+    for _ in range(100): eng.step(random_actions=True, **KW)
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 100 * 1000
     byt = spec.algorithmic_bytes_per_env_step() * E

@@ -236,7 +236,9 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
  * rows[a][e * env_stride + (c * V + i) * V + j] for env e -- a row of that agent's replay buffer (env_stride = C*V*V) or
  * slot a of the observation tensor (rows[a] = obs + a*C*V*V, env_stride = A*C*V*V); element type = sgw_set_obs_format's.
  * sgw_observe_rows needs SGW_CAP_OBSERVE_ROWS (one-hot float32 windows of an instantiated layers / channels / radius),
- * sgw_act needs SGW_CAP_ACT (SGW_AGENT_RULE_MOVE; any appearance table, float32 or uint8 windows); rows entries of agents
+ * sgw_act (SGW_CAP_ACT) serves every agent rule -- MovingAgent.act, TagAgent.act (the tagger's and its victim's cells are
+ * repaired too; agent_state / state_at_pov kept as by sgw_step) and CleanupAgent.act (beam cells too; agent_dir kept) --
+ * for any appearance table and float32 or uint8 windows; rows entries of agents
  * <= `agent` are ignored by sgw_act, NULL entries (or rows == NULL) are skipped.
  * sgw_act's optional extras keep the host out of the agent loop: `agent_action` (device, [E], element type
  * `action_kind`) is read INSTEAD of actions[:, agent] -- the policy's output tensor as it is, no narrowing copy; the

@@ -361,18 +361,25 @@ __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 
 struct MoveOut {
     int old_y, old_x, new_y, new_x;
     uint32_t my_type;
+    uint32_t found;      // what the target cell held before the agent entered it
+};
+struct ActIO {                   // sgw_act's optional extras (see RowPtrs), passed by value
+    const void* agent_action = nullptr;
+    int action_kind = 0;
+    float* reward_row = nullptr;
+    int64_t* action_row = nullptr;
 };
 __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, uint8_t* g, const int64_t env, const int a,
-                                        const double* wval, const bool writer, MoveOut& mo, const RowPtrs* io = nullptr) {
+                                        const double* wval, const bool writer, MoveOut& mo, const ActIO io = ActIO{}) {
     const int H = p.H, W = p.W, HW = H * W;
     int st = 0;
     uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
     uint32_t act;
     int64_t act_raw;
-    if (io && io->agent_action) {                        // the policy's own output tensor: one action per env
-        act_raw = io->action_kind == SGW_ACT_I64 ? reinterpret_cast<const int64_t*>(io->agent_action)[env]
-                : io->action_kind == SGW_ACT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(io->agent_action)[env]
-                                                    : (int64_t)reinterpret_cast<const uint8_t*>(io->agent_action)[env];
+    if (io.agent_action) {                               // the policy's own output tensor: one action per env
+        act_raw = io.action_kind == SGW_ACT_I64 ? reinterpret_cast<const int64_t*>(io.agent_action)[env]
+                : io.action_kind == SGW_ACT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(io.agent_action)[env]
+                                                   : (int64_t)reinterpret_cast<const uint8_t*>(io.agent_action)[env];
         act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;     // out of range either way: SGW_STATUS_BAD_ACTION
     } else {
         act = p.actions[env * p.A + a];
@@ -392,7 +399,7 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
     const double val = tok ? (wval ? wval[t & 31u] : gtab->value[t & 31u]) : 0.0;   // reward read BEFORE the move
     const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
     st |= !act_ok ? SGW_STATUS_BAD_ACTION : (!tinb ? SGW_STATUS_OOB_MOVE : (!tok ? SGW_STATUS_BAD_TYPE : 0));
-    mo.old_y = -1; mo.old_x = 0; mo.new_y = -1; mo.new_x = 0; mo.my_type = my_type;
+    mo.old_y = -1; mo.old_x = 0; mo.new_y = -1; mo.new_x = 0; mo.my_type = my_type; mo.found = t;
     if (pass) { mo.old_y = my; mo.old_x = mx; mo.new_y = ty; mo.new_x = tx; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (writer) {
@@ -403,11 +410,9 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
         }
         p.rewards[env * p.A + a] = (float)val;
         p.total[env] = tot + val;                                              // float64, agent order (agent.py:172)
-        if (io) {
-            if (io->agent_action) p.actions[env * p.A + a] = (uint8_t)act;     // the record of what was taken
-            if (io->reward_row) io->reward_row[env] = (float)val;
-            if (io->action_row) io->action_row[env] = act_raw;
-        }
+        if (io.agent_action) p.actions[env * p.A + a] = (uint8_t)act;         // the record of what was taken
+        if (io.reward_row) io.reward_row[env] = (float)val;
+        if (io.action_row) io.action_row[env] = act_raw;
     }
     return st;
 }
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(kBlock, 8) void phase_rows(const Params p) {
 
     // ---- the move: decided from reads only; its stores wait for every row load of this wave
     gsync<1>();                                                                // table words visible to every lane
-    MoveOut mo{-1, 0, -1, 0, 0u};
+    MoveOut mo{-1, 0, -1, 0, 0u, 0u};
     if (mover) st |= move_one(p, gtab, g, env, p.a0, wval, live && gl == 0, mo);
     if (st && live && gl == 0) atomicOr(p.status, st);
     if (!render) return;
@@ -545,16 +550,35 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
     rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, p.C, lane, live && gl < V, p.rows_mode);
 }
 
-// ---------------------------------------------------------------- sgw_act: one agent moves, later agents' windows are repaired
-// MovingAgent.act of agent a (= p.a0) of every env, and -- instead of rendering the next agent's window again -- the at
-// most two cells the move changed are rewritten in the window of every LATER agent that sees them (the windows of a turn
-// were rendered once, after the sweep: sgw_observe_rows / sgw_observe).  Agent j's window then shows the grid after the
-// moves of agents < j: exactly what its pov() reads in the reference (agent.py:155-173).  Any appearance
-// table, float32 or uint8 windows.  G lanes per env (a power of two >= A), lane j = agent j.
-template <int G>
-__global__ __launch_bounds__(kBlock, 8) void act_patch(const Params p, const RowPtrs rp) {
+// ---------------------------------------------------------------- sgw_act: one agent acts, later agents' windows are repaired
+// Agent.act of agent a (= p.a0) of every env -- MovingAgent.act (agent.py:215-225), TagAgent.act (examples/tag/agents.py:
+// 76-106) or CleanupAgent.act (examples/cleanup/agents.py:93-177), RULE -- and, instead of rendering the next agent's window
+// again, every cell the act changed is rewritten in the window of every LATER agent that sees it (the windows of a turn
+// were rendered once, after the sweep: sgw_observe_rows / SGW_STEP_NO_MOVE).  Agent j's window then shows the grid after
+// the acts of agents < j: exactly what its pov() reads in the reference (agent.py:155-173).  An act changes
+// few cells: the mover's two; for Tag the tagger's and its victim's; for Cleanup up to 3 R beam cells on the layer above.
+// Any appearance table, float32 or uint8 windows.  G lanes per env, lane j = agents j, j + G, ... (NJ of them: G * NJ >= A;
+// 9..16 agents share 8 lanes two by two -- Cleanup's ten agents: half the waves of a 16-lane group, an act without repairs
+// 23 -> ... us at 65 536 envs); every lane of a group evaluates the act from same-address loads (vector instructions
+// cost the same for 1 or 64 lanes), lane 0 of the group stores.  A changed cell is recomputed from the grid column with the changed layer's NEW type substituted (the
+// stores of this launch are never read back by it).
+template <int G, int NJ, int RULE>
+__global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) void act_patch(const Params p, const RowPtrs rp) {   // (Cleanup: 27 registers spilled at 64)
     constexpr int EPW = 64 / G;
+    // the appearance tables a repair looks up: in LDS (a repair is then ONE global round trip -- the cell's other layers --
+    // instead of a chain of dependent table loads from global memory: Cleanup's crowded 11x11 windows made an act 35-90 us)
+    __shared__ uint32_t s_delta[4 * SGW_MAX_TYPES];
+    __shared__ double s_app[SGW_MAX_TYPES * SGW_MAX_CHANNELS];
+    __shared__ double s_value[SGW_MAX_TYPES];            // Entity.value: keeps a dependent global load out of every act
     const int tid = threadIdx.x;
+    const DevTables* gtab = p.tab;
+    if (tid >= 128 && tid < 128 + SGW_MAX_TYPES) s_value[tid - 128] = gtab->value[tid - 128];
+    if (p.onehot) {
+        if (tid < 4 * SGW_MAX_TYPES) s_delta[tid] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid];
+    } else {
+        for (int i = tid; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBlock) s_app[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
+    }
+    __syncthreads();
     const int lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t env0 = ((int64_t)blockIdx.x * 4 + sub) * EPW;
@@ -563,45 +587,244 @@ __global__ __launch_bounds__(kBlock, 8) void act_patch(const Params p, const Row
     int64_t env = env0 + (lane / G);
     const bool live = env < p.E;
     if (!live) env = p.E - 1;
-    const DevTables* gtab = p.tab;
     const int H = p.H, W = p.W, HW = H * W, C = p.C, V = p.V, VV = p.VV, r = p.r, L = p.L, a = p.a0;
     uint8_t* g = p.grid + env * p.env_stride;
-    uint32_t pj = 0;
-    const bool later = live && j > a && j < p.A;
-    if (later) pj = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + j];
-    MoveOut mo;
-    const int st = move_one(p, gtab, g, env, a, nullptr, live && j == 0, mo, &rp);
-    if (st && live && j == 0) atomicOr(p.status, st);
-    if (!later || mo.old_y < 0 || rp.p[j] == nullptr) return;
-    const int yj = (int)(pj & 0xFFu), xj = (int)(pj >> 8);
+    const bool writer = live && j == 0;
+    uint32_t pjv[NJ];                                                        // where this lane's agents stand (0xFFFFFFFF: no such agent)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int cy = k ? mo.new_y : mo.old_y, cx = k ? mo.new_x : mo.old_x;
-        const uint32_t nt = k ? mo.my_type : p.default_type;
-        const int di = cy - yj + r, dj = cx - xj + r;
+    for (int n = 0; n < NJ; ++n) {
+        const int jj = j + n * G;
+        pjv[n] = (live && jj < p.A) ? (uint32_t)reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + jj] : 0xFFFFFFFFu;
+    }
+
+    // cell (cy, cx) held type `ot` on layer `zc` and now holds `nt`: rewrite it in this lane's window if the window contains
+    // it -- only the channels whose value changes (a one-hot type change touches at most two of the C channel planes; every
+    // store here is a lone 4-byte write into a tensor far bigger than the caches, so they are what a repair costs:
+    // Cleanup 21x31x3, 65 536 envs, an act with every agent firing 152 -> ... us)
+    auto patch = [&](const int cy, const int cx, const int zc, const uint32_t ot, const uint32_t nt) {
+      if (ot == nt) return;
+#pragma unroll
+      for (int n = 0; n < NJ; ++n) {
+        const int jj = j + n * G;
+        if (!(live && jj > a && jj < p.A) || rp.p[jj] == nullptr) continue;  // a later agent with a window to keep current
+        const int di = cy - (int)(pjv[n] & 0xFFu) + r, dj = cx - (int)((pjv[n] >> 8) & 0xFFu) + r;
         if ((unsigned)di >= (unsigned)V || (unsigned)dj >= (unsigned)V) continue;
         const int64_t o = env * rp.stride + di * V + dj;
+        uint32_t tz[SGW_MAX_LAYERS];
+#pragma unroll
+        for (int z = 0; z < SGW_MAX_LAYERS; ++z)                             // the column's other layers: loads issued together
+            tz[z] = z < L ? ((z == zc ? nt : (uint32_t)g[z * HW + cy * W + cx]) & 31u) : 0u;
         if (p.onehot) {                                   // one-hot tables: byte counters
             uint32_t cnt[4] = {0u, 0u, 0u, 0u};
-            for (int z = 0; z < L; ++z) {
-                const uint32_t tz = (z == p.zA ? nt : (uint32_t)g[z * HW + cy * W + cx]) & 31u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cnt[q] += gtab->delta[q][tz];
-            }
-            for (int c = 0; c < C; ++c) {
-                const uint32_t v = (cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu;
-                if (p.obs_u8) reinterpret_cast<uint8_t*>(rp.p[j])[o + (int64_t)c * VV] = (uint8_t)v;
-                else reinterpret_cast<float*>(rp.p[j])[o + (int64_t)c * VV] = (float)v;
+            for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+                if (z < L) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cnt[q] += s_delta[q * SGW_MAX_TYPES + tz[z]];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t diff = s_delta[q * SGW_MAX_TYPES + (ot & 31u)] ^ s_delta[q * SGW_MAX_TYPES + (nt & 31u)];
+                if (!diff) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = 4 * q + b;
+                    if (c < C && ((diff >> (8 * b)) & 0xFFu)) {
+                        const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
+                        if (p.obs_u8) reinterpret_cast<uint8_t*>(rp.p[jj])[o + (int64_t)c * VV] = (uint8_t)v;
+                        else reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = (float)v;
+                    }
+                }
             }
         } else {                                          // np.sum over layers: left to right, float64 (visual_field.py:51)
             for (int c = 0; c < C; ++c) {
-                double acc = 0.0;
-                for (int z = 0; z < L; ++z) {
-                    const uint32_t tz = (z == p.zA ? nt : (uint32_t)g[z * HW + cy * W + cx]) & 31u;
-                    acc = z == 0 ? gtab->appearance[tz][c] : acc + gtab->appearance[tz][c];
-                }
-                reinterpret_cast<float*>(rp.p[j])[o + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
+                if (s_app[(ot & 31u) * SGW_MAX_CHANNELS + c] == s_app[(nt & 31u) * SGW_MAX_CHANNELS + c]) continue;
+                double acc = s_app[tz[0] * SGW_MAX_CHANNELS + c];
+#pragma unroll
+                for (int z = 1; z < SGW_MAX_LAYERS; ++z)
+                    if (z < L) acc += s_app[tz[z] * SGW_MAX_CHANNELS + c];
+                reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
             }
         }
+      }
+    };
+
+    if constexpr (RULE == SGW_AGENT_RULE_MOVE) {
+        MoveOut mo;
+        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, rp.reward_row, rp.action_row});
+        if (st && writer) atomicOr(p.status, st);
+        if (mo.old_y < 0) return;
+        patch(mo.old_y, mo.old_x, p.zA, mo.my_type, p.default_type);
+        patch(mo.new_y, mo.new_x, p.zA, mo.found, mo.my_type);
+        return;
+    } else {
+        // ---- inputs of the act (same-address loads in every lane of the group)
+        int st = 0;
+        uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
+        uint32_t act;
+        int64_t act_raw;
+        if (rp.agent_action) {
+            act_raw = rp.action_kind == SGW_ACT_I64 ? reinterpret_cast<const int64_t*>(rp.agent_action)[env]
+                    : rp.action_kind == SGW_ACT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(rp.agent_action)[env]
+                                                    : (int64_t)reinterpret_cast<const uint8_t*>(rp.agent_action)[env];
+            act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;
+        } else {
+            act = p.actions[env * p.A + a];
+            act_raw = act;
+        }
+        const uint32_t my_type = p.agent_state ? p.agent_state[env * p.A + a] : gtab->agent_type[a];
+        const double tot = p.total[env];
+        if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
+        const int y = (int)(yx & 0xFFu), x = (int)(yx >> 8);
+        const bool act_ok = act < (uint32_t)p.nact;
+        double reward = 0.0, total_add = 0.0;
+        bool pass = false;
+        int ny = y, nx = x;
+        uint32_t found = 0u;                 // what the cell the agent moved onto held
+        if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
+            // CleanupAgent.act: a move action turns the agent (even if the move fails) and moves it; clean / zap place a
+            // beam on the layer above; the reward is the value summed over ALL layers of the target, read before the move
+            uint32_t dir = p.agent_dir[env * p.A + a] & 3u;
+            const uint32_t kind = act_ok ? (p.kind_pack >> (2 * (act & 15u))) & 3u : 0u;
+            if (!act_ok) {
+                st |= SGW_STATUS_BAD_ACTION;
+            } else {
+                if (kind == SGW_ACTION_MOVE) {
+                    const int dy = (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1, dx = (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+                    ny = y + dy; nx = x + dx;
+                    dir = (dy == -1 && dx == 0) ? 0u : (dy == 1 && dx == 0) ? 2u : (dy == 0 && dx == -1) ? 3u : (dy == 0 && dx == 1) ? 1u : dir;
+                }
+                // the target column's bytes are loaded BEFORE the beams are placed (one round trip for both: beams never land on
+                // the target of the same act -- a firing agent's target is its own cell, the beam cells start next to it)
+                const bool tin = (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
+                uint32_t tl[SGW_MAX_LAYERS];
+#pragma unroll
+                for (int zl = 0; zl < SGW_MAX_LAYERS; ++zl) tl[zl] = (tin && zl < L) ? (uint32_t)g[zl * HW + ny * W + nx] : 0u;
+                if (kind != SGW_ACTION_MOVE && p.zA + 1 < L) {
+                    // The beam cells (1..R ahead; 0..R-1 ahead of the right / left neighbours) are spread over the lanes of the
+                    // group: lane k tests and writes cells k, k + G, ... (independent loads, one wait), a ballot tells every
+                    // lane which cells took a beam, and each later agent's lane repairs those inside its window.
+                    const int fy = dir == 0 ? -1 : dir == 2 ? 1 : 0, fx = dir == 1 ? 1 : dir == 3 ? -1 : 0;
+                    const int ry = dir == 1 ? 1 : dir == 3 ? -1 : 0, rx = dir == 0 ? 1 : dir == 2 ? -1 : 0;
+                    const uint32_t beam = kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam;
+                    const int nb = 3 * p.beam_radius;
+                    auto beam_cell = [&](const int b, int& by, int& bx) {
+                        const int arm = b / p.beam_radius, i = b - arm * p.beam_radius;
+                        const int step = arm == 0 ? i + 1 : i, side = arm == 0 ? 0 : (arm == 1 ? 1 : -1);
+                        by = y + side * ry + step * fy;
+                        bx = x + side * rx + step * fx;
+                        return (unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W;
+                    };
+                    for (int b0 = 0; b0 < nb; b0 += G) {                    // (uniform over the wave: nb is a launch constant)
+                        int by, bx;
+                        const int b = b0 + j;
+                        bool placed = false;
+                        uint32_t was = 0u;                                      // what the beam cell held
+                        if (b < nb && beam_cell(b, by, bx)) {
+                            const int boff = (p.zA + 1) * HW + by * W + bx;
+                            was = g[boff] & 31u;
+                            placed = !((p.beam_block_mask >> was) & 1u);
+                            if (placed && live) g[boff] = (uint8_t)beam;        // (a cell is visited at most once per act)
+                        }
+                        const unsigned long long all = __ballot(placed);
+                        uint32_t mine_grp = (uint32_t)(all >> (lane & ~(G - 1))) & (G == 64 ? 0xFFFFFFFFu : ((1u << (G & 31)) - 1u));
+                        if constexpr (G == 64) {
+                            unsigned long long m = all;
+                            while (m) {
+                                const int k = __builtin_ctzll(m);
+                                m &= m - 1ull;
+                                int cy, cx;
+                                beam_cell(b0 + k, cy, cx);
+                                patch(cy, cx, p.zA + 1, (uint32_t)__builtin_amdgcn_readlane((int)was, k), beam);
+                            }
+                        } else {
+                            while (mine_grp) {                                  // (divergent across the envs of a wave: each lane walks its own group's bits)
+                                const int k = __ffs(mine_grp) - 1;
+                                mine_grp &= mine_grp - 1u;
+                                int cy, cx;
+                                beam_cell(b0 + k, cy, cx);
+                                patch(cy, cx, p.zA + 1, (uint32_t)__shfl((int)was, (lane & ~(G - 1)) + k), beam);
+                            }
+                        }
+                    }
+                }
+                if (!tin) {
+                    st |= SGW_STATUS_OOB_MOVE;
+                    ny = y; nx = x;
+                } else {
+#pragma unroll
+                    for (int zl = 0; zl < SGW_MAX_LAYERS; ++zl)
+                        if (zl < L) reward += s_value[tl[zl] & 31u];                  // every layer of the target, read BEFORE the move
+                    total_add = reward * (double)(p.total_factor - 1);       // the extra add inside act() (agents.py:172)
+                    uint32_t t = 0xFFu;
+#pragma unroll
+                    for (int zl = 0; zl < SGW_MAX_LAYERS; ++zl)
+                        if (zl == p.zA) t = tl[zl];
+                    pass = t < (uint32_t)p.T && ((p.pass_mask >> (t & 31u)) & 1u);
+                    found = t;
+                }
+            }
+            if (writer) p.agent_dir[env * p.A + a] = (uint8_t)dir;
+        } else {
+            // TagAgent.act: the move of MovingAgent.act without its reward ...
+            if (!act_ok) {
+                st |= SGW_STATUS_BAD_ACTION;
+            } else {
+                const int ty = y + (int)((p.dy_pack >> (2 * (act & 15u))) & 3u) - 1, tx = x + (int)((p.dx_pack >> (2 * (act & 15u))) & 3u) - 1;
+                if ((unsigned)ty >= (unsigned)H || (unsigned)tx >= (unsigned)W) {
+                    st |= SGW_STATUS_OOB_MOVE;
+                } else {
+                    const uint32_t t = g[p.zA * HW + ty * W + tx];
+                    if (t >= (uint32_t)p.T) st |= SGW_STATUS_BAD_TYPE;
+                    else if ((p.pass_mask >> (t & 31u)) & 1u) { pass = true; ny = ty; nx = tx; found = t; }
+                }
+            }
+        }
+        if (!pass) { ny = y; nx = x; }
+        // ---- Tag: an agent that is "it" hands the flag to the first NotIt neighbour of the cell it now stands on
+        uint32_t mine_now = my_type;
+        int vy = -1, vx = -1;
+        if constexpr (RULE == SGW_AGENT_RULE_TAG) {
+            if (my_type == p.tag_it) {
+#pragma unroll
+                for (int d = 3; d >= 0; --d) {          // Location.adjacent order: up, right, down, left; the first match wins
+                    const int ay = ny + (d == 0 ? -1 : d == 2 ? 1 : 0), ax = nx + (d == 1 ? 1 : d == 3 ? -1 : 0);
+                    if ((unsigned)ay >= (unsigned)H || (unsigned)ax >= (unsigned)W) continue;
+                    // (the one cell this act has already changed is the agent's old cell: default type now, never NotIt)
+                    const uint32_t nt = (pass && ay == y && ax == x) ? p.default_type : (uint32_t)g[p.zA * HW + ay * W + ax];
+                    if (nt == p.tag_notit) { vy = ay; vx = ax; }
+                }
+                if (vy >= 0) mine_now = p.tag_notit;
+            }
+            reward = mine_now != p.tag_it ? p.tag_reward : 0.0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every read of the grid above has returned: now the stores
+        if (writer) {
+            if (pass) {
+                g[p.zA * HW + y * W + x] = (uint8_t)p.default_type;
+                reinterpret_cast<uint16_t*>(p.pos)[env * p.A + a] = (uint16_t)((uint32_t)ny | ((uint32_t)nx << 8));
+            }
+            if (pass || mine_now != my_type) g[p.zA * HW + ny * W + nx] = (uint8_t)mine_now;
+            if (vy >= 0) g[p.zA * HW + vy * W + vx] = (uint8_t)p.tag_it;
+            if (RULE == SGW_AGENT_RULE_TAG) {
+                p.agent_state[env * p.A + a] = (uint8_t)mine_now;
+                if (p.state_at_pov) p.state_at_pov[env * p.A + a] = (uint8_t)my_type;      // what TagAgent.pov appended
+            }
+            p.rewards[env * p.A + a] = (float)reward;
+            p.total[env] = (tot + total_add) + reward;               // float64, in the reference's order of additions
+            if (rp.agent_action) p.actions[env * p.A + a] = (uint8_t)act;
+            if (rp.reward_row) rp.reward_row[env] = (float)reward;
+            if (rp.action_row) rp.action_row[env] = act_raw;
+            if (st) atomicOr(p.status, st);
+        }
+        if (RULE == SGW_AGENT_RULE_TAG && vy >= 0 && live) {
+#pragma unroll
+            for (int n = 0; n < NJ; ++n)
+                if (j + n * G != a && pjv[n] == ((uint32_t)vy | ((uint32_t)vx << 8)))
+                    p.agent_state[env * p.A + j + n * G] = (uint8_t)p.tag_it;   // the agent standing on the victim's cell
+        }
+        if (pass) patch(y, x, p.zA, my_type, p.default_type);
+        if (pass || mine_now != my_type) patch(ny, nx, p.zA, pass ? found : my_type, mine_now);
+        if (vy >= 0) patch(vy, vx, p.zA, p.tag_notit, p.tag_it);
     }
 }

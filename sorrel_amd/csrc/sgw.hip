@@ -994,7 +994,7 @@ int sgw_capabilities(sgw_engine* e) {
     if (!e) return 0;
     int caps = 0;
     if (e->obs_rows_fn && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_OBSERVE_ROWS;
-    if (e->cfg.agent_rule == SGW_AGENT_RULE_MOVE) caps |= SGW_CAP_ACT;
+    caps |= SGW_CAP_ACT;      // MovingAgent.act, TagAgent.act and CleanupAgent.act all have an sgw_act instance
     return caps;
 }
 
@@ -1061,8 +1061,8 @@ int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, 
             float* reward_row, int64_t* action_row, void* stream) {
     if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_act: NULL argument");
     if (agent < 0 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_act: agent %d out of range", agent);
-    if (!(sgw_capabilities(e) & SGW_CAP_ACT))
-        return fail(SGW_EINVAL, "sgw_act: only MovingAgent.act (SGW_AGENT_RULE_MOVE) is served; other agent rules step through sgw_step");
+    if (e->cfg.agent_rule == SGW_AGENT_RULE_TAG && !e->agent_state) return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
+    if (e->cfg.agent_rule == SGW_AGENT_RULE_CLEANUP && !e->agent_dir) return fail(SGW_EINVAL, "SGW_AGENT_RULE_CLEANUP needs sgw_bind_agent_dir");
     RowPtrs rp;
     memset(&rp, 0, sizeof(rp));
     if (rows)
@@ -1074,13 +1074,18 @@ int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, 
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.rewards = rewards; p.total = total_reward;
     p.a0 = agent; p.a1 = agent + 1; p.flags = SGW_STEP_NO_OBS; p.do_move = 1;
     p.agent_state = e->agent_state;
+    p.state_at_pov = e->state_at_pov;
+    p.agent_dir = e->agent_dir;
     p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = time_begin(e, s)) return rc;
     const int A = e->cfg.num_agents;
-    const int G = A <= 8 ? 8 : (A <= 16 ? 16 : (A <= 32 ? 32 : 64));
+    const int G = A <= 16 ? 8 : (A <= 32 ? 32 : 64);      // lanes per env; 9..16 agents: two per lane
     const unsigned blocks = (unsigned)ceil_div(p.E, 4 * (64 / G));
-    RowsFn fn = G == 8 ? act_patch<8> : (G == 16 ? act_patch<16> : (G == 32 ? act_patch<32> : act_patch<64>));
+#define ACT_PICK(R) (A <= 8 ? act_patch<8, 1, R> : (A <= 16 ? act_patch<8, 2, R> : (A <= 32 ? act_patch<32, 1, R> : act_patch<64, 1, R>)))
+    RowsFn fn = e->cfg.agent_rule == SGW_AGENT_RULE_TAG ? ACT_PICK(SGW_AGENT_RULE_TAG)
+              : e->cfg.agent_rule == SGW_AGENT_RULE_CLEANUP ? ACT_PICK(SGW_AGENT_RULE_CLEANUP) : ACT_PICK(SGW_AGENT_RULE_MOVE);
+#undef ACT_PICK
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, s, p, rp);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);

@@ -240,9 +240,9 @@ def test_sgw_act_and_observe_rows_reject_what_they_cannot_serve(torch_cuda):
 
     d, spec = H.load_golden("tag_9x9")
     tag = make_engine(H.world_spec(spec), 8)
-    assert tag.capabilities() == 0
+    assert tag.capabilities() == N.CAP_ACT                # sgw_act serves TagAgent.act; there is no row-load instance for Tag worlds
     with pytest.raises(ValueError):
-        tag.act(0, tag.window_rows(None))
+        tag.observe_rows(tag.window_rows(None))
     ws = _move_world(16, 16, 2, 6, 4, 2, seed=1)
     eng = make_engine(ws, 8)
     per_env = int(np.prod(ws.obs_shape[1:]))
@@ -555,4 +555,93 @@ def test_big_tag_worlds_on_the_workgroup_per_env_kernel_vs_oracle(torch_cuda, ca
     assert ((eng.agent_state == ws.tag_it_type).sum(dim=1) == 1).all()
     if case == "tag_crowded_66x64":
         assert len(np.unique(eng.agent_state.cpu().numpy(), axis=0)) > 1        # the flag really moved around
+    assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ sgw_act for Tag and Cleanup agents
+@pytest.mark.parametrize("case", ["tag_11x11", "tag_crowded_12x9", "tag_big_70x66", "cleanup_15x16", "cleanup_21x31", "cleanup_big_40x48", "cleanup_u8"])
+def test_sgw_act_tag_and_cleanup_vs_oracle(torch_cuda, case):
+    """The patched-window protocol for the agents with interaction rules: sweep + every window in one launch
+    (SGW_STEP_NO_MOVE), then per agent sgw_act = TagAgent.act / CleanupAgent.act + repair of the later agents' windows (the
+    mover's cells, the tagger's and its victim's, the beam cells).  What each agent's policy would read, rewards, grid,
+    positions, totals, the agents' types / types at observation time / facings: all against the C oracle."""
+    torch = torch_cuda
+    import dataclasses
+
+    kw = {}
+    grid0 = pos0 = None
+    if case.startswith("tag"):
+        d, spec = H.load_golden("tag_11x11_default")
+        ws = H.world_spec(spec)
+        h, w, a, E = {"tag_11x11": (11, 11, 5, 90), "tag_crowded_12x9": (12, 9, 30, 25), "tag_big_70x66": (70, 66, 40, 6)}[case]
+        ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a,
+                                 vision_radius=min(ws.vision_radius, (min(h, w) - 1) // 2))
+        T = 12
+    else:
+        name = "cleanup_21x31_default" if case == "cleanup_21x31" else "cleanup_15x16"
+        d, spec = H.load_golden(name)
+        ws = H.world_spec(spec)
+        E, T = 23, 14
+        if case == "cleanup_big_40x48":
+            h, w, a = 40, 48, 10
+            ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a, beam_radius=7)
+            g = np.zeros((3, h, w), np.uint8)
+            g[:, 0, :] = g[:, -1, :] = 2
+            g[:, :, 0] = g[:, :, -1] = 2
+            g[0, 1:12, 1:-1] = 3
+            g[0, 12:28, 1:-1] = 1
+            g[0, 28:39, 1:-1] = 5
+            pos = np.array([[14 + (i // 5) * 6, 4 + (i % 5) * 9] for i in range(a)], np.uint8)
+            for (y, x) in pos:
+                g[1, y, x] = 11
+            grid0, pos0 = g, pos
+            E = 7
+        else:
+            grid0, pos0 = d["grid0"][0], d["pos0"][0]
+        if case == "cleanup_u8":
+            kw["obs_dtype"] = torch.uint8
+    A = ws.num_agents
+    eng, co = make_engine(ws, E, first=21, **kw), H.COracle(ws, E, first_env_id=21)
+    if grid0 is not None:
+        eng.grid.copy_(torch.from_numpy(np.broadcast_to(grid0, (E,) + grid0.shape).copy()))
+        eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos0, (E,) + pos0.shape).copy()))
+        eng.total_reward.zero_()
+        co.grid[...] = grid0
+        co.pos[...] = pos0
+        co.total[...] = 0
+    else:
+        eng.reset(0)
+        co.reset(0)
+    if eng.agent_state is not None:
+        assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state)
+    rows = eng.window_rows(None)
+    for t in range(1, T + 1):
+        assert co.step(0, t, random_actions=True) == 0
+        eng.actions.copy_(torch.from_numpy(co.actions))
+        eng.obs.fill_(77)
+        eng.step(eng.actions, sweep=True, no_move=True, turn=t)                 # the sweep and every agent's window, once
+        seen = torch.zeros_like(eng.obs)
+        rew = torch.zeros_like(eng.rewards)
+        pov_types = torch.zeros_like(eng.actions)
+        for a in range(A):
+            seen[:, a] = eng.obs[:, a]                                           # what agent a's policy reads
+            if eng.agent_state is not None:
+                pov_types[:, a] = eng.agent_state[:, a]                          # ... and the flag TagAgent.pov appends
+            eng.act(a, rows, action=eng.actions[:, a].to(torch.int64).contiguous() if a % 2 else None)
+            rew[:, a] = eng.rewards[:, a]
+        torch.cuda.synchronize()
+        assert np.array_equal(seen.cpu().numpy().astype(np.float32), co.obs), f"{case} turn {t}: windows"
+        assert np.array_equal(rew.cpu().numpy(), co.rewards), f"{case} turn {t}: rewards"
+        assert np.array_equal(eng.grid.cpu().numpy(), co.grid), f"{case} turn {t}: grid"
+        assert np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), f"{case} turn {t}: positions"
+        assert np.array_equal(eng.total_reward.cpu().numpy(), co.total), f"{case} turn {t}: total_reward"
+        if eng.agent_state is not None:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), f"{case} turn {t}: agent_state"
+            assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov) and np.array_equal(pov_types.cpu().numpy(), co.state_at_pov), t
+        if eng.agent_dir is not None:
+            assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), f"{case} turn {t}: agent_dir"
+    if case.startswith("tag"):
+        assert len(np.unique(eng.agent_state.cpu().numpy(), axis=0)) > 1 or E < 10    # the flag really moved around
+    if case.startswith("cleanup"):
+        assert (eng.grid[:, 2] != eng.grid[0, 2, 1, 1]).any(), "no beam was ever fired"
     assert eng.status() == 0

@@ -43,5 +43,17 @@ def phased_turn():          # what a policy-driven Environment.take_turn launche
     eng.turn += 1
 
 
-print(f"  policy-driven, 1 + A launches {timed(lambda: [phased_turn() for _ in range(20)], 3) / 20:8.1f} us/turn")
+print(f"  policy-driven, 1 + A launches (round 2: a window per launch) {timed(lambda: [phased_turn() for _ in range(20)], 3) / 20:8.1f} us/turn")
+
+ROWS = eng.window_rows(None)
+
+
+def patched_turn():         # round 3: sweep + every window in ONE launch, then per agent sgw_act (CleanupAgent.act + repair of later windows)
+    eng.step(eng.actions, sweep=True, no_move=True, advance_turn=False)
+    for a in range(10):
+        eng.act(a, ROWS)
+    eng.turn += 1
+
+
+print(f"  policy-driven, 1 + A launches (round 3: NO_MOVE + sgw_act)   {timed(lambda: [patched_turn() for _ in range(20)], 3) / 20:8.1f} us/turn")
 assert eng.status() == 0

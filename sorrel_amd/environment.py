@@ -468,7 +468,7 @@ class Environment:
         """What an observation spec compiles to, as a hashable key.  Computed once per (spec object, entity-map object,
         scalar settings) and kept on the spec: every agent's ``pov`` asks for it every turn, and serialising the
         appearance vectors each time cost ~7 us per agent phase.  Replace ``entity_map`` (or change radius / fill kind) to
-        have a spec recompiled; editing an appearance vector in place after first use is not seen."""
+        have a spec recompiled; after editing an appearance vector IN PLACE call ``ObservationSpec.invalidate()``."""
         sig = (id(ospec.entity_map), len(ospec.entity_map), ospec.vision_radius, ospec.fill_entity_kind, getattr(ospec, "obs_post", 0))
         cached = ospec.__dict__.get("_sgw_key")
         if cached is not None and cached[0] == sig:
@@ -556,6 +556,8 @@ class Environment:
         mem = getattr(self.agents[a].model, "memory", None)
         if not self.write_obs_into_replay or not isinstance(mem, Buffer) or eng is None or eng.obs is None:
             return None
+        if type(self.agents[a]).transition is not Agent.transition or type(self.agents[a]).add_memory is not Agent.add_memory:
+            return None        # (the row is pre-written: only safe if this agent's pov is always followed by its add_memory)
         if acting is not None and mem is getattr(self.agents[acting].model, "memory", None):
             return None
         row = mem.states[mem.idx]

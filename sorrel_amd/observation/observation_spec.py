@@ -55,6 +55,12 @@ class ObservationSpec:
     def override_input_size(self, input_size) -> None:
         self.input_size = input_size
 
+    def invalidate(self) -> None:
+        """Call after editing an appearance vector of ``entity_map`` IN PLACE: the engine's tables are compiled from the
+        map once per (map object, radius, fill kind) and cached on the spec; replacing the map (``override_entity_map``)
+        or changing ``vision_radius`` / ``fill_entity_kind`` is seen by itself, an in-place edit is not."""
+        self.__dict__.pop("_sgw_key", None)
+
     @property
     def num_channels(self) -> int:
         return len(next(iter(self.entity_map.values())))

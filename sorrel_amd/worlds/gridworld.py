@@ -90,6 +90,12 @@ class Gridworld(World):
         self.max_turns = 0
         self.is_done = False
 
+    def mark_dirty(self) -> None:
+        """Tell the Environment that ``grid`` / ``agent_pos`` were written DIRECTLY (tensor indexing instead of
+        ``add`` / ``remove`` / ``move``, which call this themselves): observations rendered ahead of an agent's ``pov``
+        are dropped and rendered again on demand."""
+        self.mutations += 1
+
     # ------------------------------------------------------------------ reference API
     def create_world(self) -> None:
         """Fill every cell of every env with the default entity and zero ``total_reward``

@@ -362,6 +362,7 @@ struct MoveOut {
     int old_y, old_x, new_y, new_x;
     uint32_t my_type;
     uint32_t found;      // what the target cell held before the agent entered it
+    uint32_t left;       // what the agent's own cell held (its type, unless the caller's grid and agent types disagree)
 };
 struct ActIO {                   // sgw_act's optional extras (see RowPtrs), passed by value
     const void* agent_action = nullptr;
@@ -395,11 +396,12 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
     const int ty = my + dy, tx = mx + dx;
     const bool tinb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
     const uint32_t t = tinb ? (uint32_t)g[p.zA * HW + ty * W + tx] : 0xFFu;
+    const uint32_t here = g[p.zA * HW + my * W + mx];                               // (issued with the target's byte)
     const bool tok = tinb && t < (uint32_t)p.T;
     const double val = tok ? (wval ? wval[t & 31u] : gtab->value[t & 31u]) : 0.0;   // reward read BEFORE the move
     const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
     st |= !act_ok ? SGW_STATUS_BAD_ACTION : (!tinb ? SGW_STATUS_OOB_MOVE : (!tok ? SGW_STATUS_BAD_TYPE : 0));
-    mo.old_y = -1; mo.old_x = 0; mo.new_y = -1; mo.new_x = 0; mo.my_type = my_type; mo.found = t;
+    mo.old_y = -1; mo.old_x = 0; mo.new_y = -1; mo.new_x = 0; mo.my_type = my_type; mo.found = t; mo.left = here;
     if (pass) { mo.old_y = my; mo.old_x = mx; mo.new_y = ty; mo.new_x = tx; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (writer) {
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(kBlock, 8) void phase_rows(const Params p) {
 
     // ---- the move: decided from reads only; its stores wait for every row load of this wave
     gsync<1>();                                                                // table words visible to every lane
-    MoveOut mo{-1, 0, -1, 0, 0u, 0u};
+    MoveOut mo{-1, 0, -1, 0, 0u, 0u, 0u};
     if (mover) st |= move_one(p, gtab, g, env, p.a0, wval, live && gl == 0, mo);
     if (st && live && gl == 0) atomicOr(p.status, st);
     if (!render) return;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
         const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, rp.reward_row, rp.action_row});
         if (st && writer) atomicOr(p.status, st);
         if (mo.old_y < 0) return;
-        patch(mo.old_y, mo.old_x, p.zA, mo.my_type, p.default_type);
+        patch(mo.old_y, mo.old_x, p.zA, mo.left, p.default_type);
         patch(mo.new_y, mo.new_x, p.zA, mo.found, mo.my_type);
         return;
     } else {
@@ -677,6 +679,7 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
         if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
         const int y = (int)(yx & 0xFFu), x = (int)(yx >> 8);
         const bool act_ok = act < (uint32_t)p.nact;
+        const uint32_t left = g[p.zA * HW + y * W + x];      // what the agent's own cell holds (its type, unless the caller's grid and agent types disagree)
         double reward = 0.0, total_add = 0.0;
         bool pass = false;
         int ny = y, nx = x;
@@ -823,8 +826,8 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                 if (j + n * G != a && pjv[n] == ((uint32_t)vy | ((uint32_t)vx << 8)))
                     p.agent_state[env * p.A + j + n * G] = (uint8_t)p.tag_it;   // the agent standing on the victim's cell
         }
-        if (pass) patch(y, x, p.zA, my_type, p.default_type);
-        if (pass || mine_now != my_type) patch(ny, nx, p.zA, pass ? found : my_type, mine_now);
+        if (pass) patch(y, x, p.zA, left, p.default_type);
+        if (pass || mine_now != my_type) patch(ny, nx, p.zA, pass ? found : left, mine_now);
         if (vy >= 0) patch(vy, vx, p.zA, p.tag_notit, p.tag_it);
     }
 }

@@ -645,3 +645,70 @@ def test_sgw_act_tag_and_cleanup_vs_oracle(torch_cuda, case):
     if case.startswith("cleanup"):
         assert (eng.grid[:, 2] != eng.grid[0, 2, 1, 1]).any(), "no beam was ever fired"
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ soak: the patched-window protocol on random rule worlds
+@pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "48"))))
+def test_patched_window_protocol_soak_random_rule_worlds(torch_cuda, case):
+    """Random layered worlds (2-4 layers, spawners, BECOME_IF tables, timers; plain movers, Tag or Cleanup agents; random
+    maps, radii, agent counts, beam radii): every turn is played as sweep + every window once (SGW_STEP_NO_MOVE, or
+    sgw_observe_rows where an instance exists) and one sgw_act per agent, the policy's actions handed over as int64 / int32 /
+    uint8 tensors; what every agent's policy would read and every piece of state against the C oracle's take_turn."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+
+    rng = np.random.default_rng(9100 + case)
+    ws, g, pos = H.random_rule_world(rng)
+    E, T = int(rng.integers(2, 40)), int(rng.integers(3, 10))
+    first = int(rng.integers(0, 2**31))
+    kw = {}
+    onehot = bool(((ws.appearance == 0) | (ws.appearance == 1)).all() and (ws.appearance.sum(axis=1) <= 1).all())
+    if onehot and case % 5 == 4:
+        kw["obs_dtype"] = torch.uint8
+    eng = make_engine(ws, E, first=first, **kw)
+    co = H.COracle(ws, E, first_env_id=first)
+    eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+    eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+    eng.total_reward.zero_()
+    co.grid[...] = g
+    co.pos[...] = pos
+    co.total[...] = 0
+    epoch = int(rng.integers(0, 9))
+    eng.epoch = epoch
+    A = ws.num_agents
+    caps = eng.capabilities()
+    assert caps & N.CAP_ACT
+    per_env = int(np.prod(ws.obs_shape[1:]))
+    kinds = (torch.int64, torch.int32, torch.uint8)
+    for t in range(1, T + 1):
+        assert co.step(epoch, t, random_actions=True) == 0
+        acts = torch.from_numpy(co.actions.copy()).cuda()
+        own_rows = bool(caps & N.CAP_OBSERVE_ROWS) and t % 2 == 0
+        dests = [torch.full((E, per_env), -3.0, device="cuda:0") for _ in range(A)] if own_rows else None
+        rows = eng.window_rows(dests)
+        if own_rows:
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t, advance_turn=False)
+            eng.observe_rows(rows)
+        else:
+            eng.step(acts, sweep=True, no_move=True, turn=t, advance_turn=False)
+        eng.actions.fill_(99)                                  # the acts below read the policy's tensors, not this table
+        seen = torch.zeros_like(eng.obs)
+        rew = torch.zeros_like(eng.rewards)
+        for a in range(A):
+            seen[:, a] = dests[a].view(E, *ws.obs_shape[1:]) if own_rows else eng.obs[:, a]
+            eng.act(a, rows, action=acts[:, a].to(kinds[(a + case) % 3]).contiguous())
+            rew[:, a] = eng.rewards[:, a]
+        torch.cuda.synchronize()
+        ctx = f"case {case} turn {t} (rule {ws.agent_rule}, {ws.layers} layers, {A} agents, r {ws.vision_radius})"
+        assert np.array_equal(seen.cpu().numpy().astype(np.float32), co.obs), ctx + ": windows"
+        assert np.array_equal(rew.cpu().numpy(), co.rewards), ctx + ": rewards"
+        assert np.array_equal(eng.actions.cpu().numpy(), co.actions), ctx + ": recorded actions"
+        assert np.array_equal(eng.grid.cpu().numpy(), co.grid), ctx + ": grid"
+        assert np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), ctx + ": positions"
+        assert np.array_equal(eng.total_reward.cpu().numpy(), co.total), ctx + ": total_reward"
+        if eng.agent_dir is not None:
+            assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), ctx + ": agent_dir"
+        if eng.agent_state is not None:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), ctx + ": agent_state"
+            assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov), ctx + ": state_at_pov"
+    assert eng.status() == 0

@@ -562,16 +562,24 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.total_factor = c.reward_total_factor > 0 ? c.reward_total_factor : 1;
 
     // ---- group geometry: one wave per env while a slice stays small, else a workgroup per env
-    e->wpe = (p.cells_pad <= 4096) ? 1 : 4;
-    const int epb = kBlock / (e->wpe * kWave);
-    e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // step_big implements MovingAgent.act only
     const bool simple_rules = !p.has_become && c.agent_rule != SGW_AGENT_RULE_CLEANUP;   // else: generic kernel
     const bool vec16 = (p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad;   // 16-byte loads/stores per env are legal
+    // Layered rule sets (BECOME_IF, Cleanup) stay on the wave-per-env RULES kernel up to 8 KiB per env: above 4 KiB their
+    // alternative is the ticket-ordered workgroup-per-env generic kernel, where every act is a hand-off between waves
+    // (Cleanup 48x48x3, 4 096 envs: 95 us there against ... here).  SGW_RULES_8K=0: A/B and test hook.
+    bool rules_8k = !simple_rules && c.agent_rule != SGW_AGENT_RULE_TAG && vec16 && p.cells_pad > 4096 &&
+                    (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128;
+    if (const char* f = getenv("SGW_RULES_8K")) { if (f[0] == '0') rules_8k = false; }
+    if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') rules_8k = false; }
+    if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') rules_8k = false; }    // (the tests of the ticket-ordered workgroup-per-env kernel)
+    e->wpe = (p.cells_pad <= 4096 || rules_8k) ? 1 : 4;
+    const int epb = kBlock / (e->wpe * kWave);
+    e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
     // the layered rule set on the wave-per-env kernel (RULES variant): any spawners, BECOME_IF rules, Cleanup or plain agents
-    e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && p.VV <= 128 &&
-                    c.agent_rule != SGW_AGENT_RULE_TAG;
+    e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128 &&
+                    c.agent_rule != SGW_AGENT_RULE_TAG && (p.cells_pad <= 4096 || rules_8k);
     if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') e->fast_rules = false; }   // test hook: generic kernel instead
     e->fast = e->fast || e->fast_rules;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
@@ -600,6 +608,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             // kernels -- Cleanup 21x31x3 at 65 536 envs, agents per burst 1 / 2 / 3 / 4 / 5 / 10: 666 / 695 / 643-680 / 640 / 643 / 850 us
             // (16 384 envs: 201 / 193 / 185-190 / 188 / 181 / 240).
             int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16 : (int)(kLdsPerCu / 8 / 4) - base - 16;
+            for (int wg = 4; e->fast_rules && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
+                budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - 16;
             if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16;
             if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook
             int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;

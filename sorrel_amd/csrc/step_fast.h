@@ -16,7 +16,9 @@
 //     read the target type from LDS, test passability, patch two bytes;
 //   * window geometry (L, C, r, and for the BASELINE shapes H, W) is compile-time,
 //     so gather/emit is branch-free: v_cvt_f32_ubyteN + global_store_dword.
-constexpr int kMaxUnits = 4;   // 16-byte units per lane (cells <= 4096)
+constexpr int kMaxUnits = 4;        // 16-byte units per lane (cells <= 4096)
+constexpr int kMaxUnitsRules = 8;   // ... of the RULES variant, whose sweep runs in LDS: units beyond the first kMaxUnits per lane go from HBM to LDS in a
+                                    // second round (cells <= 8192)
 constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr size_t kCacheResidentGrid = (size_t)288 << 20;   // on-die capacity: 256 MiB Infinity Cache + 8 x 4 MiB L2; grids of a batch up to this size can stay
                                                             // resident from turn to turn (measured: 256 MiB of grids still do, 512 MiB do not)
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     constexpr bool kStatic = TL && TH && TW;
     const int cells = kStatic ? TL * TH * TW : p.cells;
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
-    constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane
+    constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
     const int zoff = p.zA * HW;
     constexpr int NW = TC ? (TC + 3) / 4 : 4;   // counter words
 
@@ -242,6 +244,25 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 #pragma unroll
         for (int k = 0; k < NU; ++k)
             if (lane + 64 * k < nunits) lg16[lane + 64 * k] = u[k];
+        if constexpr (RULES) {
+            // layered rule sets above 4 KiB per env (up to 8 KiB): the rest of the grid in a second round, straight to LDS
+            const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
+            for (int i = 64 * NU + lane; i < nunits; i += 64) {
+                uint4 v = src[i];
+                if ((cells & 15) && i == nunits - 1) {
+                    const int tail = cells & 15;
+                    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int keep = tail - 4 * q;
+                        if (keep <= 0) d[q] = 0xFFFFFFFFu;
+                        else if (keep < 4) d[q] |= 0xFFFFFFFFu << (8 * keep);
+                    }
+                    v = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+                lg16[i] = v;
+            }
+        }
         int st_lane = 0;
         uint32_t taddr_v = 0xFFFFFFFFu, oaddr_v = 0, npos = 0, rew_bits = 0, moved = 0;   // per turn; the write-back reads the last turn's
         const uint32_t nturns = MULTI ? p.nturns : 1u;
@@ -617,6 +638,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
                     if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
+                if constexpr (RULES)
+                    for (int i = 64 * NU + lane; i < nunits; i += 64) dst[i] = lg16[i];
             }
         }
         if (p.do_move) {

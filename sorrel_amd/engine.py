@@ -255,20 +255,30 @@ class GridEngine:
         output needs no narrowing copy; ``self.actions[:, agent]`` still records what was taken).  Rewards land in
         ``self.rewards[:, agent]`` and, with ``reward_row`` (float32 ``[E]``) / ``action_row`` (int64 ``[E]``), a second
         time in those rows -- e.g. the rows of the agent's replay buffer."""
-        arr, stride = (None, 0) if rows is None else rows[:2]
-        E = self.num_envs
-        kind = 0
+        arr, stride = (None, 0) if rows is None else (rows[0], rows[1])
+        E, dev = self.num_envs, self.device
+        kind = pa = prr = par = 0
         if action is not None:
             kind = self._ACTION_KINDS.get(action.dtype)
-            if kind is None or action.device != self.device or action.numel() != E or not action.is_contiguous():
-                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {E} elements on {self.device}")
-        for t, dt, name in ((reward_row, torch.float32, "reward_row"), (action_row, torch.int64, "action_row")):
-            if t is not None and (t.dtype != dt or t.device != self.device or t.numel() != E or not t.is_contiguous()):
-                raise ValueError(f"{name} must be a contiguous {dt} tensor of {E} elements on {self.device}")
+            if kind is None or action.device != dev or action.numel() != E or not action.is_contiguous():
+                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {E} elements on {dev}")
+            pa = action.data_ptr()
+        if reward_row is not None:
+            if reward_row.dtype != torch.float32 or reward_row.device != dev or reward_row.numel() != E or not reward_row.is_contiguous():
+                raise ValueError(f"reward_row must be a contiguous float32 tensor of {E} elements on {dev}")
+            prr = reward_row.data_ptr()
+        if action_row is not None:
+            if action_row.dtype != torch.int64 or action_row.device != dev or action_row.numel() != E or not action_row.is_contiguous():
+                raise ValueError(f"action_row must be a contiguous int64 tensor of {E} elements on {dev}")
+            par = action_row.data_ptr()
+        # (plain integers for the pointers: this call sits in the per-agent loop of a policy turn, where the host is the
+        # bottleneck below ~16 k envs)
         with self._on_device():
-            N.check(self._lib.sgw_act(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), self._ptr(self.actions), arr, stride,
-                                      self._ptr(self.rewards), self._ptr(self.total_reward), int(agent), self._ptr(action), kind,
-                                      self._ptr(reward_row), self._ptr(action_row), self._stream()))
+            rc = self._lib.sgw_act(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), arr, stride,
+                                   self.rewards.data_ptr(), self.total_reward.data_ptr(), int(agent), pa or None, kind,
+                                   prr or None, par or None, self._stream())
+        if rc:
+            N.check(rc)
         return self.rewards[:, agent] if reward_row is None else reward_row
 
     def observe_full(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -712,3 +712,72 @@ def test_patched_window_protocol_soak_random_rule_worlds(torch_cuda, case):
             assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), ctx + ": agent_state"
             assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov), ctx + ": state_at_pov"
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ layered rule sets between 4 and 8 KiB per env on the wave-per-env RULES kernel
+@pytest.mark.parametrize("case", ["cleanup_40x48", "cleanup_48x48_wide_beam", "cleanup_ragged_45x43", "become_if_movers_50x52", "phased_40x48", "rollout_40x48"])
+def test_layered_rule_worlds_up_to_8k_per_env_vs_oracle(torch_cuda, case):
+    """Cleanup / BECOME_IF worlds above 4 KiB (up to 8 KiB) per env stay on step_fast<..., RULES>: the part of the grid
+    beyond the first 4 KiB reaches LDS in a second round.  Fused turns, the 1 + A phased form, sgw_rollout, a ragged world
+    (byte count not a multiple of 16) and plain movers under BECOME_IF rules, against the C oracle."""
+    torch = torch_cuda
+    import dataclasses
+
+    d, spec = H.load_golden("cleanup_15x16")
+    ws = H.world_spec(spec)
+    h, w, a, R = {"cleanup_40x48": (40, 48, 10, 3), "cleanup_48x48_wide_beam": (48, 48, 12, 9), "cleanup_ragged_45x43": (45, 43, 7, 3),
+                  "become_if_movers_50x52": (50, 52, 9, 3), "phased_40x48": (40, 48, 6, 3), "rollout_40x48": (40, 48, 8, 3)}[case]
+    ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a, beam_radius=R)
+    if case == "become_if_movers_50x52":      # the same layered rule tables with MovingAgent.act agents
+        ws = dataclasses.replace(ws, agent_rule=0, action_kind=[0] * len(ws.action_dy))
+    g = np.zeros((3, h, w), np.uint8)
+    g[:, 0, :] = g[:, -1, :] = 2
+    g[:, :, 0] = g[:, :, -1] = 2
+    g[0, 1:h // 3, 1:-1] = 3
+    g[0, h // 3:2 * h // 3, 1:-1] = 1
+    g[0, 2 * h // 3:h - 1, 1:-1] = 5
+    pos = np.array([[h // 3 + 1 + (i // 5) * 3, 4 + (i % 5) * 7] for i in range(a)], np.uint8)
+    for (y, x) in pos:
+        g[1, y, x] = 11
+    E, T = 9, 10
+    eng, co = make_engine(ws, E, first=5), H.COracle(ws, E, first_env_id=5)
+    info = eng.launch_info()
+    assert "step_fast<" in info and "group=64 " in info, info
+    eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
+    eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
+    eng.total_reward.zero_()
+    co.grid[...] = g
+    co.pos[...] = pos
+    co.total[...] = 0
+
+    def same(ctx, what=("grid", "agent_pos", "total_reward", "rewards", "actions", "obs")):
+        torch.cuda.synchronize()
+        ref = dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions)
+        for k in what:
+            assert np.array_equal(getattr(eng, k).cpu().numpy(), ref[k]), f"{case} {ctx}: {k}"
+        if eng.agent_dir is not None:
+            assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), f"{case} {ctx}: agent_dir"
+
+    if case == "rollout_40x48":
+        for t in range(1, T + 1):
+            assert co.step(0, t, random_actions=True) == 0
+        eng.rollout(T)
+        same("after sgw_rollout")
+    else:
+        for t in range(1, T + 1):
+            assert co.step(0, t, random_actions=True) == 0
+            if case == "phased_40x48":
+                acts = torch.from_numpy(co.actions.copy()).cuda()
+                seen = torch.zeros_like(eng.obs)
+                eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+                for i in range(a):
+                    seen[:, i] = eng.obs[:, i]
+                    eng.step(acts, sweep=False, agent_begin=i, agent_end=i + 1, obs_next=i + 1 < a, write_obs=False, turn=t, advance_turn=False)
+                torch.cuda.synchronize()
+                assert np.array_equal(seen.cpu().numpy(), co.obs), f"{case} turn {t}: phased windows"
+                same(f"turn {t}", ("grid", "agent_pos", "total_reward"))
+            else:
+                eng.step(random_actions=True, turn=t, advance_turn=False)
+                same(f"turn {t}")
+    assert (eng.grid[:, 2] != eng.grid[0, 2, 1, 1]).any() or case == "become_if_movers_50x52", "no beam was ever fired"
+    assert eng.status() == 0

@@ -26,6 +26,7 @@ struct DevTables {
     uint8_t rule_become[SGW_MAX_TYPES];
     uint8_t pad2_[SGW_MAX_TYPES];
     uint32_t rule_mask[SGW_MAX_TYPES];
+    uint32_t delta3[SGW_MAX_TYPES];      // one-hot, <= 10 channels: ONE word per type, 1 << 3 * c for its channel c (3-bit counters: <= 7 layers)
     double appearance[SGW_MAX_TYPES][SGW_MAX_CHANNELS];  // general (non one-hot) path only
 };
 constexpr int kTabFastBytes = offsetof(DevTables, appearance);
@@ -45,6 +46,7 @@ struct Params {
     uint32_t agent_mask;       // types the agents have
     uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
     uint32_t fill_delta[4];
+    uint32_t fill_delta3;      // the fill entity's word of DevTables::delta3
     // single-spawner fast path (exactly one type carries SGW_RULE_SPAWN)
     uint32_t spawn_pat;      // type id replicated in 4 bytes
     uint32_t spawn_thr;      // low 32 bits of floor(p * 2^32)

@@ -285,8 +285,11 @@ StepFn pick_step(int group, bool onehot, int L, int C, int rule, int r, int H, i
 // the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
 // a loop of single-turn launches
 StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
-    if (onehot && rules && stage && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, true>);   // Cleanup
-    if (onehot && rules && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true>);    // layered rule sets
+    const bool p3 = onehot && rules && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
+    if (p3 && stage && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, true, true>);   // Cleanup
+    if (p3 && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true, true>);    // layered rule sets
+    if (onehot && rules && stage && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, true>);
+    if (onehot && rules && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true>);
     if (!onehot || tag || rules || L != 2 || C != 6) return nullptr;
     if (r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32, false, false, false, true>);
     if (r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16, false, false, false, true>);
@@ -348,7 +351,13 @@ StepFn pick_rows(int L, int NW, int r, const char** name, RowsFn* obs_fn, const 
 
 StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
     if (rules) {
-        if (onehot && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true>);   // Cleanup's tables (3 layers, 9 kinds)
+        // one-hot tables of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of ceil(C / 4))
+        const bool p3 = onehot && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
+        if (p3 && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, false, true>);   // Cleanup's tables (3 layers, 9 kinds)
+        if (p3 && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, false, false, true>);
+        if (p3 && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, false, true>);
+        if (p3) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, false, false, true>);
+        if (onehot && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true>);
         if (onehot && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true>);
         if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true>);
@@ -460,6 +469,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         }
         if (other || ones > 1) onehot = false;
         if (ones == 1 && !other) h.delta[ch >> 2][t] = 1u << (8 * (ch & 3));
+        if (ones == 1 && !other && ch < 10) h.delta3[t] = 1u << (3 * ch);
         h.value[t] = c.type_value[t];
         h.thr_lo[t] = (uint32_t)(prob_threshold(c.spawn_prob[t]) & 0xFFFFFFFFull);
         h.spawn_count[t] = c.spawn_count[t];
@@ -503,6 +513,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         p.dx_pack |= (uint32_t)(c.action_dx[a] + 1) << (2 * a);
     }
     for (int q = 0; q < 4; ++q) p.fill_delta[q] = h.delta[q][c.fill_type];
+    p.fill_delta3 = h.delta3[c.fill_type];
     int nspawn = 0;
     p.spawn_pat = 0xFFFFFFFFu;   // matches no valid type id
     for (int t = 0; t < c.num_types; ++t) {

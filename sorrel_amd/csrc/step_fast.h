@@ -102,7 +102,10 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
                                  // instance spills two registers, and a scratch reload waits on vmcnt -- behind the observation
                                  // stores in flight; 8 / 7 / 6 / 5 / 4: 112.4 / 107.6 / 102.2 / 103.2 / 103.2 us per turn (config 3, 50 turns)
 #endif
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false>
+// P3 (round 3; RULES instances with one-hot tables of <= 10 channels): 3-bit packed counters -- the appearance of a type is
+// ONE word (1 << 3 c for its channel c; a count never exceeds the <= 7 layers), so a cell costs one table read and one add
+// per layer instead of ceil(C / 4) of each (Cleanup: 9 channels, three words).
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false, bool P3 = false>
 __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (STAGE ? 7 : SGW_FAST_RULES_PLAIN_WAVES) : 8)) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
@@ -132,7 +135,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
     const int zoff = p.zA * HW;
-    constexpr int NW = TC ? (TC + 3) / 4 : 4;   // counter words
+    constexpr int NW = P3 ? 1 : (TC ? (TC + 3) / 4 : 4);   // counter words
+    constexpr int CMAX = P3 ? (TC ? TC : 10) : 4 * NW;      // channels the counter words can hold
 
     // wave-private LDS: [table words][grid]
     uint8_t* wl = smem + sub * p.env_lds;
@@ -164,8 +168,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     if constexpr (ONEHOT) {
         // the one-hot counter words this wave looks up, [NW][32] u32
         uint32_t* wd = reinterpret_cast<uint32_t*>(wl);
+        if constexpr (P3) {
+            if (lane < SGW_MAX_TYPES) wd[lane] = gtab->delta3[lane];
+        } else {
 #pragma unroll
-        for (int q = 0; q < (NW + 1) / 2; ++q) wd[lane + 64 * q] = reinterpret_cast<const uint32_t*>(gtab->delta)[lane + 64 * q];
+            for (int q = 0; q < (NW + 1) / 2; ++q) wd[lane + 64 * q] = reinterpret_cast<const uint32_t*>(gtab->delta)[lane + 64 * q];
+        }
     } else {
         double* wa = reinterpret_cast<double*>(wl);
         for (int i = lane; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += 64) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
@@ -431,38 +439,28 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                                 }
                             }
 #pragma unroll
-                            for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
+                            for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : (P3 ? p.fill_delta3 : p.fill_delta[q]);
+                            // the count of channel c: a byte of the counter words, or (P3) a 3-bit field of the one word
+                            auto chan = [&](const int c) -> uint32_t {
+                                if constexpr (P3) return (cnt[0] >> (3 * c)) & 7u;
+                                else return (cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+                            };
                             if (stage) {
                                 uint8_t* os = ob + (kStageAlways ? (int)ch_shift + ((a - ch_a0) * C) * VV : (a * C) * VV) + w;
 #pragma unroll
-                                for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                                    for (int b = 0; b < 4; ++b) {
-                                        const int c = 4 * q + b;
-                                        if (c < C) os[c * VV] = (uint8_t)(cnt[q] >> (8 * b));
-                                    }
-                                }
+                                for (int c = 0; c < CMAX; ++c)
+                                    if (c < C) os[c * VV] = (uint8_t)chan(c);
                             } else if constexpr (kStageAlways) {
                                 // unreachable: a STAGE kernel always stages
                             } else if (!p.obs_u8) {
 #pragma unroll
-                                for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                                    for (int b = 0; b < 4; ++b) {
-                                        const int c = 4 * q + b;
-                                        if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
-                                    }
-                                }
+                                for (int c = 0; c < CMAX; ++c)
+                                    if (c < C) OBS_STORE(o + c * VV, (float)chan(c));
                             } else {   // compact format: the same counts as bytes
                                 uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
 #pragma unroll
-                                for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                                    for (int b = 0; b < 4; ++b) {
-                                        const int c = 4 * q + b;
-                                        if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
-                                    }
-                                }
+                                for (int c = 0; c < CMAX; ++c)
+                                    if (c < C) o8[c * VV] = (uint8_t)chan(c);
                             }
                         } else {
                             for (int c = 0; c < C; ++c) {

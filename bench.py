@@ -217,6 +217,59 @@ def side_config(name, dev, steps, prewarm, envs=0):
     return out
 
 
+def policy_turn_bench(eng, iters: int = 40):
+    """Engine time of a POLICY-DRIVEN turn (SURVEY a6 as a trained model runs it: pov -> get_action -> act, agent after agent)
+    on the engine the headline was measured on, outside its timed region: the entity sweep + every agent's window once
+    (SGW_STEP_NO_MOVE), then one sgw_act per agent (the act + the repair of the later agents' windows).  Actions are
+    precomputed (a real policy's forward pass comes on top); HIP events around the loop, per turn."""
+    import torch
+
+    A = eng.spec.num_agents
+    eng.random_actions()                       # some valid actions in eng.actions
+    rows = eng.window_rows(None)
+    dests = [torch.empty((eng.num_envs, eng.obs[0, 0].numel()), dtype=eng.obs_dtype, device=eng.device) for _ in range(A)]
+    rows_own = eng.window_rows(dests)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(eng.device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize(eng.device)
+        return a.elapsed_time(b) / iters
+
+    def fused():
+        eng.step(eng.actions)
+
+    def tensor_windows():
+        eng.turn += 1
+        eng.step(eng.actions, sweep=True, no_move=True, turn=eng.turn)
+        for a in range(A):
+            eng.act(a, rows)
+
+    def replay_rows():
+        eng.turn += 1
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=eng.turn)
+        eng.observe_rows(rows_own)
+        for a in range(A):
+            eng.act(a, rows_own)
+
+    out = {"fused_turn_ms": timed(fused), "policy_turn_ms": timed(tensor_windows), "launches": 1 + A,
+           "what": "policy_turn_ms: sgw_step(SGW_STEP_NO_MOVE) = sweep + every agent's window (into the observation tensor), then "
+                   "sgw_act per agent; fused_turn_ms: the same engine's one-launch turn with given actions; the policy's own forward "
+                   "pass is not in either"}
+    from sorrel_amd import _native as N
+    if eng.capabilities() & N.CAP_OBSERVE_ROWS:
+        out["policy_turn_replay_rows_ms"] = timed(replay_rows)
+        out["replay_rows_what"] = "windows rendered straight into per-agent [E][C*V*V] rows (what Environment.take_turn does when every agent has a replay Buffer): sweep, sgw_observe_rows, sgw_act per agent"
+    out["status"] = eng.status()
+    return out
+
+
 def ensure_built() -> None:
     """Both native libraries, checked (and, outside a profiler, rebuilt if stale) BEFORE torch or anything else touches
     the GPU: no compiler is ever started from a GPU-initialised process.  Ranks of one node take turns on a lock."""
@@ -521,6 +574,8 @@ def main() -> int:
                         "first_env_id_rank0": 0, "first_env_id_last_rank": (world - 1) * E},
         }
         valid_line = write_obs and sweep and args.diag_agents < 0 and args.obs_dtype == "f32"
+        if world == 1 and valid_line and not args.no_side_configs and args.max_turns == 0:
+            out["policy_turn"] = policy_turn_bench(eng)          # (after every timed region of the headline; same engine)
         if world == 1 and args.config == "c3" and valid_line and not args.no_side_configs:
             # the other 1-GPU BASELINE shapes, briefly, AFTER the headline run (its numbers are not touched by them)
             eng_obs, eng.obs = eng.obs, None                       # give the headline's 617 MB observation tensor back first

@@ -631,6 +631,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                     g[oaddr_v] = lg[oaddr_v];
                     g[taddr_v] = lg[taddr_v];
                 }
+            } else if (!RULES && nturns == 1 && !(p.do_move && p.a1 > p.a0)) {
+                // the sweep alone changed the grid (a policy-driven turn's first launch: nobody acts in it): write back only
+                // the 16-byte units in which something spawned -- ~4 of config 3's 128 units per env; the sweep-only launch
+                // is then a read of the grid plus a few scattered units instead of a read and a full write
+                uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
+#pragma unroll
+                for (int k = 0; k < NU; ++k)
+                    if (lane + 64 * k < nunits && hits[k]) dst[lane + 64 * k] = lg16[lane + 64 * k];
             } else {
                 uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll

@@ -13,8 +13,14 @@ def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 
 
-print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+print("== kernel stats (rocprofv3 --kernel-trace --stats; the headline workload alone) ==")
 for f in find("trace", "*kernel_stats.csv"):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            print("  %-60s calls=%s avg_ns=%s total_ns=%s pct=%s" % (row.get("Name", "")[:60], row.get("Calls"), row.get("AverageNs"),
+                                                                      row.get("TotalDurationNs"), row.get("Percentage")))
+for f in find("trace_full", "*kernel_stats.csv"):
+    print("== kernel stats of the FULL line (side configs + policy-turn leg; bench.py --steps 100) ==")
     with open(f) as fh:
         for row in csv.DictReader(fh):
             print("  %-60s calls=%s avg_ns=%s total_ns=%s pct=%s" % (row.get("Name", "")[:60], row.get("Calls"), row.get("AverageNs"),

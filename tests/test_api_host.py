@@ -486,3 +486,53 @@ def test_reference_import_paths_resolve_to_the_mirror(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path),
                          env=dict(env, PYTHONPATH=H.ROOT + ":" + str(tmp_path)))
     assert out.returncode == 0 and out.stdout.split() == ["refused", "sorrel_amd.worlds.gridworld"], out.stdout + out.stderr
+
+
+def test_buffer_add_copies_only_what_the_kernels_have_not_written():
+    """``Buffer.add`` skips the state / reward / action copies when the kernels already wrote them into the row
+    (``sgw_act``'s ``reward_row`` / ``action_row``, a window rendered into the state row) -- and ONLY then; the all-zero
+    ``dones`` rows are rewritten only once a non-zero ``done`` has ever been stored."""
+    from sorrel_amd.buffers import Buffer
+
+    E = 4
+    buf = Buffer(capacity=3, obs_shape=(5,), num_envs=E, device="cpu")
+    state = torch.arange(E * 5, dtype=torch.float32).reshape(E, 5)
+    action = torch.tensor([3, 1, 0, 2])
+    reward = torch.tensor([1.0, -1.0, 0.0, 10.0])
+    buf.add(state, action, reward, False)                            # nothing prefilled: everything is copied
+    assert torch.equal(buf.states[0], state) and torch.equal(buf.actions[0], action) and torch.equal(buf.rewards[0], reward)
+    assert buf.idx == 1 and buf.size == 1 and not buf._dones_dirty
+    # the kernels wrote row 1 in place: the state row, the reward row and (announced through _prefilled) the action row
+    buf.states[1].copy_(state * 2)
+    buf.rewards[1].copy_(reward * 3)
+    buf.actions[1].copy_(action + 1)
+    other_action = action + 1                                        # the policy's tensor (another storage than the row)
+    buf._prefilled = (1, other_action.data_ptr())
+    buf.add(buf.states[1], other_action, buf.rewards[1], False)
+    assert torch.equal(buf.states[1], state * 2) and torch.equal(buf.rewards[1], reward * 3) and torch.equal(buf.actions[1], action + 1)
+    assert buf._prefilled is None
+    # a _prefilled mark for another row, or another action tensor, is not trusted
+    buf._prefilled = (0, action.data_ptr())
+    buf.add(state, action, reward * 5, True)
+    assert torch.equal(buf.actions[2], action) and torch.equal(buf.rewards[2], reward * 5) and bool((buf.dones[2] == 1).all())
+    assert buf._dones_dirty and buf.idx == 0 and buf.size == 3
+    buf.add(state, action, reward, False)                            # row 0 again: the ring is dirty now, zeros are written
+    assert bool((buf.dones[0] == 0).all())
+    # a reward tensor of another dtype sharing the row's address is still copied (never the case in practice; cheap to keep right)
+    buf.add(state, action, reward.double(), 0)
+    assert torch.equal(buf.rewards[1], reward)
+
+
+def test_mark_dirty_and_invalidate_hooks():
+    env = make_env()
+    w = env.world
+    m = w.mutations
+    w.mark_dirty()
+    assert w.mutations == m + 1
+    spec = env.agents[0].observation_spec
+    key = Environment._ospec_key(spec)
+    assert Environment._ospec_key(spec) is key                       # cached on the spec
+    spec.entity_map["Gem"][0] = 0.5                                   # in-place edit: not seen ...
+    assert Environment._ospec_key(spec) is key
+    spec.invalidate()                                                 # ... until the spec is told
+    assert Environment._ospec_key(spec) != key

@@ -244,7 +244,9 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
  * `action_kind`) is read INSTEAD of actions[:, agent] -- the policy's output tensor as it is, no narrowing copy; the
  * uint8 record actions[:, agent] is still written -- and `reward_row` (float [E]) / `action_row` (int64 [E]) receive a
  * second copy of the rewards / the actions: the rows of the agent's replay buffer (sorrel/buffers.py:46-63 stores
- * int64 actions and float32 rewards), so add_memory has nothing left to copy.  All three may be NULL. */
+ * int64 actions and float32 rewards), so add_memory has nothing left to copy.  All three may be NULL.
+ * sgw_act never runs the in-stream reset of sgw_set_auto_reset (that belongs to whole-turn sgw_step / sgw_rollout calls):
+ * a policy-driven epoch loop resets with sgw_reset, as Environment.run_experiment does. */
 #define SGW_CAP_OBSERVE_ROWS 1
 #define SGW_CAP_ACT 2
 #define SGW_ACT_U8 0

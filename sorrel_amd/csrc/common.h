@@ -222,7 +222,8 @@ __device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
 // At most one spawning type (every Treasurehunt-shaped world): byte-parallel match of the spawner id, one Philox block
 // per dword that holds a spawner, thresholds and choices from scalar registers instead of per-byte table reads.
 template <int G>
-__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn) {
+__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn,
+                                             uint32_t* through = nullptr) {   // through: the env's grid in global memory -- changed dwords go there too
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
     const int ndw = (p.cells + 3) >> 2;
     for (int d = gtid; d < ndw; d += G) {
@@ -243,6 +244,7 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
                 const uint32_t pick = __umulhi(word_of(k, b), p.spawn_n);
                 lds_grid[4 * d + b] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
             }
+        if (through) through[d] = g32[d];
     }
 }
 

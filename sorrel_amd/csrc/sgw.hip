@@ -353,6 +353,8 @@ StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool 
     if (rules) {
         // one-hot tables of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of ceil(C / 4))
         const bool p3 = onehot && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
+        if (p3 && L == 3 && C == 9 && stage && r == 5 && H == 21 && W == 31 && !(getenv("SGW_NO_STATIC_CLEANUP") && getenv("SGW_NO_STATIC_CLEANUP")[0] == '1'))
+            PICK(step_fast<true, 3, 9, 5, 21, 31, false, true, true, false, true>);   // Cleanup as shipped (21x31x3 map, 11x11 windows)
         if (p3 && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, false, true>);   // Cleanup's tables (3 layers, 9 kinds)
         if (p3 && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, false, false, true>);
         if (p3 && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, false, true>);
@@ -618,16 +620,16 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             // fewer half-written observation streams open at once beat the extra waves, as for the occupancy cap of the plain
             // kernels -- Cleanup 21x31x3 at 65 536 envs, agents per burst 1 / 2 / 3 / 4 / 5 / 10: 666 / 695 / 643-680 / 640 / 643 / 850 us
             // (16 384 envs: 201 / 193 / 185-190 / 188 / 181 / 240).
-            int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16 : (int)(kLdsPerCu / 8 / 4) - base - 16;
+            int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - 48 : (int)(kLdsPerCu / 8 / 4) - base - 48;
             for (int wg = 4; e->fast_rules && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
-                budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - 16;
-            if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - 16;
+                budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - 48;
+            if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - 48;
             if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook
             int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;
             if (const char* f = getenv("SGW_STAGE_AGENTS")) apc = std::min(c.num_agents, atoi(f));   // A/B hook
             if (apc > 0) {
                 e->stage_agents = apc;
-                e->obs_stage = (apc * per_agent + 3 + 15) & ~15;    // + 3: the chunk's misalignment in global memory
+                e->obs_stage = (apc * per_agent + 31 + 15) & ~15;   // + 31: the chunk's offset from a 128-byte line of global memory (step_fast.h: emit_chunk)
                 stage_kernel = true;
             }
         }

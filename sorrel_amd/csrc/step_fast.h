@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     constexpr bool kStatic = TL && TH && TW;
     const int cells = kStatic ? TL * TH * TW : p.cells;
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
-    constexpr int NU = kStatic ? (TL * TH * TW / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
+    constexpr int NU = kStatic ? ((TL * TH * TW + 15) / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
     const int zoff = p.zA * HW;
     constexpr int NW = P3 ? 1 : (TC ? (TC + 3) / 4 : 4);   // counter words
     constexpr int CMAX = P3 ? (TC ? TC : 10) : 4 * NW;      // channels the counter words can hold
@@ -200,11 +200,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     // leave for HBM in one burst of 16-byte stores after the agent loop (instead of 6 dword stores per agent
     // dribbling out over the wave's life): the chip then has far fewer half-written observation streams open.
     uint8_t* ob = lg + ((cells + 15) & ~15);
-    constexpr bool kStageAlways = ONEHOT && STAGE && !(TL && TH && TW);
-    const bool stage = kStageAlways || (ONEHOT && (TL && TH && TW) && p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A);
+    constexpr bool kStageAlways = ONEHOT && STAGE;   // (compile-time shapes too: Cleanup as shipped stages bursts of agents)
+    const bool stage = kStageAlways || (ONEHOT && kStatic && p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A);
+#ifdef SGW_DIAG_NO_LINE_ALIGN
+    constexpr uint32_t kLineMask = 3u;     // diagnostic A/B: 16-byte aligned chunks as before round 3
+#else
+    constexpr uint32_t kLineMask = 31u;    // elements per 128-byte line of f32 observations, minus one
+#endif
     [[maybe_unused]] int ch_a0 = 0;            // first agent of the chunk being staged (STAGE)
-    [[maybe_unused]] uint32_t ch_shift = 0;    // misalignment (in elements) of the chunk's first element in global memory
-    if constexpr (kStageAlways) ch_shift = (uint32_t)(env * (int64_t)(p.A * C * VV)) & 3u;
+    [[maybe_unused]] uint32_t ch_shift = 0;    // staging byte of the chunk's first element = its offset (in elements) from a 128-byte line of global memory
+    [[maybe_unused]] uint32_t ch_lo = 0;       // first staged byte that has not left yet (bytes carried over from the chunk before sit in front of ch_shift)
+    if constexpr (kStageAlways) ch_lo = ch_shift = (uint32_t)(env * (int64_t)(p.A * C * VV)) & kLineMask;
 
     // per-lane window geometry: up to two cells per lane
     int wdi[2], wdj[2], woff[2];
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     const bool write_obs = !(p.flags & SGW_STEP_NO_OBS);
     const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
     const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
+    const bool sweep_only = !RULES && (MULTI ? p.nturns : 1u) == 1u && !(p.do_move && p.a1 > p.a0);   // nobody acts in this launch
 
     {
         double tot = p.do_move ? p.total[env] : 0.0;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         STAMP(1);   // global loads have arrived
         // ---- grid -> LDS; the Bernoulli half of the sweep runs on the registers
         [[maybe_unused]] uint32_t hits[NU];
-        if constexpr (!kStatic) {
+        if constexpr (!kStatic || ((TL * TH * TW) & 15) != 0) {
             if (cells & 15) {   // ragged world: bytes past the last cell are not cells (no type, no RNG index)
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
@@ -281,6 +288,16 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
             if (do_sweep) {
                 // Ordered sweep in LDS (common.h): layer by layer, lower layers first, a dword (four cells, one Philox block) per lane
                 sweep_ordered<1, 64>(p, rt, lg, env_id, lane, turn, L, HW);
+            }
+        } else if constexpr (!kStatic) {
+            // run-time shapes: one dword per lane and round on the LDS copy.  The unit-per-lane form below leaves a last
+            // round with a handful of lanes paying four Philox blocks each (32x33x2: 132 units = 64 + 64 + 4), and a wave
+            // skips the blocks of a round only when NO lane of it holds a spawner -- dword rounds are 4x finer on both counts
+            gsync<1>();
+            if (do_sweep) {
+                sweep_single<64>(p, lg, env_id, lane, turn,
+                                 sweep_only ? reinterpret_cast<uint32_t*>(p.grid + env * p.env_stride) : nullptr);
+                gsync<1>();
             }
         } else {
             if (tix > 0) {   // later turns of a rollout: the units come back from LDS (moves and spawns of the turns before)
@@ -342,58 +359,78 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         const int64_t turn_obs = tix * p.ts_obs;   // this turn's observation slot (elements)
         if constexpr (kStageAlways) {
             ch_a0 = 0;
-            ch_shift = (uint32_t)(turn_obs + env * (int64_t)(p.A * C * VV)) & 3u;
+            ch_lo = ch_shift = (uint32_t)(turn_obs + env * (int64_t)(p.A * C * VV)) & kLineMask;
         }
 
         STAMP(3);   // move inputs (action draw) done
-        // STAGE: the staged chunk [a_lo, a_hi) leaves for HBM.  Dword i of the (shifted) staging area is the 16-byte
-        // aligned float4 number i of the chunk's span in global memory; the span's first and last float4 may also hold
-        // elements of a neighbouring chunk / env, so those two leave element by element.
-        [[maybe_unused]] auto emit_chunk = [&](const int a_lo, const int a_hi) {
+        // STAGE: the staged chunk [a_lo, a_hi) leaves for HBM.  Byte s of the staging area is element (e0 - sh) + s of the
+        // observation tensor, and e0 - sh is a multiple of 32 elements: dword i of the staging area is float4 number i of a
+        // 128-BYTE LINE-ALIGNED span, so lane 0 of every wave-wide store sits on a line boundary and the store covers eight
+        // whole lines.  (Round 3.  A streaming store that covers PART of a line is expensive -- tools/micro/region_writer.hip:
+        // the same 1 KiB stores shifted by 16 / 32 / 64 bytes write 4.44 / 4.44 / 4.91 TB/s against 5.48 aligned -- and with
+        // 16-byte alignment only, every store of a chunk had a partial line at both ends.)  A chunk that is not the env's last
+        // leaves only up to its last line boundary; the < 32 bytes behind it are carried to the front of the staging area and
+        // leave with the next chunk.  What remains partial: the env's first and last line (shared with the neighbouring envs'
+        // waves), element-wise where they do not fill a float4.
+        [[maybe_unused]] auto emit_chunk = [&](const int a_lo, const int a_hi, const bool last) {
             gsync<1>();
             typedef float vfloat4 __attribute__((ext_vector_type(4)));
             const int N = (a_hi - a_lo) * C * VV;
             const int64_t e0 = turn_obs + (env * p.A + a_lo) * (int64_t)(C * VV);
-            const int sh = (int)ch_shift;
-            const int nd = (sh + N + 3) >> 2;
+            const int sh = (int)ch_shift, lo = (int)ch_lo;
+            const int hi = sh + N;
+            const int he = last ? hi : (hi & ~(int)kLineMask);    // bytes [lo, he) leave now
+            if (he <= lo) {                           // (a chunk that ends inside the env's first line: nothing to write yet)
+                ch_shift = (uint32_t)hi;
+                return;
+            }
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
-            // dwords [i0, i1) lie wholly inside the chunk: unconditional 16-byte streaming stores; the (at most two) edge
-            // dwords leave element by element (round 3: the bounds test sat on every float4 of the loop)
-            const int i0 = sh > 0 ? 1 : 0, i1 = (sh + N) >> 2;
+            const int i0 = (lo + 3) >> 2, i1 = he >> 2;   // dwords [i0, i1) lie wholly inside [lo, he): unconditional 16-byte streaming stores
+            // edge dwords (the env's first / last float4, partly another env's): element by element, by lanes 0 / 1
+            const int ie = lane == 0 ? i0 - 1 : i1;
+            const bool edge = lane == 0 ? (lo & 3) != 0 : (lane == 1 && (he & 3) != 0 && (i1 >= i0 || (lo & 3) == 0));
             if (!p.obs_u8) {
                 float* gb = p.obs + (e0 - sh);
-                for (int i = i0 + lane; i < i1; i += 64) {
+                for (int i = lane; i < i1; i += 64) {
+                    if (i < i0) continue;
                     const uint32_t b = ob4[i];
                     vfloat4 v;
                     v.x = (float)(b & 0xFFu);
                     v.y = (float)((b >> 8) & 0xFFu);
                     v.z = (float)((b >> 16) & 0xFFu);
                     v.w = (float)(b >> 24);
+#ifdef SGW_DIAG_PLAIN_STORES
+                    *reinterpret_cast<vfloat4*>(gb + 4 * i) = v;
+#else
                     __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
+#endif
                 }
-                if (lane < 2) {
-                    const int i = lane == 0 ? 0 : i1;                     // the first and the last dword of the span
-                    if ((lane == 0 ? sh > 0 : (i1 < nd && (i1 > 0 || sh == 0)))) {
-                        const uint32_t b = ob4[i];
-                        const int lo = 4 * i - sh;
+                if (edge) {
+                    const uint32_t b = ob4[ie];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (lo + j >= 0 && lo + j < N) gb[4 * i + j] = (float)((b >> (8 * j)) & 0xFFu);
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * ie + j >= lo && 4 * ie + j < he) gb[4 * ie + j] = (float)((b >> (8 * j)) & 0xFFu);
                 }
             } else {
                 uint8_t* gb = reinterpret_cast<uint8_t*>(p.obs) + (e0 - sh);
-                for (int i = i0 + lane; i < i1; i += 64) __builtin_nontemporal_store(ob4[i], reinterpret_cast<uint32_t*>(gb + 4 * i));
-                if (lane < 2) {
-                    const int i = lane == 0 ? 0 : i1;
-                    if ((lane == 0 ? sh > 0 : (i1 < nd && (i1 > 0 || sh == 0)))) {
-                        const uint32_t b = ob4[i];
-                        const int lo = 4 * i - sh;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (lo + j >= 0 && lo + j < N) gb[4 * i + j] = (uint8_t)(b >> (8 * j));
-                    }
+                for (int i = lane; i < i1; i += 64) {
+                    if (i < i0) continue;
+                    __builtin_nontemporal_store(ob4[i], reinterpret_cast<uint32_t*>(gb + 4 * i));
                 }
+                if (edge) {
+                    const uint32_t b = ob4[ie];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * ie + j >= lo && 4 * ie + j < he) gb[4 * ie + j] = (uint8_t)(b >> (8 * j));
+                }
+            }
+            if (!last) {   // the bytes behind the last line boundary: to the front, they leave with the next chunk
+                uint8_t t = 0;
+                if (lane < hi - he) t = ob[he + lane];
+                gsync<1>();
+                if (lane < hi - he) ob[lane] = t;
+                ch_shift = (uint32_t)(hi - he);
+                ch_lo = 0;
             }
             gsync<1>();
         };
@@ -402,9 +439,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         for (int a = p.a0; a < a_end; ++a) {
             if constexpr (kStageAlways) {
                 if (a - ch_a0 == p.stage_agents) {   // the staging area is full: out with it, start the next chunk
-                    if (write_obs) emit_chunk(ch_a0, a);
+                    if (write_obs) emit_chunk(ch_a0, a, false);   // (moves ch_shift / ch_lo on to the next chunk)
                     ch_a0 = a;
-                    ch_shift = (uint32_t)(turn_obs + (env * p.A + a) * (int64_t)(C * VV)) & 3u;
                 }
             }
             const int s_o = __builtin_amdgcn_readlane((int)oaddr_v, a);
@@ -418,6 +454,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                     if (64 * k >= VV) break;
                     const int w = lane + 64 * k;
                     if (w < VV) {
+#ifdef SGW_DIAG_SKIP_GATHER
+                        if (p.turn != 0xFFFFFFFFu) continue;
+#endif
                         const bool inb = (unsigned)(y + wdi[k]) < (unsigned)H && (unsigned)(x + wdj[k]) < (unsigned)W;
                         const int off = inb ? cbase + woff[k] : 0;   // clamped: the read is always in range
                         float* o = obase + w;
@@ -590,7 +629,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 
         STAMP(4);   // agent loop done
         if constexpr (kStageAlways) {
-            if (write_obs) emit_chunk(ch_a0, p.a1);
+            if (write_obs) emit_chunk(ch_a0, p.a1, true);
         } else if (stage && write_obs) {
             gsync<1>();
             const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
@@ -602,7 +641,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                 // stores of the unstaged path, which write partial lines, was measured SLOWER.)
                 typedef float vfloat4 __attribute__((ext_vector_type(4)));
                 vfloat4* o4 = reinterpret_cast<vfloat4*>(p.obs + turn_obs + env * (int64_t)(p.A * C * VV));
-                for (int i = lane; i < nd; i += 64) {
+                // (round 3) lane 0 of every store sits on a 128-byte line: an env's block is a whole number of 64-byte half lines
+                // (config 3: 9 408 B = 73.5 lines), so every second env starts mid-line, and a streaming store that covers part
+                // of a line costs as if ... tools/micro/region_writer.hip: 1 KiB stores shifted by 64 / 32 / 16 bytes write at
+                // 4.91 / 4.44 / 4.44 TB/s against 5.48 aligned.  mis = float4s between the line and the env's first element.
+                const int mis = (int)((reinterpret_cast<uintptr_t>(o4) >> 4) & 7u);
+                for (int i = lane - mis; i < nd; i += 64) {
+                    if (i < 0) continue;
                     const uint32_t b = ob4[i];
                     vfloat4 v;
                     v.x = (float)(b & 0xFFu);
@@ -631,14 +676,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                     g[oaddr_v] = lg[oaddr_v];
                     g[taddr_v] = lg[taddr_v];
                 }
-            } else if (!RULES && nturns == 1 && !(p.do_move && p.a1 > p.a0)) {
+            } else if (sweep_only) {
                 // the sweep alone changed the grid (a policy-driven turn's first launch: nobody acts in it): write back only
                 // the 16-byte units in which something spawned -- ~4 of config 3's 128 units per env; the sweep-only launch
                 // is then a read of the grid plus a few scattered units instead of a read and a full write
-                uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
+                // (run-time shapes: the dword sweep above stored its changed dwords as it went)
+                if constexpr (kStatic) {
+                    uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll
-                for (int k = 0; k < NU; ++k)
-                    if (lane + 64 * k < nunits && hits[k]) dst[lane + 64 * k] = lg16[lane + 64 * k];
+                    for (int k = 0; k < NU; ++k)
+                        if (lane + 64 * k < nunits && hits[k]) dst[lane + 64 * k] = lg16[lane + 64 * k];
+                }
             } else {
                 uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
 #pragma unroll

@@ -97,7 +97,7 @@ def run_cleanup(E=16384, K=50):
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / K * 1000
     byt = spec.algorithmic_bytes_per_env_step() * E
-    print(f"{'cleanup 21x31x3 A10 r5 (RULES kernel)':34s} E={E:7d} {us:8.1f} us/step  {E*10/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)")
+    print(f"{'cleanup 21x31x3 A10 r5 (RULES kernel)':34s} E={E:7d} {us:8.1f} us/step  {E*10/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)  [{eng.launch_info().split(' group')[0]}]")
     assert eng.status() == 0
 
 

@@ -20,7 +20,7 @@ t1.record(); torch.cuda.synchronize()
 us = t0.elapsed_time(t1) / 200 * 1000
 print("%%7.1f us  %%.3f  %%s" %% (us, spec.algorithmic_bytes_per_env_step() * E / us / 1e3 / 8000, eng.launch_info().split(" threads")[0]))
 ''' % ROOT
-shapes = [(10, 10, 2, 2), (16, 16, 4, 2), (21, 21, 2, 2), (21, 21, 8, 2), (24, 24, 4, 3), (28, 28, 8, 3), (32, 32, 2, 2), (32, 32, 8, 3), (30, 30, 8, 4), (32, 32, 16, 4)]
+shapes = [(10, 10, 2, 2), (16, 16, 4, 2), (21, 21, 2, 2), (21, 21, 8, 2), (24, 24, 4, 3), (28, 28, 8, 3), (32, 32, 2, 2), (32, 32, 8, 2), (32, 32, 4, 3), (20, 20, 4, 4), (32, 32, 8, 3), (30, 30, 8, 4), (32, 32, 16, 4)]
 E = 65536
 for h, w, a, r in shapes:
     for env in ({"SGW_GROUP": "64"}, {"SGW_GROUP": "16"}, {"SGW_GROUP": "32"}, {"SGW_GROUP": "64", "SGW_FORCE_GENERIC": "1"}):

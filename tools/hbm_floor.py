@@ -20,11 +20,16 @@ def both():
     obs.fill_(1.0); g2.copy_(g1)
 t_both = timeit(both)
 mb = obs.numel() * 4 / 1e6
-print(f"fill {mb:.0f} MB: {t_fill:.1f} us = {mb/t_fill/1e3:.2f} TB/s")
-print(f"copy 134+134 MB: {t_copy:.1f} us = {268.4/t_copy/1e3:.2f} TB/s")
-print(f"fill+copy (serial launches): {t_both:.1f} us = {(mb+268.4)/t_both/1e3:.2f} TB/s")
+print(f"fill {mb:.0f} MB: {t_fill:.1f} us = {mb/t_fill:.2f} TB/s")
+print(f"copy 134+134 MB: {t_copy:.1f} us = {268.4/t_copy:.2f} TB/s")
+print(f"fill+copy (serial launches): {t_both:.1f} us = {(mb+268.4)/t_both:.2f} TB/s")
 big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); big2 = torch.empty_like(big)
 t = timeit(lambda: big2.copy_(big), 20)
-print(f"1 GiB copy: {t:.1f} us = {2*1073.7/t/1e3:.2f} TB/s")
+print(f"1 GiB copy: {t:.1f} us = {2*1073.7/t:.2f} TB/s")
 t = timeit(lambda: big.fill_(3), 20)
-print(f"1 GiB fill: {t:.1f} us = {1073.7/t/1e3:.2f} TB/s")
+print(f"1 GiB fill: {t:.1f} us = {1073.7/t:.2f} TB/s")
+for gb in (0.6, 1.2, 2.85, 5.7):
+    x = torch.empty(int(gb * 1e9) // 4, dtype=torch.float32, device="cuda")
+    t = timeit(lambda: x.fill_(1.0), 20)
+    print(f"{gb} GB f32 fill: {t:.1f} us = {x.numel() * 4 / t / 1e6:.2f} TB/s")
+    del x

@@ -90,6 +90,8 @@ struct Params {
     int obs_A, obs_a0; // where agent a's window goes: obs + ((env * obs_A + (a - obs_a0)) * C) * V * V.  (A, 0): the [E][A][C][V][V]
                       // tensor; (1, a1) with SGW_STEP_OBS_NEXT_PACKED: one window per env, [E][C][V][V] (an agent's replay slot)
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
+    int big_stage;    // step_big: bytes of LDS observation staging per wave (0: windows go straight to HBM, a dword store per lane and channel)
+    int big_stage_off; // ... and where the first wave's area starts (behind the grid image)
     int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
     int rows_mode;        // phase_rows / observe_rows: how the staged windows leave (kRowsFlat / kRowsPair / kRowsSingle, phase.h)
     int rows_by_agent;    // observe_rows: a wave carries consecutive envs of ONE agent (per-agent destinations) instead of consecutive agents of an env

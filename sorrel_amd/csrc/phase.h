@@ -322,7 +322,11 @@ __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 
                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)o_lo));
         typedef float vfloat4 __attribute__((ext_vector_type(4)));
         const uint32_t* s4 = reinterpret_cast<const uint32_t*>(stage);
-        for (int k = lane; 4 * k + 3 < total; k += 64) {
+        // lane 0 of every store on a 128-byte line (a run starts on a 16-byte boundary, config 3's on a 64-byte one: a streaming
+        // store that covers part of a line costs 10-20 % of the write rate, tools/micro/region_writer.hip)
+        const int mis = (int)((reinterpret_cast<uintptr_t>(ow) >> 4) & 7u);
+        for (int k = lane - mis; 4 * k + 3 < total; k += 64) {
+            if (k < 0) continue;
             const uint32_t b = s4[k];
             vfloat4 v;
             v.x = (float)(b & 0xFFu);

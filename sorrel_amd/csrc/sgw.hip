@@ -101,6 +101,7 @@ struct sgw_engine {
     const char* kernel_name_walk = "-";
     int walk_blocks = 0;                            // how many workgroups of it the chip holds at once
     int64_t walk_min_envs = 0, walk_max_envs = 0;  // batches above min and up to max take it (multiples of what the plain kernel holds at once)
+    int64_t big_stage_min_envs = 0;                // step_big stages its windows for batches above this
     const char* kernel_name_plain = "?";
     int stage_agents = 0;      // agents per staged chunk (STAGE kernels)
     bool phase_ok = false;     // the phase kernel applies (plain moves)
@@ -118,7 +119,9 @@ struct sgw_engine {
     bool fast_rules = false;   // the RULES variant of step_fast applies
     int step_env_lds = 0;
     int obs_stage = 0;     // bytes of LDS observation staging per wave (step_fast, one-hot)
+    int big_stage = 0;     // ... per wave of step_big (0: direct stores)
     int fast_tab_bytes = 0;
+    int big_tab_bytes = 0;   // step_big: only the counter words of the channels in use
     int grid_blocks = 1;
     int fast_wg_cap = 5;   // step_fast workgroups per CU when writing large float32 observations of a large batch (0: no cap)
     int wg_per_cu = 0;     // sgw_set_wg_per_cu: 0 = the automatic rule above, 1..8 = forced, -1 = never capped
@@ -675,13 +678,35 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb_step * e->step_env_lds;
     p.big_pitch = c.width;
     if (e->big) {
-        // padded LDS rows (bank-conflict-free window gather) where a row is whole 16-byte units and the image still
-        // leaves four workgroups per CU (LDS is handed out in 1 KiB granules)
-        const size_t fixed = (size_t)e->fast_tab_bytes + kBigAgentLds;
-        const size_t padded = fixed + (size_t)c.layers * c.height * (c.width + 16);
-        if ((c.width & 15) == 0 && (p.cells & 15) == 0 && ((padded + 1023) & ~(size_t)1023) * 4 <= kLdsPerCu) p.big_pitch = c.width + 16;
+        // LDS of a workgroup: [counter words of the channels in use | appearance table][agent arrays][grid image][staging].
+        // Staging of the one-hot windows (a wave's window leaves as line-aligned 16-byte streaming stores, step_big.h phase
+        // R): on for config 5's compile-time instance (434 -> 347-372 us per turn of
+        // config 5 at 8 192 envs); the run-time-table instance pays more for the byte staging than the stores give back
+        // (64x64 / 16 agents / 7x7 windows: 229 -> 270 us) and is compiled without it.  SGW_BIG_STAGE=0: A/B and test hook.
+        // Padded rows (W + 16: the ~3 rows a 32-lane group of the window gather touches fall on disjoint banks) where a row
+        // is whole 16-byte units -- unless the padding costs a workgroup per CU (LDS is handed out in 1 KiB granules): with
+        // the staging, config 5's image fits four times into a CU only unpadded (39 936 bytes: exactly), and a fourth workgroup is
+        // worth more than the conflict-free gather (1 280 envs: 55 us at four per CU, 71 at three).
+        const bool tagk = c.agent_rule == SGW_AGENT_RULE_TAG;
+        const bool static_tables = onehot && (tagk ? (c.layers == 1 && c.num_channels == 4 && c.vision_radius == 4)
+                                                    : (c.layers == 2 && c.num_channels == 6 && c.vision_radius == 5));   // = pick_big's compile-time instances
+        e->big_tab_bytes = static_tables ? ((c.num_channels + 3) / 4) * SGW_MAX_TYPES * 4 : e->fast_tab_bytes;   // (the run-time instance adds all four counter words)
+        const size_t fixed = (size_t)e->big_tab_bytes + big_agent_lds(tagk);
+        bool stage_on = static_tables && !tagk;   // (the Tag example's 9x9x4 windows are ten lines each: staged 54 / 79 us, direct 47 / 74, 128x128 at 2 048 envs / 72x72 at 8 192)
+        if (const char* f = getenv("SGW_BIG_STAGE")) stage_on = stage_on && f[0] != '0';
+        e->big_stage = stage_on ? (c.num_channels * p.VV + 31 + 3) & ~3 : 0;
+        const size_t stage_all = (size_t)kBigWaves * e->big_stage;
+        auto per_cu = [&](size_t bytes) { return std::min<size_t>(4, kLdsPerCu / (((bytes + 1023) & ~(size_t)1023) + 1024)); };   // (a workgroup's request must stay 1 KiB below its share)
+        const size_t plain_img = (size_t)p.cells_pad, padded_img = (size_t)c.layers * c.height * (c.width + 16);
+        const bool can_pad = (c.width & 15) == 0 && (p.cells & 15) == 0;
+        if (can_pad && per_cu(fixed + padded_img + stage_all) >= per_cu(fixed + plain_img + stage_all)) p.big_pitch = c.width + 16;
         if (const char* f = getenv("SGW_BIG_NO_PAD")) { if (f[0] == '1') p.big_pitch = c.width; }   // A/B hook
-        e->step_lds_bytes = fixed + (p.big_pitch == c.width ? (size_t)p.cells_pad : (size_t)c.layers * c.height * p.big_pitch);
+        e->step_lds_bytes = fixed + (p.big_pitch == c.width ? plain_img : padded_img);
+        p.big_stage = p.big_stage_off = 0;
+        if (e->big_stage) {
+            p.big_stage_off = (int)e->step_lds_bytes;        // (a multiple of 16: every piece before it is)
+            e->step_lds_bytes += stage_all;
+        }
     }
     const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
     const size_t lds_max = 160 * 1024;
@@ -768,9 +793,13 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     if (e->step_fn_walk) {
         int per_cu = 0;
-        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_fn_walk, kBigThreads, e->step_lds_bytes);
+        const size_t walk_lds = e->step_lds_bytes - (size_t)kBigWaves * e->big_stage;   // (the walking variant stores directly: no staging area)
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_fn_walk, kBigThreads, walk_lds);
         int plain_per_cu = 0;
         if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain_per_cu, sk, kBigThreads, e->step_lds_bytes);
+        // (the runtime's answer for the plain kernel is three per CU whatever it asks for; the hardware admits a fourth
+        // while the request stays 1 KiB below a quarter of the CU's LDS -- 1 280 envs of config 5: 55 us there, 71 above)
+        if (oe == hipSuccess && ((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024 <= kLdsPerCu / 4) plain_per_cu = std::max(plain_per_cu, 4);
         if (oe != hipSuccess || per_cu < 1 || plain_per_cu < 1) e->step_fn_walk = nullptr;
         else {
             // Engaged for batches of 1.5x to 3x what the plain kernel holds at once (one env per workgroup, four
@@ -782,8 +811,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             // 683 workgroups (three envs each, evenly) 100 us, 512 100 us, 1 024 / 1 365 (oversubscribed) 93-107 us, a
             // 64-VGPR build (four per CU, six spilled registers) 95-98 us, staggered starts 96-101 us.
             e->walk_blocks = per_cu * e->num_cus;
+            // Round 3, with the staged windows (config 5, us per launch, plain direct / walking direct / plain staged): 1 024 envs
+            // 47 / - / 59, 1 280 54 / 54 / 69, 1 536 70 / 76 / 78, 2 048 105 / 91 / 97, 2 560 132 / 128 / 117, 3 072 155 / 168 / 141,
+            // 4 096 216 / - / 174-181, 8 192 415 / - / 347: the window is 1.5x to 2.25x now, staging takes over above it.
             e->walk_min_envs = (int64_t)plain_per_cu * e->num_cus * 3 / 2;
-            e->walk_max_envs = (int64_t)plain_per_cu * e->num_cus * 3;
+            e->walk_max_envs = e->big_stage ? (int64_t)plain_per_cu * e->num_cus * 9 / 4 : (int64_t)plain_per_cu * e->num_cus * 3;
         }
         if (const char* f = getenv("SGW_BIG_WALK_BLOCKS")) {   // tuning / test hook: this many workgroups, whatever the batch
             e->walk_blocks = std::max(1, atoi(f));
@@ -791,6 +823,10 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             e->walk_max_envs = INT64_MAX;
         }
     }
+    // staged windows pay once the batch is a few rounds of workgroups (a single round is latency-bound, and the staging adds
+    // an LDS round trip per window): above 1.75x what the chip holds at once (see the table above)
+    if (e->big) e->big_stage_min_envs = (int64_t)4 * e->num_cus * 7 / 4;
+    if (const char* f = getenv("SGW_BIG_STAGE")) { if (f[0] == '1') e->big_stage_min_envs = 0; }   // test hook: staged whatever the batch
     e->reset_blocks = (int)ceil_div(p.E, epb);   // one env per group and launch
     *out = e;
     return SGW_OK;
@@ -861,11 +897,16 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (p.agent_rule == SGW_AGENT_RULE_TAG && p.do_move && !p.agent_state)
         return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
     p.env_lds = e->step_env_lds;
-    if (e->fast || e->big) p.tab_bytes = e->fast_tab_bytes;
+    if (e->fast || e->big) p.tab_bytes = e->big ? e->big_tab_bytes : e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
     int cap = 0;
-    const size_t lds = step_lds_request(e, p, &cap);
+    size_t lds = step_lds_request(e, p, &cap);
+    // step_big: the walking variant keeps the direct stores (measured faster there), and so does a launch whose observation
+    // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
+    const bool walk = e->big && p.nturns == 1 && e->step_fn_walk && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
+    p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
+    if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)kBigWaves * e->big_stage;
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
@@ -894,7 +935,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         fn = e->step_fn_plain;
     if (p.nturns > 1 && (e->fast || e->big)) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
     int blocks = e->grid_blocks;
-    if (e->big && p.nturns == 1 && e->step_fn_walk && p.E > e->walk_min_envs && p.E <= e->walk_max_envs) {   // two to three rounds of the plain kernel
+    if (walk) {   // two to three rounds of the plain kernel
         fn = e->step_fn_walk;
         blocks = e->walk_blocks;
     }
@@ -1248,18 +1289,20 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     p.obs = reinterpret_cast<float*>(16); p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
     p.obs_stage = e->fast ? e->obs_stage : 0;
     int cap = 0;
-    const size_t lds = step_lds_request(e, p, &cap);
+    size_t lds = step_lds_request(e, p, &cap);
+    const bool big_staged = e->big && !walk && e->base.E > e->big_stage_min_envs;
+    if (e->big && !big_staged) lds -= (size_t)kBigWaves * e->big_stage;
     const int threads = e->big ? kBigThreads : kBlock;
     StepFn fn = walk ? e->step_fn_walk : e->step_fn;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
     const char* phase = e->rows_fn ? e->kernel_name_rows : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
-    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s",
+    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d",
              walk ? e->kernel_name_walk : e->kernel_name,
              (e->fast || e->big) ? e->wpe * kWave * (e->big ? kBigWaves / 4 : 1) : e->group,
              threads, lds, e->step_env_lds, e->obs_stage, e->stage_agents,
              walk ? e->walk_blocks : e->grid_blocks, per_cu,
-             e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase);
+             e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase, big_staged ? e->big_stage : 0);
     return SGW_OK;
 }
 

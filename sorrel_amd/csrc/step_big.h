@@ -29,7 +29,10 @@ constexpr int kBigThreads = SGW_BIG_THREADS;
 #define SGW_WALK_WAVES 6   // waves per SIMD the WALK variant is compiled for (8 = 64 VGPRs: spills the prefetched units)
 #endif
 constexpr int kBigWaves = kBigThreads / 64;
-constexpr int kBigAgentLds = 64 * 4 * 4 + 64 * 8 + 16 + 32 * 8 + 64;   // ta, oa, npos, rew | val f64 | turn+moved | value table | agent types
+constexpr int kBigAgentLds = 64 * 4 * 3 + 64;   // ta, oa, npos | agent types  (round 3: the f64 rewards of a turn and the value table live in wave 0's
+                                                // registers -- with the observation staging, config 5's image then fits a CU four times)
+constexpr int kBigTagLds = 64 * 4;                                       // ... and, for Tag, the tag journal behind them
+constexpr int big_agent_lds(bool tag) { return kBigAgentLds + (tag ? kBigTagLds : 0); }
 
 // MULTI: sgw_rollout's variant -- a turn loop around sweep / moves / observations with the env's 32 KiB resident in LDS
 // (later turns sweep the units read back from LDS; only the last turn is followed by the write-back).
@@ -99,11 +102,9 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
     uint32_t* s_ta = reinterpret_cast<uint32_t*>(smem + p.tab_bytes);      // journal entry of each agent (phase M -> R)
     uint32_t* s_oa = s_ta + 64;                                             // packed (y, x) at the start of the turn
     uint32_t* s_np = s_oa + 64;                                             // packed (y, x) if the move succeeds
-    uint32_t* s_rm = s_np + 64;                                             // TAG: the tag journal -- victim's cell (y, x) | type the agent carried when it acted << 16 | tagged << 24
-    double* s_val = reinterpret_cast<double*>(s_rm + 64);                   // reward f64 (for total, in agent order)
-    double* s_vtab = s_val + 64 + 2;                                         // value[32] (keeps global loads out of the chain)
-    uint8_t* s_atype = reinterpret_cast<uint8_t*>(s_vtab + 32);                       // agent_type[64]
-    uint8_t* lg = smem + p.tab_bytes + kBigAgentLds;
+    uint8_t* s_atype = reinterpret_cast<uint8_t*>(s_np + 64);                         // agent_type[64]
+    [[maybe_unused]] uint32_t* s_rm = reinterpret_cast<uint32_t*>(s_atype + 64);      // TAG: the tag journal -- victim's cell (y, x) | type the agent carried when it acted << 16 | tagged << 24
+    uint8_t* lg = smem + p.tab_bytes + big_agent_lds(TAG);
     uint4* lg16 = reinterpret_cast<uint4*>(lg);
     const DevTables* gtab = p.tab;
 
@@ -115,12 +116,12 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
     // ---- tables -> LDS
     if constexpr (ONEHOT) {
         uint32_t* wd = reinterpret_cast<uint32_t*>(smem);
-        if (tid0 < 4 * SGW_MAX_TYPES) wd[tid0] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid0];
+        if (tid0 < (p.tab_bytes >> 2)) wd[tid0] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid0];   // (the counter words of the channels in use)
     } else {
         double* wa = reinterpret_cast<double*>(smem);
         for (int i = tid0; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBigThreads) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
     }
-    if (tid0 < 32) s_vtab[tid0] = gtab->value[tid0];
+    const double vtab = gtab->value[tid0 & 31];   // lane t (of wave 0): value[t], f64 (keeps global loads out of the chain)
     if (tid0 >= 64 && tid0 < 128) s_atype[tid0 - 64] = gtab->agent_type[tid0 - 64];
     const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(smem);
     const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(smem);
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
         } else {
             if (passed_v) lg[ta_v] = (uint8_t)atype_v;
         }
-        double val = (jr & 0x100u) ? s_vtab[jr & 31u] : 0.0;           // reward = value of the target BEFORE the move
+        double val = __shfl(vtab, (int)(jr & 31u));                     // reward = value of the target BEFORE the move
+        if (!(jr & 0x100u)) val = 0.0;
         if constexpr (TAG) {
             // TagAgent.act: reward_per_turn for not being "it" once its own act is over (agents.py:100-106)
             const uint32_t after = tagj ? p.tag_notit : pov_v;
@@ -376,13 +378,17 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
             if (lane < p.A) p.agent_state[env * p.A + lane] = (uint8_t)type_v;
             if (mine && p.state_at_pov) p.state_at_pov[env * p.A + lane] = (uint8_t)pov_v;
         }
-        s_val[lane] = val;
         s_ta[lane] = jr;                                                // journal for the render phase
         if (jr & 0x400u) st_lane |= SGW_STATUS_BAD_TYPE;
         if (mine) p.rewards[tix * p.ts_rew + env * p.A + tid] = (float)val;   // this turn's rewards
         gsync<1>();
-        if (tid == 0)
-            for (int a = p.a0; a < p.a1; ++a) tot += s_val[a];           // float64, agent order (agent.py:172)
+        {   // float64, agent order (agent.py:172): the same sum in every lane, lane 0's is kept
+            const uint32_t v_lo = (uint32_t)__double_as_longlong(val), v_hi = (uint32_t)(__double_as_longlong(val) >> 32);
+            for (int a = p.a0; a < p.a1; ++a) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v_lo, a), hi = (uint32_t)__builtin_amdgcn_readlane((int)v_hi, a);
+                tot += __longlong_as_double(((long long)hi << 32) | lo);
+            }
+        }
     }
     __syncthreads();
     STAMPB(2);                   // phase M done
@@ -501,43 +507,116 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
                 }
             }
             float* obase = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
+            if constexpr (ONEHOT) {
+                // the packed byte counts of window cell lane + 64 k: one table word per layer and group of four channels
+                auto counts = [&](const int k, uint32_t (&cq)[NW]) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int w = lane + 64 * k;
-                if (w < VV) {
-                    float* o = obase + w;
-                    if constexpr (ONEHOT) {
-                        uint32_t cnt[NW];
+                    for (int q = 0; q < NW; ++q) cq[q] = 0;
+                    for (int z = 0; z < L; ++z) {
+                        const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
 #pragma unroll
-                        for (int q = 0; q < NW; ++q) cnt[q] = 0;
-                        for (int z = 0; z < L; ++z) {
-                            const uint32_t t = z < 4 ? (tb[k][0] >> (8 * z)) & 31u : (tb[k][1] >> (8 * (z - 4))) & 31u;
+                        for (int q = 0; q < NW; ++q) cq[q] += wdelta[q * 32 + t];
+                    }
 #pragma unroll
-                            for (int q = 0; q < NW; ++q) cnt[q] += wdelta[q * 32 + t];
+                    for (int q = 0; q < NW; ++q) cq[q] = inbk[k] ? cq[q] : p.fill_delta[q];
+                };
+                if (TC != 0 && p.big_stage > 0) {   // (compiled into the instances with compile-time tables only: the others spill with it)
+                    // (round 3) the window's byte counts are staged in this wave's LDS area, plane by plane as they lie in the
+                    // tensor, and leave as 16-byte streaming stores whose lane 0 sits on a 128-byte line of global memory
+                    // (step_fast.h, emit_chunk: same scheme) instead of a dword store per lane and channel whose 484-byte runs
+                    // start anywhere.  Config 5 at 8 192 envs: 434 -> 372 us per turn; 48x48 / 8 agents at 16 384: 176 -> 156.
+                    // The walking variant keeps the direct stores (2 048 envs: 93 us against 104 staged).
+                    typedef float vfloat4 __attribute__((ext_vector_type(4)));
+                    uint8_t* ob = smem + p.big_stage_off + wv * p.big_stage;
+                    const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
+                    const int64_t e0 = obase - p.obs;       // the window's first element in the tensor
+                    const int sh = (int)(e0 & 31);          // ... and its distance from a line boundary: staged byte s is element (e0 - sh) + s
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int w = lane + 64 * k;
+                        if (w < VV) {
+                            uint32_t cnt[NW];
+                            counts(k, cnt);
+#pragma unroll
+                            for (int c = 0; c < 4 * NW; ++c)
+                                if (c < C) ob[sh + c * VV + w] = (uint8_t)((cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu);
                         }
+                    }
+                    gsync<1>();
+                    const int he = sh + C * VV;
+                    const int i0 = (sh + 3) >> 2, i1 = he >> 2;   // dwords [i0, i1) lie wholly inside the window: 16-byte streaming stores
+                    // the window's first / last float4 may be partly a neighbouring window's: element by element, by lanes 0 / 1
+                    const int ie = lane == 0 ? i0 - 1 : i1;
+                    const bool edge = lane == 0 ? (sh & 3) != 0 : (lane == 1 && (he & 3) != 0);
+                    if (!p.obs_u8) {
+                        float* gb = p.obs + (e0 - sh);
+                        for (int i = lane; i < i1; i += 64) {
+                            if (i < i0) continue;
+                            const uint32_t b = ob4[i];
+                            vfloat4 v;
+                            v.x = (float)(b & 0xFFu);
+                            v.y = (float)((b >> 8) & 0xFFu);
+                            v.z = (float)((b >> 16) & 0xFFu);
+                            v.w = (float)(b >> 24);
+                            __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
+                        }
+                        if (edge) {
+                            const uint32_t b = ob4[ie];
 #pragma unroll
-                        for (int q = 0; q < NW; ++q) cnt[q] = inbk[k] ? cnt[q] : p.fill_delta[q];
-                        if (!p.obs_u8) {
-#pragma unroll
-                            for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                                for (int b = 0; b < 4; ++b) {
-                                    const int c = 4 * q + b;
-                                    if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
-                                }
-                            }
-                        } else {   // compact format: the same counts as bytes
-                            uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
-#pragma unroll
-                            for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                                for (int b = 0; b < 4; ++b) {
-                                    const int c = 4 * q + b;
-                                    if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
-                                }
-                            }
+                            for (int j = 0; j < 4; ++j)
+                                if (4 * ie + j >= sh && 4 * ie + j < he) gb[4 * ie + j] = (float)((b >> (8 * j)) & 0xFFu);
                         }
                     } else {
+                        uint8_t* gb = reinterpret_cast<uint8_t*>(p.obs) + (e0 - sh);
+                        for (int i = lane; i < i1; i += 64) {
+                            if (i < i0) continue;
+                            __builtin_nontemporal_store(ob4[i], reinterpret_cast<uint32_t*>(gb + 4 * i));
+                        }
+                        if (edge) {
+                            const uint32_t b = ob4[ie];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (4 * ie + j >= sh && 4 * ie + j < he) gb[4 * ie + j] = (uint8_t)(b >> (8 * j));
+                        }
+                    }
+                    gsync<1>();   // the next window of this wave overwrites the staging area
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int w = lane + 64 * k;
+                        if (w < VV) {
+                            float* o = obase + w;
+                            uint32_t cnt[NW];
+                            counts(k, cnt);
+                            if (!p.obs_u8) {
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) OBS_STORE(o + c * VV, (float)((cnt[q] >> (8 * b)) & 0xFFu));
+                                    }
+                                }
+                            } else {   // compact format: the same counts as bytes
+                                uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
+#pragma unroll
+                                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                                    for (int b = 0; b < 4; ++b) {
+                                        const int c = 4 * q + b;
+                                        if (c < C) o8[c * VV] = (uint8_t)((cnt[q] >> (8 * b)) & 0xFFu);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int w = lane + 64 * k;
+                    if (w < VV) {
+                        float* o = obase + w;
                         for (int c = 0; c < C; ++c) {
                             double acc = wapp[tb[k][0] & 31u][c];   // left-to-right float64 layer sum
                             for (int z = 1; z < L; ++z) {

@@ -781,3 +781,72 @@ def test_layered_rule_worlds_up_to_8k_per_env_vs_oracle(torch_cuda, case):
                 same(f"turn {t}")
     assert (eng.grid[:, 2] != eng.grid[0, 2, 1, 1]).any() or case == "become_if_movers_50x52", "no beam was ever fired"
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ step_big: windows staged in LDS, line-aligned streaming stores
+@pytest.mark.parametrize("case", ["config5_shape", "crowded_48x48", "odd_70x90", "u8", "phased", "rollout", "misaligned_obs"])
+def test_big_kernel_staged_windows_vs_oracle(torch_cuda, monkeypatch, case):
+    """Worlds above 4 KiB whose tables have a compile-time step_big instance stage each window's byte counts in the rendering
+    wave's LDS area and write them as 16-byte streaming stores on 128-byte lines (batches of more than ~1.75 rounds of
+    workgroups; SGW_BIG_STAGE=1 forces it for the small batches a test can check element by element).  Windows whose first
+    element sits anywhere in a line (A * C * V * V odd multiples), the uint8 format, the phased 1 + A form (one window per
+    launch), sgw_rollout, and an observation tensor that is not 16-byte aligned (falls back to the direct stores); every
+    tensor against the C oracle."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_BIG_STAGE", "1")
+    kw = {}
+    h, w, a, E, T = {"config5_shape": (128, 128, 64, 5, 4), "crowded_48x48": (48, 48, 64, 21, 8), "odd_70x90": (70, 90, 13, 11, 6),
+                     "u8": (64, 80, 17, 6, 5), "phased": (80, 64, 7, 5, 5), "rollout": (72, 72, 9, 6, 6),
+                     "misaligned_obs": (64, 80, 5, 7, 4)}[case]
+    ws = treasurehunt_spec(h, w, a, 5, spawn_prob=0.05, seed=31, dense_prob=0.3 if case == "crowded_48x48" else 0.1)
+    if case == "u8":
+        kw["obs_dtype"] = torch.uint8
+    eng = make_engine(ws, E, first=5, **kw)
+    info = eng.launch_info()
+    assert "step_big<" in info and "big_stage=0" not in info, info
+    co = H.COracle(ws, E, first_env_id=5)
+    eng.reset(0)
+    co.reset(0)
+    if case == "misaligned_obs":      # a view that starts 4 bytes into the allocation: the kernel must not stage (and must still be right)
+        flat = torch.full((eng.obs.numel() + 4,), -7.0, device="cuda")
+        eng.obs = flat[1:1 + eng.obs.numel()].view(eng.obs.shape)
+        assert eng.obs.data_ptr() % 16 == 4
+    ref = lambda: dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions)
+    if case == "rollout":
+        obs_t = torch.empty((T,) + tuple(eng.obs.shape), device="cuda")
+        eng.rollout(T, obs_out=obs_t)
+        torch.cuda.synchronize()
+        for t in range(1, T + 1):
+            assert co.step(0, t, random_actions=True) == 0
+            assert np.array_equal(obs_t[t - 1].cpu().numpy(), co.obs), f"rollout turn {t}: obs"
+        for k in ("grid", "agent_pos", "total_reward"):
+            assert np.array_equal(getattr(eng, k).cpu().numpy(), ref()[k]), f"rollout: {k}"
+        return
+    for t in range(1, T + 1):
+        assert co.step(0, t, random_actions=True) == 0
+        if case == "phased":
+            acts = torch.from_numpy(co.actions.copy()).cuda()
+            a = ws.num_agents
+            seen = torch.zeros_like(eng.obs)
+            eng.obs.fill_(-3.0)
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for i in range(a):
+                seen[:, i] = eng.obs[:, i]
+                eng.step(acts, sweep=False, agent_begin=i, agent_end=i + 1, obs_next=i + 1 < a, write_obs=False, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(seen.cpu().numpy(), co.obs), f"phased turn {t}: windows"
+            what = ("grid", "agent_pos", "total_reward")
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            what = ("grid", "agent_pos", "total_reward", "rewards", "actions", "obs")
+        for k in what:
+            assert np.array_equal(getattr(eng, k).cpu().numpy().astype(ref()[k].dtype), ref()[k]), f"{case} turn {t}: {k}"
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy().astype(co.obs.dtype), co.obs), f"{case}: sgw_observe"
+    assert eng.status() == 0

@@ -850,3 +850,35 @@ def test_big_kernel_staged_windows_vs_oracle(torch_cuda, monkeypatch, case):
     torch.cuda.synchronize()
     assert np.array_equal(eng.obs.cpu().numpy().astype(co.obs.dtype), co.obs), f"{case}: sgw_observe"
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ compile-time window on a run-time map
+@pytest.mark.parametrize("shape", [(33, 32, 8, 3), (24, 24, 8, 2), (20, 20, 4, 4), (30, 26, 7, 5), (19, 23, 5, 3)])
+def test_static_radius_instances_on_runtime_maps_vs_oracle(torch_cuda, monkeypatch, shape):
+    """Treasurehunt-shaped worlds whose MAP has no compile-time instance run on step_fast<true, 2, 6, r, 0, 0, ..., STAGE> for
+    r = 2 ... 5 (compile-time window, run-time map; ragged maps included: 19x23x2 = 874 cells).  Every tensor against the C
+    oracle, turn by turn, then sgw_observe; SGW_GROUP=64 keeps small worlds off the packed kernel."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_GROUP", "64")
+    h, w, a, r = shape
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.06, seed=41, dense_prob=0.15)
+    E, T = 37, 9
+    eng, co = make_engine(ws, E, first=7), H.COracle(ws, E, first_env_id=7)
+    assert f"step_fast<true, 2, 6, {r}, 0, 0, false, false, true>" in eng.launch_info(), eng.launch_info()
+    eng.reset(0)
+    co.reset(0)
+    for t in range(1, T + 1):
+        eng.step(random_actions=True)
+        assert co.step(0, t, random_actions=True) == 0
+        torch.cuda.synchronize()
+        for k, ref in (("grid", co.grid), ("agent_pos", co.pos), ("total_reward", co.total), ("rewards", co.rewards),
+                       ("actions", co.actions), ("obs", co.obs)):
+            assert np.array_equal(getattr(eng, k).cpu().numpy(), ref), f"{shape} turn {t}: {k}"
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy(), co.obs)
+    assert eng.status() == 0

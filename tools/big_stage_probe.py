@@ -1,5 +1,5 @@
 """Worlds above 4 KiB (step_big): direct per-channel dword stores against LDS-staged, line-aligned 16-byte streaming stores
-(the default where a compile-time instance exists; SGW_BIG_STAGE=0: off; SGW_BIG_STAGE_WALK=1: also in the walking variant), us per turn; every variant's tensors compared with the first one's.  GPU only."""
+(the default where a compile-time instance exists; SGW_BIG_STAGE=0: off), us per turn; every variant's tensors compared with the first one's.  GPU only."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -22,7 +22,7 @@ t1.record(); torch.cuda.synchronize()
 print("RESULT %%7.1f us  %%s  %%s" %% (t0.elapsed_time(t1) * 10, dig, eng.launch_info().split(" threads")[0] + " " + " ".join(x for x in eng.launch_info().split() if x.startswith(("lds=", "big_stage=")))))
 ''' % ROOT
 shapes = [(128, 128, 64, 5, 2048), (128, 128, 64, 5, 4096), (128, 128, 64, 5, 8192), (48, 48, 8, 5, 16384), (72, 72, 16, 5, 8192)]
-variants = [{}, {"SGW_BIG_STAGE": "0"}, {"SGW_BIG_STAGE_WALK": "1"}, {"SGW_BIG_NO_PAD": "1"}]
+variants = [{}, {"SGW_BIG_STAGE": "0"}, {"SGW_BIG_NO_PAD": "1"}]
 if os.environ.get("PROBE_WALK"):   # where does the walking variant pay?
     shapes = [(128, 128, 64, 5, e) for e in (1024, 1280, 1536, 2048, 2560, 3072, 4096)]
     variants = [{}, {"SGW_BIG_NO_WALK": "1"}, {"SGW_BIG_NO_WALK": "1", "SGW_BIG_STAGE": "0"}]

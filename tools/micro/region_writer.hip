@@ -97,27 +97,24 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out, (size_t)E * R4 * 16));
     const double mb = E * R4 * 16.0 / 1e6;
     printf("E = %ld, %.0f MB written per launch\n", E, mb);
-    for (int ldsb : {32768}) {   // 8 / 5 workgroups per CU (LDS is handed out in 1 KiB granules of 160 KiB) -- 7 / 4 with 32 KiB... see the printed numbers
-        for (int nb : {1}) {
-            for (int spin : {0, 400}) {
-                float t0 = run<0, true>(out, E, nb, spin, ldsb, 20), t0p = run<0, false>(out, E, nb, spin, ldsb, 20);
-                float t1 = run<1, true>(out, E, nb, spin, ldsb, 20), t1p = run<1, false>(out, E, nb, spin, ldsb, 20);
-                printf("lds %5d  bursts %2d  spin %3d | wave-per-region nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s | workgroup-per-region nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s\n",
-                       ldsb, nb, spin, t0, mb / t0, t0p, mb / t0p, t1, mb / t1, t1p, mb / t1p);
-            }
+    for (int nb : {1, 4, 10})        // 1. who writes a region, in how many bursts, with how much dependent work between the bursts (five workgroups per CU)
+        for (int spin : {0, 400}) {
+            float t0 = run<0, true>(out, E, nb, spin, 32768, 20), t0p = run<0, false>(out, E, nb, spin, 32768, 20);
+            float t1 = run<1, true>(out, E, nb, spin, 32768, 20), t1p = run<1, false>(out, E, nb, spin, 32768, 20);
+            printf("bursts %2d  spin %3d | wave-per-region nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s | workgroup-per-region nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s\n",
+                   nb, spin, t0, mb / t0, t0p, mb / t0p, t1, mb / t1, t1p, mb / t1p);
         }
-    }
-    for (int ldsb : {32768})
-        for (int nb : {1, 4})
-            for (int sp : {0, 1, 5, 2, 6}) {
-                float t3 = run<3, true>(out, E, nb, sp, ldsb, 20), t3p = run<3, false>(out, E, nb, sp, ldsb, 20);
-                printf("lds %5d  bursts %2d  misalign %d | wave-per-region from LDS bytes: nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s\n", ldsb, nb, sp, t3, mb / t3, t3p, mb / t3p);
-            }
-    for (int off4 : {0, 1, 2, 4})   // the whole pattern shifted by 16 / 32 / 64 bytes: every wave-wide store then starts inside a 128-byte line
+    for (int nb : {1, 4})            // 2. data from LDS bytes; a region 4 / 8 bytes off a 16-byte boundary, without (1, 2) and with (5, 6) lane 0 on a 128-byte line
+        for (int sp : {0, 1, 5, 2, 6}) {
+            float t3 = run<3, true>(out, E, nb, sp, 32768, 20), t3p = run<3, false>(out, E, nb, sp, 32768, 20);
+            printf("bursts %2d  misalign %d | wave-per-region from LDS bytes: nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s\n", nb, sp, t3, mb / t3, t3p, mb / t3p);
+        }
+    for (int off4 : {0, 1, 2, 4})   // 3. the whole pattern shifted by 16 / 32 / 64 bytes: every wave-wide store then starts inside a 128-byte line
     {
         float t0 = run<0, true>(out + off4, E - 1, 1, 0, 32768, 20), t0p = run<0, false>(out + off4, E - 1, 1, 0, 32768, 20);
         printf("wave-per-region shifted by %2d bytes: nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s\n", off4 * 16, t0, mb / t0, t0p, mb / t0p);
     }
+    // 4. torch's fill shape
     float t2 = run<2, true>(out, E, 1, 0, 1024, 20), t2p = run<2, false>(out, E, 1, 0, 1024, 20);
     printf("linear: nt %.1f us %.2f TB/s  plain %.1f us %.2f TB/s\n", t2, mb / t2, t2p, mb / t2p);
     return 0;

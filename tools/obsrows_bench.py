@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import treasurehunt_spec

@@ -882,3 +882,33 @@ def test_static_radius_instances_on_runtime_maps_vs_oracle(torch_cuda, monkeypat
     torch.cuda.synchronize()
     assert np.array_equal(eng.obs.cpu().numpy(), co.obs)
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ line-aligned bursts: chunks smaller than a line, every alignment
+@pytest.mark.parametrize("case", [(24, 20, 1, 2, 7, 1, 1), (24, 20, 1, 2, 7, 1, 2), (24, 20, 2, 3, 9, 1, 1), (18, 22, 2, 6, 5, 1, 1),
+                                  (16, 16, 1, 1, 6, 2, 1), (20, 24, 2, 5, 11, 2, 3), (32, 33, 2, 6, 8, 3, 3), (21, 31, 3, 9, 10, 5, 3)],
+                         ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}_C{c[3]}_A{c[4]}_r{c[5]}_burst{c[6]}")
+def test_staged_bursts_carry_partial_lines_vs_oracle(torch_cuda, monkeypatch, case):
+    """emit_chunk: a chunk leaves up to its last 128-byte line boundary and the bytes behind it are carried into the next
+    chunk.  Forced small bursts (SGW_STAGE_AGENTS) over windows of 18 / 27 / 25 / 54 bytes -- chunks that end inside the
+    env's first line and write nothing yet, chunks smaller than a line, 99 envs so that an env's block starts at every
+    multiple of 8 / 4 bytes -- in both observation formats, then the ordinary burst sizes; every element against the C oracle."""
+    torch = torch_cuda
+    h, w, L, C, a, r, burst = case
+    monkeypatch.setenv("SGW_GROUP", "64")
+    monkeypatch.setenv("SGW_STAGE_AGENTS", str(burst))
+    ws = _move_world(h, w, L, C, a, r, seed=5)
+    for dtype in (torch.float32, torch.uint8):
+        E, T = 99, 4
+        eng, co = make_engine(ws, E, first=2, obs_dtype=dtype), H.COracle(ws, E, first_env_id=2)
+        assert f"stage_agents={burst}" in eng.launch_info(), eng.launch_info()
+        eng.reset(0)
+        co.reset(0)
+        for t in range(1, T + 1):
+            eng.obs.fill_(77)
+            eng.step(random_actions=True)
+            assert co.step(0, t, random_actions=True) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(eng.obs.cpu().numpy().astype(co.obs.dtype), co.obs), f"{case} {dtype} turn {t}: obs"
+            assert np.array_equal(eng.grid.cpu().numpy(), co.grid) and np.array_equal(eng.total_reward.cpu().numpy(), co.total)
+        assert eng.status() == 0

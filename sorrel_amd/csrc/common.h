@@ -117,6 +117,12 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t k) {
 // Philox-4x32-10 (Salmon et al., SC'11); key = (k0, k1) wave-uniform.
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
+#ifndef SGW_DIAG_SHARED_KEYS
+    // every block walks its OWN key schedule (two s_add per round): left to itself the compiler computes the twenty round keys
+    // once and keeps them in SGPRs across all the blocks of a kernel -- the headline kernel then spills 22 scalars into vector
+    // lanes (v_writelane / v_readlane are vector instructions, and the kernel is bound by those)
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;

@@ -251,39 +251,48 @@ using StepFn = void (*)(const Params);
 // windows 51.0 -> 46.2 us (65 536 envs, same box).  A compile-time world size on top: Tag 2 % (and 72 VGPRs = a seventh
 // wave per SIMD), Treasurehunt 21x21 nothing (46.2 both: not instantiated); Cleanup's wave-per-env kernel with r = 5:
 // nothing (699 against 704 us: not instantiated).
+// step_kernel<G, ONEHOT, L, C, RULE, r, H, W, MULTI>: the single-turn instance, or (multi) the one with sgw_rollout's turn loop
+#define PICK_SK(G_, OH, L_, C_, RULE_, R_, H_, W_, NAME)                          \
+    do {                                                                          \
+        *name = multi ? NAME " (turn loop)" : NAME;                               \
+        return multi ? static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, true>) \
+                     : static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>); \
+    } while (0)
 template <int G>
-StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, const char** name) {
+StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
+    constexpr int kMove = SGW_AGENT_RULE_MOVE, kTag = SGW_AGENT_RULE_TAG, kCleanup = SGW_AGENT_RULE_CLEANUP;
     if (rule == SGW_AGENT_RULE_CLEANUP) {
-        if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>);
-        PICK(step_kernel<G, false, 0, 0, SGW_AGENT_RULE_CLEANUP>);
+        if (onehot) PICK_SK(G, true, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>");
+        PICK_SK(G, false, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, false, 0, 0, SGW_AGENT_RULE_CLEANUP>");
     }
     if (rule == SGW_AGENT_RULE_TAG) {
         if constexpr (G == 32) {
-            if (onehot && L == 1 && C == 4 && r == 4 && H == 11 && W == 11) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4, 11, 11>);   // the Tag example as shipped
-            if (onehot && L == 1 && C == 4 && r == 4) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>);
-            if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3, 32, 32>);   // Tag at the headline's shape
-            if (onehot && L == 1 && C == 4 && r == 3) PICK(step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>);
+            if (onehot && L == 1 && C == 4 && r == 4 && H == 11 && W == 11) PICK_SK(32, true, 1, 4, kTag, 4, 11, 11, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4, 11, 11>");   // the Tag example as shipped
+            if (onehot && L == 1 && C == 4 && r == 4) PICK_SK(32, true, 1, 4, kTag, 4, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>");
+            if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK_SK(32, true, 1, 4, kTag, 3, 32, 32, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3, 32, 32>");   // Tag at the headline's shape
+            if (onehot && L == 1 && C == 4 && r == 3) PICK_SK(32, true, 1, 4, kTag, 3, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>");
         }
-        if (onehot && L == 1 && C == 4) PICK(step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>);   // the Tag example's tables
-        if (onehot) PICK(step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>);
-        PICK(step_kernel<G, false, 0, 0, SGW_AGENT_RULE_TAG>);
+        if (onehot && L == 1 && C == 4) PICK_SK(G, true, 1, 4, kTag, 0, 0, 0, "step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>");   // the Tag example's tables
+        if (onehot) PICK_SK(G, true, 0, 0, kTag, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>");
+        PICK_SK(G, false, 0, 0, kTag, 0, 0, 0, "step_kernel<G, false, 0, 0, SGW_AGENT_RULE_TAG>");
     }
     if constexpr (G == 16)
-        if (onehot && L == 2 && C == 6 && r == 2) PICK(step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>);   // the Treasurehunt example's 5x5 windows
-    if (onehot && L == 2 && C == 6) PICK(step_kernel<G, true, 2, 6>);                             // Treasurehunt-shaped tables
-    if (onehot) PICK(step_kernel<G, true>);
-    PICK(step_kernel<G, false>);
+        if (onehot && L == 2 && C == 6 && r == 2) PICK_SK(16, true, 2, 6, kMove, 2, 0, 0, "step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>");   // the Treasurehunt example's 5x5 windows
+    if (onehot && L == 2 && C == 6) PICK_SK(G, true, 2, 6, kMove, 0, 0, 0, "step_kernel<G, true, 2, 6>");                             // Treasurehunt-shaped tables
+    if (onehot) PICK_SK(G, true, 0, 0, kMove, 0, 0, 0, "step_kernel<G, true>");
+    PICK_SK(G, false, 0, 0, kMove, 0, 0, 0, "step_kernel<G, false>");
 }
+#undef PICK_SK
 
-StepFn pick_step(int group, bool onehot, int L, int C, int rule, int r, int H, int W, const char** name) {
+StepFn pick_step(int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
     if (const char* f = getenv("SGW_NO_STATIC_RADIUS")) {   // A/B hook: 1 = the run-time-shape instances, 2 = static radius but run-time world size
         if (f[0] == '1') r = -1;
         if (f[0] == '2') H = W = -1;
     }
-    if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, name);
-    if (group == 32) return pick_step_g<32>(onehot, L, C, rule, r, H, W, name);
-    if (group == 64) return pick_step_g<64>(onehot, L, C, rule, r, H, W, name);
-    return pick_step_g<256>(onehot, L, C, rule, r, H, W, name);
+    if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, multi, name);
+    if (group == 32) return pick_step_g<32>(onehot, L, C, rule, r, H, W, multi, name);
+    if (group == 64) return pick_step_g<64>(onehot, L, C, rule, r, H, W, multi, name);
+    return pick_step_g<256>(onehot, L, C, rule, r, H, W, multi, name);
 }
 // the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
 // a loop of single-turn launches
@@ -764,7 +773,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.stage_agents = e->stage_agents;
     StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, &e->kernel_name)
-                         : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, &e->kernel_name);
+                         : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, false, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
     e->step_fn = sk;
@@ -773,7 +782,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         e->step_fn_multi = pick_fast_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width,
                                            c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name_multi);
     if (e->big && !tag_move) e->step_fn_multi = pick_big_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_multi);
-    e->multi_turn = (e->fast || e->big) ? e->step_fn_multi != nullptr : true;   // kernels with sgw_rollout's turn loop
+    if (!e->fast && !e->big)   // the generic kernel's instance with the turn loop
+        e->step_fn_multi = pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, true, &e->kernel_name_multi);
+    e->multi_turn = e->step_fn_multi != nullptr;   // kernels with sgw_rollout's turn loop
     if (e->big && !tag_move && ((p.cells + 15) >> 4) <= 4 * kBigThreads)   // the prefetch holds one 4-unit round per thread
         e->step_fn_walk = pick_big_walk(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_walk);
     if (const char* f = getenv("SGW_BIG_NO_WALK")) { if (f[0] == '1') e->step_fn_walk = nullptr; }   // A/B hook
@@ -940,7 +951,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast && e->stage_agents > 0 && e->step_fn_plain &&
         (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS)))
         fn = e->step_fn_plain;
-    if (p.nturns > 1 && (e->fast || e->big)) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
+    if (p.nturns > 1) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
     int blocks = e->grid_blocks;
     if (walk) {   // two to three rounds of the plain kernel
         fn = e->step_fn_walk;

@@ -25,7 +25,10 @@ constexpr int kAgentLds = kTicketOff + 16;              // 656 bytes, multiple o
 // TR: compile-time vision radius (0 = run-time) for the example defaults: the window size becomes a constant, so the
 // channel planes of an observation are immediate store offsets and the cell -> (i, j) split needs no division.
 // TH, TW: compile-time world size on top of that (the examples' own maps).
-template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0>
+// MULTI: sgw_rollout's instance (the turn loop; nturns > 1).  The single-turn instances are compiled without the loop: its
+// loop-carried state cost the small-world kernels a fifth of their speed when it was added to the one kernel (round 2: 16x16 / 4
+// agents, 32 lanes per env, 54 -> 67 us; found in round 3 by bisecting tools/group_sweep.py).
+template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0, bool MULTI = false>
 __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         }
         int st_bits = 0;
         // sgw_rollout: nturns whole turns on the LDS-resident env (nturns == 1: an ordinary sgw_step / sgw_observe)
-        for (uint32_t tix = 0; tix < p.nturns; ++tix) {
+        const uint32_t nturns = MULTI ? p.nturns : 1u;
+        for (uint32_t tix = 0; tix < nturns; ++tix) {
         const uint32_t turn = p.turn + tix;
         if (gtid < p.A && p.do_move && gtid >= p.a0 && gtid < p.a1) {
             uint8_t* acts = p.actions + tix * p.ts_act;
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         }   // turns
 
         if (dirty) {
-            if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP) && p.nturns == 1) {   // (a rollout's earlier turns moved other cells too)
+            if (RULE == SGW_AGENT_RULE_MOVE && !(p.flags & SGW_STEP_SWEEP) && nturns == 1) {   // (a rollout's earlier turns moved other cells too)
                 // a policy-driven phase (no sweep, plain moves): only the movers' two cells changed -- write those bytes,
                 // not the whole grid (with agents i < j both touching a cell, both write its FINAL content: no race)
                 if (gtid >= p.a0 && gtid < p.a1) {

@@ -6,7 +6,7 @@ import torch
 from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import treasurehunt_spec
 
-SHAPES = ((32, 32, 8, 3), (32, 33, 8, 3), (24, 24, 8, 3), (30, 30, 8, 4), (16, 16, 4, 2), (21, 21, 2, 2), (10, 10, 2, 2), (48, 48, 8, 5), (128, 128, 64, 5))
+SHAPES = ((32, 32, 8, 3), (32, 33, 8, 3), (24, 24, 8, 3), (40, 40, 8, 3), (20, 20, 4, 4), (30, 30, 8, 4), (30, 26, 7, 5), (16, 16, 4, 2), (21, 21, 2, 2), (10, 10, 2, 2))
 E = int(os.environ.get("E", 65536))
 if os.environ.get("RT_SHAPES"):   # counter passes: one compile-time and one run-time shape
     SHAPES = ((32, 32, 8, 3), (32, 33, 8, 3)) if os.environ["RT_SHAPES"] == "1" else ((21, 21, 2, 2), (10, 10, 2, 2), (16, 16, 4, 2))

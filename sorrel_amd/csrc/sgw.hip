@@ -397,6 +397,12 @@ StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool 
         if (stage) PICK(step_fast<true, 2, 6, 0, 0, 0, false, false, true>);
         PICK(step_fast<true, 2, 6, 0, 0, 0>);
     }
+    // any other one-hot table of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of four, ten
+    // guarded channel planes instead of sixteen); 32x32x2 with 5 / 8 channels, 8 agents, 7x7 windows: 235 / 247 us -> ...
+    const bool p3 = onehot && stage && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
+    if (p3 && L == 1) PICK(step_fast<true, 1, 0, 0, 0, 0, false, false, true, false, true>);
+    if (p3 && L == 2) PICK(step_fast<true, 2, 0, 0, 0, 0, false, false, true, false, true>);
+    if (p3) PICK(step_fast<true, 0, 0, 0, 0, 0, false, false, true, false, true>);
     if (stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, false, true>);
     PICK(step_fast<true, 0, 0, 0, 0, 0>);
 }
@@ -639,16 +645,20 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             // fewer half-written observation streams open at once beat the extra waves, as for the occupancy cap of the plain
             // kernels -- Cleanup 21x31x3 at 65 536 envs, agents per burst 1 / 2 / 3 / 4 / 5 / 10: 666 / 695 / 643-680 / 640 / 643 / 850 us
             // (16 384 envs: 201 / 193 / 185-190 / 188 / 181 / 240).
-            int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - 48 : (int)(kLdsPerCu / 8 / 4) - base - 48;
+            // instances with a run-time channel count write their planes in groups of four: up to three planes of slack behind a chunk
+            const bool tagk = c.agent_rule == SGW_AGENT_RULE_TAG;
+            const bool static_channels = e->fast_rules ? (c.layers == 3 && c.num_channels == 9) : (!tagk && c.layers == 2 && c.num_channels == 6);
+            const int slack = 48 + (static_channels ? 0 : 3 * p.VV);
+            int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack : (int)(kLdsPerCu / 8 / 4) - base - slack;
             for (int wg = 4; e->fast_rules && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
-                budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - 48;
-            if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - 48;
+                budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - slack;
+            if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack;
             if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook
             int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;
             if (const char* f = getenv("SGW_STAGE_AGENTS")) apc = std::min(c.num_agents, atoi(f));   // A/B hook
             if (apc > 0) {
                 e->stage_agents = apc;
-                e->obs_stage = (apc * per_agent + 31 + 15) & ~15;   // + 31: the chunk's offset from a 128-byte line of global memory (step_fast.h: emit_chunk)
+                e->obs_stage = (apc * per_agent + slack - 48 + 31 + 15) & ~15;   // + 31: the chunk's offset from a 128-byte line of global memory (step_fast.h: emit_chunk)
                 stage_kernel = true;
             }
         }

@@ -486,9 +486,23 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                             };
                             if (stage) {
                                 uint8_t* os = ob + (kStageAlways ? (int)ch_shift + ((a - ch_a0) * C) * VV : (a * C) * VV) + w;
+                                if constexpr (TC != 0) {
 #pragma unroll
-                                for (int c = 0; c < CMAX; ++c)
-                                    if (c < C) os[c * VV] = (uint8_t)chan(c);
+                                    for (int c = 0; c < CMAX; ++c)
+                                        if (c < C) os[c * VV] = (uint8_t)chan(c);
+                                } else {
+                                    // run-time channel count: the planes go out in groups of four behind ONE test per group (a test per
+                                    // plane is a scalar branch each, on conditions that end up spilled into vector lanes).  The up to three
+                                    // planes past C land in the next agent's area, which that agent rewrites, or -- behind a chunk's last
+                                    // agent -- in the 3 * V * V bytes of slack the host adds to the staging area for these instances
+#pragma unroll
+                                    for (int g = 0; g < (CMAX + 3) / 4; ++g)
+                                        if (4 * g < C) {
+#pragma unroll
+                                            for (int b = 0; b < 4; ++b)
+                                                if (4 * g + b < CMAX) os[(4 * g + b) * VV] = (uint8_t)chan(4 * g + b);
+                                        }
+                                }
                             } else if constexpr (kStageAlways) {
                                 // unreachable: a STAGE kernel always stages
                             } else if (!p.obs_u8) {

@@ -1,0 +1,41 @@
+"""Worlds whose (layers, channels) have no compile-time tables: us per turn on the wave-per-env kernel, 65 536 envs.  GPU only."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sorrel_amd.engine import GridEngine
+from sorrel_amd.spec import WorldSpec, action_deltas, treasurehunt_spec
+
+
+def move_world(h, w, layers, channels, a, r, seed=3):
+    T = max(6, min(channels + 1, 12))
+    app = np.zeros((T, channels))
+    for t in range(1, T):
+        app[t, (t * 5 + 1) % channels] = 1.0
+    dy, dx = action_deltas(["up", "down", "left", "right", "stay"])
+    return WorldSpec(height=h, width=w, layers=layers, num_agents=a, vision_radius=r, num_channels=channels, agent_layer=layers - 1,
+                     default_type=0, fill_type=1, action_dy=dy, action_dx=dx, agent_type=[T - 1] * a,
+                     type_value=[0.0, -1.0, 10.0, 5.0, -10.0] + [1.0] * (T - 6) + [0.0],
+                     type_passable=[1, 0, 1, 1, 1] + [1] * (T - 6) + [0], type_rule=[1] + [0] * (T - 1),
+                     spawn_prob=[0.005] + [0.0] * (T - 1), spawn_choices=[[2, 3, 4]] + [[] for _ in range(T - 1)],
+                     appearance=app, seed=seed, layer_fill_type=[0] * layers, layer_border_type=[1] * layers)
+
+
+E = 65536
+for name, spec in (("treasurehunt tables 32x32x2 C6 A8 r3", treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005)),
+                   ("32x32x2 C8 A8 r3", move_world(32, 32, 2, 8, 8, 3)), ("32x32x2 C5 A8 r3", move_world(32, 32, 2, 5, 8, 3)),
+                   ("32x32x1 C4 A8 r3", move_world(32, 32, 1, 4, 8, 3)), ("32x32x3 C10 A8 r3", move_world(32, 32, 3, 10, 8, 3)),
+                   ("24x24x2 C8 A6 r4", move_world(24, 24, 2, 8, 6, 4)), ("40x40x2 C12 A8 r2", move_world(40, 40, 2, 12, 8, 2))):
+    eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
+    for _ in range(100): eng.step(random_actions=True)
+    torch.cuda.synchronize()
+    x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    x.record()
+    for _ in range(100): eng.step(random_actions=True)
+    y.record(); torch.cuda.synchronize()
+    us = x.elapsed_time(y) * 10
+    by = spec.algorithmic_bytes_per_env_step() * E
+    print(f"{name:40s} {us:7.1f} us  {by / us / 1e3 / 8000:.2f} of 8 TB/s  {eng.launch_info().split(' threads')[0]}", flush=True)
+    del eng
+    torch.cuda.empty_cache()

@@ -687,8 +687,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         if (c.agent_rule == SGW_AGENT_RULE_TAG)
             g = (enough(32) && !(e->fast && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, true))) ? 32 : 0;
         else if (c.agent_rule == SGW_AGENT_RULE_MOVE && !p.has_become) {
+            // (round 3, profiles/r03_group_sweep.txt -- the wave-per-env kernels have gained more than the packed ones since the rule
+            // was set: 24x24 A4 r3 98 / 157 / 122 us, 32x32 A8 r2 136 / 193 / 152, 32x32 A4 r3 90 / 197 / 144, while 21x21 A8 r2
+            // 122 / 132 / 105 and 32x32 A2 r2 94 / 104 / 80 still pack: two envs per wave only while the windows OR the map are small)
             if (avv <= 100 && p.cells_pad <= 1024 && enough(16)) g = 16;
-            else if (avv <= 200 && enough(32)) g = 32;
+            else if (avv <= 200 && (avv <= 100 || p.cells_pad <= 1024) && enough(32)) g = 32;
         }
         if (const char* f = getenv("SGW_GROUP")) g = atoi(f);
         const bool fits = (g == 16 || g == 32) && c.num_agents <= g &&

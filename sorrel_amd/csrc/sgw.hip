@@ -379,6 +379,9 @@ StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool 
     }
     if (tag) {
         if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK(step_fast<true, 1, 4, 3, 32, 32, true>);   // Tag on the headline's map
+        const bool p3t = onehot && stage && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');   // 3-bit packed counters
+        if (p3t && L == 1) PICK(step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>);
+        if (p3t) PICK(step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>);
         if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, true, false, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, true>);
         PICK(step_fast<false, 0, 0, 0, 0, 0, true>);
@@ -684,8 +687,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         auto enough = [&](int G) { return c.num_agents <= G && (int64_t)c.num_envs * G / kWave >= 12288; };
         int g = 0;
         // (Tag on a map with a compile-time-shape wave-per-env instance stays there: 32x32 / 8 agents 117 us against 143 packed)
+        // (round 3, tools/tag_group_probe.py, two envs per wave / wave per env: 11x11 A5 r4 99 / 131 us, 16x16 A4 r3 51 / 104, 20x20 A5 r4 116 / 127,
+        // 24x24 A6 r3 80 / 125, 28x28 A6 r3 96 / 115, but 30x30 A6 r4 183 / 128, 32x32 A8 r4 217 / 148, 40x40 A8 r3 163 / 135, 48x48 A10 r4 323 / 180, 64x64 A8 r3 221 / 183
+        // (wave-per-env: the 3-bit-counter Tag instance): pack while map bytes + 2 x window cells of all agents stay below 1 500)
         if (c.agent_rule == SGW_AGENT_RULE_TAG)
-            g = (enough(32) && !(e->fast && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, true))) ? 32 : 0;
+            g = (enough(32) && p.cells_pad + 2 * avv < 1500 && !(e->fast && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, true))) ? 32 : 0;
         else if (c.agent_rule == SGW_AGENT_RULE_MOVE && !p.has_become) {
             // (round 3, profiles/r03_group_sweep.txt -- the wave-per-env kernels have gained more than the packed ones since the rule
             // was set: 24x24 A4 r3 98 / 157 / 122 us, 32x32 A8 r2 136 / 193 / 152, 32x32 A4 r3 90 / 197 / 144, while 21x21 A8 r2

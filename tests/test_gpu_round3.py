@@ -458,8 +458,12 @@ def O_full(spec, grid):
 @pytest.mark.parametrize("shape", [(32, 32, 8, 3, 150, "step_fast<true, 1, 4, 3, 32, 32, true>"),     # wave per env, static 32x32 map
                                    (32, 32, 8, 3, 65536, "step_fast<true, 1, 4, 3, 32, 32, true>"),   # ... also for big batches (not packed)
                                    (20, 24, 6, 3, 40000, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>"),     # packed, static 7x7 window
-                                   (32, 32, 20, 3, 90, "step_fast<true, 1, 4, 3, 32, 32, true>")],    # crowded: many tags per turn
-                         ids=["static_32x32", "static_32x32_full_batch", "packed_static_radius", "static_32x32_crowded"])
+                                   (32, 32, 20, 3, 90, "step_fast<true, 1, 4, 3, 32, 32, true>"),     # crowded: many tags per turn
+                                   (30, 30, 6, 4, 70000, "step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>"),   # wave per env, 3-bit packed counters (what the rule picks for a full batch)
+                                   (48, 48, 10, 4, 130, "step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>"),
+                                   (17, 61, 21, 5, 77, "step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>")],    # ragged, crowded, 11x11 windows
+                         ids=["static_32x32", "static_32x32_full_batch", "packed_static_radius", "static_32x32_crowded", "p3_30x30_full_batch",
+                              "p3_48x48", "p3_ragged_crowded"])
 def test_tag_static_instances_vs_oracle(torch_cuda, shape):
     """TagAgent.act on the instances round 3 added (only the agent that is "it" looks at its neighbours; compile-time
     32x32 map on the wave-per-env kernel; compile-time 7x7 window on the packed kernel): every tensor, the agents' types

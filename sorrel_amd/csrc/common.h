@@ -115,13 +115,16 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t k) {
 }
 
 // Philox-4x32-10 (Salmon et al., SC'11); key = (k0, k1) wave-uniform.
+// OWN_KEYS: the block walks its own key schedule (two s_add per round).  Left to itself the compiler computes the twenty round
+// keys once and keeps them in SGPRs across all the blocks of a kernel, and spills other scalars into vector lanes for it
+// (v_writelane / v_readlane are vector instructions, and these kernels are bound by those): the packed small-world kernels gain
+// 5-9 % from own keys, the run-time-shape wave-per-env kernels 1.5 %; the compile-time-shape instances of step_fast (the
+// headline: 22 -> 6 spilled scalars, but 772 instead of 673 scalar instructions per wave) LOSE 0.5-1.3 % and keep the shared keys.
+template <bool OWN_KEYS = true>
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
 #ifndef SGW_DIAG_SHARED_KEYS
-    // every block walks its OWN key schedule (two s_add per round): left to itself the compiler computes the twenty round keys
-    // once and keeps them in SGPRs across all the blocks of a kernel -- the headline kernel then spills 22 scalars into vector
-    // lanes (v_writelane / v_readlane are vector instructions, and the kernel is bound by those)
-    asm volatile("" : "+s"(k0), "+s"(k1));
+    if constexpr (OWN_KEYS) asm volatile("" : "+s"(k0), "+s"(k1));
 #endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {

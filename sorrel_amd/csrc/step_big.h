@@ -53,6 +53,9 @@ constexpr int big_agent_lds(bool tag) { return kBigAgentLds + (tag ? kBigTagLds 
 template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false>
 __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_WAVES : 6) : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
     static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
+    // Philox key schedule per block (common.h): config 5's share on the walking variant 94 -> 90 us; the plain variant is indifferent at
+    // config 5's shape and loses 3.6 % on a 48x48 world, so it keeps the shared keys
+    constexpr bool kBigOwnKeys = WALK;
     static_assert(!(TAG && (MULTI || WALK)), "Tag: single-turn, one env per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid0 = threadIdx.x;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
                 hits[k] = 0;
                 if (idx < nunits) {
                     if (!(MULTI && tix > 0)) lg16[lunit(idx)] = u[k];
-                    if (do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)idx, p, env_id, turn);
+                    if (do_sweep) hits[k] = sweep_hits<kBigOwnKeys>(u[k], (uint32_t)idx, p, env_id, turn);
                 }
             }
             if (do_sweep) {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
                         h2 = k == 2 ? cleared : h2;
                         h3 = k == 3 ? cleared : h3;
                         const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
-                        const U4 kw = philox4x32_10(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                        const U4 kw = philox4x32_10<kBigOwnKeys>(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
                                                    p.seed_lo, p.seed_hi);
                         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
                         lg[lbyte(off)] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
             if (p.do_move && mine) {
                 uint32_t act;
                 if (rnd) {
-                    const U4 w = philox4x32_10(opaque((uint32_t)tid >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                    const U4 w = philox4x32_10<kBigOwnKeys>(opaque((uint32_t)tid >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
                                                p.seed_lo, p.seed_hi);
                     act = __umulhi(word_of(w, tid & 3), (uint32_t)p.nact);
                     p.actions[tix * p.ts_act + env * p.A + tid] = (uint8_t)act;

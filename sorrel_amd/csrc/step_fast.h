@@ -28,6 +28,7 @@ constexpr size_t kCacheResidentGrid = (size_t)288 << 20;   // on-die capacity: 2
 
 
 // Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
+template <bool OWN_KEYS>
 __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id, const uint32_t turn) {
     uint32_t hits = 0;
 #pragma unroll
@@ -35,7 +36,7 @@ __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t un
         const uint32_t dv = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
         const uint32_t m = match_bytes(dv, p.spawn_pat);
         if (m) {
-            const U4 w = philox4x32_10(opaque(unit * 4 + k), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+            const U4 w = philox4x32_10<OWN_KEYS>(opaque(unit * 4 + k), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
             const bool f = p.spawn_full != 0;
             uint32_t hb = 0;
             hb |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
@@ -49,13 +50,14 @@ __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t un
 }
 
 // Rare second draw: what spawns in each hit cell; written straight into the LDS grid.
+template <bool OWN_KEYS>
 __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, uint8_t* lg, const Params& p,
                                             const uint32_t env_id, const uint32_t turn) {
     while (hits) {
         const uint32_t cell = (uint32_t)__ffs(hits) - 1u;
         hits &= hits - 1u;
         const uint32_t off = unit * 16u + cell;   // byte offset == RNG index
-        const U4 kw = philox4x32_10(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const U4 kw = philox4x32_10<OWN_KEYS>(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
         lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
     }
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     const int V = 2 * r + 1, VV = V * V;
     const int H = TH ? TH : p.H, W = TW ? TW : p.W, HW = H * W;
     constexpr bool kStatic = TL && TH && TW;
+    constexpr bool kOwnKeys = !kStatic;   // Philox key schedule per block (common.h): pays for the run-time-shape instances only
     const int cells = kStatic ? TL * TH * TW : p.cells;
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     constexpr int NU = kStatic ? ((TL * TH * TW + 15) / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
@@ -309,13 +312,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 #pragma unroll
             for (int k = 0; k < NU; ++k) {
                 hits[k] = 0;
-                if (lane + 64 * k < nunits && do_sweep) hits[k] = sweep_hits(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
+                if (lane + 64 * k < nunits && do_sweep) hits[k] = sweep_hits<kOwnKeys>(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
             }
             gsync<1>();
             if (do_sweep) {
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
-                    if (lane + 64 * k < nunits) sweep_apply(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn);
+                    if (lane + 64 * k < nunits) sweep_apply<kOwnKeys>(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn);
                 gsync<1>();
             }
         }
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         npos = yx;                               // position if the move succeeds
         if (p.do_move && mine) {
             if (rnd) {
-                const U4 w = philox4x32_10(opaque((uint32_t)lane >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                const U4 w = philox4x32_10<kOwnKeys>(opaque((uint32_t)lane >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
                                            p.seed_lo, p.seed_hi);
                 act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
                 p.actions[tix * p.ts_act + env * p.A + lane] = (uint8_t)act;

@@ -45,6 +45,11 @@ FILES = {
     "r03_cleanup_observe_probe.txt": ("cleanup_observe_probe.txt",
         "# tools/cleanup_observe_probe.py (SGW_STAGE_AGENTS = 1 / 3 / 5 / 10), round 3: Cleanup 21x31x3 at 65 536 envs, sgw_observe of every agent against the whole turn -- the window pipeline alone\n"
         "# takes as long as the turn (before the line-aligned bursts: observe 683 us / turn 680 us at 3 agents per burst; with the gather skipped 663, with the stores skipped 121: the emit was the bottleneck)\n"),
+    "r03_generic_tables.txt": ("generic_tables.txt",
+        "# tools/generic_tables_probe.py (then PROBE_SMALL=1), round 3: worlds whose (layers, channels) have no compile-time tables -- 3-bit packed counters for any one-hot table of <= 10 channels,\n"
+        "# channel planes staged in groups of four; before: 32x32x2 C8 246.6 us, C5 235.0, 32x32x1 C4 182.7, 32x32x3 C10 309.0, 24x24x2 C8 r4 236.3, 40x40x2 C12 (packed then) 350.6\n"),
+    "r03_tag_group_probe.txt": ("tag_group_probe.txt",
+        "# tools/tag_group_probe.py, round 3: Tag worlds up to 4 KiB, the dispatcher's choice / a wave per env (3-bit-counter Tag instance) / two envs per wave -- the data behind Tag's packing rule in sgw_create\n"),
 }
 for name, (src, hdr) in FILES.items():
     open(os.path.join(P, name), "w").write(hdr + body(src))

@@ -124,6 +124,7 @@ struct sgw_engine {
     int big_tab_bytes = 0;   // step_big: only the counter words of the channels in use
     int grid_blocks = 1;
     int fast_wg_cap = 5;   // step_fast workgroups per CU when writing large float32 observations of a large batch (0: no cap)
+    bool fast_wg_cap_forced = false;   // SGW_FAST_WG_PER_CU given: that value for the staged path too (default there: 6)
     int wg_per_cu = 0;     // sgw_set_wg_per_cu: 0 = the automatic rule above, 1..8 = forced, -1 = never capped
     const char* kernel_name = "?";
     uint32_t auto_max_turns = 0;       // sgw_set_auto_reset
@@ -794,7 +795,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, &e->kernel_name)
                          : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, false, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
-    if (const char* f = getenv("SGW_FAST_WG_PER_CU")) e->fast_wg_cap = atoi(f);   // tuning hook
+    if (const char* f = getenv("SGW_FAST_WG_PER_CU")) { e->fast_wg_cap = atoi(f); e->fast_wg_cap_forced = true; }   // tuning hook
     e->step_fn = sk;
     e->reset_fn = rk;
     if (e->fast)
@@ -905,8 +906,9 @@ int sgw_reset(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, double* total_re
 // five workgroups per CU for whole-turn float32 observation writes of 8 KiB or more per env in large batches, where fewer
 // concurrent waves mean fewer half-written lines open in HBM --
 //  - the unstaged path (Cleanup, 21x31x3 at 65 536 envs: 893 -> 801 us);
-//  - the staged path only when the grids of the batch no longer fit the caches (262 144 envs of config 3: 662 -> 578 us,
-//    524 288: 1375 -> 1146 us).  While they do fit (configs 3/4: 65 536 envs, 134 MB) the staged emit with its streaming
+//  - the staged path only when the grids of the batch no longer fit the caches, and SIX per CU there since its bursts sit on
+//    128-byte lines (round 3, config 3's shape, us per launch at 8 / 7 / 6 / 5 / 4 per CU: 524 288 envs 1 321 / 1 061 / 1 082 / 1 167 / 1 347,
+//    262 144 envs 640 / 598 / 566 / 595 / 679; before the aligned bursts five was best: 262 144 envs 662 -> 578 us, 524 288: 1375 -> 1146 us).  While they do fit (configs 3/4: 65 536 envs, 134 MB) the staged emit with its streaming
 //    full-line stores is fastest at full occupancy (124 us at 8 and 7 per CU, 126 at 6, 131 at 5; 131 072 envs: 248 vs 281).
 // The uint8 format, small batches and the shapes with small windows, which are latency-bound (Tag 11x11, 6.5 KB per env:
 // 164 us at full occupancy, 192 us capped), are not capped.
@@ -917,7 +919,7 @@ static size_t step_lds_request(const sgw_engine* e, const Params& p, int* cap_ou
     else if (e->fast && e->wg_per_cu == 0 && e->fast_wg_cap > 0 && p.obs && !(p.flags & SGW_STEP_NO_OBS) && !p.obs_u8 &&
              (!p.obs_stage || (size_t)p.E * (size_t)p.env_stride > kCacheResidentGrid) && p.a1 == p.A && p.a0 == 0 &&
              (size_t)p.A * p.C * p.VV * 4 >= 8192 && p.E >= (int64_t)e->num_cus * 32 * 2)
-        cap = e->fast_wg_cap;
+        cap = (p.obs_stage && !e->fast_wg_cap_forced) ? 6 : e->fast_wg_cap;   // (staged, line-aligned bursts: six -- see above)
     if (cap > 0) lds = std::max(lds, (size_t)(kLdsPerCu / cap - 1024) & ~(size_t)511);   // 1 KiB below the share: LDS is handed out in 1 KiB granules
     if (cap_out) *cap_out = cap;
     return lds;

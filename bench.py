@@ -17,7 +17,10 @@ Order of a run: build check (before anything touches the GPU) -> reset -> P unti
 pre-warm steps (``--prewarm-steps``, reported, and each of them timed with its own pair of
 HIP events: ``roofline.prewarm_series`` shows the cold start -- a fresh process runs
 launches ~10-100 slower than the settled kernel and the driver's default ``--steps 20
---warmup 5`` is 3 ms of work) -> W untimed warm-up steps -> barrier + synchronize ->
+--warmup 5`` is 3 ms of work) -> R more untimed steps (``--rewarm-steps``, reported: reading the
+pre-warm pass's 1 500 timers leaves the chip idle for a few ms, and an idle of 3 / 10 ms costs the
+next 20 launches 5 / 15-20 %, tools/idle_probe.py) flowing without a host-side gap into the
+W untimed warm-up steps -> barrier + synchronize ->
 EXACTLY K timed steps (``value`` / ``ms_per_step`` / ``roofline.kernel_ms`` come from here;
 nothing but the K launches and two HIP events is in the region) -> barrier + synchronize ->
 the same K steps once more with a pair of HIP events around EVERY launch
@@ -230,8 +233,8 @@ def policy_turn_bench(eng, iters: int = 40):
     dests = [torch.empty((eng.num_envs, eng.obs[0, 0].numel()), dtype=eng.obs_dtype, device=eng.device) for _ in range(A)]
     rows_own = eng.window_rows(dests)
 
-    def timed(fn):
-        for _ in range(5):
+    def timed(fn, warm):
+        for _ in range(warm):                      # ~60 ms of uninterrupted launches: what ran before left the chip idle for a while
             fn()
         torch.cuda.synchronize(eng.device)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -258,13 +261,13 @@ def policy_turn_bench(eng, iters: int = 40):
         for a in range(A):
             eng.act(a, rows_own)
 
-    out = {"fused_turn_ms": timed(fused), "policy_turn_ms": timed(tensor_windows), "launches": 1 + A,
+    out = {"fused_turn_ms": timed(fused, 500), "policy_turn_ms": timed(tensor_windows, 400), "launches": 1 + A,
            "what": "policy_turn_ms: sgw_step(SGW_STEP_NO_MOVE) = sweep + every agent's window (into the observation tensor), then "
                    "sgw_act per agent; fused_turn_ms: the same engine's one-launch turn with given actions; the policy's own forward "
                    "pass is not in either"}
     from sorrel_amd import _native as N
     if eng.capabilities() & N.CAP_OBSERVE_ROWS:
-        out["policy_turn_replay_rows_ms"] = timed(replay_rows)
+        out["policy_turn_replay_rows_ms"] = timed(replay_rows, 300)
         out["replay_rows_what"] = "windows rendered straight into per-agent [E][C*V*V] rows (what Environment.take_turn does when every agent has a replay Buffer): sweep, sgw_observe_rows, sgw_act per agent"
     out["status"] = eng.status()
     return out
@@ -317,6 +320,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the config's)")
+    ap.add_argument("--rewarm-steps", type=int, default=600,
+                    help="untimed launches between the drain of the pre-warm pass's per-launch timers (a few ms of GPU idle) and the "
+                         "warm-up launches: the timed region then starts on a chip that has been busy for ~70 ms without a gap")
     ap.add_argument("--prewarm-steps", type=int, default=1500,
                     help="untimed clock-ramp steps before the W warm-up steps (0 = none); reported in the JSON line")
     ap.add_argument("--max-turns", type=int, default=0,
@@ -424,6 +430,12 @@ def main() -> int:
                           "what": "the untimed pre-warm launches, first launch of the process onwards, each between its own pair of HIP "
                                   "events: a fresh process runs launches ~10-100 slower than the settled kernel (profiles/r03_c3_launch_ramp.txt "
                                   "has the clock / power samples taken alongside)"}
+    # Draining the 1 500 event pairs above leaves the GPU idle for a few milliseconds, and this chip answers an idle of that length
+    # with its power ramp again (tools/idle_probe.py, config 3: after 0 / 1 / 3 / 10 / 30 ms of idle the next 20 launches take
+    # 118 / 119 / 123-126 / 133-143 / 141-145 us, and the 200 after a 10 ms idle still 129) -- so the launches flow on without a
+    # host-side gap from here to the timed region: `rewarm_steps` untimed launches, the W warm-up launches, barrier, K timed.
+    for _ in range(max(0, args.rewarm_steps) if args.prewarm_steps > 0 else 0):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -538,6 +550,7 @@ def main() -> int:
             "metric": "agent-steps/sec" if args.obs_dtype == "f32" else "agent-steps/sec (compact uint8 observations; NOT the contract metric)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm_steps),
+            "rewarm_steps": max(0, args.rewarm_steps) if args.prewarm_steps > 0 else 0,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 grid, " + args.obs_dtype + " obs",   # entity type ids are uint8 (the path's arithmetic); observations leave as float32
@@ -582,9 +595,10 @@ def main() -> int:
             del eng_obs
             torch.cuda.empty_cache()
             out["configs"] = {
-                "c2": side_config("c2", dev, args.side_steps, 300),
-                "c5": side_config("c5", dev, args.side_steps, 300),
-                "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 40, envs=524288),
+                # (pre-warm counts: ~60 ms of uninterrupted launches each -- the engine's creation leaves the chip idle)
+                "c2": side_config("c2", dev, args.side_steps, 5000),
+                "c5": side_config("c5", dev, args.side_steps, 700),
+                "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 60, envs=524288),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], played = cpu_baseline(spec, args.config, args.cpu_seconds)

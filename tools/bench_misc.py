@@ -7,6 +7,8 @@ os.chdir(ROOT)
 import numpy as np, torch
 from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import WorldSpec, treasurehunt_spec, action_deltas
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _warm import timed_us
 
 def tag_spec(h, w, a, r):
     app = np.zeros((4, 4)); app[1, 1] = app[2, 2] = app[3, 3] = 1.0
@@ -28,12 +30,7 @@ def run(name, spec, E, K=100):
         return
     eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
     for _ in range(200): eng.step(random_actions=True, **KW)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(K): eng.step(random_actions=True, **KW)
-    b.record(); torch.cuda.synchronize()
-    us = a.elapsed_time(b) / K * 1000
+    us = timed_us(lambda: eng.step(random_actions=True, **KW), K)
     byt = spec.algorithmic_bytes_per_env_step() * E
     print(f"{name:34s} E={E:7d} {us:8.1f} us/step  {E*spec.num_agents/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)")
 
@@ -49,13 +46,7 @@ def run_observe(name, spec, E, K=100):
     if ONLY and ONLY not in name:
         return
     eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
-    for _ in range(5): eng.observe()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(K): eng.observe()
-    b.record(); torch.cuda.synchronize()
-    us = a.elapsed_time(b) / K * 1000
+    us = timed_us(lambda: eng.observe(), K)
     byt = (spec.grid_bytes_per_env() + spec.num_agents * spec.num_channels * spec.window ** 2 * 4) * E
     print(f"{name:34s} E={E:7d} {us:8.1f} us/call  {byt/us/1e3:7.1f} GB/s")
 
@@ -90,12 +81,7 @@ def run_cleanup(E=16384, K=50):
     eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
     eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
     for _ in range(100): eng.step(random_actions=True, **KW)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(K): eng.step(random_actions=True, **KW)
-    b.record(); torch.cuda.synchronize()
-    us = a.elapsed_time(b) / K * 1000
+    us = timed_us(lambda: eng.step(random_actions=True, **KW), K)
     byt = spec.algorithmic_bytes_per_env_step() * E
     print(f"{'cleanup 21x31x3 A10 r5 (RULES kernel)':34s} E={E:7d} {us:8.1f} us/step  {E*10/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)  [{eng.launch_info().split(' group')[0]}]")
     assert eng.status() == 0
@@ -112,12 +98,7 @@ def run_big_rule_worlds():
                           ("big tag 128x128x1 A64 r4", tag_spec(128, 128, 64, 4), 2048)):
         eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
         for _ in range(100): eng.step(random_actions=True, **KW)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(100): eng.step(random_actions=True, **KW)
-        b.record(); torch.cuda.synchronize()
-        us = a.elapsed_time(b) / 100 * 1000
+        us = timed_us(lambda: eng.step(random_actions=True, **KW), 100)
         byt = spec.algorithmic_bytes_per_env_step() * E
         print(f"{name:34s} E={E:7d} {us:8.1f} us/step  {E*spec.num_agents/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)  [{eng.launch_info().split(' group')[0]}]")
     spec = cleanup_spec(48, 48, 10, 5)
@@ -131,12 +112,7 @@ def run_big_rule_worlds():
     eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
     eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))
     for _ in range(100): eng.step(random_actions=True, **KW)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(100): eng.step(random_actions=True, **KW)
-    b.record(); torch.cuda.synchronize()
-    us = a.elapsed_time(b) / 100 * 1000
+    us = timed_us(lambda: eng.step(random_actions=True, **KW), 100)
     byt = spec.algorithmic_bytes_per_env_step() * E
     print(f"{'big cleanup 48x48x3 A10 r5':34s} E={E:7d} {us:8.1f} us/step  {E*10/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s ({byt/us/1e3/8000:.3f} of 8 TB/s)  [{eng.launch_info().split(' group')[0]}]")
     assert eng.status() == 0

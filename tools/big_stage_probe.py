@@ -14,13 +14,11 @@ for _ in range(30): eng.step(random_actions=True)
 torch.cuda.synchronize()
 dig = hashlib.sha256(eng.obs.cpu().numpy().tobytes() + eng.grid.cpu().numpy().tobytes() + eng.total_reward.cpu().numpy().tobytes()).hexdigest()[:12]
 for _ in range(100): eng.step(random_actions=True)
-torch.cuda.synchronize()
-t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-t0.record()
-for _ in range(100): eng.step(random_actions=True)
-t1.record(); torch.cuda.synchronize()
-print("RESULT %%7.1f us  %%s  %%s" %% (t0.elapsed_time(t1) * 10, dig, eng.launch_info().split(" threads")[0] + " " + " ".join(x for x in eng.launch_info().split() if x.startswith(("lds=", "big_stage=")))))
-''' % ROOT
+sys.path.insert(0, os.path.join(%r, "tools"))
+from _warm import timed_us
+us = timed_us(lambda: eng.step(random_actions=True), 100)
+print("RESULT %%7.1f us  %%s  %%s" %% (us, dig, eng.launch_info().split(" threads")[0] + " " + " ".join(x for x in eng.launch_info().split() if x.startswith(("lds=", "big_stage=")))))
+''' % (ROOT, ROOT)
 shapes = [(128, 128, 64, 5, 2048), (128, 128, 64, 5, 4096), (128, 128, 64, 5, 8192), (48, 48, 8, 5, 16384), (72, 72, 16, 5, 8192)]
 variants = [{}, {"SGW_BIG_STAGE": "0"}, {"SGW_BIG_NO_PAD": "1"}]
 if os.environ.get("PROBE_WALK"):   # where does the walking variant pay?

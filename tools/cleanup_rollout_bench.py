@@ -22,7 +22,8 @@ eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy
 
 
 def timed(fn, reps):
-    fn(); torch.cuda.synchronize()
+    from _warm import warm
+    warm(fn, 80.0, probe=3)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps): fn()

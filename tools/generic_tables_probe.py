@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import WorldSpec, action_deltas, treasurehunt_spec
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _warm import timed_us
 
 
 def move_world(h, w, layers, channels, a, r, seed=3):
@@ -31,12 +33,7 @@ for name, spec in SMALL if os.environ.get("PROBE_SMALL") else (("treasurehunt ta
                    ("24x24x2 C8 A6 r4", move_world(24, 24, 2, 8, 6, 4)), ("40x40x2 C12 A8 r2", move_world(40, 40, 2, 12, 8, 2))):
     eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
     for _ in range(100): eng.step(random_actions=True)
-    torch.cuda.synchronize()
-    x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    x.record()
-    for _ in range(100): eng.step(random_actions=True)
-    y.record(); torch.cuda.synchronize()
-    us = x.elapsed_time(y) * 10
+    us = timed_us(lambda: eng.step(random_actions=True), 100)
     by = spec.algorithmic_bytes_per_env_step() * E
     print(f"{name:40s} {us:7.1f} us  {by / us / 1e3 / 8000:.2f} of 8 TB/s  {eng.launch_info().split(' threads')[0]}", flush=True)
     del eng

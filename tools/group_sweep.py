@@ -12,14 +12,11 @@ h, w, a, r, E = (int(v) for v in sys.argv[1:6])
 spec = treasurehunt_spec(h, w, a, r)
 eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
 for _ in range(200): eng.step(random_actions=True)
-torch.cuda.synchronize()
-t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-t0.record()
-for _ in range(200): eng.step(random_actions=True)
-t1.record(); torch.cuda.synchronize()
-us = t0.elapsed_time(t1) / 200 * 1000
+sys.path.insert(0, os.path.join(%r, "tools"))
+from _warm import timed_us
+us = timed_us(lambda: eng.step(random_actions=True), 200)
 print("%%7.1f us  %%.3f  %%s" %% (us, spec.algorithmic_bytes_per_env_step() * E / us / 1e3 / 8000, eng.launch_info().split(" threads")[0]))
-''' % ROOT
+''' % (ROOT, ROOT)
 shapes = [(10, 10, 2, 2), (16, 16, 4, 2), (21, 21, 2, 2), (21, 21, 8, 2), (24, 24, 4, 3), (28, 28, 8, 3), (32, 32, 2, 2), (32, 32, 8, 2), (32, 32, 4, 3), (20, 20, 4, 4), (32, 32, 8, 3), (30, 30, 8, 4), (32, 32, 16, 4)]
 E = 65536
 for h, w, a, r in shapes:

@@ -10,8 +10,8 @@ eng.reset(0)
 for _ in range(30): eng.step(random_actions=True)
 rows = eng.window_rows(None)
 def t(fn, K=50):
-    for _ in range(10): fn()
-    torch.cuda.synchronize()
+    from _warm import warm
+    warm(fn, 80.0, probe=5)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(K): fn()

@@ -24,9 +24,8 @@ K = 100                                # another tensor would add a copy kernel 
 
 
 def timed(fn, warm=30):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+    from _warm import warm as warm_ms        # ~80 ms of uninterrupted launches first: a few ms of idle bring the chip's power ramp back
+    warm_ms(fn, 80.0, probe=max(3, warm // 6))
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(K):

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import treasurehunt_spec
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _warm import timed_us
 
 SHAPES = ((32, 32, 8, 3), (32, 33, 8, 3), (24, 24, 8, 3), (40, 40, 8, 3), (20, 20, 4, 4), (30, 30, 8, 4), (30, 26, 7, 5), (16, 16, 4, 2), (21, 21, 2, 2), (10, 10, 2, 2))
 E = int(os.environ.get("E", 65536))
@@ -14,12 +16,7 @@ for (h, w, a, r) in SHAPES:
     spec = treasurehunt_spec(h, w, a, r, spawn_prob=0.005, seed=0)
     eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
     for _ in range(200): eng.step(random_actions=True)
-    torch.cuda.synchronize()
-    x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    x.record()
-    for _ in range(100): eng.step(random_actions=True)
-    y.record(); torch.cuda.synchronize()
-    us = x.elapsed_time(y) * 10
+    us = timed_us(lambda: eng.step(random_actions=True), 100)
     V = 2 * r + 1
     C = eng.obs.shape[-3] if eng.obs.dim() >= 4 else 0
     by = E * (2 * ((h * w * 2 + 15) // 16 * 16) + eng.obs[0].numel() * 4 + a * 9)

@@ -13,12 +13,9 @@ spec = bm.tag_spec(h, w, a, r)
 E = 65536
 eng = GridEngine(spec, E, device="cuda:0"); eng.reset(0)
 for _ in range(200): eng.step(random_actions=True)
-torch.cuda.synchronize()
-x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-x.record()
-for _ in range(100): eng.step(random_actions=True)
-y.record(); torch.cuda.synchronize()
-us = x.elapsed_time(y) * 10
+sys.path.insert(0, "tools")
+from _warm import timed_us
+us = timed_us(lambda: eng.step(random_actions=True), 100)
 print("RESULT %%7.1f us  %%.2f  %%s" %% (us, spec.algorithmic_bytes_per_env_step() * E / us / 1e3 / 8000, eng.launch_info().split(" threads")[0]))
 ''' % (ROOT, ROOT)
 for shape in ((11, 11, 5, 4), (24, 24, 6, 3), (28, 28, 6, 3), (30, 30, 6, 4), (32, 32, 8, 4), (40, 40, 8, 3), (48, 48, 10, 4), (64, 64, 8, 3)):

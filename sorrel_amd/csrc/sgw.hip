@@ -615,10 +615,23 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (const char* f = getenv("SGW_RULES_8K")) { if (f[0] == '0') rules_8k = false; }
     if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') rules_8k = false; }
     if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') rules_8k = false; }    // (the tests of the ticket-ordered workgroup-per-env kernel)
-    e->wpe = (p.cells_pad <= 4096 || rules_8k) ? 1 : 4;
+    // Plain and Tag worlds between 4 and 8 KiB per env: a LARGE batch of them also runs a wave per env (step_big spends a 512-thread
+    // workgroup and three barriers on an env; per env that is about twice the time of the wave-per-env kernel, which pays only when the
+    // batch is too small to fill the chip with waves).  tools/mid_world_probe.py, us per turn at 2 048 / 4 096 / 8 192 / 65 536 envs,
+    // workgroup per env -> wave per env: 48x48x2 A8 r5 23 / 40 / 73 / 640 -> 22 / 31 / 56 / 373; 64x64x2 A16 r3 33 / 57 / 107 / 858 ->
+    // 28 / 39 / 69 / 488; 50x50x2 A8 r3 26 / 46 / 84 / 686 -> 19 / 25 / 41 / 272; Tag 72x72 A16 r4 23 / 41 / 74 / 727 -> 25 / 34 / 61 / 447;
+    // Tag 90x90 A12 r3 27 / 48 / 90 / 741 -> 20 / 25 / 48 / 347.  SGW_FAST_8K = 0 / 1: never / whatever the batch (A/B and test hook).
+    bool fast_8k = simple_rules && onehot && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules &&
+                   p.VV <= 128 && c.num_envs >= 4096;
+    if (const char* f = getenv("SGW_FAST_8K")) {
+        if (f[0] == '0') fast_8k = false;
+        if (f[0] == '1') fast_8k = simple_rules && onehot && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128;
+    }
+    if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') fast_8k = false; }
+    e->wpe = (p.cells_pad <= 4096 || rules_8k || fast_8k) ? 1 : 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
-    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnits && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
+    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsRules : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
     // the layered rule set on the wave-per-env kernel (RULES variant): any spawners, BECOME_IF rules, Cleanup or plain agents
     e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128 &&
                     c.agent_rule != SGW_AGENT_RULE_TAG && (p.cells_pad <= 4096 || rules_8k);
@@ -654,7 +667,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             const bool static_channels = e->fast_rules ? (c.layers == 3 && c.num_channels == 9) : (!tagk && c.layers == 2 && c.num_channels == 6);
             const int slack = 48 + (static_channels ? 0 : 3 * p.VV);
             int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack : (int)(kLdsPerCu / 8 / 4) - base - slack;
-            for (int wg = 4; e->fast_rules && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
+            for (int wg = 4; (e->fast_rules || fast_8k) && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
                 budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - slack;
             if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack;
             if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook

@@ -262,8 +262,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 #pragma unroll
         for (int k = 0; k < NU; ++k)
             if (lane + 64 * k < nunits) lg16[lane + 64 * k] = u[k];
-        if constexpr (RULES) {
-            // layered rule sets above 4 KiB per env (up to 8 KiB): the rest of the grid in a second round, straight to LDS
+        if constexpr (RULES || !kStatic) {
+            // worlds above 4 KiB per env (up to 8 KiB: layered rule sets; plain and Tag worlds of large batches): the rest of the grid in a
+            // second round, straight to LDS
             const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
             for (int i = 64 * NU + lane; i < nunits; i += 64) {
                 uint4 v = src[i];
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
                     if (lane + 64 * k < nunits) dst[lane + 64 * k] = lg16[lane + 64 * k];
-                if constexpr (RULES)
+                if constexpr (RULES || !kStatic)
                     for (int i = 64 * NU + lane; i < nunits; i += 64) dst[i] = lg16[i];
             }
         }

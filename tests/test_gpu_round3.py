@@ -916,3 +916,88 @@ def test_staged_bursts_carry_partial_lines_vs_oracle(torch_cuda, monkeypatch, ca
             assert np.array_equal(eng.obs.cpu().numpy().astype(co.obs.dtype), co.obs), f"{case} {dtype} turn {t}: obs"
             assert np.array_equal(eng.grid.cpu().numpy(), co.grid) and np.array_equal(eng.total_reward.cpu().numpy(), co.total)
         assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ plain / Tag worlds of 4-8 KiB on the wave-per-env kernel
+@pytest.mark.parametrize("case", ["th_48x48_r5", "th_64x64_A16", "th_ragged_51x47", "th_u8", "th_phased", "th_rollout", "th_policy_protocol",
+                                  "tag_72x72", "tag_ragged_89x91_crowded", "generic_tables_60x60"])
+def test_mid_size_worlds_on_the_wave_per_env_kernel_vs_oracle(torch_cuda, monkeypatch, case):
+    """Worlds between 4 and 8 KiB per env run a wave per env when the batch is large (>= 4 096 envs; SGW_FAST_8K=1 forces it for the
+    batches a test can check element by element): the part of the grid beyond the first 4 KiB reaches LDS in a second round.
+    Treasurehunt tables with compile-time windows, ragged maps, uint8 windows, the phased 1 + A form, sgw_rollout, the
+    patched-window policy protocol (NO_MOVE + sgw_act), Tag (3-bit counters), another entity set; every tensor vs the C oracle."""
+    torch = torch_cuda
+    import dataclasses
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_FAST_8K", "1")
+    kw = {}
+    tag = case.startswith("tag")
+    if tag:
+        d, spec = H.load_golden("tag_11x11_default")
+        ws = H.world_spec(spec)
+        h, w, a, r = {"tag_72x72": (72, 72, 16, 4), "tag_ragged_89x91_crowded": (89, 91, 40, 3)}[case]
+        ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, vision_radius=r, agent_type=[ws.agent_type[0]] * a)
+    elif case == "generic_tables_60x60":
+        ws = _move_world(60, 60, 2, 8, 9, 3, seed=8)
+    else:
+        h, w, a, r = {"th_48x48_r5": (48, 48, 8, 5), "th_64x64_A16": (64, 64, 16, 3), "th_ragged_51x47": (51, 47, 7, 4), "th_u8": (50, 50, 6, 2),
+                      "th_phased": (48, 50, 5, 3), "th_rollout": (56, 56, 6, 3), "th_policy_protocol": (48, 48, 6, 3)}[case]
+        ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.04, seed=51, dense_prob=0.2)
+        if case == "th_u8":
+            kw["obs_dtype"] = torch.uint8
+    E, T = 21, 6
+    eng, co = make_engine(ws, E, first=4, **kw), H.COracle(ws, E, first_env_id=4)
+    assert "step_fast<" in eng.launch_info() and 4096 < ws.layers * ws.height * ws.width <= 8192, eng.launch_info()
+    eng.reset(0)
+    co.reset(0)
+    ref = lambda: dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions)
+    if case == "th_rollout":
+        obs_t = torch.empty((T,) + tuple(eng.obs.shape), device="cuda")
+        eng.rollout(T, obs_out=obs_t)
+        torch.cuda.synchronize()
+        for t in range(1, T + 1):
+            assert co.step(0, t, random_actions=True) == 0
+            assert np.array_equal(obs_t[t - 1].cpu().numpy(), co.obs), f"rollout turn {t}: obs"
+        for k in ("grid", "agent_pos", "total_reward"):
+            assert np.array_equal(getattr(eng, k).cpu().numpy(), ref()[k]), f"rollout: {k}"
+        return
+    A = ws.num_agents
+    for t in range(1, T + 1):
+        assert co.step(0, t, random_actions=True) == 0
+        acts = torch.from_numpy(co.actions.copy()).cuda()
+        if case == "th_phased":
+            seen = torch.zeros_like(eng.obs)
+            eng.obs.fill_(-3.0)
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for i in range(A):
+                seen[:, i] = eng.obs[:, i]
+                eng.step(acts, sweep=False, agent_begin=i, agent_end=i + 1, obs_next=i + 1 < A, write_obs=False, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(seen.cpu().numpy(), co.obs), f"phased turn {t}: windows"
+            what = ("grid", "agent_pos", "total_reward")
+        elif case == "th_policy_protocol":
+            eng.actions.copy_(acts)
+            eng.step(eng.actions, sweep=True, no_move=True, turn=t, advance_turn=False)      # sweep + every window, nobody moves
+            rows = eng.window_rows(None)
+            seen = torch.zeros_like(eng.obs)
+            for i in range(A):
+                seen[:, i] = eng.obs[:, i]              # what agent i's policy reads: the grid after the acts of agents < i
+                eng.act(i, rows)
+            torch.cuda.synchronize()
+            assert np.array_equal(seen.cpu().numpy(), co.obs), f"policy protocol turn {t}: windows"
+            what = ("grid", "agent_pos", "total_reward", "rewards")
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            what = ("grid", "agent_pos", "total_reward", "rewards", "actions", "obs")
+        for k in what:
+            assert np.array_equal(getattr(eng, k).cpu().numpy().astype(ref()[k].dtype), ref()[k]), f"{case} turn {t}: {k}"
+        if tag:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), f"{case} turn {t}: agent_state"
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy().astype(co.obs.dtype), co.obs), f"{case}: sgw_observe"
+    assert eng.status() == 0

@@ -48,6 +48,9 @@ FILES = {
     "r03_generic_tables.txt": ("generic_tables.txt",
         "# tools/generic_tables_probe.py (then PROBE_SMALL=1), round 3: worlds whose (layers, channels) have no compile-time tables -- 3-bit packed counters for any one-hot table of <= 10 channels,\n"
         "# channel planes staged in groups of four; before: 32x32x2 C8 246.6 us, C5 235.0, 32x32x1 C4 182.7, 32x32x3 C10 309.0, 24x24x2 C8 r4 236.3, 40x40x2 C12 (packed then) 350.6\n"),
+    "r03_mid_worlds.txt": ("mid_worlds.txt",
+        "# tools/mid_world_probe.py, round 3: plain (th) and Tag worlds between 4 and 8 KiB per env, 2 048 ... 65 536 envs: step_big (SGW_FAST_8K=0) against the wave-per-env kernel (SGW_FAST_8K=1);\n"
+        "# sgw_create takes the wave-per-env kernel from 4 096 envs on\n"),
     "r03_tag_group_probe.txt": ("tag_group_probe.txt",
         "# tools/tag_group_probe.py, round 3: Tag worlds up to 4 KiB, the dispatcher's choice / a wave per env (3-bit-counter Tag instance) / two envs per wave -- the data behind Tag's packing rule in sgw_create\n"),
 }

@@ -26,4 +26,5 @@ $T 100 python3 tools/hbm_floor.py > $OUT/hbm_floor.txt 2>&1 || exit 1
 $T 200 python3 tools/cleanup_observe_probe.py 1 3 5 10 > $OUT/cleanup_observe_probe.txt 2>&1 || exit 1
 $T 300 python3 tools/generic_tables_probe.py > $OUT/generic_tables.txt 2>&1 && PROBE_SMALL=1 $T 300 python3 tools/generic_tables_probe.py >> $OUT/generic_tables.txt 2>&1 || exit 1
 $T 600 python3 tools/tag_group_probe.py > $OUT/tag_group_probe.txt 2>&1 || exit 1
+$T 900 python3 tools/mid_world_probe.py > $OUT/mid_worlds.txt 2>&1 || exit 1
 echo all done

@@ -621,17 +621,19 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     // workgroup per env -> wave per env: 48x48x2 A8 r5 23 / 40 / 73 / 640 -> 22 / 31 / 56 / 373; 64x64x2 A16 r3 33 / 57 / 107 / 858 ->
     // 28 / 39 / 69 / 488; 50x50x2 A8 r3 26 / 46 / 84 / 686 -> 19 / 25 / 41 / 272; Tag 72x72 A16 r4 23 / 41 / 74 / 727 -> 25 / 34 / 61 / 447;
     // Tag 90x90 A12 r3 27 / 48 / 90 / 741 -> 20 / 25 / 48 / 347.  SGW_FAST_8K = 0 / 1: never / whatever the batch (A/B and test hook).
-    bool fast_8k = simple_rules && onehot && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules &&
-                   p.VV <= 128 && c.num_envs >= 4096;
+    const bool fast_8k_ok = simple_rules && onehot && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsPlain && p.VV <= 128;
+    // (between 8 and 11 KiB -- three workgroups per CU -- from 16 384 envs on: 72x72x2 A8 r5 at 4 096 / 16 384 / 32 768 envs 47 / 166 / 429 ->
+    // 55 / 156 / 341 us, Tag 100x100 A16 r4 43 / 219 / 429 -> 49 / 140 / 306; above that two workgroups per CU no longer pay: 90x90x2 555 -> 640)
+    bool fast_8k = fast_8k_ok && c.num_envs >= (p.cells_pad <= 8192 ? 4096 : 16384);
     if (const char* f = getenv("SGW_FAST_8K")) {
         if (f[0] == '0') fast_8k = false;
-        if (f[0] == '1') fast_8k = simple_rules && onehot && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128;
+        if (f[0] == '1') fast_8k = fast_8k_ok;
     }
     if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') fast_8k = false; }
     e->wpe = (p.cells_pad <= 4096 || rules_8k || fast_8k) ? 1 : 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
-    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsRules : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
+    e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsPlain : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
     // the layered rule set on the wave-per-env kernel (RULES variant): any spawners, BECOME_IF rules, Cleanup or plain agents
     e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128 &&
                     c.agent_rule != SGW_AGENT_RULE_TAG && (p.cells_pad <= 4096 || rules_8k);

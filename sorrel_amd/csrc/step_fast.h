@@ -19,6 +19,7 @@
 constexpr int kMaxUnits = 4;        // 16-byte units per lane (cells <= 4096)
 constexpr int kMaxUnitsRules = 8;   // ... of the RULES variant, whose sweep runs in LDS: units beyond the first kMaxUnits per lane go from HBM to LDS in a
                                     // second round (cells <= 8192)
+constexpr int kMaxUnitsPlain = 11;  // ... of plain / Tag worlds of large batches on the same second round (cells <= 11 264: three workgroups per CU)
 constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr size_t kCacheResidentGrid = (size_t)288 << 20;   // on-die capacity: 256 MiB Infinity Cache + 8 x 4 MiB L2; grids of a batch up to this size can stay
                                                             // resident from turn to turn (measured: 256 MiB of grids still do, 512 MiB do not)

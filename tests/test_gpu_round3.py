@@ -920,9 +920,9 @@ def test_staged_bursts_carry_partial_lines_vs_oracle(torch_cuda, monkeypatch, ca
 
 # ------------------------------------------------------------------ plain / Tag worlds of 4-8 KiB on the wave-per-env kernel
 @pytest.mark.parametrize("case", ["th_48x48_r5", "th_64x64_A16", "th_ragged_51x47", "th_u8", "th_phased", "th_rollout", "th_policy_protocol",
-                                  "tag_72x72", "tag_ragged_89x91_crowded", "generic_tables_60x60"])
+                                  "tag_72x72", "tag_ragged_89x91_crowded", "generic_tables_60x60", "th_74x75_11k", "tag_105x106_11k"])
 def test_mid_size_worlds_on_the_wave_per_env_kernel_vs_oracle(torch_cuda, monkeypatch, case):
-    """Worlds between 4 and 8 KiB per env run a wave per env when the batch is large (>= 4 096 envs; SGW_FAST_8K=1 forces it for the
+    """Worlds between 4 and 8 KiB per env (11 KiB from 16 384 envs on) run a wave per env when the batch is large (>= 4 096 envs; SGW_FAST_8K=1 forces it for the
     batches a test can check element by element): the part of the grid beyond the first 4 KiB reaches LDS in a second round.
     Treasurehunt tables with compile-time windows, ragged maps, uint8 windows, the phased 1 + A form, sgw_rollout, the
     patched-window policy protocol (NO_MOVE + sgw_act), Tag (3-bit counters), another entity set; every tensor vs the C oracle."""
@@ -936,19 +936,19 @@ def test_mid_size_worlds_on_the_wave_per_env_kernel_vs_oracle(torch_cuda, monkey
     if tag:
         d, spec = H.load_golden("tag_11x11_default")
         ws = H.world_spec(spec)
-        h, w, a, r = {"tag_72x72": (72, 72, 16, 4), "tag_ragged_89x91_crowded": (89, 91, 40, 3)}[case]
+        h, w, a, r = {"tag_72x72": (72, 72, 16, 4), "tag_ragged_89x91_crowded": (89, 91, 40, 3), "tag_105x106_11k": (105, 106, 20, 4)}[case]
         ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, vision_radius=r, agent_type=[ws.agent_type[0]] * a)
     elif case == "generic_tables_60x60":
         ws = _move_world(60, 60, 2, 8, 9, 3, seed=8)
     else:
         h, w, a, r = {"th_48x48_r5": (48, 48, 8, 5), "th_64x64_A16": (64, 64, 16, 3), "th_ragged_51x47": (51, 47, 7, 4), "th_u8": (50, 50, 6, 2),
-                      "th_phased": (48, 50, 5, 3), "th_rollout": (56, 56, 6, 3), "th_policy_protocol": (48, 48, 6, 3)}[case]
+                      "th_phased": (48, 50, 5, 3), "th_rollout": (56, 56, 6, 3), "th_policy_protocol": (48, 48, 6, 3), "th_74x75_11k": (74, 75, 9, 5)}[case]
         ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.04, seed=51, dense_prob=0.2)
         if case == "th_u8":
             kw["obs_dtype"] = torch.uint8
     E, T = 21, 6
     eng, co = make_engine(ws, E, first=4, **kw), H.COracle(ws, E, first_env_id=4)
-    assert "step_fast<" in eng.launch_info() and 4096 < ws.layers * ws.height * ws.width <= 8192, eng.launch_info()
+    assert "step_fast<" in eng.launch_info() and 4096 < ws.layers * ws.height * ws.width <= 11264, eng.launch_info()
     eng.reset(0)
     co.reset(0)
     ref = lambda: dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions)

@@ -610,8 +610,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     // Layered rule sets (BECOME_IF, Cleanup) stay on the wave-per-env RULES kernel up to 8 KiB per env: above 4 KiB their
     // alternative is the ticket-ordered workgroup-per-env generic kernel, where every act is a hand-off between waves
     // (Cleanup 48x48x3, 4 096 envs: 95 us there against ... here).  SGW_RULES_8K=0: A/B and test hook.
+    // (up to 11 KiB from 16 384 envs on, as for the plain worlds below: Cleanup 56x64x3 at 4 096 / 16 384 / 65 536 envs 97 / 394 / 1 499 us
+    // on the generic kernel, 107 / 308 / 1 229 here)
+    const int rules_units = (c.num_envs >= 16384 || (getenv("SGW_RULES_11K") && getenv("SGW_RULES_11K")[0] == '1')) ? kMaxUnitsPlain : kMaxUnitsRules;   // (hook: tests)
     bool rules_8k = !simple_rules && c.agent_rule != SGW_AGENT_RULE_TAG && vec16 && p.cells_pad > 4096 &&
-                    (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128;
+                    (p.cells_pad >> 4) <= 64 * rules_units && p.VV <= 128;
     if (const char* f = getenv("SGW_RULES_8K")) { if (f[0] == '0') rules_8k = false; }
     if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') rules_8k = false; }
     if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') rules_8k = false; }    // (the tests of the ticket-ordered workgroup-per-env kernel)
@@ -635,7 +638,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsPlain : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
     // the layered rule set on the wave-per-env kernel (RULES variant): any spawners, BECOME_IF rules, Cleanup or plain agents
-    e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * kMaxUnitsRules && p.VV <= 128 &&
+    e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * rules_units && p.VV <= 128 &&
                     c.agent_rule != SGW_AGENT_RULE_TAG && (p.cells_pad <= 4096 || rules_8k);
     if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') e->fast_rules = false; }   // test hook: generic kernel instead
     e->fast = e->fast || e->fast_rules;

@@ -719,8 +719,9 @@ def test_patched_window_protocol_soak_random_rule_worlds(torch_cuda, case):
 
 
 # ------------------------------------------------------------------ layered rule sets between 4 and 8 KiB per env on the wave-per-env RULES kernel
-@pytest.mark.parametrize("case", ["cleanup_40x48", "cleanup_48x48_wide_beam", "cleanup_ragged_45x43", "become_if_movers_50x52", "phased_40x48", "rollout_40x48"])
-def test_layered_rule_worlds_up_to_8k_per_env_vs_oracle(torch_cuda, case):
+@pytest.mark.parametrize("case", ["cleanup_40x48", "cleanup_48x48_wide_beam", "cleanup_ragged_45x43", "become_if_movers_50x52", "phased_40x48", "rollout_40x48",
+                                  "cleanup_56x64_11k", "become_if_movers_ragged_59x61_11k"])
+def test_layered_rule_worlds_up_to_8k_per_env_vs_oracle(torch_cuda, monkeypatch, case):
     """Cleanup / BECOME_IF worlds above 4 KiB (up to 8 KiB) per env stay on step_fast<..., RULES>: the part of the grid
     beyond the first 4 KiB reaches LDS in a second round.  Fused turns, the 1 + A phased form, sgw_rollout, a ragged world
     (byte count not a multiple of 16) and plain movers under BECOME_IF rules, against the C oracle."""
@@ -730,9 +731,12 @@ def test_layered_rule_worlds_up_to_8k_per_env_vs_oracle(torch_cuda, case):
     d, spec = H.load_golden("cleanup_15x16")
     ws = H.world_spec(spec)
     h, w, a, R = {"cleanup_40x48": (40, 48, 10, 3), "cleanup_48x48_wide_beam": (48, 48, 12, 9), "cleanup_ragged_45x43": (45, 43, 7, 3),
-                  "become_if_movers_50x52": (50, 52, 9, 3), "phased_40x48": (40, 48, 6, 3), "rollout_40x48": (40, 48, 8, 3)}[case]
+                  "become_if_movers_50x52": (50, 52, 9, 3), "phased_40x48": (40, 48, 6, 3), "rollout_40x48": (40, 48, 8, 3),
+                  "cleanup_56x64_11k": (56, 64, 10, 4), "become_if_movers_ragged_59x61_11k": (59, 61, 9, 3)}[case]
+    if case.endswith("_11k"):      # up to 11 KiB per env from 16 384 envs on; the hook takes the path for a batch a test can check
+        monkeypatch.setenv("SGW_RULES_11K", "1")
     ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a, beam_radius=R)
-    if case == "become_if_movers_50x52":      # the same layered rule tables with MovingAgent.act agents
+    if case.startswith("become_if_movers"):      # the same layered rule tables with MovingAgent.act agents
         ws = dataclasses.replace(ws, agent_rule=0, action_kind=[0] * len(ws.action_dy))
     g = np.zeros((3, h, w), np.uint8)
     g[:, 0, :] = g[:, -1, :] = 2

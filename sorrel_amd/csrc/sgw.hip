@@ -120,6 +120,7 @@ struct sgw_engine {
     int step_env_lds = 0;
     int obs_stage = 0;     // bytes of LDS observation staging per wave (step_fast, one-hot)
     int big_stage = 0;     // ... per wave of step_big (0: direct stores)
+    int big_threads = kBigThreads;   // threads per workgroup of the step_big instance in use (the rollout instance: always kBigThreads)
     int fast_tab_bytes = 0;
     int big_tab_bytes = 0;   // step_big: only the counter words of the channels in use
     int grid_blocks = 1;
@@ -312,15 +313,31 @@ StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag,
 
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
-StepFn pick_big(bool onehot, int L, int C, int r, bool tag, const char** name) {
+StepFn pick_big(bool onehot, int L, int C, int r, bool tag, int threads, const char** name) {
     if (tag) {   // TagAgent.act on the workgroup-per-env kernel (moves in registers, the "it" token walked by wave 0)
+        if (threads == 256) {
+            if (onehot && L == 1 && C == 4 && r == 4) PICK(step_big<true, 1, 4, 4, false, false, true, 256>);
+            if (onehot) PICK(step_big<true, 0, 0, 0, false, false, true, 256>);
+        }
         if (onehot && L == 1 && C == 4 && r == 4) PICK(step_big<true, 1, 4, 4, false, false, true>);   // the Tag example's tables and 9x9 window
         if (onehot) PICK(step_big<true, 0, 0, 0, false, false, true>);
         PICK(step_big<false, 0, 0, 0, false, false, true>);
     }
     if (!onehot) PICK(step_big<false, 0, 0, 0>);
+    if (threads == 256) {   // up to 32 agents: four waves per workgroup
+        if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, false, false, 256>);
+        PICK(step_big<true, 0, 0, 0, false, false, false, 256>);
+    }
     if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5>);   // BASELINE config 5
     PICK(step_big<true, 0, 0, 0>);
+}
+
+// which of pick_big's choices run 256 threads (the others: kBigThreads): worlds whose windows are little work for eight waves --
+// agents x window cells up to 2 048 (round 3, 8 192 envs, us at 512 -> 256 threads: 90x90x2 A16 r3 123 -> 98, 100x100x2 A8 r5 106 -> 89,
+// Tag 128x128 A32 r3 143 -> 119, Tag 160x160 A16 r4 141 -> 135, 128x128x2 A16 r3 194 -> 200; but 128x128x2 A32 r5 211 -> 243, config 5 352 -> 394)
+int big_threads_for(bool onehot, int num_agents, int window_cells) {
+    if (const char* f = getenv("SGW_BIG_THREADS_RT")) { if (atoi(f) == 256 || atoi(f) == 512) return onehot ? atoi(f) : kBigThreads; }   // A/B and test hook
+    return (onehot && num_agents * window_cells <= 2048) ? 256 : kBigThreads;
 }
 
 bool fixed_fast_shape(int L, int C, int r, int H, int W, bool tag) {   // = the compile-time-shape instances of pick_fast
@@ -334,8 +351,12 @@ StepFn pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
     PICK(step_big<true, 0, 0, 0, true>);
 }
 
-StepFn pick_big_walk(bool onehot, int L, int C, int r, const char** name) {
+StepFn pick_big_walk(bool onehot, int L, int C, int r, int threads, const char** name) {
     if (!onehot) PICK(step_big<false, 0, 0, 0, false, true>);
+    if (threads == 256) {
+        if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, true, false, 256>);
+        PICK(step_big<true, 0, 0, 0, false, true, false, 256>);
+    }
     if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, true>);
     PICK(step_big<true, 0, 0, 0, false, true>);
 }
@@ -649,6 +670,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     const bool tag_move = c.agent_rule == SGW_AGENT_RULE_TAG;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
     e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && (plain_move || tag_move) && simple_rules;
     if (const char* f = getenv("SGW_NO_BIG_TAG")) { if (f[0] == '1' && tag_move) e->big = false; }   // A/B and test hook: the ticket-ordered generic kernel
+    if (e->big) e->big_threads = big_threads_for(onehot, c.num_agents, p.VV);
     bool stage_kernel = false;   // a run-time-shape STAGE kernel applies
     {   // LDS staging of one-hot observations
         const int ob_elems = c.num_agents * c.num_channels * p.VV;
@@ -749,7 +771,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         bool stage_on = static_tables && !tagk;   // (the Tag example's 9x9x4 windows are ten lines each: staged 54 / 79 us, direct 47 / 74, 128x128 at 2 048 envs / 72x72 at 8 192)
         if (const char* f = getenv("SGW_BIG_STAGE")) stage_on = stage_on && f[0] != '0';
         e->big_stage = stage_on ? (c.num_channels * p.VV + 31 + 3) & ~3 : 0;
-        const size_t stage_all = (size_t)kBigWaves * e->big_stage;
+        const size_t stage_all = (size_t)(e->big_threads / 64) * e->big_stage;
         auto per_cu = [&](size_t bytes) { return std::min<size_t>(4, kLdsPerCu / (((bytes + 1023) & ~(size_t)1023) + 1024)); };   // (a workgroup's request must stay 1 KiB below its share)
         const size_t plain_img = (size_t)p.cells_pad, padded_img = (size_t)c.layers * c.height * (c.width + 16);
         const bool can_pad = (c.width & 15) == 0 && (p.cells & 15) == 0;
@@ -810,7 +832,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (const char* f = getenv("SGW_PHASE_ROWS")) { if (f[0] == '0') e->rows_fn = nullptr; }   // A/B and test hook: the older phase paths (sgw_step's phases only)
     p.stage_agents = e->stage_agents;
     StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
-                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, &e->kernel_name)
+                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, e->big_threads, &e->kernel_name)
                          : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, false, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
     if (const char* f = getenv("SGW_FAST_WG_PER_CU")) { e->fast_wg_cap = atoi(f); e->fast_wg_cap_forced = true; }   // tuning hook
@@ -823,8 +845,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (!e->fast && !e->big)   // the generic kernel's instance with the turn loop
         e->step_fn_multi = pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, true, &e->kernel_name_multi);
     e->multi_turn = e->step_fn_multi != nullptr;   // kernels with sgw_rollout's turn loop
-    if (e->big && !tag_move && ((p.cells + 15) >> 4) <= 4 * kBigThreads)   // the prefetch holds one 4-unit round per thread
-        e->step_fn_walk = pick_big_walk(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_walk);
+    if (e->big && !tag_move && ((p.cells + 15) >> 4) <= 4 * e->big_threads)   // the prefetch holds one 4-unit round per thread
+        e->step_fn_walk = pick_big_walk(e->onehot, c.layers, c.num_channels, c.vision_radius, e->big_threads, &e->kernel_name_walk);
     if (const char* f = getenv("SGW_BIG_NO_WALK")) { if (f[0] == '1') e->step_fn_walk = nullptr; }   // A/B hook
     if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
@@ -849,10 +871,10 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
     if (e->step_fn_walk) {
         int per_cu = 0;
-        const size_t walk_lds = e->step_lds_bytes - (size_t)kBigWaves * e->big_stage;   // (the walking variant stores directly: no staging area)
-        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_fn_walk, kBigThreads, walk_lds);
+        const size_t walk_lds = e->step_lds_bytes - (size_t)(e->big_threads / 64) * e->big_stage;   // (the walking variant stores directly: no staging area)
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_fn_walk, e->big_threads, walk_lds);
         int plain_per_cu = 0;
-        if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain_per_cu, sk, kBigThreads, e->step_lds_bytes);
+        if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain_per_cu, sk, e->big_threads, e->step_lds_bytes);
         // (the runtime's answer for the plain kernel is three per CU whatever it asks for; the hardware admits a fourth
         // while the request stays 1 KiB below a quarter of the CU's LDS -- 1 280 envs of config 5: 55 us there, 71 above)
         if (oe == hipSuccess && ((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024 <= kLdsPerCu / 4) plain_per_cu = std::max(plain_per_cu, 4);
@@ -881,7 +903,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     }
     // staged windows pay once the batch is a few rounds of workgroups (a single round is latency-bound, and the staging adds
     // an LDS round trip per window): above 1.75x what the chip holds at once (see the table above)
-    if (e->big) e->big_stage_min_envs = (int64_t)4 * e->num_cus * 7 / 4;
+    if (e->big) {
+        const int64_t by_lds = (int64_t)(kLdsPerCu / (((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024));
+        const int64_t resident = std::max<int64_t>(1, std::min<int64_t>(2048 / e->big_threads, by_lds));   // workgroups a CU holds at once
+        e->big_stage_min_envs = resident * e->num_cus * 7 / 4;
+    }
     if (const char* f = getenv("SGW_BIG_STAGE")) { if (f[0] == '1') e->big_stage_min_envs = 0; }   // test hook: staged whatever the batch
     e->reset_blocks = (int)ceil_div(p.E, epb);   // one env per group and launch
     *out = e;
@@ -963,7 +989,8 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
     const bool walk = e->big && p.nturns == 1 && e->step_fn_walk && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
     p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
-    if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)kBigWaves * e->big_stage;
+    if (e->big && p.nturns > 1 && e->big_threads != kBigThreads) p.big_stage = 0;   // (the rollout instance runs kBigThreads: the staging area is sized for this engine's waves)
+    if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
@@ -996,7 +1023,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         fn = e->step_fn_walk;
         blocks = e->walk_blocks;
     }
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(e->big ? kBigThreads : kBlock), lds, s, p);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock), lds, s, p);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
 }
@@ -1348,15 +1375,15 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     int cap = 0;
     size_t lds = step_lds_request(e, p, &cap);
     const bool big_staged = e->big && !walk && e->base.E > e->big_stage_min_envs;
-    if (e->big && !big_staged) lds -= (size_t)kBigWaves * e->big_stage;
-    const int threads = e->big ? kBigThreads : kBlock;
+    if (e->big && !big_staged) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
+    const int threads = e->big ? e->big_threads : kBlock;
     StepFn fn = walk ? e->step_fn_walk : e->step_fn;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
     const char* phase = e->rows_fn ? e->kernel_name_rows : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
     snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d",
              walk ? e->kernel_name_walk : e->kernel_name,
-             (e->fast || e->big) ? e->wpe * kWave * (e->big ? kBigWaves / 4 : 1) : e->group,
+             (e->fast || e->big) ? (e->big ? e->big_threads : e->wpe * kWave) : e->group,
              threads, lds, e->step_env_lds, e->obs_stage, e->stage_agents,
              walk ? e->walk_blocks : e->grid_blocks, per_cu,
              e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase, big_staged ? e->big_stage : 0);

@@ -50,8 +50,12 @@ constexpr int big_agent_lds(bool tag) { return kBigAgentLds + (tag ? kBigTagLds 
 // one per env and turn): lane b knows where agent b stands at that moment (its new cell if it has already acted, its old
 // one if not), four ballots find the neighbours in Location.adjacent order.  The journal of an agent then also says what
 // type it carried when it acted and whom it tagged, and phase R undoes tags along with moves, latest first.
-template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false>
-__global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_WAVES : 6) : (kBigThreads == 256 ? 3 : 1)) void step_big(const Params p) {
+// BT: threads per workgroup.  512 (eight waves) for worlds with many agents (config 5: 64); 256 for up to 32 agents, where eight waves
+// have one or two windows each and mostly wait at the barriers (round 3, 8 192 envs: 90x90x2 / 16 agents 122 -> 103 us, 100x100x2 / 8
+// agents / 11x11 104 -> 88, Tag 128x128 / 32 agents 145 -> 116; config 5 itself 352 -> 394: it keeps 512).
+template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false, int BT = kBigThreads>
+__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const Params p) {
+    constexpr int kBT = BT, kBW = BT / 64;   // threads / waves of this instance
     static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
     // Philox key schedule per block (common.h): config 5's share on the walking variant 94 -> 90 us; the plain variant is indifferent at
     // config 5's shape and loses 3.6 % on a 48x48 world, so it keeps the shared keys
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
         if (tid0 < (p.tab_bytes >> 2)) wd[tid0] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid0];   // (the counter words of the channels in use)
     } else {
         double* wa = reinterpret_cast<double*>(smem);
-        for (int i = tid0; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBigThreads) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
+        for (int i = tid0; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBT) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
     }
     const double vtab = gtab->value[tid0 & 31];   // lane t (of wave 0): value[t], f64 (keeps global loads out of the chain)
     if (tid0 >= 64 && tid0 < 128) s_atype[tid0 - 64] = gtab->agent_type[tid0 - 64];
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
         const uint4* nsrc = reinterpret_cast<const uint4*>(p.grid + e * p.env_stride);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int idx = k * kBigThreads + t;
+            const int idx = k * kBT + t;
             if (idx < nunits) nu[k] = nsrc[idx];
         }
         if (t < p.A) {
@@ -179,13 +183,13 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
     // ---- grid -> LDS (first turn), sweep on the registers, 4 units per thread per round
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
-        for (int base = 0; base < nunits; base += 4 * kBigThreads) {
+        for (int base = 0; base < nunits; base += 4 * kBT) {
             uint4 u[4];
             uint32_t hits[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int idx = base + k * kBigThreads + tid;
-                if constexpr (WALK) u[k] = nu[k];   // (nunits <= 4 * kBigThreads: host)
+                const int idx = base + k * kBT + tid;
+                if constexpr (WALK) u[k] = nu[k];   // (nunits <= 4 * kBT: host)
                 else if (idx < nunits) u[k] = (MULTI && tix > 0) ? lg16[lunit(idx)] : src[idx];
                 if ((cells & 15) && idx == nunits - 1) {   // ragged world: mask the bytes past the last cell
                     const int tail = cells & 15;
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int idx = base + k * kBigThreads + tid;
+                const int idx = base + k * kBT + tid;
                 hits[k] = 0;
                 if (idx < nunits) {
                     if (!(MULTI && tix > 0)) lg16[lunit(idx)] = u[k];
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
                         h1 = k == 1 ? cleared : h1;
                         h2 = k == 2 ? cleared : h2;
                         h3 = k == 3 ? cleared : h3;
-                        const uint32_t off = (uint32_t)(base + k * kBigThreads + tid) * 16u + cell;
+                        const uint32_t off = (uint32_t)(base + k * kBT + tid) * 16u + cell;
                         const U4 kw = philox4x32_10<kBigOwnKeys>(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
                                                    p.seed_lo, p.seed_hi);
                         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
         const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
         // SGW_STEP_OBS_NEXT: only agent a1, which sees the grid after ALL moves of this call (nothing to undo)
         const int r_lo = p.obs_next ? p.a1 : p.a0, r_hi = p.obs_next ? (p.a1 < p.A ? p.a1 + 1 : p.a1) : p.a1;
-        for (int a = r_lo + wv; a < r_hi; a += kBigWaves) {
+        for (int a = r_lo + wv; a < r_hi; a += kBW) {
             const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
             const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
             const int cbase = y * P + x;
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads == 512 ? (WALK ? SGW_WALK_
         }
     } else if (dirty) {
         uint4* dst = reinterpret_cast<uint4*>(p.grid + env * p.env_stride);
-        for (int idx = tid; idx < nunits; idx += kBigThreads) dst[idx] = lg16[lunit(idx)];
+        for (int idx = tid; idx < nunits; idx += kBT) dst[idx] = lg16[lunit(idx)];
     }
     STAMPB(4);                   // write-back issued
 #ifdef SGW_STAMPS

@@ -524,7 +524,8 @@ def test_big_tag_worlds_on_the_workgroup_per_env_kernel_vs_oracle(torch_cuda, ca
     if case == "tag_u8":
         kw["obs_dtype"] = torch.uint8
     eng = make_engine(ws, E, first=17, **kw)
-    assert "step_big<" in eng.launch_info() and ", true>" in eng.launch_info().split(" group")[0], eng.launch_info()
+    name = eng.launch_info().split(" group")[0]
+    assert name.startswith("step_big<") and (name.endswith(", true>") or name.endswith(", true, 256>")), eng.launch_info()   # the TAG instance (256 threads up to 32 agents)
     co = H.COracle(ws, E, first_env_id=17)
     eng.reset(0)
     co.reset(0)
@@ -1004,4 +1005,56 @@ def test_mid_size_worlds_on_the_wave_per_env_kernel_vs_oracle(torch_cuda, monkey
     co.observe()
     torch.cuda.synchronize()
     assert np.array_equal(eng.obs.cpu().numpy().astype(co.obs.dtype), co.obs), f"{case}: sgw_observe"
+    assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ step_big with four or eight waves per workgroup
+@pytest.mark.parametrize("threads", ["256", "512"])
+@pytest.mark.parametrize("case", ["plain_90x90_A16", "config5_shape_A64", "crowded_48x48_A64", "staged_100x100_A8_r5", "walking_96x96_A12",
+                                  "tag_128x128_A32", "tag_crowded_80x80_A64", "generic_tables_96x96"])
+def test_big_kernel_four_or_eight_waves_vs_oracle(torch_cuda, monkeypatch, case, threads):
+    """step_big<..., BT>: 256 threads per workgroup where agents x window cells <= 2 048, else 512 (SGW_BIG_THREADS_RT forces either).
+    Both on few and on many agents (more agents than waves x 8, crowded maps), with the staged windows, on the walking
+    variant, for Tag and for another entity set; every tensor against the C oracle, then sgw_observe."""
+    torch = torch_cuda
+    import dataclasses
+    from sorrel_amd.spec import treasurehunt_spec
+
+    monkeypatch.setenv("SGW_BIG_THREADS_RT", threads)
+    tag = case.startswith("tag")
+    if tag:
+        d, spec = H.load_golden("tag_11x11_default")
+        ws = H.world_spec(spec)
+        h, w, a, r = {"tag_128x128_A32": (128, 128, 32, 3), "tag_crowded_80x80_A64": (80, 80, 64, 4)}[case]
+        ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, vision_radius=r, agent_type=[ws.agent_type[0]] * a)
+    elif case == "generic_tables_96x96":
+        ws = _move_world(96, 96, 2, 8, 11, 3, seed=9)
+    else:
+        h, w, a, r = {"plain_90x90_A16": (90, 90, 16, 3), "config5_shape_A64": (128, 128, 64, 5), "crowded_48x48_A64": (48, 48, 64, 5),
+                      "staged_100x100_A8_r5": (100, 100, 8, 5), "walking_96x96_A12": (96, 96, 12, 4)}[case]
+        ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=61, dense_prob=0.3 if "crowded" in case else 0.1)
+    if case.startswith("staged"):
+        monkeypatch.setenv("SGW_BIG_STAGE", "1")
+    if case.startswith("walking"):
+        monkeypatch.setenv("SGW_BIG_WALK_BLOCKS", "3")
+    monkeypatch.setenv("SGW_FAST_8K", "0")      # (the 4-8 KiB cases stay on this kernel)
+    E, T = 10, 6
+    eng, co = make_engine(ws, E, first=6), H.COracle(ws, E, first_env_id=6)
+    info = eng.launch_info()
+    assert "step_big<" in info and f"threads={threads}" in info, info
+    eng.reset(0)
+    co.reset(0)
+    for t in range(1, T + 1):
+        eng.step(random_actions=True, turn=t, advance_turn=False)
+        assert co.step(0, t, random_actions=True) == 0
+        torch.cuda.synchronize()
+        for k, ref in (("grid", co.grid), ("agent_pos", co.pos), ("total_reward", co.total), ("rewards", co.rewards), ("actions", co.actions), ("obs", co.obs)):
+            assert np.array_equal(getattr(eng, k).cpu().numpy(), ref), f"{case} / {threads} threads, turn {t}: {k}"
+        if tag:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), f"{case} turn {t}: agent_state"
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy(), co.obs)
     assert eng.status() == 0

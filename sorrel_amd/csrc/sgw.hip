@@ -725,7 +725,11 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->group = e->wpe * kWave;
     if (e->wpe == 1) {
         const int64_t avv = (int64_t)c.num_agents * p.VV;
-        auto enough = [&](int G) { return c.num_agents <= G && (int64_t)c.num_envs * G / kWave >= 12288; };
+        // (round 3: the batch a packing needs, re-measured on the single-turn instances -- us per step at 1 024 / 4 096 / 8 192 / 16 384 /
+        // 32 768 envs, wave per env | 32 lanes | 16 lanes: 16x16 A4 r2 7.6 / 11.1 / 15.9 / 26.1 / 45.4 | 8.6 / 10.2 / 12.6 / 19.3 / 31.2 |
+        // 10.5 / 11.6 / 13.0 / 17.4 / 28.1; 10x10 A2 r2 7.2 / 9.2 / 12.8 / 21.1 / 36.8 | 7.2 / 8.2 / 10.1 / 15.1 / 24.1 | 7.5 / 8.0 / 9.1 /
+        // 11.2 / 18.0: two envs per wave from 4 096 envs on, four from 12 288; the rule used to ask for 24 576 / 49 152)
+        auto enough = [&](int G) { return c.num_agents <= G && (int64_t)c.num_envs * G / kWave >= (G == 16 ? 3072 : 2048); };
         int g = 0;
         // (Tag on a map with a compile-time-shape wave-per-env instance stays there: 32x32 / 8 agents 117 us against 143 packed)
         // (round 3, tools/tag_group_probe.py, two envs per wave / wave per env: 11x11 A5 r4 99 / 131 us, 16x16 A4 r3 51 / 104, 20x20 A5 r4 116 / 127,

@@ -28,6 +28,10 @@ struct DevTables {
     uint32_t rule_mask[SGW_MAX_TYPES];
     uint32_t delta3[SGW_MAX_TYPES];      // one-hot, <= 10 channels: ONE word per type, 1 << 3 * c for its channel c (3-bit counters: <= 7 layers)
     double appearance[SGW_MAX_TYPES][SGW_MAX_CHANNELS];  // general (non one-hot) path only
+    // integer appearance tables behind SGW_OBS_POST_CLIP255_DIV255 (the reference's RGBObservationSpec: uint8 colours, np.clip(sum, 0, 255) / 255):
+    // 16-bit counters, two channels per word (a sum over <= 7 layers of values <= 9 362 cannot carry), and the 256 possible results
+    uint32_t delta16[2][SGW_MAX_TYPES];
+    float post_lut[256];                                 // (float)(min(k, 255) / 255.0), k = 0 .. 255: what obs_finish returns for an integer sum
 };
 constexpr int kTabFastBytes = offsetof(DevTables, appearance);
 static_assert(kTabFastBytes % 16 == 0, "LDS table block must keep 16-byte alignment");
@@ -47,6 +51,7 @@ struct Params {
     uint32_t dy_pack, dx_pack;  // 2 bits per action: (d + 1)
     uint32_t fill_delta[4];
     uint32_t fill_delta3;      // the fill entity's word of DevTables::delta3
+    uint32_t fill_delta16[2];  // ... of DevTables::delta16
     // single-spawner fast path (exactly one type carries SGW_RULE_SPAWN)
     uint32_t spawn_pat;      // type id replicated in 4 bytes
     uint32_t spawn_thr;      // low 32 bits of floor(p * 2^32)

@@ -91,6 +91,8 @@ struct sgw_engine {
     int wpe = 1;          // waves per env
     int group = 64;       // generic step kernel: threads per env (16 / 32: several envs share a wave)
     bool onehot = true;
+    bool rgb16 = false;   // integer appearance tables behind clip / 255: step_fast's I16 instances
+    int plain_tab_bytes = 0;   // ... whose direct-store variant is the float64 kernel with its own, larger table area
     bool fast = false;    // step_fast specialisation applies
     bool big = false;     // step_big (workgroup per env, pipelined agents) applies
     void (*step_fn)(const Params) = nullptr;
@@ -383,7 +385,16 @@ StepFn pick_rows(int L, int NW, int r, const char** name, RowsFn* obs_fn, const 
     return nullptr;
 }
 
-StepFn pick_fast(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
+StepFn pick_fast(bool onehot, bool rgb16, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
+    if (rgb16 && stage && !rules && C == 3) {   // integer colour tables behind clip / 255 (the reference's RGBObservationSpec): 16-bit counters, result table
+        if (tag) {
+            if (L == 1) PICK(step_fast<true, 1, 3, 0, 0, 0, true, false, true, false, false, true>);
+            PICK(step_fast<true, 0, 3, 0, 0, 0, true, false, true, false, false, true>);
+        }
+        if (L == 1) PICK(step_fast<true, 1, 3, 0, 0, 0, false, false, true, false, false, true>);
+        if (L == 2) PICK(step_fast<true, 2, 3, 0, 0, 0, false, false, true, false, false, true>);
+        PICK(step_fast<true, 0, 3, 0, 0, 0, false, false, true, false, false, true>);
+    }
     if (rules) {
         // one-hot tables of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of ceil(C / 4))
         const bool p3 = onehot && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
@@ -539,6 +550,21 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     memcpy(h.layer_border, c.layer_border_type, 8);
     if (c.obs_post != SGW_OBS_POST_NONE) onehot = false;   // post-processing lives on the general float64 path
     e->onehot = onehot;
+    // ... except the reference's RGBObservationSpec as it builds its own maps (uint8 colours, clip / 255): integer tables of <= 4
+    // channels take the byte-staging window pipeline with 16-bit counters and a table of the 256 possible results (step_fast.h, I16)
+    bool rgb16 = c.obs_post == SGW_OBS_POST_CLIP255_DIV255 && c.num_channels <= 4 && c.layers <= 7;
+    for (int t = 0; t < c.num_types && rgb16; ++t)
+        for (int k = 0; k < c.num_channels; ++k) {
+            const double v = c.appearance[t][k];
+            if (!(v >= 0.0 && v <= 9362.0 && v == std::floor(v))) rgb16 = false;
+        }
+    if (const char* f = getenv("SGW_NO_RGB16")) { if (f[0] == '1') rgb16 = false; }   // A/B and test hook: the float64 path
+    if (rgb16) {
+        for (int t = 0; t < c.num_types; ++t)
+            for (int k = 0; k < c.num_channels; ++k) h.delta16[k >> 1][t] |= (uint32_t)c.appearance[t][k] << (16 * (k & 1));
+        for (int k = 0; k < 256; ++k) h.post_lut[k] = (float)(std::fmin(std::fmax((double)k, 0.0), 255.0) / 255.0);   // = obs_finish of an integer sum
+    }
+    e->rgb16 = rgb16;
 
     // ---- static launch parameters
     Params& p = e->base;
@@ -566,6 +592,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     }
     for (int q = 0; q < 4; ++q) p.fill_delta[q] = h.delta[q][c.fill_type];
     p.fill_delta3 = h.delta3[c.fill_type];
+    p.fill_delta16[0] = h.delta16[0][c.fill_type];
+    p.fill_delta16[1] = h.delta16[1][c.fill_type];
     int nspawn = 0;
     p.spawn_pat = 0xFFFFFFFFu;   // matches no valid type id
     for (int t = 0; t < c.num_types; ++t) {
@@ -664,7 +692,10 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') e->fast_rules = false; }   // test hook: generic kernel instead
     e->fast = e->fast || e->fast_rules;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
-    e->fast_tab_bytes = onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
+    // (the integer-table RGB instances exist for three channels, plain or Tag movers, worlds <= 4 KiB)
+    const bool rgb16_fast = e->rgb16 && e->fast && !e->fast_rules && c.num_channels == 3 && p.cells_pad <= 4096;
+    const bool bytes_ok = onehot || rgb16_fast;        // the byte-staging window pipeline applies
+    e->fast_tab_bytes = bytes_ok ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
     const bool tag_move = c.agent_rule == SGW_AGENT_RULE_TAG;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
@@ -678,10 +709,10 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         const bool fixed_shape = !e->fast_rules && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width,
                                                                     c.agent_rule == SGW_AGENT_RULE_TAG);   // = pick_fast's fixed-shape kernels
         e->obs_stage = 0;
-        if (e->fast && onehot && fixed_shape) {
+        if (e->fast && onehot && fixed_shape) {   // (never an RGB world: six channels)
             // whole envs of a multiple of 4 elements, at most 4 KiB of byte counts
             if ((ob_elems & 3) == 0 && ob_elems <= 4096) e->obs_stage = (ob_elems + 15) & ~15;
-        } else if (e->fast && onehot) {
+        } else if (e->fast && bytes_ok) {
             // run-time shapes: as many agents per burst as fit the wave's share of LDS at full occupancy (8 workgroups
             // of 4 waves per CU, 1 KiB granules: 5 120 bytes per wave); if not even one agent fits, at 5 workgroups per CU
             const int base = e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad;
@@ -753,9 +784,17 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         }
     }
     if (!e->fast) { e->obs_stage = 0; stage_kernel = false; }
+    e->rgb16 = rgb16_fast && e->fast && stage_kernel;      // the I16 instances are STAGE kernels: no staging area, no integer path
+    if (!onehot && !e->rgb16) {
+        e->fast_tab_bytes = SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
+        e->obs_stage = 0;
+        stage_kernel = false;
+    }
+    // what the float64 kernel (calls the STAGE kernel cannot serve: agent ranges, OBS_NEXT, unaligned tensors) needs instead
+    e->plain_tab_bytes = e->rgb16 ? SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8 : 0;
     const int epb_step = (e->fast || e->big) ? epb : kBlock / e->group;   // envs per workgroup of the step kernel
     e->step_env_lds = e->fast ? e->fast_tab_bytes + (e->fast_rules ? kRuleLds : 0) + p.cells_pad + e->obs_stage : p.env_lds;
-    e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds : (size_t)p.tab_bytes + (size_t)epb_step * e->step_env_lds;
+    e->step_lds_bytes = e->fast ? (size_t)epb * e->step_env_lds + (e->rgb16 ? 1024 : 0) : (size_t)p.tab_bytes + (size_t)epb_step * e->step_env_lds;   // (+ the I16 result table)
     p.big_pitch = c.width;
     if (e->big) {
         // LDS of a workgroup: [counter words of the channels in use | appearance table][agent arrays][grid image][staging].
@@ -820,7 +859,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     p.tmpl = e->d_tmpl;
     p.status = e->d_status;
 
-    if (e->fast) e->step_fn_plain = pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, false, &e->kernel_name_plain);
+    if (e->fast) e->step_fn_plain = pick_fast(e->onehot, false, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, false, &e->kernel_name_plain);
     // Worlds above 4 KiB only: there, gathering one window from global memory beats staging 32 KiB through LDS (config 5:
     // 14.9 against 24.4 us per phase launch); a 2 KiB env is staged with four coalesced 16-byte loads per lane and the
     // byte gather from global is the slower way (config 3: 62.9 against 46.1 us).  SGW_NO_PHASE_KERNEL = 1 / 0 forces.
@@ -835,7 +874,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     }
     if (const char* f = getenv("SGW_PHASE_ROWS")) { if (f[0] == '0') e->rows_fn = nullptr; }   // A/B and test hook: the older phase paths (sgw_step's phases only)
     p.stage_agents = e->stage_agents;
-    StepFn sk = e->fast  ? pick_fast(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
+    StepFn sk = e->fast  ? pick_fast(e->onehot, e->rgb16, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
                 : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, e->big_threads, &e->kernel_name)
                          : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, false, &e->kernel_name);
     StepFn rk = pick_reset(e->wpe);
@@ -1021,6 +1060,12 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->fast && e->stage_agents > 0 && e->step_fn_plain &&
         (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS)))
         fn = e->step_fn_plain;
+    if (fn == e->step_fn_plain && e->rgb16 && fn != e->step_fn) {   // the float64 kernel: its own table area, no staging, no result table
+        p.tab_bytes = e->plain_tab_bytes;
+        p.env_lds = e->plain_tab_bytes + p.cells_pad;
+        p.obs_stage = 0;
+        lds = (size_t)(kBlock / kWave) * p.env_lds;
+    }
     if (p.nturns > 1) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
     int blocks = e->grid_blocks;
     if (walk) {   // two to three rounds of the plain kernel

@@ -108,7 +108,11 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // P3 (round 3; RULES instances with one-hot tables of <= 10 channels): 3-bit packed counters -- the appearance of a type is
 // ONE word (1 << 3 c for its channel c; a count never exceeds the <= 7 layers), so a cell costs one table read and one add
 // per layer instead of ceil(C / 4) of each (Cleanup: 9 channels, three words).
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false, bool P3 = false>
+// I16 (round 3; integer appearance tables of <= 4 channels behind the clip / 255 post-processing = the reference's RGBObservationSpec with
+// its uint8 colours): the window pipeline of the one-hot path with 16-bit counters -- the layer sum of a cell is an integer, the clip
+// makes it a byte, the byte is staged, and the burst turns it into (float)(k / 255.0) through a 256-entry table of exactly those
+// floats (DevTables::post_lut, one copy per workgroup in LDS) instead of a float64 sum, clip and DIVISION per cell and channel.
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false, bool P3 = false, bool I16 = false>
 __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (STAGE ? 7 : SGW_FAST_RULES_PLAIN_WAVES) : 8)) void step_fast(const Params p) {
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
@@ -139,8 +143,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     constexpr int NU = kStatic ? ((TL * TH * TW + 15) / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
     const int zoff = p.zA * HW;
-    constexpr int NW = P3 ? 1 : (TC ? (TC + 3) / 4 : 4);   // counter words
-    constexpr int CMAX = P3 ? (TC ? TC : 10) : 4 * NW;      // channels the counter words can hold
+    static_assert(!I16 || (ONEHOT && !P3 && !RULES && !(TL && TH && TW)), "I16: a byte-staging instance with run-time map");
+    constexpr int NW = P3 ? 1 : I16 ? 2 : (TC ? (TC + 3) / 4 : 4);   // counter words
+    constexpr int CMAX = P3 ? (TC ? TC : 10) : I16 ? (TC ? TC : 4) : 4 * NW;      // channels the counter words can hold
 
     // wave-private LDS: [table words][grid]
     uint8_t* wl = smem + sub * p.env_lds;
@@ -172,7 +177,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     if constexpr (ONEHOT) {
         // the one-hot counter words this wave looks up, [NW][32] u32
         uint32_t* wd = reinterpret_cast<uint32_t*>(wl);
-        if constexpr (P3) {
+        if constexpr (I16) {
+            wd[lane] = reinterpret_cast<const uint32_t*>(gtab->delta16)[lane];           // [2][32]
+            float* l = reinterpret_cast<float*>(smem + 4 * p.env_lds);                   // the result table: one copy per workgroup, every wave writes the same floats
+#pragma unroll
+            for (int j = 0; j < 4; ++j) l[lane + 64 * j] = gtab->post_lut[lane + 64 * j];
+        } else if constexpr (P3) {
             if (lane < SGW_MAX_TYPES) wd[lane] = gtab->delta3[lane];
         } else {
 #pragma unroll
@@ -183,6 +193,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         for (int i = lane; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += 64) wa[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
     }
     const uint32_t* wdelta = reinterpret_cast<const uint32_t*>(wl);                 // [NW][32]
+    // a staged / counted value as the float the tensor holds: the count itself, or (I16) the post-processed colour out of the result table
+    [[maybe_unused]] const float* post_lut = reinterpret_cast<const float*>(smem + 4 * p.env_lds);
+    auto tof = [&](const uint32_t k) -> float {
+        if constexpr (I16) return post_lut[k];
+        else return (float)k;
+    };
     const double(*wapp)[SGW_MAX_CHANNELS] = reinterpret_cast<const double(*)[SGW_MAX_CHANNELS]>(wl);
     uint8_t* lg = wl + p.tab_bytes + (RULES ? kRuleLds : 0);
     uint4* lg16 = reinterpret_cast<uint4*>(lg);
@@ -400,10 +416,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                     if (i < i0) continue;
                     const uint32_t b = ob4[i];
                     vfloat4 v;
-                    v.x = (float)(b & 0xFFu);
-                    v.y = (float)((b >> 8) & 0xFFu);
-                    v.z = (float)((b >> 16) & 0xFFu);
-                    v.w = (float)(b >> 24);
+                    v.x = tof(b & 0xFFu);
+                    v.y = tof((b >> 8) & 0xFFu);
+                    v.z = tof((b >> 16) & 0xFFu);
+                    v.w = tof(b >> 24);
 #ifdef SGW_DIAG_PLAIN_STORES
                     *reinterpret_cast<vfloat4*>(gb + 4 * i) = v;
 #else
@@ -414,7 +430,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                     const uint32_t b = ob4[ie];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (4 * ie + j >= lo && 4 * ie + j < he) gb[4 * ie + j] = (float)((b >> (8 * j)) & 0xFFu);
+                        if (4 * ie + j >= lo && 4 * ie + j < he) gb[4 * ie + j] = tof((b >> (8 * j)) & 0xFFu);
                 }
             } else {
                 uint8_t* gb = reinterpret_cast<uint8_t*>(p.obs) + (e0 - sh);
@@ -483,10 +499,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                                 }
                             }
 #pragma unroll
-                            for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : (P3 ? p.fill_delta3 : p.fill_delta[q]);
-                            // the count of channel c: a byte of the counter words, or (P3) a 3-bit field of the one word
+                            for (int q = 0; q < NW; ++q) cnt[q] = inb ? cnt[q] : (P3 ? p.fill_delta3 : I16 ? p.fill_delta16[q] : p.fill_delta[q]);
+                            // the count of channel c: a byte of the counter words, (P3) a 3-bit field of the one word, (I16) a 16-bit field clipped to 255
                             auto chan = [&](const int c) -> uint32_t {
                                 if constexpr (P3) return (cnt[0] >> (3 * c)) & 7u;
+                                else if constexpr (I16) return min((cnt[c >> 1] >> (16 * (c & 1))) & 0xFFFFu, 255u);
                                 else return (cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu;
                             };
                             if (stage) {
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
                             } else if (!p.obs_u8) {
 #pragma unroll
                                 for (int c = 0; c < CMAX; ++c)
-                                    if (c < C) OBS_STORE(o + c * VV, (float)chan(c));
+                                    if (c < C) OBS_STORE(o + c * VV, tof(chan(c)));
                             } else {   // compact format: the same counts as bytes
                                 uint8_t* o8 = reinterpret_cast<uint8_t*>(p.obs) + (o - p.obs);
 #pragma unroll

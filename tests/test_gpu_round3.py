@@ -1058,3 +1058,96 @@ def test_big_kernel_four_or_eight_waves_vs_oracle(torch_cuda, monkeypatch, case,
     torch.cuda.synchronize()
     assert np.array_equal(eng.obs.cpu().numpy(), co.obs)
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ RGB observation specs (integer colour tables, clip / 255) on the byte-staging pipeline
+@pytest.mark.parametrize("case", ["fixture_turns", "th_32x32", "th_ragged_23x29_r4", "three_layers", "tag_rgb_20x24", "bright_colours_clip",
+                                  "phased_and_ranges", "float_colours_fall_back"])
+def test_rgb_integer_tables_on_the_byte_staging_pipeline_vs_oracle(torch_cuda, monkeypatch, case):
+    """RGBObservationSpec as the reference builds it (uint8 colours summed over the layers, np.clip(.., 0, 255) / 255) runs on the
+    wave-per-env kernel's I16 instances: 16-bit counters, the clipped sum staged as a byte, the burst reading (float)(k / 255.0)
+    from a 256-entry table.  The reference-generated fixture turn by turn, batches at other shapes, three layers whose colours add
+    up past 255 (the clip), Tag, calls the staged kernel cannot serve (agent ranges / OBS_NEXT: the float64 kernel with its own LDS
+    layout), and non-integer colours (must stay on the float64 path); every float bit for bit against the C oracle."""
+    torch = torch_cuda
+    import dataclasses
+
+    monkeypatch.setenv("SGW_GROUP", "64")
+    d, spec = H.load_golden("rgb_treasurehunt")
+    ws = H.world_spec(spec)
+    E, T = 45, 6
+    expect_i16 = True
+    if case == "fixture_turns":
+        E = 3
+    elif case == "th_32x32":
+        ws = dataclasses.replace(ws, height=32, width=32, num_agents=8, vision_radius=3, agent_type=[ws.agent_type[0]] * 8)
+    elif case == "th_ragged_23x29_r4":
+        ws = dataclasses.replace(ws, height=23, width=29, num_agents=5, vision_radius=4, agent_type=[ws.agent_type[0]] * 5)
+    elif case == "three_layers":
+        ws = dataclasses.replace(ws, height=20, width=22, layers=3, agent_layer=2, num_agents=6, vision_radius=3, agent_type=[ws.agent_type[0]] * 6,
+                                 layer_fill_type=[ws.layer_fill_type[0], ws.layer_fill_type[0], ws.layer_fill_type[1]],
+                                 layer_border_type=[ws.layer_border_type[0], ws.layer_border_type[0], ws.layer_border_type[1]])
+    elif case == "tag_rgb_20x24":
+        d2, spec2 = H.load_golden("tag_11x11_default")
+        wt = H.world_spec(spec2)
+        app = np.zeros((len(wt.appearance), 3))
+        for t in range(len(app)):
+            app[t] = [(37 * t) % 256, (91 * t + 5) % 256, (160 * t) % 256]
+        ws = dataclasses.replace(wt, height=20, width=24, num_agents=7, vision_radius=3, agent_type=[wt.agent_type[0]] * 7, num_channels=3,
+                                 appearance=app, obs_post=1)
+    elif case == "bright_colours_clip":       # two layers of bright entities: sums above 255 in every channel
+        app = np.asarray(ws.appearance, dtype=np.float64).copy()
+        app[app > 0] = 255.0
+        app[0] = [200.0, 180.0, 90.0]        # the empty kind glows too: every cell's two layers add up
+        ws = dataclasses.replace(ws, height=18, width=18, num_agents=4, vision_radius=2, agent_type=[ws.agent_type[0]] * 4, appearance=app)
+    elif case == "phased_and_ranges":
+        ws = dataclasses.replace(ws, height=24, width=24, num_agents=5, vision_radius=3, agent_type=[ws.agent_type[0]] * 5)
+    elif case == "float_colours_fall_back":
+        app = np.asarray(ws.appearance, dtype=np.float64).copy()
+        app[2, 0] = 254.5
+        ws = dataclasses.replace(ws, height=24, width=24, num_agents=5, vision_radius=3, agent_type=[ws.agent_type[0]] * 5, appearance=app)
+        expect_i16 = False
+    eng, co = make_engine(ws, E, first=2), H.COracle(ws, E, first_env_id=2)
+    name = eng.launch_info().split(" group")[0]
+    assert name.startswith("step_fast<"), eng.launch_info()
+    assert name.endswith("false, false, true>") == expect_i16, eng.launch_info()       # ..., MULTI = false, P3 = false, I16 = true
+    eng.reset(0)
+    co.reset(0)
+    tag = case.startswith("tag")
+    A = ws.num_agents
+    for t in range(1, T + 1):
+        assert co.step(0, t, random_actions=True) == 0
+        if case == "phased_and_ranges" and t % 2 == 0:
+            acts = torch.from_numpy(co.actions.copy()).cuda()
+            seen = torch.zeros_like(eng.obs)
+            eng.obs.fill_(-3.0)
+            eng.step(acts, sweep=True, agent_begin=0, agent_end=0, obs_next=True, turn=t, advance_turn=False)
+            for i in range(A):
+                seen[:, i] = eng.obs[:, i]
+                eng.step(acts, sweep=False, agent_begin=i, agent_end=i + 1, obs_next=i + 1 < A, write_obs=False, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(seen.cpu().numpy(), co.obs), f"phased turn {t}: windows"
+            what = ("grid", "agent_pos", "total_reward")
+        else:
+            eng.step(random_actions=True, turn=t, advance_turn=False)
+            torch.cuda.synchronize()
+            what = ("grid", "agent_pos", "total_reward", "rewards", "actions", "obs")
+        for k, ref in dict(grid=co.grid, agent_pos=co.pos, total_reward=co.total, rewards=co.rewards, obs=co.obs, actions=co.actions).items():
+            if k in what:
+                assert np.array_equal(getattr(eng, k).cpu().numpy(), ref), f"{case} turn {t}: {k}"
+        if tag:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), f"{case} turn {t}: agent_state"
+    if case == "phased_and_ranges":      # a range of agents through sgw_observe: the float64 kernel again
+        eng.obs.fill_(7.0)
+        eng.observe(agent_begin=1, agent_end=3)
+        co.observe()
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.obs[:, 1:3].cpu().numpy(), co.obs[:, 1:3]) and float(eng.obs[:, 0].min()) == 7.0
+    eng.obs.zero_()
+    eng.observe()
+    co.observe()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.obs.cpu().numpy(), co.obs), f"{case}: sgw_observe"
+    if case == "bright_colours_clip":
+        assert float(eng.obs.max()) == 1.0
+    assert eng.status() == 0

@@ -673,7 +673,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     // workgroup per env -> wave per env: 48x48x2 A8 r5 23 / 40 / 73 / 640 -> 22 / 31 / 56 / 373; 64x64x2 A16 r3 33 / 57 / 107 / 858 ->
     // 28 / 39 / 69 / 488; 50x50x2 A8 r3 26 / 46 / 84 / 686 -> 19 / 25 / 41 / 272; Tag 72x72 A16 r4 23 / 41 / 74 / 727 -> 25 / 34 / 61 / 447;
     // Tag 90x90 A12 r3 27 / 48 / 90 / 741 -> 20 / 25 / 48 / 347.  SGW_FAST_8K = 0 / 1: never / whatever the batch (A/B and test hook).
-    const bool fast_8k_ok = simple_rules && onehot && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsPlain && p.VV <= 128;
+    const bool fast_8k_ok = simple_rules && (onehot || (e->rgb16 && c.num_channels == 3)) && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsPlain && p.VV <= 128;
     // (between 8 and 11 KiB -- three workgroups per CU -- from 16 384 envs on: 72x72x2 A8 r5 at 4 096 / 16 384 / 32 768 envs 47 / 166 / 429 ->
     // 55 / 156 / 341 us, Tag 100x100 A16 r4 43 / 219 / 429 -> 49 / 140 / 306; above that two workgroups per CU no longer pay: 90x90x2 555 -> 640)
     bool fast_8k = fast_8k_ok && c.num_envs >= (p.cells_pad <= 8192 ? 4096 : 16384);
@@ -693,7 +693,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->fast = e->fast || e->fast_rules;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     // (the integer-table RGB instances exist for three channels, plain or Tag movers, worlds <= 4 KiB)
-    const bool rgb16_fast = e->rgb16 && e->fast && !e->fast_rules && c.num_channels == 3 && p.cells_pad <= 4096;
+    const bool rgb16_fast = e->rgb16 && e->fast && !e->fast_rules && c.num_channels == 3;
     const bool bytes_ok = onehot || rgb16_fast;        // the byte-staging window pipeline applies
     e->fast_tab_bytes = bytes_ok ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;

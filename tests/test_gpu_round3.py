@@ -1062,7 +1062,7 @@ def test_big_kernel_four_or_eight_waves_vs_oracle(torch_cuda, monkeypatch, case,
 
 # ------------------------------------------------------------------ RGB observation specs (integer colour tables, clip / 255) on the byte-staging pipeline
 @pytest.mark.parametrize("case", ["fixture_turns", "th_32x32", "th_ragged_23x29_r4", "three_layers", "tag_rgb_20x24", "bright_colours_clip",
-                                  "phased_and_ranges", "float_colours_fall_back"])
+                                  "phased_and_ranges", "float_colours_fall_back", "th_60x60_8k"])
 def test_rgb_integer_tables_on_the_byte_staging_pipeline_vs_oracle(torch_cuda, monkeypatch, case):
     """RGBObservationSpec as the reference builds it (uint8 colours summed over the layers, np.clip(.., 0, 255) / 255) runs on the
     wave-per-env kernel's I16 instances: 16-bit counters, the clipped sum staged as a byte, the burst reading (float)(k / 255.0)
@@ -1083,6 +1083,10 @@ def test_rgb_integer_tables_on_the_byte_staging_pipeline_vs_oracle(torch_cuda, m
         ws = dataclasses.replace(ws, height=32, width=32, num_agents=8, vision_radius=3, agent_type=[ws.agent_type[0]] * 8)
     elif case == "th_ragged_23x29_r4":
         ws = dataclasses.replace(ws, height=23, width=29, num_agents=5, vision_radius=4, agent_type=[ws.agent_type[0]] * 5)
+    elif case == "th_60x60_8k":          # 7 200 bytes per env: the second round of the grid copy (large batches; forced here)
+        monkeypatch.setenv("SGW_FAST_8K", "1")
+        ws = dataclasses.replace(ws, height=60, width=60, num_agents=9, vision_radius=3, agent_type=[ws.agent_type[0]] * 9)
+        E = 19
     elif case == "three_layers":
         ws = dataclasses.replace(ws, height=20, width=22, layers=3, agent_layer=2, num_agents=6, vision_radius=3, agent_type=[ws.agent_type[0]] * 6,
                                  layer_fill_type=[ws.layer_fill_type[0], ws.layer_fill_type[0], ws.layer_fill_type[1]],

@@ -1155,3 +1155,21 @@ def test_rgb_integer_tables_on_the_byte_staging_pipeline_vs_oracle(torch_cuda, m
     if case == "bright_colours_clip":
         assert float(eng.obs.max()) == 1.0
     assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ bench.py: the timed launches as one hipGraph
+@pytest.mark.gpu
+def test_bench_timed_region_as_a_graph_plays_the_same_rollout(built):
+    """bench.py --graph captures its K timed sgw_step launches in one hipGraph (each node with the turn number it carries when the
+    region runs) and replays it inside the region.  The same launches with the same turn numbers: the rollout it reports -- float64
+    totals summed over the batch -- must be exactly what the plain loop reports, with and without pre-warm / re-warm launches in
+    front.  This test makes no GPU call itself."""
+    from tests.test_gpu_round2 import _run_bench
+
+    for extra in (["--prewarm-steps", "0"], ["--prewarm-steps", "40", "--rewarm-steps", "7"]):
+        common = ["--gpus", "1", "--envs", "2048", "--steps", "9", "--warmup", "3", "--no-cpu-baseline", "--no-side-configs", "--no-self-check"] + extra
+        a = _run_bench(common + ["--graph"], 1, {})
+        b = _run_bench(common, 1, {})
+        assert "hipGraph" in a["timed_region_submission"] and b["timed_region_submission"] == "K sgw_step calls"
+        assert a["rollout"]["sum_total_reward"] == b["rollout"]["sum_total_reward"] and a["rollout"]["status"] == b["rollout"]["status"] == 0
+        assert a["steps"] == b["steps"] == 9 and a["roofline"]["kernel_ms"] > 0

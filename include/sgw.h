@@ -338,6 +338,61 @@ int sgw_set_auto_reset(sgw_engine* eng, uint32_t max_turns, double* episode_retu
 int sgw_set_wg_per_cu(sgw_engine* eng, int wg_per_cu);
 int sgw_launch_info(sgw_engine* eng, char* buf, int64_t capacity);
 
+/* ---- Options, the plan, specialised instances (round 4) -----------------------------------------------------------
+ * The reference's plugin API takes ANY entity list, channel count and map size (sorrel/observation/observation_spec.py:128-173,
+ * sorrel/entities/entity.py:9-68, sorrel/worlds/gridworld.py:36).  The step kernels are templates over exactly those
+ * constants; sgw_create instantiates them for the engine's own world in-process (hipRTC; no compiler is spawned), keeps the
+ * code object on disk (option "jit_cache_dir", default <directory of libsgw.so>/jit_cache) and falls back to the prebuilt
+ * instances of the library when hipRTC is absent, the library was built without its embedded sources, or a compile fails.
+ *
+ * sgw_set_option: every dispatcher knob is a (key, value) pair of strings; value NULL or "" restores the key's default, key
+ * NULL restores all.  eng == NULL addresses the process-wide defaults that the NEXT sgw_create / sgw_plan copies; on a live
+ * engine only the keys that do not shape its plan are accepted ("rows_mode", "jit_verbose").  Keys (sorrel_amd/csrc/
+ * options.h holds the table): jit, jit_cache, jit_cache_dir, jit_verbose, burst, static_radius, pack3, static_cleanup, rgb16,
+ * force_generic, fast_rules, rules_8k, rules_11k, fast_8k, big_tag, group, phase_kernel, phase_rows, stage, stage_bytes,
+ * stage_agents, fast_wg_per_cu, big_threads, big_stage, big_pad, big_walk, big_walk_blocks, rows_mode.  The library reads ONE
+ * environment variable, SGW_DEBUG=1 (log lines of the specialiser on stderr).
+ *
+ * sgw_plan: what sgw_create would decide for `cfg` on a device with `num_cus` compute units and `lds_per_workgroup` bytes of
+ * LDS per workgroup -- kernel family, lanes per env, LDS layout, staging, the walk window, the instances to launch -- as pure
+ * host arithmetic: no HIP call, no device needed (tests/test_plan.py enumerates it on the CPU).  It answers for a machine
+ * where specialised instances are available unless option "jit" is 0. */
+#define SGW_FAMILY_WAVE 1       /* step_fast: a wave per env (worlds <= 4 KiB; up to 11 KiB in large batches) */
+#define SGW_FAMILY_WORKGROUP 2  /* step_big: a workgroup per env */
+#define SGW_FAMILY_GENERIC 3    /* step_kernel: 16 / 32 lanes per env (small worlds of large batches), 64, or 256 (ticket-ordered) */
+typedef struct sgw_plan_info {
+    int32_t family;            /* SGW_FAMILY_* */
+    int32_t lanes_per_env;     /* 16 / 32 / 64, or the workgroup size for a workgroup per env */
+    int32_t threads;           /* per workgroup */
+    int32_t grid_blocks;       /* workgroups of a whole-batch launch */
+    int64_t lds_bytes;         /* dynamic LDS of the whole-turn kernel (before any occupancy cap) */
+    int32_t env_lds;           /* ... of one env's slice */
+    int32_t obs_stage;         /* bytes of window staging per wave (0: direct stores) */
+    int32_t stage_agents;      /* agents per staged burst (0: the whole env at once, or no staging) */
+    int32_t whole_env_burst;   /* the env's windows leave in ONE burst (compile-time shape) */
+    int32_t big_stage;         /* step_big: bytes of window staging per wave */
+    int32_t big_pitch;         /* step_big: LDS bytes between grid rows */
+    int32_t onehot, rgb16, rules;
+    int32_t specialised;       /* the plan counts on instances compiled for this engine */
+    int32_t phase_kernel;      /* policy-driven phases of worlds above 4 KiB take the byte-gather phase kernel */
+    int32_t rollout_in_one_launch;   /* sgw_rollout runs its turns inside one launch */
+    int32_t walk_blocks;       /* step_big<..., WALK>: resident workgroups (0: not used) */
+    int64_t walk_min_envs, walk_max_envs;   /* batches in (min, max] take the walking variant */
+    int64_t big_stage_min_envs;             /* step_big stages its windows for batches above this */
+    char kernel[192];              /* template-id of the whole-turn kernel (the specialised instance when `specialised`) */
+    char kernel_prebuilt[192];     /* ... of the prebuilt instance used when the specialised one is unavailable ("-": none fits this plan) */
+    char kernel_plain[192];        /* direct-store twin of a STAGE kernel (agent ranges, OBS_NEXT, unaligned tensors) */
+    char kernel_rollout[192];      /* the instance with sgw_rollout's turn loop */
+    char kernel_walk[192];
+    char kernel_phase[96];         /* what a policy-driven phase (one agent) launches */
+    char kernel_observe_rows[96];  /* sgw_observe_rows */
+} sgw_plan_info;
+int sgw_set_option(sgw_engine* eng, const char* key, const char* value);
+int sgw_plan(const sgw_config* cfg, int32_t num_cus, int64_t lds_per_workgroup, sgw_plan_info* out);
+/* out6 = { instances compiled, loaded from the disk cache, reused in memory, refused, ms spent compiling, ms spent loading }
+ * of this process so far. */
+int sgw_jit_stats(double* out6);
+
 const char* sgw_last_error(void);
 const char* sgw_version(void);
 

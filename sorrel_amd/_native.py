@@ -59,6 +59,34 @@ class SgwConfig(C.Structure):
     ]
 
 
+FAMILY_WAVE, FAMILY_WORKGROUP, FAMILY_GENERIC = 1, 2, 3
+
+
+class SgwPlan(C.Structure):
+    """Mirror of ``struct sgw_plan_info`` (include/sgw.h): what ``sgw_create`` decides for a config, as pure host arithmetic."""
+
+    _fields_ = [
+        ("family", C.c_int32), ("lanes_per_env", C.c_int32), ("threads", C.c_int32), ("grid_blocks", C.c_int32),
+        ("lds_bytes", C.c_int64),
+        ("env_lds", C.c_int32), ("obs_stage", C.c_int32), ("stage_agents", C.c_int32), ("whole_env_burst", C.c_int32),
+        ("big_stage", C.c_int32), ("big_pitch", C.c_int32),
+        ("onehot", C.c_int32), ("rgb16", C.c_int32), ("rules", C.c_int32),
+        ("specialised", C.c_int32), ("phase_kernel", C.c_int32), ("rollout_in_one_launch", C.c_int32),
+        ("walk_blocks", C.c_int32),
+        ("walk_min_envs", C.c_int64), ("walk_max_envs", C.c_int64), ("big_stage_min_envs", C.c_int64),
+        ("kernel", C.c_char * 192), ("kernel_prebuilt", C.c_char * 192), ("kernel_plain", C.c_char * 192),
+        ("kernel_rollout", C.c_char * 192), ("kernel_walk", C.c_char * 192),
+        ("kernel_phase", C.c_char * 96), ("kernel_observe_rows", C.c_char * 96),
+    ]
+
+    def as_dict(self) -> dict:
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = v.decode() if isinstance(v, bytes) else int(v)
+        return out
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")   # SGW_LIB: diagnostic builds (tools/)
 
@@ -68,6 +96,7 @@ EXPORTS = (
     "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
+    "sgw_set_option", "sgw_plan", "sgw_jit_stats",
     "sgw_last_error", "sgw_version",
 )
 
@@ -159,12 +188,63 @@ def load():
     lib.sgw_observe_rows.restype = C.c_int
     lib.sgw_act.argtypes = [vp, u8p, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, f32p, f64p, C.c_int32, vp, C.c_int32, vp, vp, vp]
     lib.sgw_act.restype = C.c_int
+    lib.sgw_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.sgw_set_option.restype = C.c_int
+    lib.sgw_plan.argtypes = [cfgp, C.c_int32, C.c_int64, C.POINTER(SgwPlan)]
+    lib.sgw_plan.restype = C.c_int
+    lib.sgw_jit_stats.argtypes = [C.POINTER(C.c_double)]
+    lib.sgw_jit_stats.restype = C.c_int
     lib.sgw_last_error.argtypes = []
     lib.sgw_last_error.restype = C.c_char_p
     lib.sgw_version.argtypes = []
     lib.sgw_version.restype = C.c_char_p
     _lib = lib
+    # tools pass dispatcher options to child processes as SGW_OPTIONS="key=value,key=value": read HERE, by the Python
+    # tooling -- the library itself reads no environment variable except SGW_DEBUG
+    for item in filter(None, os.environ.get("SGW_OPTIONS", "").split(",")):
+        key, _, value = item.partition("=")
+        set_option(key.strip(), value.strip())
     return lib
+
+
+def set_option(key, value=None, engine=None) -> None:
+    """``sgw_set_option``: a dispatcher knob (``sorrel_amd/csrc/options.h``) for engines created from now on, or -- the live
+    keys only -- for one engine handle.  ``value=None`` restores the key's default, ``key=None`` all of them."""
+    lib = load()
+    k = None if key is None else str(key).encode()
+    v = None if value is None else str(int(value) if isinstance(value, bool) else value).encode()
+    check(lib.sgw_set_option(engine, k, v))
+
+
+class options:
+    """``with options(group=16, jit=0): ...`` -- process-wide options for the engines created inside the block."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None)
+        return False
+
+
+def plan(cfg: "SgwConfig", num_cus: int = 256, lds_per_workgroup: int = 160 * 1024) -> dict:
+    """``sgw_plan``: kernel family, LDS layout, staging and instances ``sgw_create`` would choose -- no device needed."""
+    out = SgwPlan()
+    check(load().sgw_plan(C.byref(cfg), num_cus, lds_per_workgroup, C.byref(out)))
+    return out.as_dict()
+
+
+def jit_stats() -> dict:
+    buf = (C.c_double * 6)()
+    check(load().sgw_jit_stats(buf))
+    return dict(compiled=int(buf[0]), disk_hits=int(buf[1]), mem_hits=int(buf[2]), failed=int(buf[3]),
+                compile_ms=float(buf[4]), load_ms=float(buf[5]))
 
 
 def check(rc: int) -> None:

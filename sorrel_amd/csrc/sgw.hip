@@ -35,14 +35,23 @@
 // point replaces and oracle/gridstep_oracle.py for the line-by-line CPU restatement the kernels are tested against
 // (the product never calls it).
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/sgw.h"
@@ -57,7 +66,10 @@ namespace {
 #include "small_kernels.h"
 
 // ---------------------------------------------------------------- host side
-thread_local char g_err[512] = "";
+#include "options.h"
+#include "jit.h"
+
+thread_local char g_err[768] = "";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -75,10 +87,23 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kEventPool = 4096;
 
+// One launchable kernel of an engine: a prebuilt instance of the library, and / or the instance specialised for this engine
+// that hipRTC compiles (at sgw_create for the whole-turn kernel, at first use for the others).
+struct Kernel {
+    const void* host = nullptr;     // prebuilt instance (nullptr: none that fits this engine's plan)
+    const char* host_name = "-";
+    std::string want;               // template-id of the specialised instance ("" : none wanted)
+    hipFunction_t jit = nullptr;
+    bool tried = false;             // the specialised instance has been asked for (and, if jit is still null, was refused)
+    bool usable() const { return host != nullptr || !want.empty(); }
+    const char* name() const { return (jit || (!host && !want.empty())) ? want.c_str() : host_name; }
+};
+
 }  // namespace
 
 struct sgw_engine {
     sgw_config cfg;
+    Options opt;          // the process-wide options as they were at sgw_create (live keys: sgw_set_option on the engine)
     Params base;          // everything except per-call fields
     DevTables* d_tab = nullptr;
     uint8_t* d_tmpl = nullptr;   // fill + border image of one env (reset)
@@ -95,22 +120,19 @@ struct sgw_engine {
     int plain_tab_bytes = 0;   // ... whose direct-store variant is the float64 kernel with its own, larger table area
     bool fast = false;    // step_fast specialisation applies
     bool big = false;     // step_big (workgroup per env, pipelined agents) applies
-    void (*step_fn)(const Params) = nullptr;
-    void (*step_fn_plain)(const Params) = nullptr;   // run-time-shape STAGE kernels: the direct-store variant for calls that cannot be staged
-    void (*step_fn_multi)(const Params) = nullptr;   // step_fast<..., MULTI>: sgw_rollout's turns in one launch
-    const char* kernel_name_multi = "-";
-    void (*step_fn_walk)(const Params) = nullptr;   // step_big<..., WALK>: resident workgroups walking the batch
-    const char* kernel_name_walk = "-";
-    int walk_blocks = 0;                            // how many workgroups of it the chip holds at once
+    bool jit = false;     // the plan counts on instances specialised for this engine (hipRTC)
+    bool whole_env_burst = false;   // step_fast with a compile-time shape: the whole env's windows leave in one burst
+    Kernel k_step;        // a whole turn (sgw_step of all agents, sgw_observe)
+    Kernel k_plain;       // STAGE kernels: the direct-store variant for calls that cannot be staged
+    Kernel k_multi;       // sgw_rollout's turns in one launch
+    Kernel k_walk;        // step_big<..., WALK>: resident workgroups walking the batch
+    Kernel k_rows;        // phase_rows<L, NW, R>: a policy-driven phase with a lane per window row (one-hot, plain moves)
+    Kernel k_obs_rows;    // observe_rows<L, NW, R>: a range of agents, per-agent destinations
+    int walk_blocks = 0;                            // how many workgroups of the walking kernel the chip holds at once
     int64_t walk_min_envs = 0, walk_max_envs = 0;  // batches above min and up to max take it (multiples of what the plain kernel holds at once)
     int64_t big_stage_min_envs = 0;                // step_big stages its windows for batches above this
-    const char* kernel_name_plain = "?";
     int stage_agents = 0;      // agents per staged chunk (STAGE kernels)
     bool phase_ok = false;     // the phase kernel applies (plain moves)
-    void (*rows_fn)(const Params) = nullptr;   // phase_rows<L, NW, R>: a policy-driven phase with a lane per window row (one-hot, plain moves)
-    void (*obs_rows_fn)(const Params, const RowPtrs) = nullptr;   // observe_rows<L, NW, R>: a range of agents, per-agent destinations
-    const char* kernel_name_rows = "-";
-    const char* kernel_name_obs_rows = "-";
     int rows_wpb = 0;          // windows per 256-thread workgroup of observe_rows
     int rows_epb = 0;          // envs per 256-thread workgroup of it
     size_t rows_lds = 0;
@@ -127,13 +149,16 @@ struct sgw_engine {
     int big_tab_bytes = 0;   // step_big: only the counter words of the channels in use
     int grid_blocks = 1;
     int fast_wg_cap = 5;   // step_fast workgroups per CU when writing large float32 observations of a large batch (0: no cap)
-    bool fast_wg_cap_forced = false;   // SGW_FAST_WG_PER_CU given: that value for the staged path too (default there: 6)
+    bool fast_wg_cap_forced = false;   // option fast_wg_per_cu given: that value for the staged path too (default there: 6)
     int wg_per_cu = 0;     // sgw_set_wg_per_cu: 0 = the automatic rule above, 1..8 = forced, -1 = never capped
-    const char* kernel_name = "?";
     uint32_t auto_max_turns = 0;       // sgw_set_auto_reset
     double* episode_return = nullptr;  // caller-owned
     int reset_blocks = 1;
     int num_cus = 256;
+    size_t lds_cap = 65536;  // sharedMemPerBlock of the device
+    int dev = 0;
+    std::string arch = "gfx950";
+    DevTables h_tab;         // host copy of the tables (plan_engine builds it; sgw_create uploads it)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev0, ev1;
@@ -233,37 +258,27 @@ int validate(const sgw_config* c) {
     return SGW_OK;
 }
 
-template <typename K>
-int occupancy_blocks(K kernel, size_t lds, int num_cus, int* out) {
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds));
-    if (per_cu < 1) per_cu = 1;
-    *out = per_cu * num_cus;
-    return SGW_OK;
-}
-
 using StepFn = void (*)(const Params);
+using RowsFn = void (*)(const Params, const RowPtrs);
 
-#define PICK(...)                 \
-    do {                          \
-        *name = #__VA_ARGS__;     \
-        return __VA_ARGS__;       \
+// ---- prebuilt instances (the path when hipRTC is absent; also what a specialised instance falls back to) -----------
+#define PICK(...)                                             \
+    do {                                                      \
+        *name = #__VA_ARGS__;                                 \
+        return reinterpret_cast<const void*>(static_cast<StepFn>(__VA_ARGS__)); \
     } while (0)
 
-// The examples as shipped get a compile-time vision radius (window size constant: channel planes become immediate store
-// offsets, no division in the cell -> (i, j) split): Tag 11x11 / 9x9 windows 116-119 -> 107-108 us, Treasurehunt 5x5
-// windows 51.0 -> 46.2 us (65 536 envs, same box).  A compile-time world size on top: Tag 2 % (and 72 VGPRs = a seventh
-// wave per SIMD), Treasurehunt 21x21 nothing (46.2 both: not instantiated); Cleanup's wave-per-env kernel with r = 5:
-// nothing (699 against 704 us: not instantiated).
-// step_kernel<G, ONEHOT, L, C, RULE, r, H, W, MULTI>: the single-turn instance, or (multi) the one with sgw_rollout's turn loop
+// step_kernel<G, ONEHOT, L, C, RULE, r, H, W, MULTI>: the single-turn instance, or (multi) the one with sgw_rollout's turn loop.
+// A compile-time radius for the examples as shipped (Tag 11x11 / 9x9 windows 116-119 -> 107-108 us, Treasurehunt 5x5 51.0 -> 46.2 us at
+// 65 536 envs); everything else about a user's own world comes from the specialised instance (jit.h).
 #define PICK_SK(G_, OH, L_, C_, RULE_, R_, H_, W_, NAME)                          \
     do {                                                                          \
         *name = multi ? NAME " (turn loop)" : NAME;                               \
-        return multi ? static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, true>) \
-                     : static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>); \
+        return multi ? reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, true>)) \
+                     : reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
     } while (0)
 template <int G>
-StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
+const void* pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
     constexpr int kMove = SGW_AGENT_RULE_MOVE, kTag = SGW_AGENT_RULE_TAG, kCleanup = SGW_AGENT_RULE_CLEANUP;
     if (rule == SGW_AGENT_RULE_CLEANUP) {
         if (onehot) PICK_SK(G, true, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>");
@@ -273,7 +288,6 @@ StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, boo
         if constexpr (G == 32) {
             if (onehot && L == 1 && C == 4 && r == 4 && H == 11 && W == 11) PICK_SK(32, true, 1, 4, kTag, 4, 11, 11, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4, 11, 11>");   // the Tag example as shipped
             if (onehot && L == 1 && C == 4 && r == 4) PICK_SK(32, true, 1, 4, kTag, 4, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>");
-            if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK_SK(32, true, 1, 4, kTag, 3, 32, 32, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3, 32, 32>");   // Tag at the headline's shape
             if (onehot && L == 1 && C == 4 && r == 3) PICK_SK(32, true, 1, 4, kTag, 3, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>");
         }
         if (onehot && L == 1 && C == 4) PICK_SK(G, true, 1, 4, kTag, 0, 0, 0, "step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>");   // the Tag example's tables
@@ -288,11 +302,9 @@ StepFn pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, boo
 }
 #undef PICK_SK
 
-StepFn pick_step(int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
-    if (const char* f = getenv("SGW_NO_STATIC_RADIUS")) {   // A/B hook: 1 = the run-time-shape instances, 2 = static radius but run-time world size
-        if (f[0] == '1') r = -1;
-        if (f[0] == '2') H = W = -1;
-    }
+const void* pick_step(const Options& o, int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
+    if (o.static_radius == 1) r = -1;          // A/B hook: the run-time-shape instances
+    if (o.static_radius == 2) H = W = -1;      // ... static radius but run-time world size
     if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, multi, name);
     if (group == 32) return pick_step_g<32>(onehot, L, C, rule, r, H, W, multi, name);
     if (group == 64) return pick_step_g<64>(onehot, L, C, rule, r, H, W, multi, name);
@@ -300,8 +312,8 @@ StepFn pick_step(int group, bool onehot, int L, int C, int rule, int r, int H, i
 }
 // the MULTI (turn-loop) instantiations of step_fast that sgw_rollout launches; nullptr: no such variant, the rollout is
 // a loop of single-turn launches
-StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
-    const bool p3 = onehot && rules && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
+const void* pick_fast_multi(const Options& o, bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
+    const bool p3 = onehot && rules && C <= 10 && L <= 7 && o.pack3;
     if (p3 && stage && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, true, true>);   // Cleanup
     if (p3 && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, true, true>);    // layered rule sets
     if (onehot && rules && stage && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, true>);
@@ -315,7 +327,7 @@ StepFn pick_fast_multi(bool onehot, int L, int C, int r, int H, int W, bool tag,
 
 StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>; }
 
-StepFn pick_big(bool onehot, int L, int C, int r, bool tag, int threads, const char** name) {
+const void* pick_big(bool onehot, int L, int C, int r, bool tag, int threads, const char** name) {
     if (tag) {   // TagAgent.act on the workgroup-per-env kernel (moves in registers, the "it" token walked by wave 0)
         if (threads == 256) {
             if (onehot && L == 1 && C == 4 && r == 4) PICK(step_big<true, 1, 4, 4, false, false, true, 256>);
@@ -337,8 +349,8 @@ StepFn pick_big(bool onehot, int L, int C, int r, bool tag, int threads, const c
 // which of pick_big's choices run 256 threads (the others: kBigThreads): worlds whose windows are little work for eight waves --
 // agents x window cells up to 2 048 (round 3, 8 192 envs, us at 512 -> 256 threads: 90x90x2 A16 r3 123 -> 98, 100x100x2 A8 r5 106 -> 89,
 // Tag 128x128 A32 r3 143 -> 119, Tag 160x160 A16 r4 141 -> 135, 128x128x2 A16 r3 194 -> 200; but 128x128x2 A32 r5 211 -> 243, config 5 352 -> 394)
-int big_threads_for(bool onehot, int num_agents, int window_cells) {
-    if (const char* f = getenv("SGW_BIG_THREADS_RT")) { if (atoi(f) == 256 || atoi(f) == 512) return onehot ? atoi(f) : kBigThreads; }   // A/B and test hook
+int big_threads_for(const Options& o, bool onehot, int num_agents, int window_cells) {
+    if (o.big_threads == 256 || o.big_threads == 512) return onehot ? o.big_threads : kBigThreads;   // A/B and test hook
     return (onehot && num_agents * window_cells <= 2048) ? 256 : kBigThreads;
 }
 
@@ -347,13 +359,13 @@ bool fixed_fast_shape(int L, int C, int r, int H, int W, bool tag) {   // = the 
     return L == 2 && C == 6 && ((r == 3 && H == 32 && W == 32) || (r == 2 && H == 16 && W == 16));
 }
 
-StepFn pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
+const void* pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
     if (!onehot) PICK(step_big<false, 0, 0, 0, true>);
     if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, true>);
     PICK(step_big<true, 0, 0, 0, true>);
 }
 
-StepFn pick_big_walk(bool onehot, int L, int C, int r, int threads, const char** name) {
+const void* pick_big_walk(bool onehot, int L, int C, int r, int threads, const char** name) {
     if (!onehot) PICK(step_big<false, 0, 0, 0, false, true>);
     if (threads == 256) {
         if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, true, false, 256>);
@@ -363,57 +375,41 @@ StepFn pick_big_walk(bool onehot, int L, int C, int r, int threads, const char**
     PICK(step_big<true, 0, 0, 0, false, true>);
 }
 
-// phase_rows instances: layers x counter words (channels / 4) x vision radius.  Shapes outside the table keep the
-// staging kernels (worlds <= 4 KiB) or phase_kernel (above).
-using RowsFn = void (*)(const Params, const RowPtrs);
-StepFn pick_rows(int L, int NW, int r, const char** name, RowsFn* obs_fn, const char** obs_name) {
+// phase_rows instances: layers x counter words (channels / 4) x vision radius.  Shapes outside the table are compiled on demand
+// (jit.h); without hipRTC they keep the staging kernels (worlds <= 4 KiB) or phase_kernel (above).
+const void* pick_rows(int L, int NW, int r, const char** name, const void** obs_fn, const char** obs_name) {
 #define ROWS_CASE(l, n, rr)                           \
     if (L == l && NW == n && r == rr) {               \
-        *obs_fn = observe_rows<l, n, rr>;             \
+        *obs_fn = reinterpret_cast<const void*>(static_cast<RowsFn>(observe_rows<l, n, rr>)); \
         *obs_name = "observe_rows<" #l ", " #n ", " #rr ">"; \
         PICK(phase_rows<l, n, rr>);                   \
     }
     ROWS_CASE(2, 2, 3);   // BASELINE configs 3 / 4
     ROWS_CASE(2, 2, 2);   // BASELINE config 2, the Treasurehunt example
     ROWS_CASE(2, 2, 5);   // BASELINE config 5
-    ROWS_CASE(2, 2, 1); ROWS_CASE(2, 2, 4);
-    ROWS_CASE(1, 1, 1); ROWS_CASE(1, 1, 2); ROWS_CASE(1, 1, 3); ROWS_CASE(1, 1, 4); ROWS_CASE(1, 1, 5);
-    ROWS_CASE(1, 2, 2); ROWS_CASE(1, 2, 3);
-    ROWS_CASE(2, 1, 1); ROWS_CASE(2, 1, 2); ROWS_CASE(2, 1, 3);
-    ROWS_CASE(3, 2, 2); ROWS_CASE(3, 2, 3);
 #undef ROWS_CASE
     return nullptr;
 }
 
-StepFn pick_fast(bool onehot, bool rgb16, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
+const void* pick_fast(const Options& o, bool onehot, bool rgb16, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, const char** name) {
     if (rgb16 && stage && !rules && C == 3) {   // integer colour tables behind clip / 255 (the reference's RGBObservationSpec): 16-bit counters, result table
-        if (tag) {
-            if (L == 1) PICK(step_fast<true, 1, 3, 0, 0, 0, true, false, true, false, false, true>);
-            PICK(step_fast<true, 0, 3, 0, 0, 0, true, false, true, false, false, true>);
-        }
-        if (L == 1) PICK(step_fast<true, 1, 3, 0, 0, 0, false, false, true, false, false, true>);
-        if (L == 2) PICK(step_fast<true, 2, 3, 0, 0, 0, false, false, true, false, false, true>);
+        if (tag) PICK(step_fast<true, 0, 3, 0, 0, 0, true, false, true, false, false, true>);
         PICK(step_fast<true, 0, 3, 0, 0, 0, false, false, true, false, false, true>);
     }
     if (rules) {
         // one-hot tables of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of ceil(C / 4))
-        const bool p3 = onehot && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
-        if (p3 && L == 3 && C == 9 && stage && r == 5 && H == 21 && W == 31 && !(getenv("SGW_NO_STATIC_CLEANUP") && getenv("SGW_NO_STATIC_CLEANUP")[0] == '1'))
+        const bool p3 = onehot && C <= 10 && L <= 7 && o.pack3;
+        if (p3 && L == 3 && C == 9 && stage && r == 5 && H == 21 && W == 31 && o.static_cleanup)
             PICK(step_fast<true, 3, 9, 5, 21, 31, false, true, true, false, true>);   // Cleanup as shipped (21x31x3 map, 11x11 windows)
-        if (p3 && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true, false, true>);   // Cleanup's tables (3 layers, 9 kinds)
-        if (p3 && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, false, false, true>);
         if (p3 && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, false, true>);
         if (p3) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, false, false, true>);
-        if (onehot && L == 3 && C == 9 && stage) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true, true>);
-        if (onehot && L == 3 && C == 9) PICK(step_fast<true, 3, 9, 0, 0, 0, false, true>);
         if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true>);
         PICK(step_fast<false, 0, 0, 0, 0, 0, false, true>);
     }
     if (tag) {
         if (onehot && L == 1 && C == 4 && r == 3 && H == 32 && W == 32) PICK(step_fast<true, 1, 4, 3, 32, 32, true>);   // Tag on the headline's map
-        const bool p3t = onehot && stage && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');   // 3-bit packed counters
-        if (p3t && L == 1) PICK(step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>);
+        const bool p3t = onehot && stage && C <= 10 && L <= 7 && o.pack3;   // 3-bit packed counters
         if (p3t) PICK(step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>);
         if (onehot && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, true, false, true>);
         if (onehot) PICK(step_fast<true, 0, 0, 0, 0, 0, true>);
@@ -423,102 +419,87 @@ StepFn pick_fast(bool onehot, bool rgb16, int L, int C, int r, int H, int W, boo
     if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) PICK(step_fast<true, 2, 6, 3, 32, 32>);   // BASELINE configs 3/4 (headline)
     if (L == 2 && C == 6 && r == 2 && H == 16 && W == 16) PICK(step_fast<true, 2, 6, 2, 16, 16>);   // BASELINE config 2
     if (L == 2 && C == 6) {   // treasurehunt-shaped, any size
-        // a compile-time window on a run-time map: the channel planes of the staged window are immediate offsets, the cell ->
-        // (i, j) split needs no division (32x33 / 24x24 / 40x40 with 7x7 windows: 162 / 141 / 186 -> 150 / 130 / 174 us)
-        const bool static_r = stage && !(getenv("SGW_NO_STATIC_R") && getenv("SGW_NO_STATIC_R")[0] == '1');
-        if (static_r && r == 2) PICK(step_fast<true, 2, 6, 2, 0, 0, false, false, true>);
-        if (static_r && r == 3) PICK(step_fast<true, 2, 6, 3, 0, 0, false, false, true>);
-        if (static_r && r == 4) PICK(step_fast<true, 2, 6, 4, 0, 0, false, false, true>);
-        if (static_r && r == 5) PICK(step_fast<true, 2, 6, 5, 0, 0, false, false, true>);
         if (stage) PICK(step_fast<true, 2, 6, 0, 0, 0, false, false, true>);
         PICK(step_fast<true, 2, 6, 0, 0, 0>);
     }
     // any other one-hot table of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of four, ten
-    // guarded channel planes instead of sixteen); 32x32x2 with 5 / 8 channels, 8 agents, 7x7 windows: 235 / 247 us -> ...
-    const bool p3 = onehot && stage && C <= 10 && L <= 7 && !(getenv("SGW_NO_PACK3") && getenv("SGW_NO_PACK3")[0] == '1');
-    if (p3 && L == 1) PICK(step_fast<true, 1, 0, 0, 0, 0, false, false, true, false, true>);
-    if (p3 && L == 2) PICK(step_fast<true, 2, 0, 0, 0, 0, false, false, true, false, true>);
+    // guarded channel planes instead of sixteen)
+    const bool p3 = onehot && stage && C <= 10 && L <= 7 && o.pack3;
     if (p3) PICK(step_fast<true, 0, 0, 0, 0, 0, false, false, true, false, true>);
     if (stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, false, true>);
     PICK(step_fast<true, 0, 0, 0, 0, 0>);
+}
+
+// ---- template-ids of the specialised instances (spelled like the PICK names: trailing default arguments dropped, so an instance the
+// library already holds is recognised and not compiled again)
+std::string join_args(const char* tmpl, std::vector<std::string> a, size_t keep, const char* drop) {
+    while (a.size() > keep && a.back() == drop) a.pop_back();
+    std::string s = std::string(tmpl) + "<";
+    for (size_t i = 0; i < a.size(); ++i) s += (i ? ", " : "") + a[i];
+    return s + ">";
+}
+const char* tf(bool b) { return b ? "true" : "false"; }
+std::string fast_id(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, bool multi, bool p3, bool i16) {
+    return join_args("step_fast", {tf(onehot), std::to_string(L), std::to_string(C), std::to_string(r), std::to_string(H), std::to_string(W),
+                                   tf(tag), tf(rules), tf(stage), tf(multi), tf(p3), tf(i16)}, 6, "false");
+}
+// the prebuilt choice `name` ("step_fast<...>") with its numeric arguments replaced by this engine's own (and MULTI / STAGE as asked)
+std::string fast_id_like(const char* name, int L, int C, int r, int H, int W, int stage /* -1 keep */, int multi /* -1 keep */) {
+    std::vector<std::string> a;
+    const char* s = strchr(name, '<');
+    if (!s) return "";
+    std::string cur;
+    for (++s; *s && *s != '>'; ++s) {
+        if (*s == ',') { a.push_back(cur); cur.clear(); }
+        else if (*s != ' ') cur += *s;
+    }
+    a.push_back(cur);
+    while (a.size() < 12) a.push_back("false");
+    const bool i16 = a[11] == "true";
+    return fast_id(a[0] == "true", L, C, r, i16 ? 0 : H, i16 ? 0 : W, a[6] == "true", a[7] == "true", stage < 0 ? a[8] == "true" : stage != 0,
+                   multi < 0 ? a[9] == "true" : multi != 0, a[10] == "true", i16);
+}
+std::string generic_id(int G, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi) {
+    return join_args("step_kernel", {std::to_string(G), tf(onehot), std::to_string(L), std::to_string(C), std::to_string(rule), std::to_string(r),
+                                     std::to_string(H), std::to_string(W), tf(multi)}, 8, "false");
+}
+std::string big_id(bool onehot, int L, int C, int r, bool multi, bool walk, bool tag, int threads) {
+    std::vector<std::string> a = {tf(onehot), std::to_string(L), std::to_string(C), std::to_string(r), tf(multi), tf(walk), tf(tag), std::to_string(threads)};
+    if (threads == kBigThreads) a.pop_back();
+    return join_args("step_big", a, 4, threads == kBigThreads ? "false" : "");
+}
+std::string rows_id(const char* tmpl, int L, int NW, int r) {
+    return std::string(tmpl) + "<" + std::to_string(L) + ", " + std::to_string(NW) + ", " + std::to_string(r) + ">";
 }
 
 int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr size_t kSeriesCap = (size_t)1 << 20;
 
-// Waits for the recorded event pairs and folds them into the running sum and the per-launch series.
-int time_drain(sgw_engine* e) {
-    if (e->ev_used == 0) return SGW_OK;
-    for (int i = 0; i < e->ev_used; ++i) {
-        float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(e->ev1[i]));   // each pair on its own: timed launches may have gone to different streams
-        HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
-        e->ms_acc += ms;
-        if (e->series.size() < kSeriesCap) e->series.push_back(ms);
-        else e->series_dropped++;
-    }
-    e->ev_used = 0;
-    return SGW_OK;
+// workgroups of `threads` threads and `lds` dynamic bytes a CU holds at once when the kernel is compiled for `waves_per_simd` (its
+// __launch_bounds__): what hipOccupancyMaxActiveBlocksPerMultiprocessor answers, as pure arithmetic (sgw_plan makes no HIP call)
+int resident_per_cu(int threads, size_t lds, int waves_per_simd) {
+    const int by_waves = std::max(1, (waves_per_simd * 4) / std::max(1, threads / kWave));
+    const int by_lds = lds ? (int)(kLdsPerCu / (((lds + 1023) & ~(size_t)1023))) : by_waves;
+    return std::max(1, std::min(by_waves, by_lds));
 }
 
-int time_begin(sgw_engine* e, hipStream_t s) {
-    if (!e->timing) return SGW_OK;
-    if (e->ev_used == kEventPool)   // the pool wraps: the one place a launch call waits (include/sgw.h, Conventions)
-        if (int rc = time_drain(e)) return rc;
-    HIP_TRY(hipEventRecord(e->ev0[e->ev_used], s));
-    return SGW_OK;
-}
-
-int time_end(sgw_engine* e, hipStream_t s) {
-    if (!e->timing) return SGW_OK;
-    HIP_TRY(hipEventRecord(e->ev1[e->ev_used], s));
-    e->ev_used++;
-    e->launches++;
-    return SGW_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-const char* sgw_last_error(void) { return g_err; }
-#ifdef SGW_STAMPS
-int sgw_debug_stamps(unsigned long long* out) {   // diagnostic builds only; not part of the ABI: [kStampEnvs][8] of the last launch
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * kStampEnvs) == hipSuccess ? 0 : -1;
-}
-#endif
-
-const char* sgw_version(void) { return "sgw 0.1 (gfx950)"; }
-
-int64_t sgw_obs_elems_per_env(const sgw_config* c) {
-    const int64_t V = 2 * c->vision_radius + 1;
-    return (int64_t)c->num_agents * c->num_channels * V * V;
-}
-int64_t sgw_grid_bytes_per_env(const sgw_config* c) { return (int64_t)c->layers * c->height * c->width; }
-int64_t sgw_algorithmic_bytes_per_env_step(const sgw_config* c) {
-    const int64_t V = 2 * c->vision_radius + 1;
-    // SURVEY.md 8(d): grid read+write, per agent obs f32 store + action + reward + pos load/store, total f64 rw
-    return 2 * sgw_grid_bytes_per_env(c) + (int64_t)c->num_agents * (c->num_channels * V * V * 4 + 1 + 4 + 4) + 16;
-}
-
-int sgw_create(const sgw_config* cfg, sgw_engine** out) {
-    if (!out) return fail(SGW_EINVAL, "out is NULL");
-    *out = nullptr;
-    if (int rc = validate(cfg)) return rc;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-
-    sgw_engine* e = new (std::nothrow) sgw_engine();
-    if (!e) return fail(SGW_ENOMEM, "out of host memory");
-    e->cfg = *cfg;
-    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+// Everything sgw_create decides, as a function of (config, options, CUs, LDS per workgroup) alone: kernel family, lanes per env, LDS
+// layout, staging, walk window, the instances to launch.  No HIP call (sgw_plan runs it without a device; tests/test_plan.py
+// enumerates it).  `jit`: specialised instances may be counted on.
+int plan_engine(sgw_engine* e, bool jit) {
     const sgw_config& c = e->cfg;
+    const Options& o = e->opt;
+    e->jit = jit;
+    e->k_step = e->k_plain = e->k_multi = e->k_walk = e->k_rows = e->k_obs_rows = Kernel();
+    e->stage_agents = 0;
+    e->walk_blocks = 0;
+    e->walk_min_envs = e->walk_max_envs = e->big_stage_min_envs = 0;
+    e->big_stage = 0;
+    e->whole_env_burst = false;
 
     // ---- tables
-    DevTables h;
+    DevTables& h = e->h_tab;
     memset(&h, 0, sizeof(h));
     bool onehot = true;
     for (int t = 0; t < c.num_types; ++t) {
@@ -558,7 +539,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             const double v = c.appearance[t][k];
             if (!(v >= 0.0 && v <= 9362.0 && v == std::floor(v))) rgb16 = false;
         }
-    if (const char* f = getenv("SGW_NO_RGB16")) { if (f[0] == '1') rgb16 = false; }   // A/B and test hook: the float64 path
+    if (!o.rgb16) rgb16 = false;   // A/B and test hook: the float64 path
     if (rgb16) {
         for (int t = 0; t < c.num_types; ++t)
             for (int k = 0; k < c.num_channels; ++k) h.delta16[k >> 1][t] |= (uint32_t)c.appearance[t][k] << (16 * (k & 1));
@@ -654,42 +635,37 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
 
     // ---- group geometry: one wave per env while a slice stays small, else a workgroup per env
     const bool plain_move = c.agent_rule == SGW_AGENT_RULE_MOVE;   // step_big implements MovingAgent.act only
+    const bool tagk = c.agent_rule == SGW_AGENT_RULE_TAG;
     const bool simple_rules = !p.has_become && c.agent_rule != SGW_AGENT_RULE_CLEANUP;   // else: generic kernel
     const bool vec16 = (p.env_stride & 15) == 0 && p.env_stride >= p.cells_pad;   // 16-byte loads/stores per env are legal
     // Layered rule sets (BECOME_IF, Cleanup) stay on the wave-per-env RULES kernel up to 8 KiB per env: above 4 KiB their
     // alternative is the ticket-ordered workgroup-per-env generic kernel, where every act is a hand-off between waves
-    // (Cleanup 48x48x3, 4 096 envs: 95 us there against ... here).  SGW_RULES_8K=0: A/B and test hook.
-    // (up to 11 KiB from 16 384 envs on, as for the plain worlds below: Cleanup 56x64x3 at 4 096 / 16 384 / 65 536 envs 97 / 394 / 1 499 us
-    // on the generic kernel, 107 / 308 / 1 229 here)
-    const int rules_units = (c.num_envs >= 16384 || (getenv("SGW_RULES_11K") && getenv("SGW_RULES_11K")[0] == '1')) ? kMaxUnitsPlain : kMaxUnitsRules;   // (hook: tests)
-    bool rules_8k = !simple_rules && c.agent_rule != SGW_AGENT_RULE_TAG && vec16 && p.cells_pad > 4096 &&
-                    (p.cells_pad >> 4) <= 64 * rules_units && p.VV <= 128;
-    if (const char* f = getenv("SGW_RULES_8K")) { if (f[0] == '0') rules_8k = false; }
-    if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') rules_8k = false; }
-    if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') rules_8k = false; }    // (the tests of the ticket-ordered workgroup-per-env kernel)
+    // (Cleanup 48x48x3, 4 096 envs: 95 us there against 74.5 here); up to 11 KiB from 16 384 envs on, as for the plain worlds below
+    // (Cleanup 56x64x3 at 4 096 / 16 384 / 65 536 envs 97 / 394 / 1 499 us on the generic kernel, 107 / 308 / 1 229 here)
+    const int rules_units = (c.num_envs >= 16384 || o.rules_11k) ? kMaxUnitsPlain : kMaxUnitsRules;
+    bool rules_8k = !simple_rules && !tagk && vec16 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * rules_units && p.VV <= 128;
+    if (!o.rules_8k || !o.fast_rules || o.force_generic) rules_8k = false;
     // Plain and Tag worlds between 4 and 8 KiB per env: a LARGE batch of them also runs a wave per env (step_big spends a 512-thread
     // workgroup and three barriers on an env; per env that is about twice the time of the wave-per-env kernel, which pays only when the
     // batch is too small to fill the chip with waves).  tools/mid_world_probe.py, us per turn at 2 048 / 4 096 / 8 192 / 65 536 envs,
     // workgroup per env -> wave per env: 48x48x2 A8 r5 23 / 40 / 73 / 640 -> 22 / 31 / 56 / 373; 64x64x2 A16 r3 33 / 57 / 107 / 858 ->
     // 28 / 39 / 69 / 488; 50x50x2 A8 r3 26 / 46 / 84 / 686 -> 19 / 25 / 41 / 272; Tag 72x72 A16 r4 23 / 41 / 74 / 727 -> 25 / 34 / 61 / 447;
-    // Tag 90x90 A12 r3 27 / 48 / 90 / 741 -> 20 / 25 / 48 / 347.  SGW_FAST_8K = 0 / 1: never / whatever the batch (A/B and test hook).
+    // Tag 90x90 A12 r3 27 / 48 / 90 / 741 -> 20 / 25 / 48 / 347.  Option fast_8k = 0 / 1: never / whatever the batch.
     const bool fast_8k_ok = simple_rules && (onehot || (e->rgb16 && c.num_channels == 3)) && vec16 && nspawn <= 1 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * kMaxUnitsPlain && p.VV <= 128;
     // (between 8 and 11 KiB -- three workgroups per CU -- from 16 384 envs on: 72x72x2 A8 r5 at 4 096 / 16 384 / 32 768 envs 47 / 166 / 429 ->
     // 55 / 156 / 341 us, Tag 100x100 A16 r4 43 / 219 / 429 -> 49 / 140 / 306; above that two workgroups per CU no longer pay: 90x90x2 555 -> 640)
     bool fast_8k = fast_8k_ok && c.num_envs >= (p.cells_pad <= 8192 ? 4096 : 16384);
-    if (const char* f = getenv("SGW_FAST_8K")) {
-        if (f[0] == '0') fast_8k = false;
-        if (f[0] == '1') fast_8k = fast_8k_ok;
-    }
-    if (const char* f = getenv("SGW_FORCE_GENERIC")) { if (f[0] == '1') fast_8k = false; }
+    if (o.fast_8k == 0) fast_8k = false;
+    if (o.fast_8k == 1) fast_8k = fast_8k_ok;
+    if (o.force_generic) fast_8k = false;
     e->wpe = (p.cells_pad <= 4096 || rules_8k || fast_8k) ? 1 : 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsPlain : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
     // the layered rule set on the wave-per-env kernel (RULES variant): any spawners, BECOME_IF rules, Cleanup or plain agents
     e->fast_rules = !e->fast && e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * rules_units && p.VV <= 128 &&
-                    c.agent_rule != SGW_AGENT_RULE_TAG && (p.cells_pad <= 4096 || rules_8k);
-    if (const char* f = getenv("SGW_NO_FAST_RULES")) { if (f[0] == '1') e->fast_rules = false; }   // test hook: generic kernel instead
+                    !tagk && (p.cells_pad <= 4096 || rules_8k);
+    if (!o.fast_rules) e->fast_rules = false;   // test hook: generic kernel instead
     e->fast = e->fast || e->fast_rules;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     // (the integer-table RGB instances exist for three channels, plain or Tag movers, worlds <= 4 KiB)
@@ -698,16 +674,25 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->fast_tab_bytes = bytes_ok ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
-    const bool tag_move = c.agent_rule == SGW_AGENT_RULE_TAG;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
+    const bool tag_move = tagk;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
     e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && (plain_move || tag_move) && simple_rules;
-    if (const char* f = getenv("SGW_NO_BIG_TAG")) { if (f[0] == '1' && tag_move) e->big = false; }   // A/B and test hook: the ticket-ordered generic kernel
-    if (e->big) e->big_threads = big_threads_for(onehot, c.num_agents, p.VV);
-    bool stage_kernel = false;   // a run-time-shape STAGE kernel applies
+    if (!o.big_tag && tag_move) e->big = false;   // A/B and test hook: the ticket-ordered generic kernel
+    e->big_threads = kBigThreads;
+    if (e->big) e->big_threads = big_threads_for(o, onehot, c.num_agents, p.VV);
+    bool stage_kernel = false;   // a STAGE kernel (bursts of agents) applies
+    const int ob_elems = c.num_agents * c.num_channels * p.VV;
+    // a compile-time-shape instance of step_fast whose whole env leaves in ONE burst (the headline's way): a prebuilt one, or -- with
+    // specialised instances -- any one-hot plain / Tag world of <= 4 KiB whose windows are a multiple of 4 elements and <= 4 KiB of bytes
+    bool fixed_shape = !e->fast_rules && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, tagk);
+    if (jit && !fixed_shape && e->fast && !e->fast_rules && onehot && p.cells_pad <= 4096 && (ob_elems & 3) == 0 && ob_elems <= 4096 && o.burst != 2) {
+        // ... while the wave's LDS (tables + grid + the env's window bytes) still lets seven workgroups share a CU; beyond that the
+        // chunked bursts keep the occupancy (option burst = 1: whenever legal)
+        const size_t per_wave = (size_t)e->fast_tab_bytes + p.cells_pad + ((ob_elems + 15) & ~15);
+        fixed_shape = o.burst == 1 || per_wave * 4 + 1024 <= kLdsPerCu / 7;
+    }
+    if (o.burst == 2 && jit) fixed_shape = false;
     {   // LDS staging of one-hot observations
-        const int ob_elems = c.num_agents * c.num_channels * p.VV;
         const int per_agent = c.num_channels * p.VV;
-        const bool fixed_shape = !e->fast_rules && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width,
-                                                                    c.agent_rule == SGW_AGENT_RULE_TAG);   // = pick_fast's fixed-shape kernels
         e->obs_stage = 0;
         if (e->fast && onehot && fixed_shape) {   // (never an RGB world: six channels)
             // whole envs of a multiple of 4 elements, at most 4 KiB of byte counts
@@ -721,27 +706,25 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             // kernels -- Cleanup 21x31x3 at 65 536 envs, agents per burst 1 / 2 / 3 / 4 / 5 / 10: 666 / 695 / 643-680 / 640 / 643 / 850 us
             // (16 384 envs: 201 / 193 / 185-190 / 188 / 181 / 240).
             // instances with a run-time channel count write their planes in groups of four: up to three planes of slack behind a chunk
-            const bool tagk = c.agent_rule == SGW_AGENT_RULE_TAG;
-            const bool static_channels = e->fast_rules ? (c.layers == 3 && c.num_channels == 9) : (!tagk && c.layers == 2 && c.num_channels == 6);
+            const bool static_channels = jit || (e->fast_rules ? (c.layers == 3 && c.num_channels == 9 && c.vision_radius == 5 && c.height == 21 && c.width == 31 && o.static_cleanup && o.pack3)
+                                                                 : (!tagk && c.layers == 2 && c.num_channels == 6));
             const int slack = 48 + (static_channels ? 0 : 3 * p.VV);
             int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack : (int)(kLdsPerCu / 8 / 4) - base - slack;
             for (int wg = 4; (e->fast_rules || fast_8k) && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
                 budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - slack;
             if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack;
-            if (const char* f = getenv("SGW_STAGE_BYTES")) budget = atoi(f);                 // A/B hook
+            if (o.stage_bytes >= 0) budget = o.stage_bytes;                 // A/B hook
             int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;
-            if (const char* f = getenv("SGW_STAGE_AGENTS")) apc = std::min(c.num_agents, atoi(f));   // A/B hook
+            if (o.stage_agents >= 0) apc = std::min(c.num_agents, o.stage_agents);   // A/B hook
             if (apc > 0) {
                 e->stage_agents = apc;
                 e->obs_stage = (apc * per_agent + slack - 48 + 31 + 15) & ~15;   // + 31: the chunk's offset from a 128-byte line of global memory (step_fast.h: emit_chunk)
                 stage_kernel = true;
             }
         }
-        if (const char* f = getenv("SGW_NO_STAGE")) { if (f[0] == '1') { e->obs_stage = 0; stage_kernel = false; } }   // test / tuning hook
+        if (!o.stage) { e->obs_stage = 0; stage_kernel = false; e->stage_agents = 0; }   // test / tuning hook
     }
-    if (const char* f = getenv("SGW_FORCE_GENERIC")) {   // test hook: exercise the generic kernel on shapes the specialised ones would take
-        if (f[0] == '1') e->fast = e->big = e->fast_rules = false;
-    }
+    if (o.force_generic) e->fast = e->big = e->fast_rules = false;   // test hook: the generic kernel on shapes the specialised ones would take
     // Small worlds: two or four envs per wave on the LDS-resident generic kernel (step_kernel<16 / 32>).  A wave-per-env
     // kernel spends most of a small world's life on per-env work that keeps few lanes busy (a 21x21x2 world: 29 of 64
     // lanes in the sweep, 25 in the 5x5 gather, one in the moves), and at ~700 instructions per env it is bound by
@@ -752,21 +735,21 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     //   Tag 11x11 A5 r4 171/155/111   Tag 32x32 A8 r3 194/156/140   Cleanup 21x31x3 A10 r5 694/1383/1246
     // i.e. pack while the observation work per env (A * V * V window cells) is small, and only for batches that still
     // fill the chip twice over once packed (a small batch is latency-bound: config 2, 4 096 envs, 11 us wave-per-env
-    // against 16-19 us packed).  SGW_GROUP = 16 / 32 forces a packing, 64 forbids it (A/B hook).
+    // against 16-19 us packed).  Option group = 16 / 32 forces a packing, 64 forbids it.
     e->group = e->wpe * kWave;
     if (e->wpe == 1) {
         const int64_t avv = (int64_t)c.num_agents * p.VV;
         // (round 3: the batch a packing needs, re-measured on the single-turn instances -- us per step at 1 024 / 4 096 / 8 192 / 16 384 /
         // 32 768 envs, wave per env | 32 lanes | 16 lanes: 16x16 A4 r2 7.6 / 11.1 / 15.9 / 26.1 / 45.4 | 8.6 / 10.2 / 12.6 / 19.3 / 31.2 |
         // 10.5 / 11.6 / 13.0 / 17.4 / 28.1; 10x10 A2 r2 7.2 / 9.2 / 12.8 / 21.1 / 36.8 | 7.2 / 8.2 / 10.1 / 15.1 / 24.1 | 7.5 / 8.0 / 9.1 /
-        // 11.2 / 18.0: two envs per wave from 4 096 envs on, four from 12 288; the rule used to ask for 24 576 / 49 152)
+        // 11.2 / 18.0: two envs per wave from 4 096 envs on, four from 12 288)
         auto enough = [&](int G) { return c.num_agents <= G && (int64_t)c.num_envs * G / kWave >= (G == 16 ? 3072 : 2048); };
         int g = 0;
         // (Tag on a map with a compile-time-shape wave-per-env instance stays there: 32x32 / 8 agents 117 us against 143 packed)
         // (round 3, tools/tag_group_probe.py, two envs per wave / wave per env: 11x11 A5 r4 99 / 131 us, 16x16 A4 r3 51 / 104, 20x20 A5 r4 116 / 127,
         // 24x24 A6 r3 80 / 125, 28x28 A6 r3 96 / 115, but 30x30 A6 r4 183 / 128, 32x32 A8 r4 217 / 148, 40x40 A8 r3 163 / 135, 48x48 A10 r4 323 / 180, 64x64 A8 r3 221 / 183
         // (wave-per-env: the 3-bit-counter Tag instance): pack while map bytes + 2 x window cells of all agents stay below 1 500)
-        if (c.agent_rule == SGW_AGENT_RULE_TAG)
+        if (tagk)
             g = (enough(32) && p.cells_pad + 2 * avv < 1500 && !(e->fast && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, true))) ? 32 : 0;
         else if (c.agent_rule == SGW_AGENT_RULE_MOVE && !p.has_become) {
             // (round 3, profiles/r03_group_sweep.txt -- the wave-per-env kernels have gained more than the packed ones since the rule
@@ -775,7 +758,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             if (avv <= 100 && p.cells_pad <= 1024 && enough(16)) g = 16;
             else if (avv <= 200 && (avv <= 100 || p.cells_pad <= 1024) && enough(32)) g = 32;
         }
-        if (const char* f = getenv("SGW_GROUP")) g = atoi(f);
+        if (o.group) g = o.group;
         const bool fits = (g == 16 || g == 32) && c.num_agents <= g &&
                           (c.agent_rule != SGW_AGENT_RULE_CLEANUP || 3 * c.beam_radius <= g);
         if (fits) {
@@ -783,13 +766,15 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             e->fast = e->fast_rules = false;
         }
     }
-    if (!e->fast) { e->obs_stage = 0; stage_kernel = false; }
+    if (!e->fast) { e->obs_stage = 0; stage_kernel = false; e->stage_agents = 0; }
     e->rgb16 = rgb16_fast && e->fast && stage_kernel;      // the I16 instances are STAGE kernels: no staging area, no integer path
     if (!onehot && !e->rgb16) {
         e->fast_tab_bytes = SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
         e->obs_stage = 0;
         stage_kernel = false;
+        e->stage_agents = 0;
     }
+    e->whole_env_burst = e->fast && onehot && fixed_shape && e->obs_stage > 0;
     // what the float64 kernel (calls the STAGE kernel cannot serve: agent ranges, OBS_NEXT, unaligned tensors) needs instead
     e->plain_tab_bytes = e->rgb16 ? SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8 : 0;
     const int epb_step = (e->fast || e->big) ? epb : kBlock / e->group;   // envs per workgroup of the step kernel
@@ -799,27 +784,26 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (e->big) {
         // LDS of a workgroup: [counter words of the channels in use | appearance table][agent arrays][grid image][staging].
         // Staging of the one-hot windows (a wave's window leaves as line-aligned 16-byte streaming stores, step_big.h phase
-        // R): on for config 5's compile-time instance (434 -> 347-372 us per turn of
-        // config 5 at 8 192 envs); the run-time-table instance pays more for the byte staging than the stores give back
-        // (64x64 / 16 agents / 7x7 windows: 229 -> 270 us) and is compiled without it.  SGW_BIG_STAGE=0: A/B and test hook.
+        // R): on for instances with compile-time tables (config 5: 434 -> 347-372 us per turn at 8 192 envs); an instance with run-time
+        // tables pays more for the byte staging than the stores give back (64x64 / 16 agents / 7x7 windows: 229 -> 270 us) and is
+        // compiled without it.  Option big_stage = 0: never.
         // Padded rows (W + 16: the ~3 rows a 32-lane group of the window gather touches fall on disjoint banks) where a row
         // is whole 16-byte units -- unless the padding costs a workgroup per CU (LDS is handed out in 1 KiB granules): with
         // the staging, config 5's image fits four times into a CU only unpadded (39 936 bytes: exactly), and a fourth workgroup is
         // worth more than the conflict-free gather (1 280 envs: 55 us at four per CU, 71 at three).
-        const bool tagk = c.agent_rule == SGW_AGENT_RULE_TAG;
-        const bool static_tables = onehot && (tagk ? (c.layers == 1 && c.num_channels == 4 && c.vision_radius == 4)
-                                                    : (c.layers == 2 && c.num_channels == 6 && c.vision_radius == 5));   // = pick_big's compile-time instances
+        const bool static_tables = onehot && (jit || (tagk ? (c.layers == 1 && c.num_channels == 4 && c.vision_radius == 4)
+                                                           : (c.layers == 2 && c.num_channels == 6 && c.vision_radius == 5)));   // = pick_big's compile-time instances
         e->big_tab_bytes = static_tables ? ((c.num_channels + 3) / 4) * SGW_MAX_TYPES * 4 : e->fast_tab_bytes;   // (the run-time instance adds all four counter words)
         const size_t fixed = (size_t)e->big_tab_bytes + big_agent_lds(tagk);
         bool stage_on = static_tables && !tagk;   // (the Tag example's 9x9x4 windows are ten lines each: staged 54 / 79 us, direct 47 / 74, 128x128 at 2 048 envs / 72x72 at 8 192)
-        if (const char* f = getenv("SGW_BIG_STAGE")) stage_on = stage_on && f[0] != '0';
+        if (o.big_stage == 0) stage_on = false;
         e->big_stage = stage_on ? (c.num_channels * p.VV + 31 + 3) & ~3 : 0;
         const size_t stage_all = (size_t)(e->big_threads / 64) * e->big_stage;
         auto per_cu = [&](size_t bytes) { return std::min<size_t>(4, kLdsPerCu / (((bytes + 1023) & ~(size_t)1023) + 1024)); };   // (a workgroup's request must stay 1 KiB below its share)
         const size_t plain_img = (size_t)p.cells_pad, padded_img = (size_t)c.layers * c.height * (c.width + 16);
         const bool can_pad = (c.width & 15) == 0 && (p.cells & 15) == 0;
         if (can_pad && per_cu(fixed + padded_img + stage_all) >= per_cu(fixed + plain_img + stage_all)) p.big_pitch = c.width + 16;
-        if (const char* f = getenv("SGW_BIG_NO_PAD")) { if (f[0] == '1') p.big_pitch = c.width; }   // A/B hook
+        if (!o.big_pad) p.big_pitch = c.width;   // A/B hook
         e->step_lds_bytes = fixed + (p.big_pitch == c.width ? plain_img : padded_img);
         p.big_stage = p.big_stage_off = 0;
         if (e->big_stage) {
@@ -827,17 +811,331 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
             e->step_lds_bytes += stage_all;
         }
     }
-    const size_t lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
     const size_t lds_max = 160 * 1024;
-    if (e->lds_bytes > lds_max) {
-        delete e;
+    if (e->lds_bytes > lds_max)
         return fail(SGW_EINVAL, "world of %d bytes per env does not fit the %zu-byte LDS-resident path", p.cells, lds_max);
+
+    // ---- the instances
+    const int L = c.layers, C = c.num_channels, r = c.vision_radius, H = c.height, W = c.width;
+    const bool static_map = p.cells_pad <= 4096;   // step_fast: the whole grid in NU <= 4 register units per lane
+    if (e->fast) {
+        e->k_plain.host = pick_fast(o, e->onehot, false, L, C, r, H, W, tagk, e->fast_rules, false, &e->k_plain.host_name);
+        e->k_step.host = pick_fast(o, e->onehot, e->rgb16, L, C, r, H, W, tagk, e->fast_rules, stage_kernel, &e->k_step.host_name);
+        e->k_multi.host = pick_fast_multi(o, e->onehot, L, C, r, H, W, tagk, e->fast_rules, stage_kernel, &e->k_multi.host_name);
+        if (jit) {
+            const int jh = static_map ? H : 0, jw = static_map ? W : 0;
+            if (e->whole_env_burst) {
+                e->k_step.want = fast_id(true, L, C, r, jh, jw, tagk, false, false, false, false, false);
+                e->k_multi.want = tagk ? "" : fast_id(true, L, C, r, jh, jw, false, false, false, true, false, false);
+                if (!fixed_fast_shape(L, C, r, H, W, tagk)) e->k_step.host = e->k_multi.host = nullptr;   // (no prebuilt twin stages a whole env of this shape)
+                e->k_plain = Kernel();                                                                     // the same instance serves agent ranges with direct stores
+            } else {
+                e->k_step.want = fast_id_like(e->k_step.host_name, L, C, r, jh, jw, -1, -1);
+                e->k_plain.want = fast_id_like(e->k_plain.host_name, L, C, r, jh, jw, -1, -1);
+                if (e->k_multi.host) e->k_multi.want = fast_id_like(e->k_multi.host_name, L, C, r, jh, jw, -1, -1);
+                else if (stage_kernel && e->onehot && !tagk && !e->rgb16) e->k_multi.want = fast_id_like(e->k_step.host_name, L, C, r, jh, jw, -1, 1);
+            }
+        } else if (e->whole_env_burst) {
+            e->k_plain = Kernel();
+        }
+    } else if (e->big) {
+        e->k_step.host = pick_big(e->onehot, L, C, r, tag_move, e->big_threads, &e->k_step.host_name);
+        if (!tag_move) e->k_multi.host = pick_big_multi(e->onehot, L, C, r, &e->k_multi.host_name);
+        if (!tag_move && ((p.cells + 15) >> 4) <= 4 * e->big_threads)   // the prefetch holds one 4-unit round per thread
+            e->k_walk.host = pick_big_walk(e->onehot, L, C, r, e->big_threads, &e->k_walk.host_name);
+        if (jit) {
+            e->k_step.want = big_id(e->onehot, L, C, r, false, false, tag_move, e->big_threads);
+            if (e->k_multi.host) e->k_multi.want = big_id(e->onehot, L, C, r, true, false, false, kBigThreads);
+            if (e->k_walk.host) e->k_walk.want = big_id(e->onehot, L, C, r, false, true, false, e->big_threads);
+        }
+    } else {
+        e->k_step.host = pick_step(o, e->group, e->onehot, L, C, c.agent_rule, r, H, W, false, &e->k_step.host_name);
+        e->k_multi.host = pick_step(o, e->group, e->onehot, L, C, c.agent_rule, r, H, W, true, &e->k_multi.host_name);   // the generic kernel's instance with the turn loop
+        if (jit) {
+            e->k_step.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, false);
+            e->k_multi.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, true);
+        }
     }
+    if (!o.big_walk) e->k_walk = Kernel();   // A/B hook
+    for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk})
+        if (k->host && k->want == k->host_name) k->want.clear();   // the library already holds exactly this instance
+    e->multi_turn = e->k_multi.usable();   // kernels with sgw_rollout's turn loop
+    e->reset_fn = pick_reset(e->wpe);
+    // Worlds above 4 KiB only: there, gathering one window from global memory beats staging 32 KiB through LDS (config 5:
+    // 14.9 against 24.4 us per phase launch); a 2 KiB env is staged with four coalesced 16-byte loads per lane and the
+    // byte gather from global is the slower way (config 3: 62.9 against 46.1 us).  Option phase_kernel = 0 / 1 forces.
+    e->phase_ok = plain_move && e->wpe == 4;
+    if (o.phase_kernel >= 0) e->phase_ok = plain_move && o.phase_kernel == 1;
+    e->rows_epb = e->rows_wpb = 0;
+    e->rows_lds = 0;
+    if (e->onehot && plain_move && p.cells >= 8 && o.phase_rows) {
+        const int NW = (C + 3) / 4;
+        e->k_rows.host = pick_rows(L, NW, r, &e->k_rows.host_name, &e->k_obs_rows.host, &e->k_obs_rows.host_name);
+        if (jit && !e->k_rows.host && r >= 1 && r <= 7) {
+            e->k_rows.want = rows_id("phase_rows", L, NW, r);
+            e->k_obs_rows.want = rows_id("observe_rows", L, NW, r);
+        }
+        if (e->k_rows.usable()) {
+            const int V = 2 * r + 1;
+            e->rows_epb = e->rows_wpb = 4 * (64 / (V <= 4 ? 4 : (V <= 8 ? 8 : 16)));
+            // per wave: counter words, the value table, the staging bytes of the windows it carries
+            e->rows_lds = (size_t)4 * (NW * 34 * 4 + SGW_MAX_TYPES * 8 + (((e->rows_epb / 4) * C * V * V + 15) & ~15));
+        }
+    }
+    p.stage_agents = e->stage_agents;
+    e->fast_wg_cap = 5;
+    e->fast_wg_cap_forced = false;
+    if (o.fast_wg_per_cu > 0) { e->fast_wg_cap = o.fast_wg_per_cu; e->fast_wg_cap_forced = true; }   // tuning hook
+    e->grid_blocks = (int)ceil_div(p.E, (e->fast || e->big) ? epb : epb_step);   // every step kernel: one env per group, the dispatcher balances
+    if (e->k_walk.usable()) {
+        // workgroups a CU holds at once: the walking variant is compiled for SGW_WALK_WAVES waves per SIMD (76 VGPRs: three 512-thread
+        // workgroups per CU), the plain kernel for 6 (the hardware admits a fourth workgroup while the request stays 1 KiB below a quarter
+        // of the CU's LDS -- 1 280 envs of config 5: 55 us there, 71 above)
+        const size_t walk_lds = e->step_lds_bytes - (size_t)(e->big_threads / 64) * e->big_stage;   // (the walking variant stores directly: no staging area)
+        const int per_cu = resident_per_cu(e->big_threads, walk_lds, SGW_WALK_WAVES);
+        int plain_per_cu = resident_per_cu(e->big_threads, e->step_lds_bytes, 6);
+        if (((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024 <= kLdsPerCu / 4) plain_per_cu = std::max(plain_per_cu, 4);
+        // Engaged for batches of 1.5x to 3x what the plain kernel holds at once (one env per workgroup, four
+        // workgroups per CU at config 5 = 1 024 envs), measured on config 5's shape, same box, us per launch, walking
+        // against plain: 1 280 envs 53 / 55, 1 536 74-77 / 70-72, 2 048 88-96 / 109-118, 3 072 161-183 / 174-178,
+        // 4 096 206 / 224, 8 192 511 / 436.  Fewer walking workgroups are resident (76 VGPRs: three per CU), they
+        // run in lockstep and each env's prefetch waits for the previous env's stores, so over many rounds the
+        // dispatcher's four per CU win; over two or three rounds the hidden drain does.  Also measured at 2 048 envs:
+        // 683 workgroups (three envs each, evenly) 100 us, 512 100 us, 1 024 / 1 365 (oversubscribed) 93-107 us, a
+        // 64-VGPR build (four per CU, six spilled registers) 95-98 us, staggered starts 96-101 us.
+        e->walk_blocks = per_cu * e->num_cus;
+        // Round 3, with the staged windows (config 5, us per launch, plain direct / walking direct / plain staged): 1 024 envs
+        // 47 / - / 59, 1 280 54 / 54 / 69, 1 536 70 / 76 / 78, 2 048 105 / 91 / 97, 2 560 132 / 128 / 117, 3 072 155 / 168 / 141,
+        // 4 096 216 / - / 174-181, 8 192 415 / - / 347: the window is 1.5x to 2.25x now, staging takes over above it.
+        e->walk_min_envs = (int64_t)plain_per_cu * e->num_cus * 3 / 2;
+        e->walk_max_envs = e->big_stage ? (int64_t)plain_per_cu * e->num_cus * 9 / 4 : (int64_t)plain_per_cu * e->num_cus * 3;
+        if (o.big_walk_blocks > 0) {   // tuning / test hook: this many workgroups, whatever the batch
+            e->walk_blocks = o.big_walk_blocks;
+            e->walk_min_envs = e->walk_blocks;
+            e->walk_max_envs = INT64_MAX;
+        }
+    }
+    // staged windows pay once the batch is a few rounds of workgroups (a single round is latency-bound, and the staging adds
+    // an LDS round trip per window): above 1.75x what the chip holds at once (see the table above)
+    if (e->big) {
+        const int64_t by_lds = (int64_t)(kLdsPerCu / (((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024));
+        const int64_t resident = std::max<int64_t>(1, std::min<int64_t>(2048 / e->big_threads, by_lds));   // workgroups a CU holds at once
+        e->big_stage_min_envs = resident * e->num_cus * 7 / 4;
+        if (o.big_stage == 1) e->big_stage_min_envs = 0;   // test hook: staged whatever the batch
+    }
+    e->reset_blocks = (int)ceil_div(p.E, epb);   // one env per group and launch
+    return SGW_OK;
+}
+
+// The specialised instance of `k`, compiled / loaded on first use.  A refusal leaves the prebuilt twin in charge (or, if the plan
+// has none, is an error the caller reports).
+int resolve_kernel(sgw_engine* e, Kernel& k) {
+    if (k.jit || k.want.empty() || k.tried) return (k.jit || k.host) ? SGW_OK : fail(SGW_EHIP, "no instance of %s is available", k.want.c_str());
+    k.tried = true;
+    std::string err;
+    k.jit = jit_get(k.want, e->opt, e->arch.c_str(), e->dev, &err);
+    if (!k.jit && !k.host) return fail(SGW_EHIP, "specialising %s failed and the library holds no prebuilt twin: %s", k.want.c_str(), err.c_str());
+    if (k.jit && e->step_lds_bytes > 65536)   // (what hipFuncSetAttribute does for the prebuilt instances)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(e->lds_bytes, e->step_lds_bytes));
+    return SGW_OK;
+}
+
+int launch_kernel(sgw_engine* e, Kernel& k, unsigned blocks, unsigned threads, size_t lds, hipStream_t s, Params& p, RowPtrs* rp) {
+    if (!k.jit && !k.want.empty() && !k.tried)
+        if (int rc = resolve_kernel(e, k)) return rc;
+    void* args[2] = {&p, rp};
+    if (k.jit) HIP_TRY(hipModuleLaunchKernel(k.jit, blocks, 1, 1, threads, 1, 1, (unsigned)lds, s, args, nullptr));
+    else if (k.host) HIP_TRY(hipLaunchKernel(k.host, dim3(blocks), dim3(threads), args, lds, s));
+    else return fail(SGW_EHIP, "no kernel to launch");
+    return SGW_OK;
+}
+
+// Waits for the recorded event pairs and folds them into the running sum and the per-launch series.
+int time_drain(sgw_engine* e) {
+    if (e->ev_used == 0) return SGW_OK;
+    for (int i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(e->ev1[i]));   // each pair on its own: timed launches may have gone to different streams
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]));
+        e->ms_acc += ms;
+        if (e->series.size() < kSeriesCap) e->series.push_back(ms);
+        else e->series_dropped++;
+    }
+    e->ev_used = 0;
+    return SGW_OK;
+}
+
+int time_begin(sgw_engine* e, hipStream_t s) {
+    if (!e->timing) return SGW_OK;
+    if (e->ev_used == kEventPool)   // the pool wraps: the one place a launch call waits (include/sgw.h, Conventions)
+        if (int rc = time_drain(e)) return rc;
+    HIP_TRY(hipEventRecord(e->ev0[e->ev_used], s));
+    return SGW_OK;
+}
+
+int time_end(sgw_engine* e, hipStream_t s) {
+    if (!e->timing) return SGW_OK;
+    HIP_TRY(hipEventRecord(e->ev1[e->ev_used], s));
+    e->ev_used++;
+    e->launches++;
+    return SGW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sgw_last_error(void) { return g_err; }
+#ifdef SGW_STAMPS
+int sgw_debug_stamps(unsigned long long* out) {   // diagnostic builds only; not part of the ABI: [kStampEnvs][8] of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * kStampEnvs) == hipSuccess ? 0 : -1;
+}
+#endif
+
+const char* sgw_version(void) { return "sgw 0.2 (gfx950)"; }
+
+int64_t sgw_obs_elems_per_env(const sgw_config* c) {
+    const int64_t V = 2 * c->vision_radius + 1;
+    return (int64_t)c->num_agents * c->num_channels * V * V;
+}
+int64_t sgw_grid_bytes_per_env(const sgw_config* c) { return (int64_t)c->layers * c->height * c->width; }
+int64_t sgw_algorithmic_bytes_per_env_step(const sgw_config* c) {
+    const int64_t V = 2 * c->vision_radius + 1;
+    // SURVEY.md 8(d): grid read+write, per agent obs f32 store + action + reward + pos load/store, total f64 rw
+    return 2 * sgw_grid_bytes_per_env(c) + (int64_t)c->num_agents * (c->num_channels * V * V * 4 + 1 + 4 + 4) + 16;
+}
+
+int sgw_set_option(sgw_engine* e, const char* key, const char* value) {
+    int rc;
+    if (e) {
+        rc = option_set(e->opt, key, value, true);
+    } else {
+        std::lock_guard<std::mutex> lock(g_opt_mu);
+        rc = option_set(g_opts, key, value, false);
+    }
+    if (rc == 1) return fail(SGW_EINVAL, "sgw_set_option: unknown key '%s'", key ? key : "(null)");
+    if (rc == 2) return fail(SGW_EINVAL, "sgw_set_option: value '%s' is out of range for '%s'", value ? value : "(null)", key);
+    if (rc == 3) return fail(SGW_EINVAL, "sgw_set_option: '%s' shapes the plan of an engine: set it (with a NULL engine) before sgw_create", key ? key : "(all keys)");
+    return SGW_OK;
+}
+
+static int sgw_debug(void) {   // the ONE environment variable the shipped library reads: SGW_DEBUG=1 turns on the specialiser's log lines
+    static const int v = [] { const char* f = getenv("SGW_DEBUG"); return (f && f[0] == '1') ? 1 : 0; }();
+    return v;
+}
+
+// what plan_engine decided, for sgw_plan / sgw_launch_info
+static void describe_plan(const sgw_engine* e, sgw_plan_info* out) {
+    memset(out, 0, sizeof(*out));
+    out->family = e->fast ? SGW_FAMILY_WAVE : (e->big ? SGW_FAMILY_WORKGROUP : SGW_FAMILY_GENERIC);
+    out->lanes_per_env = (e->fast || e->big) ? (e->big ? e->big_threads : kWave) : e->group;
+    out->threads = e->big ? e->big_threads : kBlock;
+    out->grid_blocks = e->grid_blocks;
+    out->lds_bytes = (int64_t)e->step_lds_bytes;
+    out->env_lds = e->step_env_lds;
+    out->obs_stage = e->obs_stage;
+    out->stage_agents = e->stage_agents;
+    out->whole_env_burst = e->whole_env_burst ? 1 : 0;
+    out->big_stage = e->big_stage;
+    out->big_pitch = e->base.big_pitch;
+    out->onehot = e->onehot ? 1 : 0;
+    out->rgb16 = e->rgb16 ? 1 : 0;
+    out->rules = e->fast_rules ? 1 : 0;
+    out->specialised = e->jit ? 1 : 0;
+    out->phase_kernel = e->phase_ok ? 1 : 0;
+    out->rollout_in_one_launch = e->multi_turn ? 1 : 0;
+    out->walk_blocks = e->walk_blocks;
+    out->walk_min_envs = e->walk_min_envs;
+    out->walk_max_envs = e->walk_max_envs;
+    out->big_stage_min_envs = e->big_stage_min_envs;
+    auto put = [](char* dst, size_t cap, const Kernel& k, bool prebuilt) {
+        const char* s = prebuilt ? (k.host ? k.host_name : "-") : (k.want.empty() ? (k.host ? k.host_name : "-") : k.want.c_str());
+        snprintf(dst, cap, "%s", s);
+    };
+    put(out->kernel, sizeof(out->kernel), e->k_step, false);
+    put(out->kernel_prebuilt, sizeof(out->kernel_prebuilt), e->k_step, true);
+    put(out->kernel_plain, sizeof(out->kernel_plain), e->k_plain, false);
+    put(out->kernel_rollout, sizeof(out->kernel_rollout), e->k_multi, false);
+    put(out->kernel_walk, sizeof(out->kernel_walk), e->k_walk, false);
+    put(out->kernel_phase, sizeof(out->kernel_phase), e->k_rows, false);
+    if (!e->k_rows.usable()) snprintf(out->kernel_phase, sizeof(out->kernel_phase), "%s", e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
+    put(out->kernel_observe_rows, sizeof(out->kernel_observe_rows), e->k_obs_rows, false);
+}
+
+int sgw_plan(const sgw_config* cfg, int32_t num_cus, int64_t lds_per_workgroup, sgw_plan_info* out) {
+    if (!out) return fail(SGW_EINVAL, "sgw_plan: out is NULL");
+    if (int rc = validate(cfg)) return rc;
+    sgw_engine* e = new (std::nothrow) sgw_engine();
+    if (!e) return fail(SGW_ENOMEM, "out of host memory");
+    e->cfg = *cfg;
+    {
+        std::lock_guard<std::mutex> lock(g_opt_mu);
+        e->opt = g_opts;
+    }
+    e->num_cus = num_cus > 0 ? num_cus : 256;
+    e->lds_cap = lds_per_workgroup > 0 ? (size_t)lds_per_workgroup : 65536;
+    // (whether hipRTC can be loaded is a property of the machine, not of the plan: sgw_plan answers for a machine that has it
+    // unless the option says otherwise; sgw_create re-plans with jit = false when a compile is refused)
+    const int rc = plan_engine(e, e->opt.jit != 0 && SGW_JIT_SOURCES);
+    if (rc == SGW_OK) describe_plan(e, out);
+    delete e;
+    return rc;
+}
+
+int sgw_jit_stats(double* out6) {
+    if (!out6) return fail(SGW_EINVAL, "sgw_jit_stats: NULL argument");
+    std::lock_guard<std::mutex> lock(g_jit_mu);
+    out6[0] = (double)g_jit_stats.compiled; out6[1] = (double)g_jit_stats.disk_hits; out6[2] = (double)g_jit_stats.mem_hits;
+    out6[3] = (double)g_jit_stats.failed; out6[4] = g_jit_stats.compile_ms; out6[5] = g_jit_stats.load_ms;
+    return SGW_OK;
+}
+
+int sgw_create(const sgw_config* cfg, sgw_engine** out) {
+    if (!out) return fail(SGW_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate(cfg)) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+
+    sgw_engine* e = new (std::nothrow) sgw_engine();
+    if (!e) return fail(SGW_ENOMEM, "out of host memory");
+    e->cfg = *cfg;
+    {
+        std::lock_guard<std::mutex> lock(g_opt_mu);
+        e->opt = g_opts;
+    }
+    if (sgw_debug()) e->opt.jit_verbose = 1;
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->lds_cap = prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536;
+    e->dev = dev;
+    e->arch = prop.gcnArchName[0] ? prop.gcnArchName : "gfx950";
+
+    // the plan; the whole-turn kernel's specialised instance is compiled / loaded now, and a refusal (no hipRTC, no embedded
+    // sources, a compile error) re-plans for the prebuilt instances -- the other kernels of the plan are resolved at first use
+    bool jit = e->opt.jit != 0 && SGW_JIT_SOURCES;
+    for (;;) {
+        if (int rc = plan_engine(e, jit)) { delete e; return rc; }
+        if (!jit) break;
+        bool ok = true;
+        if (!e->k_step.want.empty()) {
+            std::string err;
+            e->k_step.tried = true;
+            e->k_step.jit = jit_get(e->k_step.want, e->opt, e->arch.c_str(), e->dev, &err);
+            ok = e->k_step.jit != nullptr;
+        }
+        if (ok) break;
+        jit = false;
+    }
+    const Params& pc = e->base;
+    (void)pc;
 
     hipError_t err = hipMalloc(&e->d_tab, sizeof(DevTables));
-    if (err == hipSuccess) err = hipMemcpy(e->d_tab, &h, sizeof(DevTables), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(e->d_tab, &e->h_tab, sizeof(DevTables), hipMemcpyHostToDevice);
     {   // the reset image: per layer the fill type, the border type around it; bytes past the last cell are not cells
-        std::vector<uint8_t> img((size_t)p.cells_pad, (uint8_t)0xFF);
+        const sgw_config& c = e->cfg;
+        std::vector<uint8_t> img((size_t)e->base.cells_pad, (uint8_t)0xFF);
         for (int z = 0; z < c.layers; ++z)
             for (int y = 0; y < c.height; ++y)
                 for (int x = 0; x < c.width; ++x) {
@@ -855,104 +1153,24 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         sgw_destroy(e);
         return fail(SGW_EHIP, "device allocation failed: %s", hipGetErrorString(err));
     }
-    p.tab = e->d_tab;
-    p.tmpl = e->d_tmpl;
-    p.status = e->d_status;
+    e->base.tab = e->d_tab;
+    e->base.tmpl = e->d_tmpl;
+    e->base.status = e->d_status;
 
-    if (e->fast) e->step_fn_plain = pick_fast(e->onehot, false, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, false, &e->kernel_name_plain);
-    // Worlds above 4 KiB only: there, gathering one window from global memory beats staging 32 KiB through LDS (config 5:
-    // 14.9 against 24.4 us per phase launch); a 2 KiB env is staged with four coalesced 16-byte loads per lane and the
-    // byte gather from global is the slower way (config 3: 62.9 against 46.1 us).  SGW_NO_PHASE_KERNEL = 1 / 0 forces.
-    e->phase_ok = c.agent_rule == SGW_AGENT_RULE_MOVE && e->wpe == 4;
-    if (const char* f = getenv("SGW_NO_PHASE_KERNEL")) e->phase_ok = c.agent_rule == SGW_AGENT_RULE_MOVE && f[0] == '0';
-    if (e->onehot && c.agent_rule == SGW_AGENT_RULE_MOVE && p.cells >= 8) {
-        e->rows_fn = pick_rows(c.layers, (c.num_channels + 3) / 4, c.vision_radius, &e->kernel_name_rows, &e->obs_rows_fn, &e->kernel_name_obs_rows);
-        const int V = 2 * c.vision_radius + 1;
-        e->rows_epb = e->rows_wpb = 4 * (64 / (V <= 4 ? 4 : (V <= 8 ? 8 : 16)));
-        // per wave: counter words, the value table, the staging bytes of the windows it carries
-        e->rows_lds = (size_t)4 * (((c.num_channels + 3) / 4) * 34 * 4 + SGW_MAX_TYPES * 8 + (((e->rows_epb / 4) * c.num_channels * V * V + 15) & ~15));
-    }
-    if (const char* f = getenv("SGW_PHASE_ROWS")) { if (f[0] == '0') e->rows_fn = nullptr; }   // A/B and test hook: the older phase paths (sgw_step's phases only)
-    p.stage_agents = e->stage_agents;
-    StepFn sk = e->fast  ? pick_fast(e->onehot, e->rgb16, c.layers, c.num_channels, c.vision_radius, c.height, c.width, c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name)
-                : e->big ? pick_big(e->onehot, c.layers, c.num_channels, c.vision_radius, tag_move, e->big_threads, &e->kernel_name)
-                         : pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, false, &e->kernel_name);
-    StepFn rk = pick_reset(e->wpe);
-    if (const char* f = getenv("SGW_FAST_WG_PER_CU")) { e->fast_wg_cap = atoi(f); e->fast_wg_cap_forced = true; }   // tuning hook
-    e->step_fn = sk;
-    e->reset_fn = rk;
-    if (e->fast)
-        e->step_fn_multi = pick_fast_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, c.height, c.width,
-                                           c.agent_rule == SGW_AGENT_RULE_TAG, e->fast_rules, stage_kernel, &e->kernel_name_multi);
-    if (e->big && !tag_move) e->step_fn_multi = pick_big_multi(e->onehot, c.layers, c.num_channels, c.vision_radius, &e->kernel_name_multi);
-    if (!e->fast && !e->big)   // the generic kernel's instance with the turn loop
-        e->step_fn_multi = pick_step(e->group, e->onehot, c.layers, c.num_channels, c.agent_rule, c.vision_radius, c.height, c.width, true, &e->kernel_name_multi);
-    e->multi_turn = e->step_fn_multi != nullptr;   // kernels with sgw_rollout's turn loop
-    if (e->big && !tag_move && ((p.cells + 15) >> 4) <= 4 * e->big_threads)   // the prefetch holds one 4-unit round per thread
-        e->step_fn_walk = pick_big_walk(e->onehot, c.layers, c.num_channels, c.vision_radius, e->big_threads, &e->kernel_name_walk);
-    if (const char* f = getenv("SGW_BIG_NO_WALK")) { if (f[0] == '1') e->step_fn_walk = nullptr; }   // A/B hook
-    if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(lds_cap, 65536)) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
-        if (err == hipSuccess && e->step_fn_plain && e->step_fn_plain != sk)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
-        if (err == hipSuccess && e->step_fn_multi)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
-        if (err == hipSuccess && e->step_fn_walk)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->step_fn_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+    if (std::max(e->lds_bytes, e->step_lds_bytes) > std::min<size_t>(e->lds_cap, 65536)) {
+        err = hipSuccess;
+        for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk})
+            if (err == hipSuccess && k->host)
+                err = hipFuncSetAttribute(k->host, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+        if (err == hipSuccess && e->k_step.jit)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e->k_step.jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err != hipSuccess) {
             sgw_destroy(e);
             return fail(SGW_EHIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, hipGetErrorString(err));
         }
     }
-    int nb = 0;
-    if (int rc = occupancy_blocks(sk, e->step_lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
-    // generic kernel: persistent grid; fast kernel: one env per wave, the dispatcher balances
-    (void)nb;
-    e->grid_blocks = (int)ceil_div(p.E, (e->fast || e->big) ? epb : epb_step);   // every step kernel: one env per group, the dispatcher balances
-    if (int rc = occupancy_blocks(rk, e->lds_bytes, e->num_cus, &nb)) { sgw_destroy(e); return rc; }
-    if (e->step_fn_walk) {
-        int per_cu = 0;
-        const size_t walk_lds = e->step_lds_bytes - (size_t)(e->big_threads / 64) * e->big_stage;   // (the walking variant stores directly: no staging area)
-        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_fn_walk, e->big_threads, walk_lds);
-        int plain_per_cu = 0;
-        if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&plain_per_cu, sk, e->big_threads, e->step_lds_bytes);
-        // (the runtime's answer for the plain kernel is three per CU whatever it asks for; the hardware admits a fourth
-        // while the request stays 1 KiB below a quarter of the CU's LDS -- 1 280 envs of config 5: 55 us there, 71 above)
-        if (oe == hipSuccess && ((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024 <= kLdsPerCu / 4) plain_per_cu = std::max(plain_per_cu, 4);
-        if (oe != hipSuccess || per_cu < 1 || plain_per_cu < 1) e->step_fn_walk = nullptr;
-        else {
-            // Engaged for batches of 1.5x to 3x what the plain kernel holds at once (one env per workgroup, four
-            // workgroups per CU at config 5 = 1 024 envs), measured on config 5's shape, same box, us per launch, walking
-            // against plain: 1 280 envs 53 / 55, 1 536 74-77 / 70-72, 2 048 88-96 / 109-118, 3 072 161-183 / 174-178,
-            // 4 096 206 / 224, 8 192 511 / 436.  Fewer walking workgroups are resident (76 VGPRs: three per CU), they
-            // run in lockstep and each env's prefetch waits for the previous env's stores, so over many rounds the
-            // dispatcher's four per CU win; over two or three rounds the hidden drain does.  Also measured at 2 048 envs:
-            // 683 workgroups (three envs each, evenly) 100 us, 512 100 us, 1 024 / 1 365 (oversubscribed) 93-107 us, a
-            // 64-VGPR build (four per CU, six spilled registers) 95-98 us, staggered starts 96-101 us.
-            e->walk_blocks = per_cu * e->num_cus;
-            // Round 3, with the staged windows (config 5, us per launch, plain direct / walking direct / plain staged): 1 024 envs
-            // 47 / - / 59, 1 280 54 / 54 / 69, 1 536 70 / 76 / 78, 2 048 105 / 91 / 97, 2 560 132 / 128 / 117, 3 072 155 / 168 / 141,
-            // 4 096 216 / - / 174-181, 8 192 415 / - / 347: the window is 1.5x to 2.25x now, staging takes over above it.
-            e->walk_min_envs = (int64_t)plain_per_cu * e->num_cus * 3 / 2;
-            e->walk_max_envs = e->big_stage ? (int64_t)plain_per_cu * e->num_cus * 9 / 4 : (int64_t)plain_per_cu * e->num_cus * 3;
-        }
-        if (const char* f = getenv("SGW_BIG_WALK_BLOCKS")) {   // tuning / test hook: this many workgroups, whatever the batch
-            e->walk_blocks = std::max(1, atoi(f));
-            e->walk_min_envs = e->walk_blocks;
-            e->walk_max_envs = INT64_MAX;
-        }
-    }
-    // staged windows pay once the batch is a few rounds of workgroups (a single round is latency-bound, and the staging adds
-    // an LDS round trip per window): above 1.75x what the chip holds at once (see the table above)
-    if (e->big) {
-        const int64_t by_lds = (int64_t)(kLdsPerCu / (((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024));
-        const int64_t resident = std::max<int64_t>(1, std::min<int64_t>(2048 / e->big_threads, by_lds));   // workgroups a CU holds at once
-        e->big_stage_min_envs = resident * e->num_cus * 7 / 4;
-    }
-    if (const char* f = getenv("SGW_BIG_STAGE")) { if (f[0] == '1') e->big_stage_min_envs = 0; }   // test hook: staged whatever the batch
-    e->reset_blocks = (int)ceil_div(p.E, epb);   // one env per group and launch
     *out = e;
     return SGW_OK;
 }
@@ -1013,7 +1231,6 @@ static size_t step_lds_request(const sgw_engine* e, const Params& p, int* cap_ou
 }
 
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
-    if (int rc = time_begin(e, s)) return rc;
     p.agent_state = e->agent_state;
     p.state_at_pov = e->state_at_pov;
     p.agent_dir = e->agent_dir;
@@ -1022,6 +1239,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
     if (p.agent_rule == SGW_AGENT_RULE_TAG && p.do_move && !p.agent_state)
         return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
+    if (int rc = time_begin(e, s)) return rc;
     p.env_lds = e->step_env_lds;
     if (e->fast || e->big) p.tab_bytes = e->big ? e->big_tab_bytes : e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
@@ -1030,23 +1248,22 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     size_t lds = step_lds_request(e, p, &cap);
     // step_big: the walking variant keeps the direct stores (measured faster there), and so does a launch whose observation
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
-    const bool walk = e->big && p.nturns == 1 && e->step_fn_walk && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
+    const bool walk = e->big && p.nturns == 1 && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
     p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
     if (e->big && p.nturns > 1 && e->big_threads != kBigThreads) p.big_stage = 0;   // (the rollout instance runs kBigThreads: the staging area is sized for this engine's waves)
     if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
-    if (e->rows_fn && one_phase && !p.obs_u8) {
+    if (e->k_rows.usable() && one_phase && !p.obs_u8) {
         // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
         const int64_t N = (int64_t)p.C * p.VV;
         const uintptr_t dst = reinterpret_cast<uintptr_t>(p.obs);
         p.rows_mode = (p.obs_A == 1 && (dst & 15) == 0) ? kRowsFlat : (((dst & 7) == 0 && (N & 1) == 0) ? kRowsPair : kRowsSingle);
-        hipLaunchKernelGGL(e->rows_fn, dim3((unsigned)ceil_div(p.E, e->rows_epb)), dim3(kBlock), e->rows_lds, s, p);
-        HIP_TRY(hipGetLastError());
+        if (int rc = launch_kernel(e, e->k_rows, (unsigned)ceil_div(p.E, e->rows_epb), kBlock, e->rows_lds, s, p, nullptr)) return rc;
         return time_end(e, s);
     }
-    // ... otherwise, for worlds above 4 KiB: the byte-gather phase kernel (SGW_NO_PHASE_KERNEL=1: A/B and test hook).
+    // ... otherwise, for worlds above 4 KiB: the byte-gather phase kernel (option phase_kernel)
     if (e->phase_ok && p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1)) {
         Params q = p;
         q.env_lds = (e->onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8) + SGW_MAX_TYPES * 8;   // + the value table
@@ -1055,25 +1272,25 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         HIP_TRY(hipGetLastError());
         return time_end(e, s);
     }
-    // a run-time-shape STAGE kernel has no direct-store path: calls it cannot serve take the plain variant
-    StepFn fn = e->step_fn;
-    if (e->fast && e->stage_agents > 0 && e->step_fn_plain &&
-        (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS)))
-        fn = e->step_fn_plain;
-    if (fn == e->step_fn_plain && e->rgb16 && fn != e->step_fn) {   // the float64 kernel: its own table area, no staging, no result table
-        p.tab_bytes = e->plain_tab_bytes;
-        p.env_lds = e->plain_tab_bytes + p.cells_pad;
-        p.obs_stage = 0;
-        lds = (size_t)(kBlock / kWave) * p.env_lds;
+    // a STAGE kernel has no direct-store path: calls it cannot serve take the plain variant
+    Kernel* k = &e->k_step;
+    if (e->fast && e->stage_agents > 0 && e->k_plain.usable() &&
+        (p.obs_stage == 0 || p.a0 != 0 || p.a1 != p.A || p.obs_next || (p.flags & SGW_STEP_NO_OBS))) {
+        k = &e->k_plain;
+        p.obs_stage = 0;   // (a compile-time-shape plain instance would otherwise stage a whole env into a chunk-sized area)
+        if (e->rgb16) {    // the float64 kernel: its own table area, no staging, no result table
+            p.tab_bytes = e->plain_tab_bytes;
+            p.env_lds = e->plain_tab_bytes + p.cells_pad;
+            lds = (size_t)(kBlock / kWave) * p.env_lds;
+        }
     }
-    if (p.nturns > 1) fn = e->step_fn_multi;   // sgw_rollout made sure it exists and the call qualifies
+    if (p.nturns > 1) k = &e->k_multi;   // sgw_rollout made sure it exists and the call qualifies
     int blocks = e->grid_blocks;
     if (walk) {   // two to three rounds of the plain kernel
-        fn = e->step_fn_walk;
+        k = &e->k_walk;
         blocks = e->walk_blocks;
     }
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock), lds, s, p);
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, nullptr)) return rc;
     return time_end(e, s);
 }
 
@@ -1154,6 +1371,9 @@ int sgw_rollout(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actio
     if (obs_turn_stride < 0 || actions_turn_stride < 0 || rewards_turn_stride < 0)
         return fail(SGW_EINVAL, "sgw_rollout: negative turn stride");
     const int A = e->cfg.num_agents;
+    if (e->multi_turn && !e->k_multi.jit && !e->k_multi.host) {   // the turn-loop instance exists only specialised: get it now, or loop over single turns
+        if (resolve_kernel(e, e->k_multi) != SGW_OK) e->multi_turn = false;
+    }
     uint32_t done = 0;
     while (done < num_turns) {
         const uint32_t turn = first_turn + done;
@@ -1190,7 +1410,7 @@ int sgw_rollout(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actio
 int sgw_capabilities(sgw_engine* e) {
     if (!e) return 0;
     int caps = 0;
-    if (e->obs_rows_fn && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_OBSERVE_ROWS;
+    if (e->k_obs_rows.usable() && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_OBSERVE_ROWS;
     caps |= SGW_CAP_ACT;      // MovingAgent.act, TagAgent.act and CleanupAgent.act all have an sgw_act instance
     return caps;
 }
@@ -1217,8 +1437,8 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
     if (agent_begin < 0 || agent_end > e->cfg.num_agents || agent_begin >= agent_end)
         return fail(SGW_EINVAL, "sgw_observe_rows: agent range [%d, %d) invalid", agent_begin, agent_end);
     if (!(sgw_capabilities(e) & SGW_CAP_OBSERVE_ROWS))
-        return fail(SGW_EINVAL, "sgw_observe_rows: no row-load instance for this world (one-hot float32 windows of an instantiated "
-                                "layers / channels / radius only; see sgw_capabilities) -- use sgw_observe");
+        return fail(SGW_EINVAL, "sgw_observe_rows: no row-load instance for this world (one-hot float32 windows of plain movers only; "
+                                "see sgw_capabilities) -- use sgw_observe");
     RowPtrs rp;
     if (int rc = fill_rows(e, rows, env_stride, agent_begin, agent_end, true, &rp, "sgw_observe_rows")) return rc;
     Params p = e->base;
@@ -1239,17 +1459,14 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
         if (slots && (reinterpret_cast<uintptr_t>(rows[agent_begin]) & 15) == 0) p.rows_mode = kRowsFlat;
         else if (env_stride == N && al16) { p.rows_mode = kRowsFlat; p.rows_by_agent = 1; }
         else p.rows_mode = pair_ok ? kRowsPair : kRowsSingle;
-        if (const char* f = getenv("SGW_ROWS_MODE")) {   // test hook: force a slower emit (1 = single floats, 2 = float2 runs where legal)
-            const int m = atoi(f);
-            if (m == kRowsSingle || (m == kRowsPair && pair_ok)) { p.rows_mode = m; p.rows_by_agent = 0; }
-        }
+        const int m = e->opt.rows_mode;   // test hook: force a slower emit (1 = single floats, 2 = float2 runs where legal)
+        if (m == kRowsSingle || (m == kRowsPair && pair_ok)) { p.rows_mode = m; p.rows_by_agent = 0; }
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = time_begin(e, s)) return rc;
     const int wpw = e->rows_wpb / 4;                                   // windows per wave
     const int64_t waves = p.rows_by_agent ? ceil_div(p.E, wpw) * (agent_end - agent_begin) : ceil_div(p.E * (agent_end - agent_begin), wpw);
-    hipLaunchKernelGGL(e->obs_rows_fn, dim3((unsigned)ceil_div(waves, 4)), dim3(kBlock), e->rows_lds, s, p, rp);
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_kernel(e, e->k_obs_rows, (unsigned)ceil_div(waves, 4), kBlock, e->rows_lds, s, p, &rp)) return rc;
     return time_end(e, s);
 }
 
@@ -1416,7 +1633,7 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     if (!e || !buf || capacity < 1) return fail(SGW_EINVAL, "sgw_launch_info: NULL argument");
     // what a whole-batch, whole-turn sgw_step with 16-byte-aligned observations launches: the kernel, the LDS bytes it
     // REQUESTS (a workgroup-per-CU cap is part of that request) and the workgroups per CU the runtime then admits
-    const bool walk = e->step_fn_walk && e->base.E > e->walk_min_envs && e->base.E <= e->walk_max_envs;
+    const bool walk = e->k_walk.usable() && e->base.E > e->walk_min_envs && e->base.E <= e->walk_max_envs;
     Params p = e->base;
     p.a0 = 0; p.a1 = p.A; p.flags = SGW_STEP_SWEEP | SGW_STEP_RANDOM_ACTIONS; p.do_move = 1;
     p.obs = reinterpret_cast<float*>(16); p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
@@ -1426,18 +1643,21 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     const bool big_staged = e->big && !walk && e->base.E > e->big_stage_min_envs;
     if (e->big && !big_staged) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
     const int threads = e->big ? e->big_threads : kBlock;
-    StepFn fn = walk ? e->step_fn_walk : e->step_fn;
+    Kernel& k = walk ? e->k_walk : e->k_step;
+    if (walk) (void)resolve_kernel(e, k);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
-    const char* phase = e->rows_fn ? e->kernel_name_rows : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
-    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d",
-             walk ? e->kernel_name_walk : e->kernel_name,
+    hipError_t oe = k.jit ? hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.jit, threads, lds)
+                          : (k.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.host, threads, lds) : hipErrorInvalidValue);
+    if (oe != hipSuccess) per_cu = -1;
+    const char* phase = e->k_rows.usable() ? e->k_rows.name() : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
+    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d specialised=%d",
+             k.name(),
              (e->fast || e->big) ? (e->big ? e->big_threads : e->wpe * kWave) : e->group,
              threads, lds, e->step_env_lds, e->obs_stage, e->stage_agents,
              walk ? e->walk_blocks : e->grid_blocks, per_cu,
-             e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase, big_staged ? e->big_stage : 0);
+             e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase, big_staged ? e->big_stage : 0,
+             k.jit ? 1 : 0);
     return SGW_OK;
 }
 
 }  // extern "C"
-

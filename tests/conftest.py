@@ -24,3 +24,14 @@ def built():
             if not os.path.isfile(lib):
                 raise
     return g
+
+
+@pytest.fixture(autouse=True)
+def _sgw_options_back_to_defaults():
+    """Dispatcher options a test sets (``N.set_option`` -- sgw_set_option with a NULL engine) are process-wide: every test
+    starts and ends on the defaults."""
+    yield
+    from sorrel_amd import _native as N
+
+    if N._lib is not None:
+        N.set_option(None)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from tests import helpers as H
+from sorrel_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 
@@ -195,14 +196,14 @@ def test_tag_rule_batch_vs_oracle(torch_cuda):
                                   "c5_small_dense", "basic_doublewall", "cleanup_15x16", "tag_11x11_default", "cleanup_21x31_default"])
 def test_generic_kernel_matches_reference_golden(torch_cuda, name, monkeypatch):
     """The fallback kernel (any shape, every rule) on fixtures the specialised kernels would take."""
-    monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    N.set_option("force_generic", 1)
     test_hip_matches_reference_golden(torch_cuda, name)
 
 
 def test_generic_kernel_batches_vs_oracle(torch_cuda, monkeypatch):
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    N.set_option("force_generic", 1)
     rollout_vs_oracle(treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.01, seed=3), 1000, 5)                       # wave per env
     rollout_vs_oracle(treasurehunt_spec(96, 80, 40, 4, spawn_prob=0.05, seed=4, dense_prob=0.2), 30, 4)        # workgroup per env
     d, spec = H.load_golden("tag_9x9")
@@ -229,7 +230,7 @@ def test_workgroup_per_env_generic_kernel_ticket_order(torch_cuda, case, monkeyp
     import dataclasses
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+    N.set_option("force_generic", 1)
     kw = {}
     grid0 = pos0 = None
     if case.startswith("tag"):
@@ -315,7 +316,7 @@ def test_workgroup_per_env_generic_kernel_ticket_order(torch_cuda, case, monkeyp
                                   "cleanup_13x12_r2", "cleanup_21x31_default"])
 def test_packed_kernels_match_reference_golden(torch_cuda, name, group, monkeypatch):
     """Two / four envs per wave (step_kernel<32> / <16>): every fixture small enough, bit for bit."""
-    monkeypatch.setenv("SGW_GROUP", group)
+    N.set_option("group", int(group))
     test_hip_matches_reference_golden(torch_cuda, name)
 
 
@@ -326,7 +327,7 @@ def test_packed_kernels_batches_vs_oracle(torch_cuda, group, monkeypatch):
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_GROUP", group)
+    N.set_option("group", int(group))
     for (h, w, a, r, E) in ((21, 21, 2, 2, 1003), (10, 10, 2, 2, 517), (16, 16, 4, 2, 64), (13, 9, 5, 4, 77), (32, 32, 8, 3, 130)):
         eng, co = rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=31, dense_prob=0.1), E, 5, first=11)
         assert "step_kernel<" in eng.launch_info() and f"group={group} " in eng.launch_info()
@@ -392,7 +393,7 @@ def test_compact_uint8_observations(torch_cuda, shape, monkeypatch):
     h, w, a, r, E = shape
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=77, dense_prob=0.2)
     for force_generic in ("0", "1"):
-        monkeypatch.setenv("SGW_FORCE_GENERIC", force_generic)
+        N.set_option("force_generic", int(force_generic))
         f32, u8 = make_engine(ws, E), make_engine(ws, E, obs_dtype=torch.uint8)
         f32.reset(0)
         u8.reset(0)
@@ -442,7 +443,7 @@ def test_big_kernel_walking_workgroups_vs_oracle(torch_cuda, monkeypatch, blocks
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_BIG_WALK_BLOCKS", blocks)
+    N.set_option("big_walk_blocks", int(blocks))
     if variant == "config5_shape":
         ws = treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=21, dense_prob=0.25)
     elif variant == "float_appearance":
@@ -533,9 +534,9 @@ def test_random_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     rng = np.random.default_rng(1000 + case)
     ws = _random_world(rng)
     if case % 3 and ws.num_agents <= 16 and ws.layers * ws.height * ws.width <= 4096:     # two thirds of the small cases: packed kernels
-        monkeypatch.setenv("SGW_GROUP", "16" if case % 3 == 1 else "32")
+        N.set_option("group", 16 if case % 3 == 1 else 32)
     if case % 2:          # half of the cases: worlds that reach step_big take its walking-workgroups instance, 1 / 2 / 5 workgroups
-        monkeypatch.setenv("SGW_BIG_WALK_BLOCKS", str((1, 2, 5)[case % 3]))
+        N.set_option("big_walk_blocks", (1, 2, 5)[case % 3])
     rollout_vs_oracle(ws, int(rng.integers(3, 40)), int(rng.integers(2, 7)), first=int(rng.integers(0, 2**31)),
                       epoch=int(rng.integers(0, 50)))
 
@@ -546,12 +547,12 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     beams / facing / all-layer reward) from random maps: every tensor against the C oracle every turn."""
     import torch
     if case % 4 == 3:       # a quarter of the cases on the generic kernel (the wave-per-env RULES variant takes the rest)
-        monkeypatch.setenv("SGW_NO_FAST_RULES", "1")
+        N.set_option("fast_rules", 0)
     rng = np.random.default_rng(7000 + case)
     ws, g, pos = H.random_rule_world(rng)
     if ws.agent_rule == 0 and case % 4 == 1:  # plain movers: the policy-driven phases on the byte-gather phase_kernel; the other
-        monkeypatch.setenv("SGW_PHASE_ROWS", "0")        # cases take the row-load phase kernel wherever an instance exists
-        monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0")
+        N.set_option("phase_rows", 0)        # cases take the row-load phase kernel wherever an instance exists
+        N.set_option("phase_kernel", 1)
     E, T = int(rng.integers(2, 30)), int(rng.integers(3, 12))
     first = int(rng.integers(0, 2**31))
     eng = make_engine(ws, E, first=first)
@@ -647,10 +648,10 @@ def test_policy_phase_stepping_equals_fused(torch_cuda, shape, phase_kernel, mon
     from sorrel_amd.spec import treasurehunt_spec
 
     if phase_kernel == "rows":
-        monkeypatch.setenv("SGW_PHASE_ROWS", "1")
+        N.set_option("phase_rows", 1)
     else:
-        monkeypatch.setenv("SGW_PHASE_ROWS", "0")
-        monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "0" if phase_kernel == "1" else "1")
+        N.set_option("phase_rows", 0)
+        N.set_option("phase_kernel", 1 if phase_kernel == "1" else 0)
     h, w, a_, r_, E = shape
     ws = treasurehunt_spec(h, w, a_, r_, spawn_prob=0.05, seed=6, dense_prob=0.1)
     fused, phased = make_engine(ws, E), make_engine(ws, E)
@@ -754,7 +755,7 @@ def test_garbage_positions_are_flagged_and_memory_safe(torch_cuda, shape, monkey
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.01, seed=4)
     for force_generic in (False, True):
         if force_generic:
-            monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+            N.set_option("force_generic", 1)
         eng = make_engine(ws, E)
         co = H.COracle(ws, E)
         eng.reset(0)
@@ -899,7 +900,7 @@ def test_packed_kernels_edge_shapes(torch_cuda, group, monkeypatch):
     one env and of 64 / G + 1 envs (one group of the last wave), general float appearance."""
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_GROUP", group)
+    N.set_option("group", int(group))
     G = int(group)
     rollout_vs_oracle(treasurehunt_spec(12, 12, G, 2, spawn_prob=0.1, seed=1, dense_prob=0.2), 37, 5)          # A == G
     rollout_vs_oracle(treasurehunt_spec(27, 23, 3, 11, spawn_prob=0.05, seed=2), 19, 4)                          # 23x23 window: 529 cells

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from tests import helpers as H
+from sorrel_amd import _native as N
 from oracle import gridstep_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +49,7 @@ KERNEL_CASES = [
     ("fast_runtime_21", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=12), {}, 50),
     ("fast_tag", lambda: _tag_spec(11, 11, 5, 4), {}, 40),
     ("big_64", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(64, 64, 12, 4, spawn_prob=0.05, seed=13, dense_prob=0.2), {}, 9),
-    ("generic", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(18, 14, 4, 3, spawn_prob=0.05, seed=14), {"SGW_FORCE_GENERIC": "1"}, 21),
+    ("generic", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(18, 14, 4, 3, spawn_prob=0.05, seed=14), {"force_generic": 1}, 21),
 ]
 
 
@@ -61,11 +62,11 @@ def test_obs_next_phased_turn_equals_fused(torch_cuda, case, phase_kernel, monke
     torch = torch_cuda
     _, mk, env, E = case
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        N.set_option(k, v)
     if phase_kernel != "phase_rows":           # (round 3's row-load phase kernel is the default where an instance exists)
-        monkeypatch.setenv("SGW_PHASE_ROWS", "0")
+        N.set_option("phase_rows", 0)
     if phase_kernel == "staging_kernels":      # the phases on the step kernels themselves (what Tag / Cleanup phases always use)
-        monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "1")
+        N.set_option("phase_kernel", 0)
     ws = mk()
     A = ws.num_agents
     fused, phased = make_engine(ws, E, first=5), make_engine(ws, E, first=5)
@@ -128,7 +129,7 @@ def test_obs_next_on_the_rules_kernel(torch_cuda):
 
 
 @pytest.mark.parametrize("shape", [(32, 32, 8, 3, 33, {}), (21, 21, 2, 2, 20, {}), (64, 64, 10, 4, 5, {}),
-                                   (12, 10, 3, 2, 9, {"SGW_FORCE_GENERIC": "1"})],
+                                   (12, 10, 3, 2, 9, {"force_generic": 1})],
                          ids=["fast_static", "fast_runtime", "big", "generic"])
 def test_auto_reset_rolls_across_epoch_boundaries_vs_oracle(torch_cuda, shape, monkeypatch):
     """sgw_set_auto_reset: the step that completes turn max_turns also keeps the returns and resets every env for
@@ -139,7 +140,7 @@ def test_auto_reset_rolls_across_epoch_boundaries_vs_oracle(torch_cuda, shape, m
 
     h, w, a, r, E, env = shape
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        N.set_option(k, v)
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=21, dense_prob=0.1)
     eng = make_engine(ws, E, first=3)
     co = H.COracle(ws, E, first_env_id=3)
@@ -405,12 +406,12 @@ ROLLOUT_CASES = [
     ("fast_static_c3", (32, 32, 8, 3, 70), {}),
     ("fast_static_c2", (16, 16, 4, 2, 33), {}),
     ("fast_runtime_stage", (24, 24, 4, 3, 50), {}),
-    ("fast_runtime_plain", (24, 24, 4, 3, 50), {"SGW_NO_STAGE": "1"}),
-    ("packed_16", (21, 21, 2, 2, 133), {"SGW_GROUP": "16"}),
-    ("packed_32", (13, 9, 5, 4, 90), {"SGW_GROUP": "32"}),
-    ("generic_64", (18, 14, 4, 3, 21), {"SGW_FORCE_GENERIC": "1"}),
+    ("fast_runtime_plain", (24, 24, 4, 3, 50), {"stage": 0}),
+    ("packed_16", (21, 21, 2, 2, 133), {"group": 16}),
+    ("packed_32", (13, 9, 5, 4, 90), {"group": 32}),
+    ("generic_64", (18, 14, 4, 3, 21), {"force_generic": 1}),
     ("big", (64, 64, 10, 4, 7), {}),
-    ("generic_256", (64, 64, 10, 4, 5), {"SGW_FORCE_GENERIC": "1"}),
+    ("generic_256", (64, 64, 10, 4, 5), {"force_generic": 1}),
 ]
 
 
@@ -424,7 +425,7 @@ def test_rollout_equals_turn_by_turn_steps(torch_cuda, case, monkeypatch):
 
     _, (h, w, a, r, E), env = case
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        N.set_option(k, v)
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=41, dense_prob=0.1)
     one, many = make_engine(ws, E, first=17), make_engine(ws, E, first=17)
     co = H.COracle(ws, E, first_env_id=17)
@@ -481,9 +482,9 @@ def test_rollout_compact_uint8_ring(torch_cuda, monkeypatch):
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    for env in ({}, {"SGW_GROUP": "16"}):
+    for env in ({}, {"group": 16}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            N.set_option(k, v)
         ws = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=5)
         e8, e32 = make_engine(ws, 100, obs_dtype=torch.uint8), make_engine(ws, 100)
         for e in (e8, e32):
@@ -505,7 +506,7 @@ def test_rollout_on_the_widened_rule_sets(torch_cuda, which, monkeypatch):
     if which.startswith("cleanup"):
         ws, d = _cleanup_spec()
         if which == "cleanup_generic":
-            monkeypatch.setenv("SGW_NO_FAST_RULES", "1")
+            N.set_option("fast_rules", 0)
         E = 40
         one, many = make_engine(ws, E), make_engine(ws, E)
         g0 = torch.from_numpy(np.broadcast_to(d["grid0"][0], (E,) + d["grid0"][0].shape).copy())
@@ -517,7 +518,7 @@ def test_rollout_on_the_widened_rule_sets(torch_cuda, which, monkeypatch):
     else:
         ws = _tag_spec(11, 11, 5, 4)
         if which == "tag_packed":
-            monkeypatch.setenv("SGW_GROUP", "32")
+            N.set_option("group", 32)
         E = 90
         one, many = make_engine(ws, E, first=3), make_engine(ws, E, first=3)
         for e in (one, many):
@@ -547,11 +548,11 @@ def test_rollout_soak_random_worlds(torch_cuda, case, monkeypatch):
     ws, g, pos = H.random_rule_world(rng)
     pick = case % 4
     if pick == 1 and ws.num_agents <= 16 and (ws.agent_rule != 2 or 3 * ws.beam_radius <= 16):
-        monkeypatch.setenv("SGW_GROUP", "16")
+        N.set_option("group", 16)
     elif pick == 2 and ws.num_agents <= 32 and (ws.agent_rule != 2 or 3 * ws.beam_radius <= 32):
-        monkeypatch.setenv("SGW_GROUP", "32")
+        N.set_option("group", 32)
     elif pick == 3:
-        monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+        N.set_option("force_generic", 1)
     E, T = int(rng.integers(2, 40)), int(rng.integers(2, 9))
     first = int(rng.integers(0, 2**31))
     one, many = make_engine(ws, E, first=first), make_engine(ws, E, first=first)
@@ -577,7 +578,7 @@ def test_rollout_soak_random_worlds(torch_cuda, case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [("fast_static", (32, 32, 8, 3, 40), {}), ("fast_stage", (24, 24, 4, 3, 30), {}), ("big", (64, 64, 10, 4, 5), {}),
-                                  ("packed", (21, 21, 2, 2, 60), {"SGW_GROUP": "16"}), ("generic", (18, 14, 4, 3, 21), {"SGW_FORCE_GENERIC": "1"})],
+                                  ("packed", (21, 21, 2, 2, 60), {"group": 16}), ("generic", (18, 14, 4, 3, 21), {"force_generic": 1})],
                          ids=lambda c: c[0])
 def test_rollout_without_a_sweep_writes_every_turns_moves_back(torch_cuda, case, monkeypatch):
     """A world in which nothing transitions (spawn_prob = 0: the library drops the sweep flag) takes the sparse write-back
@@ -588,7 +589,7 @@ def test_rollout_without_a_sweep_writes_every_turns_moves_back(torch_cuda, case,
 
     _, (h, w, a, r, E), env = case
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        N.set_option(k, v)
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.0, seed=3, dense_prob=0.3)
     one, many = make_engine(ws, E), make_engine(ws, E)
     co = H.COracle(ws, E)
@@ -616,11 +617,11 @@ def test_obs_next_packed_destination_equals_the_tensor_slot(torch_cuda, case, mo
 
     kw = {}
     if not case.startswith("rows_"):           # the older phase paths; rows_*: the row-load phase kernel (the default)
-        monkeypatch.setenv("SGW_PHASE_ROWS", "0")
+        N.set_option("phase_rows", 0)
     if case in ("fast_32x32", "rows_32x32"):
         ws, E = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.05, seed=3, dense_prob=0.2), 70
     elif case == "packed_21x21":
-        monkeypatch.setenv("SGW_GROUP", "16")
+        N.set_option("group", 16)
         ws, E = treasurehunt_spec(21, 21, 3, 2, spawn_prob=0.05, seed=4, dense_prob=0.2), 203
     elif case == "rules_cleanup":
         d, spec = H.load_golden("cleanup_15x16")
@@ -630,9 +631,9 @@ def test_obs_next_packed_destination_equals_the_tensor_slot(torch_cuda, case, mo
         kw["obs_dtype"] = torch.uint8
     else:
         if case == "step_big_128":
-            monkeypatch.setenv("SGW_NO_PHASE_KERNEL", "1")
+            N.set_option("phase_kernel", 0)
         if case == "generic_256_128":
-            monkeypatch.setenv("SGW_FORCE_GENERIC", "1")
+            N.set_option("force_generic", 1)
         ws, E = treasurehunt_spec(128, 128, 24, 5, spawn_prob=0.05, seed=5, dense_prob=0.25), 9
     A = ws.num_agents
     a, b = make_engine(ws, E, first=5, **kw), make_engine(ws, E, first=5, **kw)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from tests import helpers as H
+from sorrel_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 
@@ -336,9 +337,9 @@ def test_observe_rows_emit_modes(torch_cuda, mode, monkeypatch):
     destinations allows; every form writes the same windows and nothing else."""
     torch = torch_cuda
     if mode == "pairs":
-        monkeypatch.setenv("SGW_ROWS_MODE", "2")
+        N.set_option("rows_mode", 2)
     if mode == "singles":
-        monkeypatch.setenv("SGW_ROWS_MODE", "1")
+        N.set_option("rows_mode", 1)
     for (h, w, layers, channels, a_, r_, E) in [(32, 32, 2, 6, 8, 3, 77), (16, 16, 2, 6, 4, 2, 201), (9, 13, 1, 3, 5, 1, 50), (40, 36, 2, 8, 3, 5, 13)]:
         ws = _move_world(h, w, layers, channels, a_, r_, seed=3)
         A = ws.num_agents
@@ -735,7 +736,7 @@ def test_layered_rule_worlds_up_to_8k_per_env_vs_oracle(torch_cuda, monkeypatch,
                   "become_if_movers_50x52": (50, 52, 9, 3), "phased_40x48": (40, 48, 6, 3), "rollout_40x48": (40, 48, 8, 3),
                   "cleanup_56x64_11k": (56, 64, 10, 4), "become_if_movers_ragged_59x61_11k": (59, 61, 9, 3)}[case]
     if case.endswith("_11k"):      # up to 11 KiB per env from 16 384 envs on; the hook takes the path for a batch a test can check
-        monkeypatch.setenv("SGW_RULES_11K", "1")
+        N.set_option("rules_11k", 1)
     ws = dataclasses.replace(ws, height=h, width=w, num_agents=a, agent_type=[ws.agent_type[0]] * a, beam_radius=R)
     if case.startswith("become_if_movers"):      # the same layered rule tables with MovingAgent.act agents
         ws = dataclasses.replace(ws, agent_rule=0, action_kind=[0] * len(ws.action_dy))
@@ -804,7 +805,7 @@ def test_big_kernel_staged_windows_vs_oracle(torch_cuda, monkeypatch, case):
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_BIG_STAGE", "1")
+    N.set_option("big_stage", 1)
     kw = {}
     h, w, a, E, T = {"config5_shape": (128, 128, 64, 5, 4), "crowded_48x48": (48, 48, 64, 21, 8), "odd_70x90": (70, 90, 13, 11, 6),
                      "u8": (64, 80, 17, 6, 5), "phased": (80, 64, 7, 5, 5), "rollout": (72, 72, 9, 6, 6),
@@ -870,7 +871,7 @@ def test_static_radius_instances_on_runtime_maps_vs_oracle(torch_cuda, monkeypat
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_GROUP", "64")
+    N.set_option("group", 64)
     h, w, a, r = shape
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.06, seed=41, dense_prob=0.15)
     E, T = 37, 9
@@ -904,8 +905,8 @@ def test_staged_bursts_carry_partial_lines_vs_oracle(torch_cuda, monkeypatch, ca
     multiple of 8 / 4 bytes -- in both observation formats, then the ordinary burst sizes; every element against the C oracle."""
     torch = torch_cuda
     h, w, L, C, a, r, burst = case
-    monkeypatch.setenv("SGW_GROUP", "64")
-    monkeypatch.setenv("SGW_STAGE_AGENTS", str(burst))
+    N.set_option("group", 64)
+    N.set_option("stage_agents", burst)
     ws = _move_world(h, w, L, C, a, r, seed=5)
     for dtype in (torch.float32, torch.uint8):
         E, T = 99, 4
@@ -935,7 +936,7 @@ def test_mid_size_worlds_on_the_wave_per_env_kernel_vs_oracle(torch_cuda, monkey
     import dataclasses
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_FAST_8K", "1")
+    N.set_option("fast_8k", 1)
     kw = {}
     tag = case.startswith("tag")
     if tag:
@@ -1020,7 +1021,7 @@ def test_big_kernel_four_or_eight_waves_vs_oracle(torch_cuda, monkeypatch, case,
     import dataclasses
     from sorrel_amd.spec import treasurehunt_spec
 
-    monkeypatch.setenv("SGW_BIG_THREADS_RT", threads)
+    N.set_option("big_threads", int(threads))
     tag = case.startswith("tag")
     if tag:
         d, spec = H.load_golden("tag_11x11_default")
@@ -1034,10 +1035,10 @@ def test_big_kernel_four_or_eight_waves_vs_oracle(torch_cuda, monkeypatch, case,
                       "staged_100x100_A8_r5": (100, 100, 8, 5), "walking_96x96_A12": (96, 96, 12, 4)}[case]
         ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.05, seed=61, dense_prob=0.3 if "crowded" in case else 0.1)
     if case.startswith("staged"):
-        monkeypatch.setenv("SGW_BIG_STAGE", "1")
+        N.set_option("big_stage", 1)
     if case.startswith("walking"):
-        monkeypatch.setenv("SGW_BIG_WALK_BLOCKS", "3")
-    monkeypatch.setenv("SGW_FAST_8K", "0")      # (the 4-8 KiB cases stay on this kernel)
+        N.set_option("big_walk_blocks", 3)
+    N.set_option("fast_8k", 0)      # (the 4-8 KiB cases stay on this kernel)
     E, T = 10, 6
     eng, co = make_engine(ws, E, first=6), H.COracle(ws, E, first_env_id=6)
     info = eng.launch_info()
@@ -1072,7 +1073,7 @@ def test_rgb_integer_tables_on_the_byte_staging_pipeline_vs_oracle(torch_cuda, m
     torch = torch_cuda
     import dataclasses
 
-    monkeypatch.setenv("SGW_GROUP", "64")
+    N.set_option("group", 64)
     d, spec = H.load_golden("rgb_treasurehunt")
     ws = H.world_spec(spec)
     E, T = 45, 6
@@ -1084,7 +1085,7 @@ def test_rgb_integer_tables_on_the_byte_staging_pipeline_vs_oracle(torch_cuda, m
     elif case == "th_ragged_23x29_r4":
         ws = dataclasses.replace(ws, height=23, width=29, num_agents=5, vision_radius=4, agent_type=[ws.agent_type[0]] * 5)
     elif case == "th_60x60_8k":          # 7 200 bytes per env: the second round of the grid copy (large batches; forced here)
-        monkeypatch.setenv("SGW_FAST_8K", "1")
+        N.set_option("fast_8k", 1)
         ws = dataclasses.replace(ws, height=60, width=60, num_agents=9, vision_radius=3, agent_type=[ws.agent_type[0]] * 9)
         E = 19
     elif case == "three_layers":

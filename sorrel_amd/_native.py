@@ -201,7 +201,7 @@ def load():
     _lib = lib
     # tools pass dispatcher options to child processes as SGW_OPTIONS="key=value,key=value": read HERE, by the Python
     # tooling -- the library itself reads no environment variable except SGW_DEBUG
-    for item in filter(None, os.environ.get("SGW_OPTIONS", "").split(",")):
+    for item in filter(None, os.environ.get("SGW_OPTIONS", "").replace(";", ",").split(",")):
         key, _, value = item.partition("=")
         set_option(key.strip(), value.strip())
     return lib

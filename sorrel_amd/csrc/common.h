@@ -239,10 +239,11 @@ __device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
 // per dword that holds a spawner, thresholds and choices from scalar registers instead of per-byte table reads.
 template <int G>
 __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn,
-                                             uint32_t* through = nullptr) {   // through: the env's grid in global memory -- changed dwords go there too
+                                             uint32_t* through = nullptr,    // through: the env's grid in global memory -- changed dwords go there too
+                                             const int d0 = 0) {             // first dword swept (step_fast: the tail behind the rounds its register sweep covers)
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
     const int ndw = (p.cells + 3) >> 2;
-    for (int d = gtid; d < ndw; d += G) {
+    for (int d = d0 + gtid; d < ndw; d += G) {
         const uint32_t m = match_bytes(g32[d], p.spawn_pat);
         if (m == 0) continue;
         const U4 w = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);

@@ -690,7 +690,7 @@ int plan_engine(sgw_engine* e, bool jit) {
         const size_t per_wave = (size_t)e->fast_tab_bytes + p.cells_pad + ((ob_elems + 15) & ~15);
         fixed_shape = o.burst == 1 || per_wave * 4 + 1024 <= kLdsPerCu / 7;
     }
-    if (o.burst == 2 && jit) fixed_shape = false;
+    if (jit && (o.burst == 2 || o.stage_agents >= 0 || o.stage_bytes >= 0)) fixed_shape = false;   // (a forced burst size asks for the chunked emit)
     {   // LDS staging of one-hot observations
         const int per_agent = c.num_channels * p.VV;
         e->obs_stage = 0;

@@ -142,6 +142,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     const int cells = kStatic ? TL * TH * TW : p.cells;
     const int nunits = (cells + 15) >> 4;   // the last unit may be partly padding (env stride is a multiple of 16)
     constexpr int NU = kStatic ? ((TL * TH * TW + 15) / 16 + 63) / 64 : kMaxUnits;   // units per lane (RULES: the first round)
+    // compile-time shapes: rounds of the register sweep in which every lane holds a unit, and whether the partly filled round behind
+    // them is swept as dwords on the LDS copy instead (it is when that takes fewer Philox blocks than the round's four)
+    constexpr int kFullRounds = kStatic ? ((TL * TH * TW + 15) / 16) / 64 : 0;
+    constexpr int kTailUnits = kStatic ? ((TL * TH * TW + 15) / 16) % 64 : 0;
+    constexpr bool kTailDword = kStatic && !RULES && kTailUnits > 0 && kTailUnits <= 48;
     const int zoff = p.zA * HW;
     static_assert(!I16 || (ONEHOT && !P3 && !RULES && !(TL && TH && TW)), "I16: a byte-staging instance with run-time map");
     constexpr int NW = P3 ? 1 : I16 ? 2 : (TC ? (TC + 3) / 4 : 4);   // counter words
@@ -330,13 +335,20 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
 #pragma unroll
             for (int k = 0; k < NU; ++k) {
                 hits[k] = 0;
-                if (lane + 64 * k < nunits && do_sweep) hits[k] = sweep_hits<kOwnKeys>(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
+                if ((k < kFullRounds || !kTailDword) && lane + 64 * k < nunits && do_sweep)
+                    hits[k] = sweep_hits<kOwnKeys>(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
             }
             gsync<1>();
             if (do_sweep) {
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
                     if (lane + 64 * k < nunits) sweep_apply<kOwnKeys>(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn);
+                // the last, partly filled round of units (a 24x24x2 map: 72 units = one full round + 8) as DWORDS on the LDS copy: a
+                // wave pays a round's four Philox blocks whether 8 or 64 of its lanes hold a unit, the dword rounds of the same cells
+                // cost ceil(tail dwords / 64) blocks (24x24x2: 8 -> 5 blocks per turn, 32x33x2: 12 -> 9)
+                if constexpr (kTailDword)
+                    sweep_single<64>(p, lg, env_id, lane, turn, sweep_only ? reinterpret_cast<uint32_t*>(p.grid + env * p.env_stride) : nullptr,
+                                     256 * kFullRounds);
                 gsync<1>();
             }
         }

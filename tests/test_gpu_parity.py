@@ -104,8 +104,23 @@ def test_hip_from_injected_state_matches_golden(torch_cuda):
 
 
 # ------------------------------------------------------------------ (2) HIP vs C oracle, seeded, bigger
-def rollout_vs_oracle(ws, E, T, first=0, epoch=0, check_every=1):
+def assert_instance(eng, jit):
+    """With specialised instances on, what launches is the instance compiled for THIS engine (its template-id carries the
+    engine's own layers / channels / radius / map) unless the library holds exactly that instance; with them off, a prebuilt one."""
+    info = eng.launch_info()
+    if not jit:
+        assert "specialised=0" in info, info
+        return
+    plan = N.plan(eng.config)
+    name = info.split(" group=")[0]
+    # (a refused compile would launch the prebuilt twin, whose template-id differs from the one the plan asks for)
+    assert plan["specialised"] == 1 and name in (plan["kernel"], plan["kernel_walk"]), (info, plan["kernel"], plan["kernel_walk"])
+
+
+def rollout_vs_oracle(ws, E, T, first=0, epoch=0, check_every=1, jit=None):
     eng = make_engine(ws, E, first=first)
+    if jit is not None:
+        assert_instance(eng, jit)
     co = H.COracle(ws, E, first_env_id=first)
     eng.reset(epoch=epoch)
     co.reset(epoch)
@@ -363,8 +378,10 @@ def test_dispatch_rule_packs_small_worlds_of_large_batches(torch_cuda):
 
     ws = treasurehunt_spec(21, 21, 2, 2, spawn_prob=0.02, seed=77)
     big = make_engine(ws, 65536, first=100)
-    assert "step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>" in big.launch_info() and "group=16 " in big.launch_info()   # the static 5x5 window
-    assert "step_kernel<G, true, 2, 6> group=16 " in make_engine(treasurehunt_spec(21, 21, 2, 1), 65536).launch_info()                  # another radius: run-time shape
+    assert "step_kernel<16, true, 2, 6, 0, 2, 21, 21>" in big.launch_info() and "group=16 " in big.launch_info()   # specialised for this map and window
+    with N.options(jit=0):      # the prebuilt instances: the example's static 5x5 window; another radius: run-time shape
+        assert "step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2> group=16 " in make_engine(ws, 65536).launch_info()
+        assert "step_kernel<G, true, 2, 6> group=16 " in make_engine(treasurehunt_spec(21, 21, 2, 1), 65536).launch_info()
     assert "step_fast" in make_engine(ws, 512).launch_info()
     assert "step_fast<true, 2, 6, 3, 32, 32>" in make_engine(treasurehunt_spec(32, 32, 8, 3), 65536).launch_info()
     big.reset(0)
@@ -492,13 +509,16 @@ def test_big_kernel_walking_workgroups_vs_oracle(torch_cuda, monkeypatch, blocks
     assert eng.status() == 0
 
 
+@pytest.mark.parametrize("jit", [1, 0], ids=["specialised", "prebuilt"])
 @pytest.mark.parametrize("shape", [(9, 13, 3, 4), (7, 7, 5, 3), (33, 21, 9, 2), (64, 64, 16, 4), (66, 70, 7, 6), (5, 5, 2, 2)])
-def test_ragged_shapes_vs_oracle(torch_cuda, shape):
-    """Grid byte counts that are not multiples of 16 / 4, odd sizes, maximum radius."""
+def test_ragged_shapes_vs_oracle(torch_cuda, shape, jit):
+    """Grid byte counts that are not multiples of 16 / 4, odd sizes, maximum radius -- on the instance specialised for each
+    shape, and on the library's prebuilt run-time-shape instances."""
     from sorrel_amd.spec import treasurehunt_spec
 
+    N.set_option("jit", jit)
     h, w, a, r = shape
-    rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.08, seed=sum(shape), dense_prob=0.2), 37, 6, first=11, epoch=2)
+    rollout_vs_oracle(treasurehunt_spec(h, w, a, r, spawn_prob=0.08, seed=sum(shape), dense_prob=0.2), 37, 6, first=11, epoch=2, jit=jit)
 
 
 def _random_world(rng):
@@ -527,10 +547,13 @@ def _random_world(rng):
     return ws
 
 
+@pytest.mark.parametrize("jit", [1, 0], ids=["specialised", "prebuilt"])
 @pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "48"))))
-def test_random_worlds_vs_oracle(torch_cuda, case, monkeypatch):
+def test_random_worlds_vs_oracle(torch_cuda, case, jit):
     """Soak: random shapes / agent counts / radii / rates through whichever kernel the dispatcher
-    picks (step_fast, step_big, generic), a few dozen envs, every tensor compared every turn."""
+    picks (step_fast, step_big, generic) -- the instance specialised for each world, and the prebuilt ones -- a few dozen envs,
+    every tensor compared every turn."""
+    N.set_option("jit", jit)
     rng = np.random.default_rng(1000 + case)
     ws = _random_world(rng)
     if case % 3 and ws.num_agents <= 16 and ws.layers * ws.height * ws.width <= 4096:     # two thirds of the small cases: packed kernels
@@ -538,14 +561,17 @@ def test_random_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     if case % 2:          # half of the cases: worlds that reach step_big take its walking-workgroups instance, 1 / 2 / 5 workgroups
         N.set_option("big_walk_blocks", (1, 2, 5)[case % 3])
     rollout_vs_oracle(ws, int(rng.integers(3, 40)), int(rng.integers(2, 7)), first=int(rng.integers(0, 2**31)),
-                      epoch=int(rng.integers(0, 50)))
+                      epoch=int(rng.integers(0, 50)), jit=jit)
 
 
+@pytest.mark.parametrize("jit", [1, 0], ids=["specialised", "prebuilt"])
 @pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "64"))))
-def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
+def test_random_rule_worlds_vs_oracle(torch_cuda, case, jit):
     """Soak for the widened rule set (ordered BECOME_IF sweep across layers, timers, several spawners, Cleanup
-    beams / facing / all-layer reward) from random maps: every tensor against the C oracle every turn."""
+    beams / facing / all-layer reward) from random maps, on the specialised and on the prebuilt instances: every tensor
+    against the C oracle every turn."""
     import torch
+    N.set_option("jit", jit)
     if case % 4 == 3:       # a quarter of the cases on the generic kernel (the wave-per-env RULES variant takes the rest)
         N.set_option("fast_rules", 0)
     rng = np.random.default_rng(7000 + case)
@@ -556,6 +582,7 @@ def test_random_rule_worlds_vs_oracle(torch_cuda, case, monkeypatch):
     E, T = int(rng.integers(2, 30)), int(rng.integers(3, 12))
     first = int(rng.integers(0, 2**31))
     eng = make_engine(ws, E, first=first)
+    assert_instance(eng, jit)
     co = H.COracle(ws, E, first_env_id=first)
     eng.grid.copy_(torch.from_numpy(np.broadcast_to(g, (E,) + g.shape).copy()))
     eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(pos, (E,) + pos.shape).copy()))

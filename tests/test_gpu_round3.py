@@ -456,26 +456,30 @@ def O_full(spec, grid):
 
 
 # ------------------------------------------------------------------ Tag on its compile-time-shape instances
-@pytest.mark.parametrize("shape", [(32, 32, 8, 3, 150, "step_fast<true, 1, 4, 3, 32, 32, true>"),     # wave per env, static 32x32 map
-                                   (32, 32, 8, 3, 65536, "step_fast<true, 1, 4, 3, 32, 32, true>"),   # ... also for big batches (not packed)
-                                   (20, 24, 6, 3, 40000, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>"),     # packed, static 7x7 window
-                                   (32, 32, 20, 3, 90, "step_fast<true, 1, 4, 3, 32, 32, true>"),     # crowded: many tags per turn
-                                   (30, 30, 6, 4, 70000, "step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>"),   # wave per env, 3-bit packed counters (what the rule picks for a full batch)
-                                   (48, 48, 10, 4, 130, "step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>"),
-                                   (17, 61, 21, 5, 77, "step_fast<true, 1, 0, 0, 0, 0, true, false, true, false, true>")],    # ragged, crowded, 11x11 windows
+@pytest.mark.parametrize("jit", [1, 0], ids=["specialised", "prebuilt"])
+@pytest.mark.parametrize("shape", [(32, 32, 8, 3, 150, "step_fast<true, 1, 4, 3, 32, 32, true>", None),     # wave per env, static 32x32 map
+                                   (32, 32, 8, 3, 65536, "step_fast<true, 1, 4, 3, 32, 32, true>", None),   # ... also for big batches (not packed)
+                                   (20, 24, 6, 3, 40000, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>", "step_kernel<32, true, 1, 4, 1, 3, 20, 24>"),     # packed, static 7x7 window
+                                   (32, 32, 20, 3, 90, "step_fast<true, 1, 4, 3, 32, 32, true>", None),     # crowded: many tags per turn
+                                   (30, 30, 6, 4, 70000, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 4, 30, 30, true>"),   # wave per env: 3-bit packed counters prebuilt, the whole-env burst specialised
+                                   (48, 48, 10, 4, 130, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 4, 48, 48, true, false, true, false, true>"),
+                                   (17, 61, 21, 5, 77, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 5, 17, 61, true, false, true, false, true>")],    # ragged, crowded, 11x11 windows
                          ids=["static_32x32", "static_32x32_full_batch", "packed_static_radius", "static_32x32_crowded", "p3_30x30_full_batch",
                               "p3_48x48", "p3_ragged_crowded"])
-def test_tag_static_instances_vs_oracle(torch_cuda, shape):
+def test_tag_static_instances_vs_oracle(torch_cuda, shape, jit):
     """TagAgent.act on the instances round 3 added (only the agent that is "it" looks at its neighbours; compile-time
-    32x32 map on the wave-per-env kernel; compile-time 7x7 window on the packed kernel): every tensor, the agents' types
-    and what they were when they observed, against the C oracle; the 1 + A phased form too."""
+    32x32 map on the wave-per-env kernel; compile-time 7x7 window on the packed kernel) and on the instances specialised for the
+    engine's own map (round 4): every tensor, the agents' types and what they were when they observed, against the C oracle;
+    the 1 + A phased form too."""
     torch = torch_cuda
-    h, w, a_, r_, E, kernel = shape
+    h, w, a_, r_, E, prebuilt, special = shape
+    N.set_option("jit", jit)
+    kernel = (special or prebuilt) if jit else prebuilt
     d, spec = H.load_golden("tag_9x9")
     ws = H.world_spec(spec)
     ws.height, ws.width, ws.num_agents, ws.vision_radius, ws.agent_type = h, w, a_, r_, [ws.agent_type[0]] * a_
     eng = make_engine(ws, E, first=9)
-    assert kernel in eng.launch_info(), eng.launch_info()
+    assert kernel in eng.launch_info() and f"specialised={1 if (jit and special) else 0}" in eng.launch_info(), eng.launch_info()
     Ec = min(E, 400)                                         # the oracle replays the first envs of the batch
     co = H.COracle(ws, Ec, first_env_id=9)
     eng.reset(0)
@@ -865,9 +869,10 @@ def test_big_kernel_staged_windows_vs_oracle(torch_cuda, monkeypatch, case):
 # ------------------------------------------------------------------ compile-time window on a run-time map
 @pytest.mark.parametrize("shape", [(33, 32, 8, 3), (24, 24, 8, 2), (20, 20, 4, 4), (30, 26, 7, 5), (19, 23, 5, 3)])
 def test_static_radius_instances_on_runtime_maps_vs_oracle(torch_cuda, monkeypatch, shape):
-    """Treasurehunt-shaped worlds whose MAP has no compile-time instance run on step_fast<true, 2, 6, r, 0, 0, ..., STAGE> for
-    r = 2 ... 5 (compile-time window, run-time map; ragged maps included: 19x23x2 = 874 cells).  Every tensor against the C
-    oracle, turn by turn, then sgw_observe; SGW_GROUP=64 keeps small worlds off the packed kernel."""
+    """Treasurehunt-shaped worlds whose MAP the library holds no instance for run on the instance specialised for that map
+    (round 3: a compile-time window on a run-time map; round 4: the map too -- whole-env burst where the windows are a multiple
+    of four elements, chunked bursts elsewhere; ragged maps included: 19x23x2 = 874 cells).  Every tensor against the C
+    oracle, turn by turn, then sgw_observe; group = 64 keeps small worlds off the packed kernel."""
     torch = torch_cuda
     from sorrel_amd.spec import treasurehunt_spec
 
@@ -876,7 +881,7 @@ def test_static_radius_instances_on_runtime_maps_vs_oracle(torch_cuda, monkeypat
     ws = treasurehunt_spec(h, w, a, r, spawn_prob=0.06, seed=41, dense_prob=0.15)
     E, T = 37, 9
     eng, co = make_engine(ws, E, first=7), H.COracle(ws, E, first_env_id=7)
-    assert f"step_fast<true, 2, 6, {r}, 0, 0, false, false, true>" in eng.launch_info(), eng.launch_info()
+    assert f"step_fast<true, 2, 6, {r}, {h}, {w}" in eng.launch_info() and "specialised=1" in eng.launch_info(), eng.launch_info()
     eng.reset(0)
     co.reset(0)
     for t in range(1, T + 1):

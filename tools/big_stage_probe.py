@@ -1,5 +1,5 @@
 """Worlds above 4 KiB (step_big): direct per-channel dword stores against LDS-staged, line-aligned 16-byte streaming stores
-(the default where a compile-time instance exists; SGW_BIG_STAGE=0: off), us per turn; every variant's tensors compared with the first one's.  GPU only."""
+(the default where a compile-time instance exists; option big_stage=0: off), us per turn; every variant's tensors compared with the first one's.  GPU only."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -20,10 +20,10 @@ us = timed_us(lambda: eng.step(random_actions=True), 100)
 print("RESULT %%7.1f us  %%s  %%s" %% (us, dig, eng.launch_info().split(" threads")[0] + " " + " ".join(x for x in eng.launch_info().split() if x.startswith(("lds=", "big_stage=")))))
 ''' % (ROOT, ROOT)
 shapes = [(128, 128, 64, 5, 2048), (128, 128, 64, 5, 4096), (128, 128, 64, 5, 8192), (48, 48, 8, 5, 16384), (72, 72, 16, 5, 8192)]
-variants = [{}, {"SGW_BIG_STAGE": "0"}, {"SGW_BIG_NO_PAD": "1"}]
+variants = [{}, {"SGW_OPTIONS": "big_stage=0"}, {"SGW_OPTIONS": "big_pad=0"}]
 if os.environ.get("PROBE_WALK"):   # where does the walking variant pay?
     shapes = [(128, 128, 64, 5, e) for e in (1024, 1280, 1536, 2048, 2560, 3072, 4096)]
-    variants = [{}, {"SGW_BIG_NO_WALK": "1"}, {"SGW_BIG_NO_WALK": "1", "SGW_BIG_STAGE": "0"}]
+    variants = [{}, {"SGW_OPTIONS": "big_walk=0"}, {"SGW_OPTIONS": "big_walk=0,big_stage=0"}]
 for sh in shapes:
     for env in variants:
         out = subprocess.run([sys.executable, "-c", CODE, *map(str, sh)], env={**os.environ, **env}, capture_output=True, text=True)

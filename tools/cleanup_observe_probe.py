@@ -1,5 +1,5 @@
 """Cleanup 21x31x3 (10 agents, 11x11 windows, 9 channels): the window pipeline alone (sgw_observe of every agent: grid
-read, gather, staged bursts) next to the whole turn, per SGW_STAGE_AGENTS.  GPU only."""
+read, gather, staged bursts) next to the whole turn, per stage_agents option (SGW_OPTIONS, read by sorrel_amd._native).  GPU only."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -36,7 +36,7 @@ for sa in sys.argv[1:] or ["3"]:
         if "=" in kv:
             k, v = kv.split("="); env[k] = v
         else:
-            env["SGW_STAGE_AGENTS"] = kv
+            env["SGW_OPTIONS"] = "stage_agents=" + kv
     out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if "observe" in l]
     print(sa, line[-1] if line else out.stderr[-400:], flush=True)

@@ -10,19 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _warm import timed_us
 
 
-def move_world(h, w, layers, channels, a, r, seed=3):
-    T = max(6, min(channels + 1, 12))
-    app = np.zeros((T, channels))
-    for t in range(1, T):
-        app[t, (t * 5 + 1) % channels] = 1.0
-    dy, dx = action_deltas(["up", "down", "left", "right", "stay"])
-    return WorldSpec(height=h, width=w, layers=layers, num_agents=a, vision_radius=r, num_channels=channels, agent_layer=layers - 1,
-                     default_type=0, fill_type=1, action_dy=dy, action_dx=dx, agent_type=[T - 1] * a,
-                     type_value=[0.0, -1.0, 10.0, 5.0, -10.0] + [1.0] * (T - 6) + [0.0],
-                     type_passable=[1, 0, 1, 1, 1] + [1] * (T - 6) + [0], type_rule=[1] + [0] * (T - 1),
-                     spawn_prob=[0.005] + [0.0] * (T - 1), spawn_choices=[[2, 3, 4]] + [[] for _ in range(T - 1)],
-                     appearance=app, seed=seed, layer_fill_type=[0] * layers, layer_border_type=[1] * layers)
-
+from generic_tables_probe_worlds import move_world
 
 E = 65536
 SMALL = (("10x10x2 C5 A2 r2", move_world(10, 10, 2, 5, 2, 2)), ("16x16x2 C8 A4 r2", move_world(16, 16, 2, 8, 4, 2)), ("21x21x2 C8 A2 r2", move_world(21, 21, 2, 8, 2, 2)),

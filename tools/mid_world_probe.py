@@ -1,5 +1,5 @@
-"""Plain and Tag worlds between 4 and 8 KiB per env: the workgroup-per-env kernel (SGW_FAST_8K=0) against a wave per env
-(SGW_FAST_8K=1) per batch size -- the data behind the batch threshold in sgw_create.  GPU only."""
+"""Plain and Tag worlds between 4 and 8 KiB per env: the workgroup-per-env kernel (option fast_8k=0) against a wave per env
+(fast_8k=1) per batch size -- the data behind the batch threshold in sgw_create.  GPU only."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -22,7 +22,7 @@ for sh in SHAPES:
     for E in (2048, 4096, 8192, 16384, 65536):
         row = []
         for v in ("0", "1"):
-            out = subprocess.run([sys.executable, "-c", CODE, *map(str, sh), str(E)], env={**os.environ, "SGW_FAST_8K": v}, capture_output=True, text=True)
+            out = subprocess.run([sys.executable, "-c", CODE, *map(str, sh), str(E)], env={**os.environ, "SGW_OPTIONS": "fast_8k=" + v}, capture_output=True, text=True)
             l = [x for x in out.stdout.splitlines() if x.startswith("RESULT")]
             row.append(l[-1][7:] if l else out.stderr[-200:])
         print(sh, E, "| workgroup per env:", row[0].split("  step_")[0], "| wave per env:", row[1], flush=True)

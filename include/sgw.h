@@ -389,6 +389,44 @@ typedef struct sgw_plan_info {
 } sgw_plan_info;
 int sgw_set_option(sgw_engine* eng, const char* key, const char* value);
 int sgw_plan(const sgw_config* cfg, int32_t num_cus, int64_t lds_per_workgroup, sgw_plan_info* out);
+/* ---- A whole policy turn as ONE submission (round 4) ---------------------------------------------------------------
+ * Agent.transition is pov -> get_action -> act, agent after agent (sorrel/agents/agent.py:155-173): 1 + A engine launches
+ * with the policies' forward passes in between.  Three things change from turn to turn and used to arrive as kernel
+ * arguments -- Environment.turn, the epoch, and the rows of the agents' replay rings (sorrel/buffers.py:46-63) -- so a turn
+ * could not be recorded once and replayed.  They now live in device memory that the engine advances itself:
+ *   sgw_turn_bind(rows)        (blocking, rare) the agents' replay rings: base pointers, capacity, the row the NEXT turn
+ *                              fills, rows per turn (agents that share one Buffer advance it together); NULL: no replay rows
+ *   sgw_turn_set(epoch, turn)  (stream-ordered) the turn the engine has counted up to: Environment.reset -> (epoch, 0)
+ *   sgw_turn_begin(...)        turn += 1 on the device, then sweep + EVERY agent's window into `obs` [E][A][C][V][V]
+ *                              (= sgw_step(0, A, SGW_STEP_SWEEP | SGW_STEP_NO_MOVE) at the device's turn)
+ *   sgw_turn_act(agent, ...)   = sgw_act with the windows in their slots of `obs` (the later agents' windows are repaired
+ *                              there); reward and int64 action also go to the agent's ring row of the turn in flight
+ *   sgw_turn_end(obs)          the windows of the turn -> each agent's ring row (what Agent.add_memory would copy), then
+ *                              every ring advances
+ * Every call is asynchronous on `stream` and takes the same arguments every turn, so begin + A x (policy forward,
+ * sgw_turn_act) + end can be captured in a hipGraph (torch.cuda.graph) and replayed without the host in the loop;
+ * `obs` is the tensor the policies read -- a fixed address, which is what a recorded graph needs -- and the copy into the
+ * ring rows is the price (one read + one write of the windows per turn).  sgw_turn_state reads the device's count back
+ * (synchronising; tests and resynchronisation of the host's counters). */
+typedef struct sgw_turn_rows {
+    void* states[SGW_MAX_AGENTS];      /* device [capacity][E][row_elems], element type = sgw_set_obs_format's; NULL: windows not kept */
+    float* rewards[SGW_MAX_AGENTS];    /* device [capacity][E]; may be NULL */
+    int64_t* actions[SGW_MAX_AGENTS];  /* device [capacity][E]; may be NULL */
+    float* dones[SGW_MAX_AGENTS];      /* device [capacity][E], zeroed for the turn's row; NULL when the ring's dones are all zero already */
+    int64_t capacity[SGW_MAX_AGENTS];  /* rows of the ring; 0: this agent keeps no replay rows */
+    int64_t row[SGW_MAX_AGENTS];       /* the row the next turn fills (Buffer.idx, + k for the k-th agent sharing the Buffer) */
+    int64_t step[SGW_MAX_AGENTS];      /* rows the ring advances per turn (how many agents share the Buffer) */
+    int64_t row_elems[SGW_MAX_AGENTS]; /* elements per env of a states row, >= C*V*V */
+} sgw_turn_rows;
+int sgw_turn_bind(sgw_engine* eng, const sgw_turn_rows* rows);
+int sgw_turn_set(sgw_engine* eng, uint32_t epoch, uint32_t turn, void* stream);
+int sgw_turn_begin(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs, float* rewards,
+                   double* total_reward, uint32_t flags, void* stream);
+int sgw_turn_act(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* obs, float* rewards,
+                 double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream);
+int sgw_turn_end(sgw_engine* eng, const void* obs, void* stream);
+int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* stream);
+
 /* out6 = { instances compiled, loaded from the disk cache, reused in memory, refused, ms spent compiling, ms spent loading }
  * of this process so far. */
 int sgw_jit_stats(double* out6);

@@ -87,6 +87,17 @@ class SgwPlan(C.Structure):
         return out
 
 
+class SgwTurnRows(C.Structure):
+    """Mirror of ``struct sgw_turn_rows`` (include/sgw.h): the agents' replay rings for ``sgw_turn_bind``."""
+
+    _fields_ = [
+        ("states", C.c_void_p * MAX_AGENTS), ("rewards", C.c_void_p * MAX_AGENTS), ("actions", C.c_void_p * MAX_AGENTS),
+        ("dones", C.c_void_p * MAX_AGENTS),
+        ("capacity", C.c_int64 * MAX_AGENTS), ("row", C.c_int64 * MAX_AGENTS), ("step", C.c_int64 * MAX_AGENTS),
+        ("row_elems", C.c_int64 * MAX_AGENTS),
+    ]
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGW_LIB") or os.path.join(_HERE, "csrc", "libsgw.so")   # SGW_LIB: diagnostic builds (tools/)
 
@@ -97,6 +108,7 @@ EXPORTS = (
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
     "sgw_set_option", "sgw_plan", "sgw_jit_stats",
+    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state",
     "sgw_last_error", "sgw_version",
 )
 
@@ -194,6 +206,18 @@ def load():
     lib.sgw_plan.restype = C.c_int
     lib.sgw_jit_stats.argtypes = [C.POINTER(C.c_double)]
     lib.sgw_jit_stats.restype = C.c_int
+    lib.sgw_turn_bind.argtypes = [vp, C.POINTER(SgwTurnRows)]
+    lib.sgw_turn_bind.restype = C.c_int
+    lib.sgw_turn_set.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    lib.sgw_turn_set.restype = C.c_int
+    lib.sgw_turn_begin.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, f64p, C.c_uint32, vp]
+    lib.sgw_turn_begin.restype = C.c_int
+    lib.sgw_turn_act.argtypes = [vp, u8p, u8p, u8p, vp, f32p, f64p, C.c_int32, vp, C.c_int32, vp]
+    lib.sgw_turn_act.restype = C.c_int
+    lib.sgw_turn_end.argtypes = [vp, vp, vp]
+    lib.sgw_turn_end.restype = C.c_int
+    lib.sgw_turn_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), vp]
+    lib.sgw_turn_state.restype = C.c_int
     lib.sgw_last_error.argtypes = []
     lib.sgw_last_error.restype = C.c_char_p
     lib.sgw_version.argtypes = []

@@ -33,7 +33,10 @@ class Buffer:
         self.idx = 0
         self.size = 0
         self._prefilled = None        # (row, data_ptr of the action tensor): sgw_act already wrote that action into actions[row]
-        self._dones_dirty = False     # a non-zero `done` was ever stored: until then the dones rows are all zero already
+        self._dones_dirty = False     # some dones row may be non-zero (a done was stored, or rows were copied / loaded in): until then
+                                      # the rows are all zero already and add(done=False) has nothing to write
+        self._deferred = False        # a captured policy turn is being recorded / replayed: the engine's own kernels fill the row
+        self._deferred_adds = 0       # (device-side row count, sgw_turn_end) -- add() only keeps the host's idx / size in step
         self.extra_data = {}
         for key, value in extra.items():
             shape = (capacity, E, *value) if isinstance(value, tuple) else (capacity, E)
@@ -44,6 +47,11 @@ class Buffer:
         Whatever the kernels have already written where it belongs is not copied again: the state (a window rendered
         straight into this row), the reward (``sgw_act``'s ``reward_row``) and the action (``sgw_act``'s ``action_row``,
         announced through ``_prefilled``)."""
+        if self._deferred:
+            self._deferred_adds += 1
+            self.idx = (self.idx + 1) % self.capacity
+            self.size = min(self.size + 1, self.capacity)
+            return
         i = self.idx
         row = self.states[i]
         src = obs.reshape(row.shape)
@@ -81,6 +89,7 @@ class Buffer:
                 self.extra_data[key] = torch.zeros((self.capacity, *value.shape[1:]), dtype=value.dtype, device=self.device)
             self.extra_data[key][lo:hi].copy_(value[:n])
         self.idx = hi
+        self._dones_dirty = True      # (the copied rows may hold terminal flags: later add(done=False) must clear them)
 
     # -- files: the reference's ``Buffer.save`` / ``Buffer.load`` format (``sorrel/buffers.py:168-201``)
     def _file_arrays(self) -> dict:
@@ -130,6 +139,7 @@ class Buffer:
             out.extra_data[k] = fold(arrays[k], out.extra_data[k])
         out.idx = idx if E == 1 else idx // E
         out.size = rows
+        out._dones_dirty = True       # loaded rows may hold terminal flags
         return out
 
     def __len__(self):
@@ -146,6 +156,7 @@ class Buffer:
         for t in (self.states, self.actions, self.rewards, self.dones, *self.extra_data.values()):
             t.zero_()
         self.idx = self.size = 0
+        self._dones_dirty = False
 
     def getidx(self):
         return self.idx
@@ -202,6 +213,7 @@ class SavedGames(Buffer):
                 self.extra_data[key][lo:hi].copy_(value[:n])
         self.idx = hi
         self.size = min(self.size + n, self.capacity)
+        self._dones_dirty = True
 
 
 class TurnBuffer:

@@ -37,6 +37,22 @@ constexpr int kTabFastBytes = offsetof(DevTables, appearance);
 static_assert(kTabFastBytes % 16 == 0, "LDS table block must keep 16-byte alignment");
 static_assert(sizeof(DevTables) % 16 == 0, "LDS table block must keep 16-byte alignment");
 
+// What changes from turn to turn of a policy-driven loop, kept in device memory and advanced by the engine's own kernels
+// (sgw_turn_begin / sgw_turn_end) instead of arriving as kernel arguments: Environment.turn and the epoch, and for every agent
+// the row of its replay ring that this turn's window / action / reward go to (sorrel/buffers.py:46-63: Buffer.add's idx).
+struct TurnState {
+    uint32_t epoch, turn;
+    uint32_t pad_[2];
+    int64_t row[SGW_MAX_AGENTS];          // ring row of the turn in flight
+    int64_t cap[SGW_MAX_AGENTS];          // rows in that agent's ring (0: the agent keeps no replay rows)
+    int64_t step[SGW_MAX_AGENTS];         // rows the ring advances per turn (agents sharing one Buffer: how many share it)
+    void* states[SGW_MAX_AGENTS];         // [cap][E][row_elems] of the observation format
+    float* rewards[SGW_MAX_AGENTS];       // [cap][E]
+    int64_t* actions[SGW_MAX_AGENTS];     // [cap][E]
+    float* dones[SGW_MAX_AGENTS];         // [cap][E]: zeroed for the turn's row (done is False inside an epoch); NULL: rows are all zero already
+    int64_t row_elems[SGW_MAX_AGENTS];    // elements per env of a states row (>= C*V*V; the tail is the caller's)
+};
+
 struct Params {
     int H, W, L, A, r, V, VV, C, T, nact, zA;
     int cells;      // L*H*W bytes of one env's grid
@@ -101,6 +117,9 @@ struct Params {
     int rows_mode;        // phase_rows / observe_rows: how the staged windows leave (kRowsFlat / kRowsPair / kRowsSingle, phase.h)
     int rows_by_agent;    // observe_rows: a wave carries consecutive envs of ONE agent (per-agent destinations) instead of consecutive agents of an env
     int onehot;           // every appearance row is a one-hot (or zero) vector and there is no post-processing: byte counters apply
+    // Device-side turn state (sgw_turn_*): when set, the kernels take epoch and turn from here instead of the two fields above, so
+    // that a launch recorded once (a hipGraph of a whole policy turn) plays the turn the engine has counted up to
+    const TurnState* ts;
     // sgw_rollout: `nturns` whole turns in ONE launch (the env's grid stays in LDS from turn to turn); turn t of the call
     // writes its observations / actions / rewards `t * ts_*` elements further on (0 = every turn overwrites the same tensors)
     uint32_t nturns;
@@ -238,7 +257,7 @@ __device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
 // At most one spawning type (every Treasurehunt-shaped world): byte-parallel match of the spawner id, one Philox block
 // per dword that holds a spawner, thresholds and choices from scalar registers instead of per-byte table reads.
 template <int G>
-__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn,
+__device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid, uint32_t env_id, int gtid, uint32_t turn, const uint32_t ep4,
                                              uint32_t* through = nullptr,    // through: the env's grid in global memory -- changed dwords go there too
                                              const int d0 = 0) {             // first dword swept (step_fast: the tail behind the rounds its register sweep covers)
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
@@ -246,7 +265,7 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
     for (int d = d0 + gtid; d < ndw; d += G) {
         const uint32_t m = match_bytes(g32[d], p.spawn_pat);
         if (m == 0) continue;
-        const U4 w = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+        const U4 w = philox4x32_10((uint32_t)d, turn, env_id, ep4 | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
         const bool f = p.spawn_full != 0;
         uint32_t hits = 0;
         hits |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
@@ -254,7 +273,7 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
         hits |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
         hits |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
         if (hits == 0) continue;
-        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
             if ((hits >> b) & 1u) {
@@ -269,10 +288,10 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
 // its byte offset in the [L][H][W] slice, so one LDS dword == one Philox block.
 template <int G>
 __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uint8_t* lds_grid,
-                                      uint32_t env_id, int gtid, uint32_t turn) {
+                                      uint32_t env_id, int gtid, uint32_t turn, const uint32_t ep4) {
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
     const int ndw = (p.cells + 3) >> 2;
-    const uint32_t c3 = (p.epoch << 4) | SGW_STREAM_SPAWN;
+    const uint32_t c3 = ep4 | SGW_STREAM_SPAWN;
     for (int d = gtid; d < ndw; d += G) {
         uint32_t v = g32[d];
         uint32_t m = 0;
@@ -294,7 +313,7 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
             }
         }
         if (hits == 0) continue;
-        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+        const U4 k = philox4x32_10((uint32_t)d, turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND,
                                    p.seed_lo, p.seed_hi);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -319,7 +338,7 @@ __device__ __forceinline__ void sweep(const Params& p, const DevTables* tab, uin
 // (Round 3: the generic kernels walked this byte by byte with a Philox block per CELL; Cleanup 48x48x3: 30 of 101 us.)
 template <int WPE, int G, typename Tab>
 __device__ __forceinline__ void sweep_ordered(const Params& p, const Tab* rt, uint8_t* lg, const uint32_t env_id, const int gtid,
-                                              const uint32_t turn, const int L, const int HW) {
+                                              const uint32_t turn, const uint32_t ep4, const int L, const int HW) {
     const uint32_t* lg32 = reinterpret_cast<const uint32_t*>(lg);
     for (int z = 0; z < L; ++z) {
         const int lo = z * HW, hi = lo + HW;
@@ -339,13 +358,13 @@ __device__ __forceinline__ void sweep_ordered(const Params& p, const Tab* rt, ui
                 any_sp = any_sp || spj[j];
             }
             if (any_sp) {
-                const U4 w = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+                const U4 w = philox4x32_10(opaque((uint32_t)d), turn, env_id, ep4 | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
                 uint32_t hit = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (spj[j] && (((p.thr_full_mask >> tj[j]) & 1u) || word_of(w, j) < rt->thr_lo[tj[j]])) hit |= 1u << j;
                 if (hit) {   // rare: what spawns
-                    const U4 kw = philox4x32_10(opaque((uint32_t)d), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+                    const U4 kw = philox4x32_10(opaque((uint32_t)d), turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if ((hit >> j) & 1u)

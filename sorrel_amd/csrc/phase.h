@@ -205,6 +205,7 @@ struct RowPtrs {
     int action_kind;            // SGW_ACT_U8 / _I32 / _I64
     float* reward_row;          // [E]: a second copy of the rewards (the row of the agent's replay buffer)
     int64_t* action_row;        // [E]: the actions as int64 (the row of the agent's replay buffer)
+    const TurnState* ts;        // sgw_turn_act: reward_row / action_row are the acting agent's ring rows of the turn the engine has counted up to
 };
 
 __device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* q) {
@@ -596,6 +597,12 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
     const int H = p.H, W = p.W, HW = H * W, C = p.C, V = p.V, VV = p.VV, r = p.r, L = p.L, a = p.a0;
     uint8_t* g = p.grid + env * p.env_stride;
     const bool writer = live && j == 0;
+    float* reward_row = rp.reward_row;
+    int64_t* action_row = rp.action_row;
+    if (rp.ts && rp.ts->cap[a] > 0) {        // the replay rows of the turn in flight, by the engine's own count
+        if (rp.ts->rewards[a]) reward_row = rp.ts->rewards[a] + rp.ts->row[a] * p.E;
+        if (rp.ts->actions[a]) action_row = rp.ts->actions[a] + rp.ts->row[a] * p.E;
+    }
     uint32_t pjv[NJ];                                                        // where this lane's agents stand (0xFFFFFFFF: no such agent)
 #pragma unroll
     for (int n = 0; n < NJ; ++n) {
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
 
     if constexpr (RULE == SGW_AGENT_RULE_MOVE) {
         MoveOut mo;
-        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, rp.reward_row, rp.action_row});
+        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, reward_row, action_row});
         if (st && writer) atomicOr(p.status, st);
         if (mo.old_y < 0) return;
         patch(mo.old_y, mo.old_x, p.zA, mo.left, p.default_type);
@@ -820,8 +827,8 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
             p.rewards[env * p.A + a] = (float)reward;
             p.total[env] = (tot + total_add) + reward;               // float64, in the reference's order of additions
             if (rp.agent_action) p.actions[env * p.A + a] = (uint8_t)act;
-            if (rp.reward_row) rp.reward_row[env] = (float)reward;
-            if (rp.action_row) rp.action_row[env] = act_raw;
+            if (reward_row) reward_row[env] = (float)reward;
+            if (action_row) action_row[env] = act_raw;
             if (st) atomicOr(p.status, st);
         }
         if (RULE == SGW_AGENT_RULE_TAG && vy >= 0 && live) {

@@ -109,6 +109,9 @@ struct sgw_engine {
     uint8_t* d_tmpl = nullptr;   // fill + border image of one env (reset)
     int* d_status = nullptr;
     double* d_part = nullptr;
+    TurnState* d_turn = nullptr;   // device-side turn state (sgw_turn_*): a whole policy turn as one capturable submission
+    bool turn_rows = false;        // sgw_turn_bind gave replay rows
+    bool turn_rows_even = false;   // ... all of them 8-byte aligned with an even row stride (float2 copies)
     int obs_format = SGW_OBS_F32;
     uint8_t* agent_state = nullptr;    // caller-owned, bound with sgw_bind_agent_state
     uint8_t* state_at_pov = nullptr;
@@ -1149,6 +1152,8 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (err == hipSuccess) err = hipMalloc(&e->d_status, 4 * sizeof(int));
     if (err == hipSuccess) err = hipMemset(e->d_status, 0, 4 * sizeof(int));
     if (err == hipSuccess) err = hipMalloc(&e->d_part, 2 * kRedBlocks * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&e->d_turn, sizeof(TurnState));
+    if (err == hipSuccess) err = hipMemset(e->d_turn, 0, sizeof(TurnState));
     if (err != hipSuccess) {
         sgw_destroy(e);
         return fail(SGW_EHIP, "device allocation failed: %s", hipGetErrorString(err));
@@ -1183,6 +1188,7 @@ void sgw_destroy(sgw_engine* e) {
     if (e->d_tmpl) (void)hipFree(e->d_tmpl);
     if (e->d_status) (void)hipFree(e->d_status);
     if (e->d_part) (void)hipFree(e->d_part);
+    if (e->d_turn) (void)hipFree(e->d_turn);
     delete e;
 }
 
@@ -1470,9 +1476,9 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
     return time_end(e, s);
 }
 
-int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
-            float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
-            float* reward_row, int64_t* action_row, void* stream) {
+static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
+                    float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
+                    float* reward_row, int64_t* action_row, const TurnState* ts, void* stream) {
     if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_act: NULL argument");
     if (agent < 0 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_act: agent %d out of range", agent);
     if (e->cfg.agent_rule == SGW_AGENT_RULE_TAG && !e->agent_state) return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
@@ -1484,6 +1490,7 @@ int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, 
     if (agent_action && action_kind != SGW_ACT_U8 && action_kind != SGW_ACT_I32 && action_kind != SGW_ACT_I64)
         return fail(SGW_EINVAL, "sgw_act: unknown action_kind %d", action_kind);
     rp.agent_action = agent_action; rp.action_kind = action_kind; rp.reward_row = reward_row; rp.action_row = action_row;
+    rp.ts = ts;
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.rewards = rewards; p.total = total_reward;
     p.a0 = agent; p.a1 = agent + 1; p.flags = SGW_STEP_NO_OBS; p.do_move = 1;
@@ -1503,6 +1510,116 @@ int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, 
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, s, p, rp);
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
+}
+
+int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
+            float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
+            float* reward_row, int64_t* action_row, void* stream) {
+    return act_impl(e, grid, agent_pos, actions, rows, env_stride, rewards, total_reward, agent, agent_action, action_kind, reward_row,
+                    action_row, nullptr, stream);
+}
+
+// ---- a whole policy turn as ONE submission (include/sgw.h: sgw_turn_*)
+int sgw_turn_bind(sgw_engine* e, const sgw_turn_rows* rows) {
+    if (!e) return fail(SGW_EINVAL, "sgw_turn_bind: NULL engine");
+    TurnState h;
+    HIP_TRY(hipMemcpy(&h, e->d_turn, sizeof(h), hipMemcpyDeviceToHost));   // (epoch and turn stay)
+    const int A = e->cfg.num_agents;
+    const int64_t N = (int64_t)e->base.C * e->base.VV;
+    for (int a = 0; a < SGW_MAX_AGENTS; ++a) {
+        h.row[a] = h.cap[a] = h.step[a] = h.row_elems[a] = 0;
+        h.states[a] = nullptr; h.rewards[a] = nullptr; h.actions[a] = nullptr; h.dones[a] = nullptr;
+    }
+    e->turn_rows = false;
+    if (rows) {
+        for (int a = 0; a < A; ++a) {
+            if (rows->capacity[a] <= 0) continue;
+            if (rows->row[a] < 0 || rows->row[a] >= rows->capacity[a] || rows->step[a] < 1)
+                return fail(SGW_EINVAL, "sgw_turn_bind: agent %d: row must be in [0, capacity) and step >= 1", a);
+            if (rows->states[a] && rows->row_elems[a] < N) return fail(SGW_EINVAL, "sgw_turn_bind: agent %d: row_elems is smaller than one window", a);
+            const int esz = e->obs_format == SGW_OBS_U8 ? 1 : 4;
+            if (rows->states[a] && (reinterpret_cast<uintptr_t>(rows->states[a]) % esz)) return fail(SGW_EINVAL, "sgw_turn_bind: agent %d: states is misaligned", a);
+            h.row[a] = rows->row[a]; h.cap[a] = rows->capacity[a]; h.step[a] = rows->step[a]; h.row_elems[a] = rows->row_elems[a];
+            h.states[a] = rows->states[a]; h.rewards[a] = rows->rewards[a]; h.actions[a] = rows->actions[a];
+            h.dones[a] = rows->states[a] ? rows->dones[a] : nullptr;   // (zeroed by the window copy)
+            if (!e->turn_rows) e->turn_rows_even = true;
+            e->turn_rows = true;
+            if (rows->states[a] && ((reinterpret_cast<uintptr_t>(rows->states[a]) & 7) || (rows->row_elems[a] & 1))) e->turn_rows_even = false;
+        }
+    }
+    HIP_TRY(hipMemcpy(e->d_turn, &h, sizeof(h), hipMemcpyHostToDevice));
+    return SGW_OK;
+}
+
+int sgw_turn_set(sgw_engine* e, uint32_t epoch, uint32_t turn, void* stream) {
+    if (!e) return fail(SGW_EINVAL, "sgw_turn_set: NULL engine");
+    if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+    hipLaunchKernelGGL(turn_set_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), e->d_turn, epoch, turn);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_turn_begin(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* obs, float* rewards, double* total_reward,
+                   uint32_t flags, void* stream) {
+    if (!e || !grid || !agent_pos || !actions || !obs || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_turn_begin: NULL argument");
+    if (flags & ~(SGW_STEP_SWEEP)) return fail(SGW_EINVAL, "sgw_turn_begin: only SGW_STEP_SWEEP may be set");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(turn_begin_kernel, dim3(1), dim3(64), 0, s, e->d_turn);
+    HIP_TRY(hipGetLastError());
+    Params p = e->base;
+    p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
+    p.ts = e->d_turn;
+    p.a0 = 0; p.a1 = e->cfg.num_agents; p.flags = flags; p.do_move = 0;
+    return launch_step(e, p, s);
+}
+
+int sgw_turn_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* obs, float* rewards, double* total_reward,
+                 int32_t agent, const void* agent_action, int32_t action_kind, void* stream) {
+    if (!e || !obs) return fail(SGW_EINVAL, "sgw_turn_act: NULL argument");
+    const int A = e->cfg.num_agents;
+    const int64_t N = (int64_t)e->base.C * e->base.VV;
+    const int esz = e->obs_format == SGW_OBS_U8 ? 1 : 4;
+    void* rows[SGW_MAX_AGENTS];
+    for (int a = 0; a < A; ++a) rows[a] = static_cast<uint8_t*>(obs) + (int64_t)a * N * esz;   // slot a of the [E][A][C][V][V] tensor
+    return act_impl(e, grid, agent_pos, actions, rows, (int64_t)A * N, rewards, total_reward, agent, agent_action, action_kind, nullptr, nullptr,
+                    e->d_turn, stream);
+}
+
+int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {
+    if (!e) return fail(SGW_EINVAL, "sgw_turn_end: NULL engine");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!e->turn_rows) return SGW_OK;
+    const int A = e->cfg.num_agents;
+    const int N = e->base.C * e->base.VV;
+    if (obs) {   // this turn's windows -> the agents' replay rows
+        // widest copy unit every row allows: the window size, the row strides and the base addresses decide (checked at bind time
+        // for the element size; here for 8 / 16 bytes)
+        const int64_t total = (int64_t)e->cfg.num_envs * A * N;
+        const int blocks = (int)std::min<int64_t>(ceil_div(total / 2 + 1, kBlock), (int64_t)e->num_cus * 16);
+        const bool even = (N & 1) == 0 && e->turn_rows_even && (reinterpret_cast<uintptr_t>(obs) & 7) == 0;
+        if (e->obs_format == SGW_OBS_U8) {
+            hipLaunchKernelGGL((turn_commit_kernel<uint8_t, 1>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, static_cast<const uint8_t*>(obs), (int64_t)e->cfg.num_envs, A, N);
+        } else if (even) {
+            hipLaunchKernelGGL((turn_commit_kernel<float, 2>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, static_cast<const float*>(obs), (int64_t)e->cfg.num_envs, A, N);
+        } else {
+            hipLaunchKernelGGL((turn_commit_kernel<float, 1>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, static_cast<const float*>(obs), (int64_t)e->cfg.num_envs, A, N);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(turn_advance_kernel, dim3(1), dim3(64), 0, s, e->d_turn, A);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_turn_state(sgw_engine* e, uint32_t* epoch_turn, int64_t* rows, void* stream) {
+    if (!e || !epoch_turn) return fail(SGW_EINVAL, "sgw_turn_state: NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TurnState h;
+    HIP_TRY(hipMemcpyAsync(&h, e->d_turn, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    epoch_turn[0] = h.epoch; epoch_turn[1] = h.turn;
+    if (rows) for (int a = 0; a < e->cfg.num_agents; ++a) rows[a] = h.row[a];
+    return SGW_OK;
 }
 
 int sgw_set_obs_format(sgw_engine* e, int format) {

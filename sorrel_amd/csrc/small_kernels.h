@@ -200,3 +200,33 @@ __global__ __launch_bounds__(kBlock) void observe_full_kernel(const Params p, vo
         }
     }
 }
+
+// ---------------------------------------------------------------- device-side turn state (sgw_turn_*)
+__global__ void turn_set_kernel(TurnState* ts, const uint32_t epoch, const uint32_t turn) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ts->epoch = epoch; ts->turn = turn; }
+}
+__global__ void turn_begin_kernel(TurnState* ts) {      // Environment.take_turn: self.turn += 1 (sorrel/environment.py:87)
+    if (threadIdx.x == 0 && blockIdx.x == 0) ts->turn += 1u;
+}
+__global__ void turn_advance_kernel(TurnState* ts, const int A) {   // Buffer.add: idx = (idx + 1) % capacity, once per agent sharing the ring
+    const int a = threadIdx.x;
+    if (blockIdx.x == 0 && a < A && ts->cap[a] > 0) ts->row[a] = (ts->row[a] + ts->step[a]) % ts->cap[a];
+}
+// The windows of the turn (the [E][A][N] tensor the policies read) into each agent's replay row of the turn in flight
+// (Agent.add_memory -> Buffer.add, sorrel/agents/agent.py:127-130, sorrel/buffers.py:46-63).  VEC elements per thread and step.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void turn_commit_kernel(const TurnState* __restrict__ ts, const T* __restrict__ obs, const int64_t E, const int A, const int N) {
+    struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+    const int NV = N / VEC;
+    const int64_t total = E * A * (int64_t)NV;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t win = i / NV;
+        const int k = (int)(i - win * NV);
+        const int64_t e = win / A;
+        const int a = (int)(win - e * A);
+        if (ts->cap[a] <= 0 || !ts->states[a]) continue;
+        if (k == 0 && ts->dones[a]) ts->dones[a][ts->row[a] * E + e] = 0.f;
+        T* dst = static_cast<T*>(ts->states[a]) + (ts->row[a] * E + e) * ts->row_elems[a];
+        reinterpret_cast<Pack*>(dst)[k] = reinterpret_cast<const Pack*>(obs + win * N)[k];
+    }
+}

@@ -119,6 +119,8 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
     const bool do_sweep = (p.flags & SGW_STEP_SWEEP) != 0;
     const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
     const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
+    uint32_t turn0 = p.turn, ep4 = p.epoch << 4;     // kernel arguments, or (sgw_turn_*) the engine's device-side count
+    if (p.ts) { turn0 = p.ts->turn; ep4 = p.ts->epoch << 4; }
 
     // ---- tables -> LDS
     if constexpr (ONEHOT) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
         else tot = p.total[env];
     }
     for (uint32_t tix = 0; tix < nturns; ++tix) {
-    const uint32_t turn = p.turn + tix;
+    const uint32_t turn = turn0 + tix;
     // ---- grid -> LDS (first turn), sweep on the registers, 4 units per thread per round
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.grid + env * p.env_stride);
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
                 hits[k] = 0;
                 if (idx < nunits) {
                     if (!(MULTI && tix > 0)) lg16[lunit(idx)] = u[k];
-                    if (do_sweep) hits[k] = sweep_hits<kBigOwnKeys>(u[k], (uint32_t)idx, p, env_id, turn);
+                    if (do_sweep) hits[k] = sweep_hits<kBigOwnKeys>(u[k], (uint32_t)idx, p, env_id, turn, ep4);
                 }
             }
             if (do_sweep) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
                         h2 = k == 2 ? cleared : h2;
                         h3 = k == 3 ? cleared : h3;
                         const uint32_t off = (uint32_t)(base + k * kBT + tid) * 16u + cell;
-                        const U4 kw = philox4x32_10<kBigOwnKeys>(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND,
+                        const U4 kw = philox4x32_10<kBigOwnKeys>(opaque(off >> 2), turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND,
                                                    p.seed_lo, p.seed_hi);
                         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
                         lg[lbyte(off)] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
             if (p.do_move && mine) {
                 uint32_t act;
                 if (rnd) {
-                    const U4 w = philox4x32_10<kBigOwnKeys>(opaque((uint32_t)tid >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                    const U4 w = philox4x32_10<kBigOwnKeys>(opaque((uint32_t)tid >> 2), turn, env_id, ep4 | SGW_STREAM_ACTION,
                                                p.seed_lo, p.seed_hi);
                     act = __umulhi(word_of(w, tid & 3), (uint32_t)p.nact);
                     p.actions[tix * p.ts_act + env * p.A + tid] = (uint8_t)act;

@@ -30,14 +30,14 @@ constexpr size_t kCacheResidentGrid = (size_t)288 << 20;   // on-die capacity: 2
 
 // Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
 template <bool OWN_KEYS>
-__device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id, const uint32_t turn) {
+__device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id, const uint32_t turn, const uint32_t ep4) {
     uint32_t hits = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t dv = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
         const uint32_t m = match_bytes(dv, p.spawn_pat);
         if (m) {
-            const U4 w = philox4x32_10<OWN_KEYS>(opaque(unit * 4 + k), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
+            const U4 w = philox4x32_10<OWN_KEYS>(opaque(unit * 4 + k), turn, env_id, ep4 | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
             const bool f = p.spawn_full != 0;
             uint32_t hb = 0;
             hb |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
@@ -53,12 +53,12 @@ __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t un
 // Rare second draw: what spawns in each hit cell; written straight into the LDS grid.
 template <bool OWN_KEYS>
 __device__ __forceinline__ void sweep_apply(uint32_t hits, const uint32_t unit, uint8_t* lg, const Params& p,
-                                            const uint32_t env_id, const uint32_t turn) {
+                                            const uint32_t env_id, const uint32_t turn, const uint32_t ep4) {
     while (hits) {
         const uint32_t cell = (uint32_t)__ffs(hits) - 1u;
         hits &= hits - 1u;
         const uint32_t off = unit * 16u + cell;   // byte offset == RNG index
-        const U4 kw = philox4x32_10<OWN_KEYS>(opaque(off >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+        const U4 kw = philox4x32_10<OWN_KEYS>(opaque(off >> 2), turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
         const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
         lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
     }
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     uint8_t* wl = smem + sub * p.env_lds;
     const DevTables* gtab = p.tab;
     const uint32_t env_id = p.first_env + (uint32_t)env;
+    uint32_t turn0 = p.turn, ep4 = p.epoch << 4;     // Environment.turn and the epoch: kernel arguments, or (sgw_turn_*) the engine's device-side count
+    if (p.ts) { turn0 = p.ts->turn; ep4 = p.ts->epoch << 4; }
 
     // ---- issue every global load of this env first
     uint4 u[NU];
@@ -308,12 +310,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         uint32_t taddr_v = 0xFFFFFFFFu, oaddr_v = 0, npos = 0, rew_bits = 0, moved = 0;   // per turn; the write-back reads the last turn's
         const uint32_t nturns = MULTI ? p.nturns : 1u;
         for (uint32_t tix = 0; tix < nturns; ++tix) {
-        const uint32_t turn = p.turn + tix;
+        const uint32_t turn = turn0 + tix;
         if constexpr (RULES) {
             gsync<1>();
             if (do_sweep) {
                 // Ordered sweep in LDS (common.h): layer by layer, lower layers first, a dword (four cells, one Philox block) per lane
-                sweep_ordered<1, 64>(p, rt, lg, env_id, lane, turn, L, HW);
+                sweep_ordered<1, 64>(p, rt, lg, env_id, lane, turn, ep4, L, HW);
             }
         } else if constexpr (!kStatic) {
             // run-time shapes: one dword per lane and round on the LDS copy.  The unit-per-lane form below leaves a last
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
             // skips the blocks of a round only when NO lane of it holds a spawner -- dword rounds are 4x finer on both counts
             gsync<1>();
             if (do_sweep) {
-                sweep_single<64>(p, lg, env_id, lane, turn,
+                sweep_single<64>(p, lg, env_id, lane, turn, ep4,
                                  sweep_only ? reinterpret_cast<uint32_t*>(p.grid + env * p.env_stride) : nullptr);
                 gsync<1>();
             }
@@ -336,18 +338,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
             for (int k = 0; k < NU; ++k) {
                 hits[k] = 0;
                 if ((k < kFullRounds || !kTailDword) && lane + 64 * k < nunits && do_sweep)
-                    hits[k] = sweep_hits<kOwnKeys>(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn);
+                    hits[k] = sweep_hits<kOwnKeys>(u[k], (uint32_t)(lane + 64 * k), p, env_id, turn, ep4);
             }
             gsync<1>();
             if (do_sweep) {
 #pragma unroll
                 for (int k = 0; k < NU; ++k)
-                    if (lane + 64 * k < nunits) sweep_apply<kOwnKeys>(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn);
+                    if (lane + 64 * k < nunits) sweep_apply<kOwnKeys>(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn, ep4);
                 // the last, partly filled round of units (a 24x24x2 map: 72 units = one full round + 8) as DWORDS on the LDS copy: a
                 // wave pays a round's four Philox blocks whether 8 or 64 of its lanes hold a unit, the dword rounds of the same cells
                 // cost ceil(tail dwords / 64) blocks (24x24x2: 8 -> 5 blocks per turn, 32x33x2: 12 -> 9)
                 if constexpr (kTailDword)
-                    sweep_single<64>(p, lg, env_id, lane, turn, sweep_only ? reinterpret_cast<uint32_t*>(p.grid + env * p.env_stride) : nullptr,
+                    sweep_single<64>(p, lg, env_id, lane, turn, ep4, sweep_only ? reinterpret_cast<uint32_t*>(p.grid + env * p.env_stride) : nullptr,
                                      256 * kFullRounds);
                 gsync<1>();
             }
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
         npos = yx;                               // position if the move succeeds
         if (p.do_move && mine) {
             if (rnd) {
-                const U4 w = philox4x32_10<kOwnKeys>(opaque((uint32_t)lane >> 2), turn, env_id, (p.epoch << 4) | SGW_STREAM_ACTION,
+                const U4 w = philox4x32_10<kOwnKeys>(opaque((uint32_t)lane >> 2), turn, env_id, ep4 | SGW_STREAM_ACTION,
                                            p.seed_lo, p.seed_hi);
                 act = __umulhi(word_of(w, lane & 3), (uint32_t)p.nact);
                 p.actions[tix * p.ts_act + env * p.A + lane] = (uint8_t)act;

@@ -80,6 +80,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     const bool dirty = (p.flags & SGW_STEP_SWEEP) || (p.do_move && p.a1 > p.a0);
     const int zoff = p.zA * H * W;
     const int HW = H * W;
+    uint32_t turn0 = p.turn, ep4 = p.epoch << 4;     // kernel arguments, or (sgw_turn_*) the engine's device-side count
+    if (p.ts) { turn0 = p.ts->turn; ep4 = p.ts->epoch << 4; }
 
     // one env per group and launch (no persistent loop: nothing stays live from one env to the next, and the
     // dispatcher balances the workgroups)
@@ -109,13 +111,13 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         // sgw_rollout: nturns whole turns on the LDS-resident env (nturns == 1: an ordinary sgw_step / sgw_observe)
         const uint32_t nturns = MULTI ? p.nturns : 1u;
         for (uint32_t tix = 0; tix < nturns; ++tix) {
-        const uint32_t turn = p.turn + tix;
+        const uint32_t turn = turn0 + tix;
         if (gtid < p.A && p.do_move && gtid >= p.a0 && gtid < p.a1) {
             uint8_t* acts = p.actions + tix * p.ts_act;
             uint32_t act;
             if (p.flags & SGW_STEP_RANDOM_ACTIONS) {
                 const U4 w = philox4x32_10((uint32_t)gtid >> 2, turn, env_id,
-                                           (p.epoch << 4) | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+                                           ep4 | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
                 act = (uint32_t)(((uint64_t)word_of(w, gtid & 3) * (uint32_t)p.nact) >> 32);
                 acts[env * p.A + gtid] = (uint8_t)act;
             } else {
@@ -128,10 +130,10 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
         gsync<WPE>();
         if (p.flags & SGW_STEP_SWEEP) {
             if (p.has_become) {
-                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid, turn, p.L, HW);
+                sweep_ordered<WPE, G>(p, tab, lg, env_id, gtid, turn, ep4, p.L, HW);
             } else {
-                if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid, turn);
-                else sweep<G>(p, tab, lg, env_id, gtid, turn);
+                if (p.single_spawner) sweep_single<G>(p, lg, env_id, gtid, turn, ep4);
+                else sweep<G>(p, tab, lg, env_id, gtid, turn, ep4);
                 gsync<WPE>();
             }
         }

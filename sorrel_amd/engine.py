@@ -281,6 +281,108 @@ class GridEngine:
             N.check(rc)
         return self.rewards[:, agent] if reward_row is None else reward_row
 
+    # ------------------------------------------------------------------ a whole policy turn as one capturable submission
+    def turn_bind(self, rings=None):
+        """``sgw_turn_bind``: the agents' replay rings -- one ``(states, rewards, actions, dones, row, step)`` per agent (or ``None``
+        for an agent that keeps no replay rows): ``states [capacity, E, >= C*V*V]`` of the engine's observation dtype, ``rewards``
+        float32 / ``actions`` int64 / ``dones`` float32 ``[capacity, E]`` (each may be ``None``; ``dones`` is zeroed for the turn's
+        row), ``row`` = the ring row the NEXT turn fills, ``step`` = rows the ring advances per turn.  ``rings=None`` unbinds.
+        Blocking; not for the inside of a capture."""
+        A, E = self.spec.num_agents, self.num_envs
+        self._turn_rings = None
+        if rings is None:
+            with self._on_device():
+                N.check(self._lib.sgw_turn_bind(self._h, None))
+            return
+        if len(rings) != A:
+            raise ValueError(f"need one ring (or None) per agent ({A}), got {len(rings)}")
+        rows = N.SgwTurnRows()
+        keep = []
+        for a, ring in enumerate(rings):
+            if ring is None:
+                continue
+            states, rewards, actions, dones, row, step = ring
+            cap = None
+            for name, t, dt in (("states", states, self.obs_dtype), ("rewards", rewards, torch.float32), ("actions", actions, torch.int64),
+                                ("dones", dones, torch.float32)):
+                if t is None:
+                    continue
+                if not torch.is_tensor(t) or t.dtype != dt or t.device != self.device or not t.is_contiguous() or t.dim() < 2 or t.shape[1] != E:
+                    raise ValueError(f"rings[{a}].{name} must be a contiguous {dt} tensor [capacity, {E}, ...] on {self.device}")
+                if cap is not None and t.shape[0] != cap:
+                    raise ValueError(f"rings[{a}]: states / rewards / actions disagree on the capacity")
+                cap = int(t.shape[0])
+            if cap is None:
+                continue
+            if states is not None:
+                rows.states[a] = states.data_ptr()
+                rows.row_elems[a] = states[0, 0].numel()
+            if rewards is not None:
+                if rewards[0].numel() != E:
+                    raise ValueError(f"rings[{a}].rewards must be [capacity, {E}]")
+                rows.rewards[a] = rewards.data_ptr()
+            if actions is not None:
+                if actions[0].numel() != E:
+                    raise ValueError(f"rings[{a}].actions must be [capacity, {E}]")
+                rows.actions[a] = actions.data_ptr()
+            if dones is not None:
+                if dones[0].numel() != E:
+                    raise ValueError(f"rings[{a}].dones must be [capacity, {E}]")
+                rows.dones[a] = dones.data_ptr()
+            rows.capacity[a], rows.row[a], rows.step[a] = cap, int(row), int(step)
+            keep.append((states, rewards, actions, dones))
+        self._turn_rings = keep            # (the device state holds raw pointers into these)
+        with self._on_device():
+            N.check(self._lib.sgw_turn_bind(self._h, C.byref(rows)))
+
+    def turn_set(self, epoch: Optional[int] = None, turn: Optional[int] = None):
+        """``sgw_turn_set``: the turn the device has counted up to (stream-ordered; ``Environment.reset`` -> ``(epoch, 0)``)."""
+        with self._on_device():
+            N.check(self._lib.sgw_turn_set(self._h, self.epoch if epoch is None else int(epoch), self.turn if turn is None else int(turn),
+                                           self._stream()))
+
+    def turn_begin(self, sweep: bool = True):
+        """``sgw_turn_begin``: ``turn += 1`` on the device, then the sweep and EVERY agent's window into ``self.obs``."""
+        if self.obs is None:
+            raise ValueError("turn_begin needs the observation tensor (allocate_obs=True)")
+        with self._on_device():
+            rc = self._lib.sgw_turn_begin(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), self.obs.data_ptr(),
+                                          self.rewards.data_ptr(), self.total_reward.data_ptr(), N.STEP_SWEEP if sweep else 0, self._stream())
+        if rc:
+            N.check(rc)
+        return self.obs
+
+    def turn_act(self, agent: int, action: Optional[torch.Tensor] = None):
+        """``sgw_turn_act``: ``act`` of one agent with the windows in ``self.obs``; reward and int64 action also go to the agent's ring
+        row of the turn in flight (by the device's own row count)."""
+        kind = pa = 0
+        if action is not None:
+            kind = self._ACTION_KINDS.get(action.dtype)
+            if kind is None or action.device != self.device or action.numel() != self.num_envs or not action.is_contiguous():
+                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {self.num_envs} elements on {self.device}")
+            pa = action.data_ptr()
+        with self._on_device():
+            rc = self._lib.sgw_turn_act(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), self.obs.data_ptr(),
+                                        self.rewards.data_ptr(), self.total_reward.data_ptr(), int(agent), pa or None, kind, self._stream())
+        if rc:
+            N.check(rc)
+        return self.rewards[:, agent]
+
+    def turn_end(self, commit_windows: bool = True):
+        """``sgw_turn_end``: the turn's windows -> the agents' ring rows, every ring advances."""
+        with self._on_device():
+            rc = self._lib.sgw_turn_end(self._h, self.obs.data_ptr() if (commit_windows and self.obs is not None) else None, self._stream())
+        if rc:
+            N.check(rc)
+
+    def turn_state(self):
+        """(epoch, turn, [row per agent]) as the device has counted them (synchronising)."""
+        et = (C.c_uint32 * 2)()
+        rows = (C.c_int64 * N.MAX_AGENTS)()
+        with self._on_device():
+            N.check(self._lib.sgw_turn_state(self._h, et, rows, self._stream()))
+        return int(et[0]), int(et[1]), [int(rows[a]) for a in range(self.spec.num_agents)]
+
     def observe_full(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The whole map as an observation, ``[E, C, H, W]`` (``ObservationSpec(full_view=True).observe``): every cell's
         appearance summed over the layers."""

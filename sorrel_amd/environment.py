@@ -120,6 +120,8 @@ class Environment:
         self._fresh_obs = None       # (slot, world mutation count): eng.obs[:, slot] was rendered by the last launch
         self._turn_windows = None    # [world mutation count, rows, first agent whose window is still current, replay slots]: this turn's windows
         self._replay_slots = None
+        self._captured = None        # CapturedTurn: a whole policy turn recorded as one graph (capture_turn)
+        self._turn_capture = False   # the turn protocol with device-side counters is in charge of this turn (recording or warming up)
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
@@ -313,11 +315,18 @@ class Environment:
         self.populate_environment()
         for agent in self.agents:
             agent.reset()
+        if self._captured is not None:
+            self._captured.resync()
 
     def take_turn(self, actions: Optional[torch.Tensor] = None) -> None:
         """One full step of every env: entity transitions, then each agent in list order
         (``environment.py:81-93``)."""
         eng = self._ensure_engine()
+        if actions is None and self._captured is not None:
+            if self._captured.valid(eng):
+                self._captured.replay()
+                return
+            self._captured = None            # the engine was rebuilt (new entity types, another obs dtype): back to the eager loop
         self.turn += 1
         eng.epoch, eng.turn = self.epoch, self.turn
         self._fresh_obs = None
@@ -400,6 +409,77 @@ class Environment:
             rows.append(row)
             self._replay_slots.append((mem, i))
         return rows
+
+    # ------------------------------------------------------------------ a whole policy turn as one graph
+    def _turn_protocol_body(self, eng) -> None:
+        """One policy-driven take_turn through the device-counted protocol (include/sgw.h, sgw_turn_*): the same calls with the same
+        arguments every turn -- what a graph can record."""
+        eng.turn_begin(sweep=True)
+        self._turn_windows = [self.world.mutations, eng.window_rows(None), 0, None]
+        self._turn_capture = True
+        try:
+            for agent in self.agents:
+                agent.transition(self.world)          # pov (a view of eng.obs) -> get_action -> act (sgw_turn_act) -> add_memory (deferred)
+        finally:
+            self._turn_capture = False
+            self._turn_windows = None
+        eng.turn_end()
+
+    def capture_turn(self, warmup: int = 2):
+        """Record ONE whole policy-driven ``take_turn`` -- sweep + every agent's window, then per agent the policy's forward pass
+        and its act, then the copy of the turn's windows into the agents' replay rows -- as a graph (``torch.cuda.graph``), so that
+        every later ``take_turn()`` is one replay without Python in the agent loop (``sorrel/agents/agent.py:155-173`` costs
+        1 + A engine launches and A policy calls from Python otherwise; below ~16 k envs the host is the bottleneck).
+
+        What makes that possible: the turn number, the epoch and the replay row of every agent live in device memory that the
+        engine's own kernels advance (``sgw_turn_begin`` / ``sgw_turn_end``), so the recorded launches carry no per-turn
+        arguments; the policies read their windows from the observation tensor (a fixed address), and ``sgw_turn_end`` copies
+        them into the ring rows ``Buffer.add`` would have filled.  Results are those of the eager loop, bit for bit.
+
+        ``warmup`` real turns are played through the same protocol first (lazy initialisation must not happen inside a
+        capture).  Returns the ``CapturedTurn``, or ``None`` -- and the eager loop stays in charge -- when the turn cannot be
+        recorded: an agent class overrides ``transition`` / ``add_memory``, a model's memory is not a ``sorrel_amd.buffers.Buffer``
+        of plain windows with ``n_frames == 1`` (frame stacks and appended features index the ring from the host), the engine has
+        no observation tensor, or a model's forward pass does something a capture forbids (a host synchronisation)."""
+        from sorrel_amd.buffers import Buffer
+
+        self._captured = None
+        eng = self._ensure_engine()
+        if eng.obs is None or not self.patch_windows:
+            return None
+        per_env = 1
+        for d in eng.spec.obs_shape[1:]:
+            per_env *= int(d)
+        sharers = {}
+        for agent in self.agents:
+            mem = getattr(agent.model, "memory", None)
+            if type(agent).transition is not Agent.transition or type(agent).add_memory is not Agent.add_memory:
+                return None
+            if mem is None:
+                continue
+            if not isinstance(mem, Buffer) or mem.n_frames != 1 or mem.extra_data or mem.num_envs != eng.num_envs or mem.device != eng.device \
+                    or mem.states.dtype != eng.obs_dtype or mem.states[0, 0].numel() != per_env:
+                return None
+            sharers.setdefault(id(mem), [mem, []])[1].append(agent.slot)
+        buffers = [v[0] for v in sharers.values()]
+
+        def rings():
+            out = [None] * len(self.agents)
+            for mem, slots in sharers.values():
+                for k, a in enumerate(slots):
+                    out[a] = (mem.states, mem.rewards, mem.actions, mem.dones if mem._dones_dirty else None,
+                              (mem.idx + k) % mem.capacity, len(slots))
+            return out
+
+        cap = CapturedTurn(self, eng, buffers, [len(v[1]) for v in sharers.values()], rings)
+        try:
+            cap.record(max(1, int(warmup)))
+        except Exception as exc:                                   # not capturable: leave everything consistent and say why
+            cap.abort()
+            self.capture_error = exc
+            return None
+        self._captured = cap
+        return cap
 
     def rollout(self, turns: int) -> None:
         """``turns`` fused ``take_turn``s with ONE engine call (``sgw_rollout``: one launch with every env's grid resident
@@ -575,6 +655,15 @@ class Environment:
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
         tw = self._turn_windows
+        if self._turn_capture:                   # the turn protocol with device-side counters (capture_turn): rows by the device's count
+            if tw is None or tw[0] != self.world.mutations or a < tw[2]:
+                raise RuntimeError("a captured policy turn cannot be recorded while host code edits the world between pov and act")
+            tw[2] = a + 1
+            direct = action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1 \
+                and action.shape[0] == eng.num_envs and action.is_contiguous()
+            if not direct:
+                eng.actions[:, a].copy_(action)
+            return eng.turn_act(a, action if direct else None)
         if tw is not None:
             if tw[0] == self.world.mutations and a >= tw[2]:
                 tw[2] = a + 1                    # the windows of the agents after a stay current: sgw_act repairs them
@@ -825,3 +914,74 @@ class Environment:
 
     def load_checkpoint(self, path) -> None:
         self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))   # tensors and plain values only
+
+
+class CapturedTurn:
+    """One policy-driven ``take_turn`` recorded as a graph (``Environment.capture_turn``).  ``replay()`` plays the next turn;
+    the host only keeps its counters (``Environment.turn``, every buffer's ``idx`` / ``size``) in step with the device's."""
+
+    def __init__(self, env, eng, buffers, adds_per_turn, rings):
+        self.env, self.eng, self.buffers, self.adds, self._rings = env, eng, buffers, adds_per_turn, rings
+        self.graph = None
+        self.turns_replayed = 0
+
+    def valid(self, eng) -> bool:
+        return self.graph is not None and eng is self.eng
+
+    def resync(self) -> None:
+        """After ``Environment.reset`` (or any host-side change of the counters): the device's turn state follows the host's."""
+        self.eng.turn_bind(self._rings())
+        self.eng.turn_set(self.env.epoch, self.env.turn)
+
+    def _host_step(self) -> None:
+        env = self.env
+        env.turn += 1
+        self.eng.epoch, self.eng.turn = env.epoch, env.turn
+        env._fresh_obs = None
+
+    def record(self, warmup: int) -> None:
+        env, eng = self.env, self.eng
+        self.resync()
+        for mem in self.buffers:
+            mem._deferred, mem._deferred_adds = True, 0
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                       # real turns: they count
+                self._host_step()
+                env._turn_protocol_body(eng)
+        torch.cuda.current_stream(eng.device).wait_stream(side)
+        torch.cuda.synchronize(eng.device)
+        for mem, n in zip(self.buffers, self.adds):
+            if mem._deferred_adds != n * warmup:
+                raise RuntimeError("an agent's add_memory did not run once per turn")
+        before = [(mem.idx, mem.size) for mem in self.buffers]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            env._turn_protocol_body(eng)                  # recorded, not run: the host-side effects are undone below
+        for mem, (idx, size) in zip(self.buffers, before):
+            mem.idx, mem.size = idx, size
+        self.graph = g
+
+    def abort(self) -> None:
+        for mem in self.buffers:
+            mem._deferred = False
+        self.graph = None
+        try:
+            self.eng.turn_bind(None)
+        except Exception:
+            pass
+
+    def replay(self) -> None:
+        self._host_step()
+        self.graph.replay()
+        for mem, n in zip(self.buffers, self.adds):
+            mem.idx = (mem.idx + n) % mem.capacity
+            mem.size = min(mem.size + n, mem.capacity)
+        self.turns_replayed += 1
+
+    def release(self) -> None:
+        """Back to the eager loop (the buffers copy for themselves again)."""
+        self.abort()
+        if self.env._captured is self:
+            self.env._captured = None

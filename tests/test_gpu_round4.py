@@ -1,0 +1,292 @@
+"""Round 4 (GPU): a whole policy turn as one graph (device-side turn state), the specialiser's cache and fallback, long horizons on
+every kernel family."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from sorrel_amd import _native as N
+from tests.test_gpu_parity import torch_cuda, make_engine, assert_same  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ sgw_turn_*: the device counts turns and replay rows
+def test_turn_protocol_counts_on_the_device_vs_oracle(torch_cuda):
+    """sgw_turn_begin / sgw_turn_act / sgw_turn_end with the SAME arguments every turn: the turn number, the epoch and each agent's
+    replay row come from device memory the engine advances itself.  Every window an agent's policy would read, the rewards, the
+    state and the rows of the rings (windows, int64 actions, float32 rewards, zeroed dones) against the C oracle, across a ring
+    wrap-around and an epoch change."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(18, 14, 5, 2, spawn_prob=0.06, seed=21, dense_prob=0.1)
+    E, A, CAP = 33, 5, 4
+    eng, co = make_engine(ws, E, first=5), H.COracle(ws, E, first_env_id=5)
+    N_ = int(np.prod(ws.obs_shape[1:]))
+    # agents 0..2 own a ring each; agents 3 and 4 SHARE one (two rows per turn)
+    def ring(cap):
+        return dict(states=torch.full((cap, E, N_), -3.0, device="cuda:0"), rewards=torch.full((cap, E), -3.0, device="cuda:0"),
+                    actions=torch.full((cap, E), -3, dtype=torch.int64, device="cuda:0"), dones=torch.full((cap, E), 9.0, device="cuda:0"))
+    own = [ring(CAP) for _ in range(3)]
+    shared = ring(2 * CAP)
+    rings = [(r["states"], r["rewards"], r["actions"], r["dones"], 1, 1) for r in own] + \
+            [(shared["states"], shared["rewards"], shared["actions"], shared["dones"], 2 + k, 2) for k in range(2)]
+    eng.turn_bind(rings)
+    rng = np.random.default_rng(3)
+    epoch = 4
+    eng.reset(epoch)
+    co.reset(epoch)
+    eng.turn_set(epoch, 0)
+    row_own, row_sh = 1, 2
+    for t in range(1, 12):
+        if t == 7:          # Environment.reset: a new epoch, the turn counter restarts
+            epoch += 1
+            eng.reset(epoch)
+            co.reset(epoch)
+            eng.turn_set(epoch, 0)
+        turn = t if t < 7 else t - 6
+        acts = rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)
+        assert co.step(epoch, turn, actions=acts) == 0
+        policy = torch.from_numpy(acts.astype(np.int64)).cuda()
+        eng.obs.fill_(-9.0)
+        eng.turn_begin()
+        seen = torch.zeros_like(eng.obs)
+        for a in range(A):
+            seen[:, a] = eng.obs[:, a]
+            eng.turn_act(a, policy[:, a].contiguous())
+        eng.turn_end()
+        torch.cuda.synchronize()
+        assert eng.turn_state()[:2] == (epoch, turn)
+        assert np.array_equal(seen.cpu().numpy(), co.obs), f"turn {t}: windows at pov time"
+        assert_same(eng, co, ("grid", "pos", "total", "rewards"), ctx=f"turn {t}")
+        for a in range(A):
+            r, row = (own[a], row_own) if a < 3 else (shared, (row_sh + (a - 3)) % (2 * CAP))
+            assert np.array_equal(r["states"][row].cpu().numpy(), co.obs[:, a].reshape(E, N_)), f"turn {t}: ring row of agent {a}"
+            assert np.array_equal(r["actions"][row].cpu().numpy(), acts[:, a].astype(np.int64))
+            assert np.array_equal(r["rewards"][row].cpu().numpy(), co.rewards[:, a])
+            assert not r["dones"][row].any()
+        row_own, row_sh = (row_own + 1) % CAP, (row_sh + 2) % (2 * CAP)
+        assert eng.turn_state()[2] == [row_own] * 3 + [row_sh, (row_sh + 1) % (2 * CAP)]
+    assert eng.status() == 0
+
+
+def _policy_env(E, shape=(13, 15, 5, 2), memory=6, seed=5):
+    import torch
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    h, w, a, r = shape
+
+    class Policy(BaseModel):
+        """A fixed linear layer + argmax: deterministic, capturable (no host synchronisation)."""
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=memory, num_envs=E, device="cuda:0")
+            n = int(np.prod(input_size))
+            g = torch.Generator().manual_seed(1234 + n)
+            self.weight = torch.randn((n, action_space), generator=g).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.weight).argmax(dim=1)
+
+    return make_env(h, w, a, r, E, p=0.05, seed=seed, model_factory=Policy)
+
+
+def test_captured_turn_equals_the_eager_turn_and_the_oracle(torch_cuda):
+    """Environment.capture_turn(): sweep + every window + A x (policy forward, act) + the copy into the replay rows recorded ONCE and
+    replayed -- 60 turns across two epoch resets and several wrap-arounds of the 6-row rings equal the eager loop (state, step
+    outputs, every buffer row, the buffers' idx / size), and the C oracle stepping the actions the policies chose."""
+    torch = torch_cuda
+    E = 37
+    a, b = _policy_env(E), _policy_env(E)
+    cap = b.capture_turn(warmup=2)
+    assert cap is not None, getattr(b, "capture_error", None)
+    for _ in range(2):                      # the warm-up turns were real turns
+        a.take_turn()
+    ws = a._engine.spec
+    co = H.COracle(ws, E, first_env_id=0)
+    co.grid[...] = a.world.grid.cpu().numpy()
+    co.pos[...] = a.world.agent_pos.cpu().numpy()
+    co.total[...] = a.world.total_reward.cpu().numpy()
+    for t in range(60):
+        if t in (20, 41):
+            a.reset()
+            b.reset()
+            co.grid[...] = a.world.grid.cpu().numpy()
+            co.pos[...] = a.world.agent_pos.cpu().numpy()
+            co.total[...] = a.world.total_reward.cpu().numpy()
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        assert (a.turn, a.epoch) == (b.turn, b.epoch)
+        assert co.step(a.epoch, a.turn, actions=a.actions.cpu().numpy()) == 0
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert torch.equal(a.rewards, b.rewards) and torch.equal(a.actions, b.actions), t
+        assert np.array_equal(b.world.grid.cpu().numpy(), co.grid) and np.array_equal(b.world.agent_pos.cpu().numpy(), co.pos), t
+        assert np.array_equal(b.rewards.cpu().numpy(), co.rewards) and np.array_equal(b.world.total_reward.cpu().numpy(), co.total), t
+        for k, (x, y) in enumerate(zip(a.agents, b.agents)):
+            mx, my = x.model.memory, y.model.memory
+            assert (mx.idx, mx.size) == (my.idx, my.size), t
+            last = (my.idx - 1) % my.capacity
+            assert np.array_equal(my.states[last].cpu().numpy().reshape(E, -1), co.obs[:, k].reshape(E, -1)), (t, k)
+            for name in ("states", "actions", "rewards", "dones"):
+                assert torch.equal(getattr(mx, name), getattr(my, name)), (t, k, name)
+    assert cap.turns_replayed == 60
+    assert b._engine.turn_state()[:2] == (b.epoch, b.turn)
+    b.raise_on_status()
+    # an agent class that overrides transition cannot be recorded: the eager loop stays
+    c = _policy_env(8)
+
+    class Custom(type(c.agents[0])):
+        def transition(self, world):
+            return super().transition(world)
+
+    c.agents[0].__class__ = Custom
+    assert c.capture_turn() is None
+    c.take_turn()
+    c.raise_on_status()
+
+
+# ------------------------------------------------------------------ the specialiser: cache, fallback, plan == what is created
+def test_specialised_instances_are_cached_and_fall_back(torch_cuda, tmp_path):
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(19, 23, 5, 3, spawn_prob=0.05, seed=8)
+    N.set_option("jit_cache_dir", str(tmp_path))
+    s0 = N.jit_stats()
+    e1 = make_engine(ws, 40)
+    s1 = N.jit_stats()
+    want = N.plan(e1.config)["kernel"]
+    assert "specialised=1" in e1.launch_info() and e1.launch_info().startswith(want), e1.launch_info()
+    files = sorted(os.listdir(tmp_path))
+    assert s1["compiled"] + s1["mem_hits"] + s1["disk_hits"] > s0["compiled"] + s0["mem_hits"] + s0["disk_hits"] and (files or s1["mem_hits"] > s0["mem_hits"])
+    e2 = make_engine(ws, 40)                               # the same world again: the loaded function is reused, nothing is compiled
+    s2 = N.jit_stats()
+    assert s2["compiled"] == s1["compiled"] and s2["mem_hits"] > s1["mem_hits"]
+    N.set_option("jit", 0)
+    e3 = make_engine(ws, 40)                               # the prebuilt run-time-shape instance
+    assert "specialised=0" in e3.launch_info() and "step_fast<true, 2, 6, 0, 0, 0" in e3.launch_info(), e3.launch_info()
+    N.set_option("jit", 1)
+    N.set_option("jit_cache_dir", "/proc/this/cannot/be/written")   # no disk cache: compiles (or reuses) all the same
+    e4 = make_engine(treasurehunt_spec(19, 25, 5, 3, spawn_prob=0.05, seed=8), 40)
+    assert "specialised=1" in e4.launch_info()
+    engines = [e1, e2, e3]
+    co = H.COracle(ws, 40, first_env_id=0)
+    for e in engines:
+        e.reset(0)
+    co.reset(0)
+    for t in range(1, 6):
+        assert co.step(0, t, random_actions=True) == 0
+        for e in engines:
+            e.step(random_actions=True)
+            assert_same(e, co, ctx=f"turn {t} {e.launch_info().split(' group')[0]}")
+    with pytest.raises(ValueError):
+        N.set_option("no_such_key", 1)
+    with pytest.raises(ValueError):
+        N.set_option("group", 48)
+    with pytest.raises(ValueError):
+        N.set_option("group", 16, engine=e1._h)           # a plan-shaping key on a live engine
+    N.set_option("rows_mode", 1, engine=e1._h)             # a live key
+
+
+# ------------------------------------------------------------------ long horizons, one per kernel family
+def _long_horizon(torch, ws, E, T, check=(1, 2, 3, 10, 50, 100, 200, 350), first=3, epoch=1, expect=None, start=None):
+    """T turns of random actions against the C oracle: every tensor (and the agents' types / facings where the rule keeps them) at
+    the check points and at the end, then the same T turns as ONE sgw_rollout call (final state and last turn's outputs).
+    ``start``: (grid, pos) of one env to begin every env from (worlds whose map the reset kernel does not build: Cleanup)."""
+    def begin(eng, co):
+        if start is None:
+            eng.reset(epoch)
+            if co is not None:
+                co.reset(epoch)
+            return
+        g0, p0 = start
+        eng.epoch = epoch
+        eng.grid.copy_(torch.from_numpy(np.broadcast_to(g0, (E,) + g0.shape).copy()))
+        eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(p0, (E,) + p0.shape).copy()))
+        eng.total_reward.zero_()
+        if co is not None:
+            co.grid[...], co.pos[...], co.total[...] = g0, p0, 0
+
+    def same(eng, co, ctx):
+        assert_same(eng, co, ctx=ctx)
+        if eng.agent_state is not None:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), ctx + ": agent_state"
+            assert np.array_equal(eng.state_at_pov.cpu().numpy(), co.state_at_pov), ctx + ": state_at_pov"
+        if eng.agent_dir is not None:
+            assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), ctx + ": agent_dir"
+
+    eng, co = make_engine(ws, E, first=first), H.COracle(ws, E, first_env_id=first)
+    if expect:
+        assert expect in eng.launch_info(), eng.launch_info()
+    begin(eng, co)
+    marks = set(check) | {T}
+    for t in range(1, T + 1):
+        eng.step(random_actions=True)
+        assert co.step(epoch, t, random_actions=True) == 0
+        if t in marks:
+            same(eng, co, f"turn {t}")
+    assert eng.status() == 0
+    roll = make_engine(ws, E, first=first)
+    begin(roll, None)
+    roll.rollout(T)
+    same(roll, co, f"sgw_rollout of {T} turns")
+    assert roll.status() == 0
+    return eng
+
+
+def _tag_spec(h, w, a, r):
+    d, spec = H.load_golden("tag_9x9")
+    ws = H.world_spec(spec)
+    ws.height, ws.width, ws.num_agents, ws.vision_radius, ws.agent_type = h, w, a, r, [ws.agent_type[0]] * a
+    return ws
+
+
+@pytest.mark.parametrize("variant", ["plain", "walking", "staged"])
+def test_long_horizon_config5_shape_on_step_big(torch_cuda, variant):
+    """Config 5's shape (128x128x2, 64 agents, 11x11 windows, dense entities) for 500 turns on step_big: the plain instance, the
+    walking workgroups, the staged windows."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    if variant == "walking":
+        N.set_option("big_walk_blocks", 5)
+    if variant == "staged":
+        N.set_option("big_stage", 1)
+    ws = treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=2, dense_prob=0.25)
+    eng = _long_horizon(torch_cuda, ws, 32, 500, expect="step_big<true, 2, 6, 5")
+    info = eng.launch_info()
+    assert ("false, true>" in info.split(" group")[0]) == (variant == "walking"), info
+    assert ("big_stage=0" not in info) == (variant == "staged"), info
+
+
+def test_long_horizon_tag_packed_and_big(torch_cuda):
+    """Tag 11x11 / 5 agents / 9x9 on the packed kernel (two envs per wave) and Tag 128x128 / 64 agents on step_big<..., TAG>: 500
+    turns -- the "it" token changes hands hundreds of times."""
+    N.set_option("group", 32)
+    _long_horizon(torch_cuda, _tag_spec(11, 11, 5, 4), 64, 500, expect="step_kernel<32, true, 1, 4, 1, 4, 11, 11>")
+    N.set_option("group", None)
+    _long_horizon(torch_cuda, _tag_spec(128, 128, 64, 4), 32, 500, expect="step_big<true, 1, 4, 4, false, false, true")
+
+
+def test_long_horizon_cleanup_rules_kernel(torch_cuda):
+    """Cleanup as shipped (21x31x3, 10 agents, 11x11 windows) on the RULES kernel for 500 turns: beam timers, pollution and apple
+    cycles (sorrel/examples/cleanup/entities.py:43-105), facing, all-layer rewards."""
+    d, spec = H.load_golden("cleanup_21x31_default")
+    ws = H.world_spec(spec)
+    _long_horizon(torch_cuda, ws, 48, 500, epoch=0, expect="step_fast<true, 3, 9, 5, 21, 31, false, true", start=(d["grid0"][0], d["pos0"][0]))
+
+
+def test_long_horizon_treasurehunt_packed_and_own_entities(torch_cuda):
+    """Treasurehunt 21x21 four envs to a wave, and a world with its own entity set (5 channels, 3 layers) on the instance
+    specialised for it: 500 turns each."""
+    from sorrel_amd.spec import treasurehunt_spec
+    from tests.test_gpu_round3 import _move_world
+
+    N.set_option("group", 16)
+    _long_horizon(torch_cuda, treasurehunt_spec(21, 21, 2, 2, spawn_prob=0.02, seed=9), 64, 500, expect="step_kernel<16, true, 2, 6, 0, 2, 21, 21>")
+    N.set_option("group", None)
+    _long_horizon(torch_cuda, _move_world(26, 30, 3, 5, 7, 3, seed=11), 48, 500, expect="step_fast<true, 3, 5, 3, 26, 30")

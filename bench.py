@@ -140,7 +140,8 @@ def cpu_baseline(spec, config_name: str, seconds_target: float = 12.0):
     out = {
         "value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
         "per_core": value / cores, "single_core_value": single,
-        "sample": f"oracle/gridstep_oracle.c sgo_rollout (envs outer / turns inner, OpenMP static blocks, {cores} threads = this "
+        "sample": f"the C port of the reference's step loop -- NOT the one-env-at-a-time numpy restatement SURVEY 8(d)(ii) named, which "
+                  f"is ~10^4 x slower and would not finish a bounded sample: oracle/gridstep_oracle.c sgo_rollout (envs outer / turns inner, OpenMP static blocks, {cores} threads = this "
                   f"process's CPU share), {E} envs x {turns} turns of the same {spec.height}x{spec.width}x{A}-agent workload, "
                   f"{dt:.1f} s; one thread: {E1} envs x {turns1} turns, {dt1:.1f} s",
     }
@@ -181,7 +182,7 @@ def check_against_oracle(spec, played, dev, obs_dtype):
                     "compared with np.array_equal"}
 
 
-def side_config(name, dev, steps, prewarm, envs=0):
+def side_config(name, dev, steps, prewarm, envs=0, check_turns=0):
     """One more BASELINE shape in the same line: a short pre-warm, then `steps` launches between two
     HIP events on the launch stream.  Random actions, sweep on, float32 observations written, no reset in the region."""
     import torch
@@ -208,12 +209,41 @@ def side_config(name, dev, steps, prewarm, envs=0):
     kernel_ms = e0.elapsed_time(e1) / steps
     alg = spec.algorithmic_bytes_per_env_step() * E
     achieved = alg / (kernel_ms * 1e-3) / 1e9
+    checked = None
+    if check_turns > 0:     # the self-check of a side config: from the state the timed launches ended in, a few more turns on the
+        # engine and on the C oracle (oracle/gridstep_oracle.c, started from a copy of that state), every tensor compared
+        import ctypes as C
+
+        import numpy as np
+
+        import __graft_entry__ as g
+
+        lib = C.CDLL(g.ORACLE_LIB)
+        cfg = spec.to_config(E, 0)
+        arr = dict(grid=np.ascontiguousarray(eng.grid.cpu().numpy()), pos=eng.agent_pos.cpu().numpy().copy(), act=np.zeros((E, A), np.uint8),
+                   obs=np.zeros((E,) + spec.obs_shape, np.float32), rew=np.zeros((E, A), np.float32), tot=eng.total_reward.cpu().numpy().copy())
+        t_at = eng.turn
+        differ = []
+        for k in range(1, check_turns + 1):
+            eng.step(random_actions=True)
+            lib.sgo_step(C.byref(cfg), *(a.ctypes.data_as(C.c_void_p) for a in (arr["grid"], arr["pos"], arr["act"], arr["obs"], arr["rew"], arr["tot"])),
+                         C.c_uint32(0), C.c_uint32(t_at + k), C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(host_cores()),
+                         C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+            torch.cuda.synchronize(dev)
+            for key, mine in (("grid", eng.grid), ("pos", eng.agent_pos), ("act", eng.actions), ("obs", eng.obs), ("rew", eng.rewards), ("tot", eng.total_reward)):
+                if not np.array_equal(mine.cpu().numpy(), arr[key]) and key not in differ:
+                    differ.append(key)
+        checked = {"envs": E, "from_turn": t_at, "turns": check_turns, "equal": not differ and eng.status() == 0, "tensors_that_differ": differ,
+                   "what": "from the state the timed launches ended in: the engine and oracle/gridstep_oracle.c (started from a copy of that state) "
+                           "step on, every tensor compared with np.array_equal each turn"}
     out = {"workload": f"{H}x{W} grid x {spec.layers} layers, {A} agents, {spec.window}x{spec.window} window, {E} envs on one GPU",
            "envs": E, "steps": steps, "prewarm_steps": prewarm, "kernel_ms": kernel_ms, "wall_ms_per_step": wall / steps * 1e3,
            "value": E * A / (kernel_ms * 1e-3), "unit": "agent-steps/s",
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "frac_of_copy_ceiling": achieved / HBM_COPY_GBS, "algorithmic_bytes_per_launch": alg},
            "kernel": eng.launch_info(), "status": eng.status()}
+    if checked is not None:
+        out["checked_vs_oracle"] = checked
     eng.close()
     del eng
     torch.cuda.empty_cache()
@@ -537,11 +567,17 @@ def main() -> int:
     metrics = eng.reduce_metrics().clone()
     kernel_ms_rank = kernel_ms
     tmax = torch.tensor([dt, kernel_ms, barrier_ms], dtype=torch.float64, device=dev)
+    per_rank_kernel_ms, group_size = [kernel_ms], 1
     if world > 1:
+        group_size = dist.get_world_size()       # what the process group itself says (the line's n_gpus is checked against it)
+        mine = torch.zeros((world,), dtype=torch.float64, device=dev)
+        mine[rank] = kernel_ms
         if rehearsal:     # gloo reduces host tensors
-            metrics, tmax = metrics.cpu(), tmax.cpu()
+            metrics, tmax, mine = metrics.cpu(), tmax.cpu(), mine.cpu()
         dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)      # (every rank wrote its own slot: the sum is the list)
+        per_rank_kernel_ms = [float(x) for x in mine.tolist()]
     dt, kernel_ms, barrier_ms = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())   # MAX over ranks: the slowest rank's kernel prices the roofline
     status = eng.status()
 
@@ -580,7 +616,7 @@ def main() -> int:
             pass
         out = {
             "metric": "agent-steps/sec" if args.obs_dtype == "f32" else "agent-steps/sec (compact uint8 observations; NOT the contract metric)",
-            "value": value, "unit": "agent-steps/s", "n_gpus": world,
+            "value": value, "unit": "agent-steps/s", "n_gpus": group_size if world > 1 else 1,
             "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm_steps),
             "rewarm_steps": max(0, args.rewarm_steps) if args.prewarm_steps > 0 else 0,
             "timed_region_submission": "one hipGraph replay of the K sgw_step launches (captured before the pre-warm pass, each node with the turn number it carries)" if timed_graph is not None else "K sgw_step calls",
@@ -594,6 +630,7 @@ def main() -> int:
                 "envs_per_gpu": E, "global_envs": total_envs, "agents": A, "grid": [H, W, spec.layers],
                 "window": spec.window, "channels": spec.num_channels, "spawn_prob": p_spawn, "dense_prob": p_dense,
                 "sharding": f"env-batch x{world}, no data-path collective; one 32-byte all-reduce at end of rollout",
+                "process_group_world_size": group_size,
                 "obs_written": write_obs, "sweep": sweep, "max_turns": args.max_turns,
             },
             "roofline": {
@@ -607,7 +644,7 @@ def main() -> int:
                 "hbm_side_what": "MODELLED, not measured: algorithmic bytes minus the grid READ of a turn, which the Infinity Cache serves while the batch's grids "
                                  f"({grid_bytes / 1e6:.0f} MB here) stay resident (<= {CACHE_RESIDENT_GRID_BYTES >> 20} MiB); 0 subtracted otherwise",
                 "kernel": eng.launch_info(), "kernel_ms": kernel_ms, "kernel_ms_what": "HIP events over the timed region / steps; MAX over ranks for N > 1",
-                "kernel_ms_rank0": kernel_ms_rank, "series": series, "prewarm_series": prewarm_series,
+                "kernel_ms_rank0": kernel_ms_rank, "kernel_ms_per_rank": per_rank_kernel_ms, "series": series, "prewarm_series": prewarm_series,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_agent_step": spec.algorithmic_bytes_per_env_step() / A,
             },
@@ -629,8 +666,8 @@ def main() -> int:
             torch.cuda.empty_cache()
             out["configs"] = {
                 # (pre-warm counts: ~60 ms of uninterrupted launches each -- the engine's creation leaves the chip idle)
-                "c2": side_config("c2", dev, args.side_steps, 5000),
-                "c5": side_config("c5", dev, args.side_steps, 700),
+                "c2": side_config("c2", dev, args.side_steps, 5000, check_turns=0 if args.no_self_check else 3),
+                "c5": side_config("c5", dev, args.side_steps, 700, check_turns=0 if args.no_self_check else 3),
                 "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 60, envs=524288),
             }
         if world == 1 and not args.no_cpu_baseline:

@@ -396,13 +396,13 @@ int sgw_plan(const sgw_config* cfg, int32_t num_cus, int64_t lds_per_workgroup, 
  * could not be recorded once and replayed.  They now live in device memory that the engine advances itself:
  *   sgw_turn_bind(rows)        (blocking, rare) the agents' replay rings: base pointers, capacity, the row the NEXT turn
  *                              fills, rows per turn (agents that share one Buffer advance it together); NULL: no replay rows
- *   sgw_turn_set(epoch, turn)  (stream-ordered) the turn the engine has counted up to: Environment.reset -> (epoch, 0)
- *   sgw_turn_begin(...)        turn += 1 on the device, then sweep + EVERY agent's window into `obs` [E][A][C][V][V]
+ *   sgw_turn_set(epoch, turn)  (stream-ordered) the turns of the epoch completed so far: Environment.reset -> (epoch, 0)
+ *   sgw_turn_begin(...)        sweep + EVERY agent's window into `obs` [E][A][C][V][V] for turn (completed + 1)
  *                              (= sgw_step(0, A, SGW_STEP_SWEEP | SGW_STEP_NO_MOVE) at the device's turn)
  *   sgw_turn_act(agent, ...)   = sgw_act with the windows in their slots of `obs` (the later agents' windows are repaired
  *                              there); reward and int64 action also go to the agent's ring row of the turn in flight
  *   sgw_turn_end(obs)          the windows of the turn -> each agent's ring row (what Agent.add_memory would copy), then
- *                              every ring advances
+ *                              every ring advances and the turn counts as completed
  * Every call is asynchronous on `stream` and takes the same arguments every turn, so begin + A x (policy forward,
  * sgw_turn_act) + end can be captured in a hipGraph (torch.cuda.graph) and replayed without the host in the loop;
  * `obs` is the tensor the policies read -- a fixed address, which is what a recorded graph needs -- and the copy into the

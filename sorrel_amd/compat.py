@@ -60,12 +60,20 @@ OUT_OF_SCOPE = {
 class _AliasLoader(importlib.abc.Loader):
     def __init__(self, module):
         self._module = module
+        # importlib's module_from_spec overwrites __spec__ / __loader__ / __package__ of whatever create_module returns with
+        # the ALIAS's; the mirror's module must keep its own (importlib.reload and relative imports go by them)
+        self._own = {k: getattr(module, k, None) for k in ("__spec__", "__loader__", "__package__", "__name__")}
 
     def create_module(self, spec):
         return self._module          # the mirror's own module object: classes compare identical under both names
 
     def exec_module(self, module):
-        pass
+        for k, v in self._own.items():
+            if v is not None or k == "__package__":
+                try:
+                    setattr(module, k, v)
+                except (AttributeError, TypeError):
+                    pass
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):

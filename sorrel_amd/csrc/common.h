@@ -41,7 +41,7 @@ static_assert(sizeof(DevTables) % 16 == 0, "LDS table block must keep 16-byte al
 // (sgw_turn_begin / sgw_turn_end) instead of arriving as kernel arguments: Environment.turn and the epoch, and for every agent
 // the row of its replay ring that this turn's window / action / reward go to (sorrel/buffers.py:46-63: Buffer.add's idx).
 struct TurnState {
-    uint32_t epoch, turn;
+    uint32_t epoch, turn;                 // turn: turns of this epoch COMPLETED (the turn in flight is turn + 1; sgw_turn_end advances it)
     uint32_t pad_[2];
     int64_t row[SGW_MAX_AGENTS];          // ring row of the turn in flight
     int64_t cap[SGW_MAX_AGENTS];          // rows in that agent's ring (0: the agent keeps no replay rows)

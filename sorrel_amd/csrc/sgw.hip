@@ -1564,11 +1564,9 @@ int sgw_turn_begin(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* ac
     if (!e || !grid || !agent_pos || !actions || !obs || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_turn_begin: NULL argument");
     if (flags & ~(SGW_STEP_SWEEP)) return fail(SGW_EINVAL, "sgw_turn_begin: only SGW_STEP_SWEEP may be set");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(turn_begin_kernel, dim3(1), dim3(64), 0, s, e->d_turn);
-    HIP_TRY(hipGetLastError());
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
-    p.ts = e->d_turn;
+    p.ts = e->d_turn;      // the turn in flight = the device's count of completed turns + 1 (Environment.take_turn: self.turn += 1)
     p.a0 = 0; p.a1 = e->cfg.num_agents; p.flags = flags; p.do_move = 0;
     return launch_step(e, p, s);
 }
@@ -1588,14 +1586,11 @@ int sgw_turn_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* acti
 int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {
     if (!e) return fail(SGW_EINVAL, "sgw_turn_end: NULL engine");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!e->turn_rows) return SGW_OK;
     const int A = e->cfg.num_agents;
     const int N = e->base.C * e->base.VV;
-    if (obs) {   // this turn's windows -> the agents' replay rows
-        // widest copy unit every row allows: the window size, the row strides and the base addresses decide (checked at bind time
-        // for the element size; here for 8 / 16 bytes)
+    if (e->turn_rows && obs) {   // this turn's windows -> the agents' replay rows
         const int64_t total = (int64_t)e->cfg.num_envs * A * N;
-        const int blocks = (int)std::min<int64_t>(ceil_div(total / 2 + 1, kBlock), (int64_t)e->num_cus * 16);
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total / 2 + 1, kBlock), (int64_t)e->num_cus * 16));
         const bool even = (N & 1) == 0 && e->turn_rows_even && (reinterpret_cast<uintptr_t>(obs) & 7) == 0;
         if (e->obs_format == SGW_OBS_U8) {
             hipLaunchKernelGGL((turn_commit_kernel<uint8_t, 1>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, static_cast<const uint8_t*>(obs), (int64_t)e->cfg.num_envs, A, N);
@@ -1606,7 +1601,7 @@ int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {
         }
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(turn_advance_kernel, dim3(1), dim3(64), 0, s, e->d_turn, A);
+    hipLaunchKernelGGL(turn_advance_kernel, dim3(1), dim3(64), 0, s, e->d_turn, A);   // every ring advances; the turn counts as completed
     HIP_TRY(hipGetLastError());
     return SGW_OK;
 }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
     const bool dirty = do_sweep || (p.do_move && p.a1 > p.a0);
     const bool rnd = (p.flags & SGW_STEP_RANDOM_ACTIONS) != 0;
     uint32_t turn0 = p.turn, ep4 = p.epoch << 4;     // kernel arguments, or (sgw_turn_*) the engine's device-side count
-    if (p.ts) { turn0 = p.ts->turn; ep4 = p.ts->epoch << 4; }
+    if (p.ts) { turn0 = p.ts->turn + 1u; ep4 = p.ts->epoch << 4; }   // (ts->turn: turns completed)
 
     // ---- tables -> LDS
     if constexpr (ONEHOT) {

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     const DevTables* gtab = p.tab;
     const uint32_t env_id = p.first_env + (uint32_t)env;
     uint32_t turn0 = p.turn, ep4 = p.epoch << 4;     // Environment.turn and the epoch: kernel arguments, or (sgw_turn_*) the engine's device-side count
-    if (p.ts) { turn0 = p.ts->turn; ep4 = p.ts->epoch << 4; }
+    if (p.ts) { turn0 = p.ts->turn + 1u; ep4 = p.ts->epoch << 4; }   // (ts->turn: turns completed)
 
     // ---- issue every global load of this env first
     uint4 u[NU];

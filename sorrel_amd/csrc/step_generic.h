@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     const int zoff = p.zA * H * W;
     const int HW = H * W;
     uint32_t turn0 = p.turn, ep4 = p.epoch << 4;     // kernel arguments, or (sgw_turn_*) the engine's device-side count
-    if (p.ts) { turn0 = p.ts->turn; ep4 = p.ts->epoch << 4; }
+    if (p.ts) { turn0 = p.ts->turn + 1u; ep4 = p.ts->epoch << 4; }   // (ts->turn: turns completed)
 
     // one env per group and launch (no persistent loop: nothing stays live from one env to the next, and the
     // dispatcher balances the workgroups)

@@ -11,9 +11,11 @@ Subclass it exactly like the reference: implement ``setup_agents`` (assign
   the act launch (``sgw_act``) moves the agent and rewrites, in the windows of the agents
   after it, the at most two cells its move changed -- so agent i+1 observes agent i's move
   exactly as in the reference (``sorrel/agents/agent.py:155-173``) without a window being
-  rendered per launch.  Where that protocol does not apply (Tag / Cleanup agents) the older
-  1 + A form runs: the launch that moves agent i also renders agent i+1's observation
-  (``SGW_STEP_OBS_NEXT``).
+  rendered per launch.  ``sgw_act`` serves every agent rule (``MovingAgent.act``, ``TagAgent.act``,
+  ``CleanupAgent.act``); ``patch_windows = False`` selects the older 1 + A form, in which the launch
+  that moves agent i also renders agent i+1's observation (``SGW_STEP_OBS_NEXT``);
+* recorded (``capture_turn()``): that whole policy-driven turn as ONE graph replay -- the turn number
+  and every agent's replay row live in device memory the engine advances itself (``sgw_turn_*``).
 
 The device status word (off-grid move, bad action index, unregistered type id -- where the
 reference raises ``IndexError`` / ``KeyError``) is polled once per epoch by ``run_experiment`` /
@@ -354,7 +356,8 @@ class Environment:
         """Steps 1 and 2 of the patched-window protocol (``include/sgw.h``): the entity sweep alone, then EVERY agent's
         window, once, from the grid after the sweep -- into the row of each agent's replay buffer that its ``add_memory``
         is about to fill where that is possible (``_replay_rows``), else into the observation tensor.  Step 3 is
-        ``_act``.  Applies to ``MovingAgent.act`` agents; returns False where it does not (Tag / Cleanup)."""
+        ``_act``.  ``sgw_act`` has an instance for every agent rule (plain movers, Tag, Cleanup), so this returns False only
+        when the protocol is switched off (``patch_windows = False``) or the engine has no observation tensor."""
         from sorrel_amd import _native as N
 
         self._turn_windows = None

@@ -536,3 +536,57 @@ def test_mark_dirty_and_invalidate_hooks():
     assert Environment._ospec_key(spec) is key
     spec.invalidate()                                                 # ... until the spec is told
     assert Environment._ospec_key(spec) != key
+
+
+def test_buffer_add_clears_terminal_flags_of_rows_that_came_in_by_copy_or_load(tmp_path):
+    """``Buffer.add`` always stores ``done`` in the reference (``sorrel/buffers.py:60``).  The mirror skips the store while every
+    dones row is known to be zero; rows that arrive through ``load`` / ``add_from_buffer`` / ``add_turns`` may hold terminal flags,
+    so a later ``add(done=False)`` onto such a row must clear it (round-3 advisor finding)."""
+    import torch
+    from sorrel_amd.buffers import Buffer, SavedGames
+
+    def filled():
+        b = Buffer(2, (3,), num_envs=2, device="cpu")
+        b.add(torch.ones(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), False)
+        b.add(torch.ones(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), True)        # the last row is terminal
+        return b
+
+    src = filled()
+    src.save(tmp_path / "b.npz")
+    loaded = Buffer.load(tmp_path / "b.npz")
+    assert loaded.dones[1].tolist() == [1.0, 1.0] and loaded.idx == 0
+    loaded.add(torch.zeros(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), False)
+    loaded.add(torch.zeros(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), False)     # lands on the row that was terminal
+    assert not loaded.dones.any()
+    dst = Buffer(4, (3,), num_envs=2, device="cpu")
+    dst.add_from_buffer(src)
+    dst.idx = 1
+    dst.add(torch.zeros(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), False)
+    assert not dst.dones[1].any()
+    sg = SavedGames(3, (3,), num_envs=2, device="cpu")
+    sg.add_turns(src.states, src.actions, src.rewards, src.dones)
+    sg.idx = 1
+    sg.add(torch.zeros(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), False)
+    assert not sg.dones[1].any()
+    fresh = Buffer(2, (3,), num_envs=2, device="cpu")
+    fresh.add(torch.ones(2, 3), torch.zeros(2, dtype=torch.int64), torch.zeros(2), True)
+    fresh.clear()
+    assert not fresh._dones_dirty and not fresh.dones.any()
+
+
+def test_alias_imports_leave_the_mirrors_module_specs_alone():
+    """``import sorrel.buffers`` hands out the mirror's module object; its ``__spec__`` must stay ``sorrel_amd.buffers``'s (reload and
+    relative imports go by it) -- round-3 advisor finding."""
+    import importlib
+
+    from sorrel_amd import compat
+
+    compat.install()
+    try:
+        import sorrel.buffers as aliased
+        import sorrel_amd.buffers as own
+
+        assert aliased is own and own.__spec__.name == "sorrel_amd.buffers" and own.__name__ == "sorrel_amd.buffers"
+        assert importlib.reload(own) is own
+    finally:
+        compat.uninstall() if hasattr(compat, "uninstall") else None

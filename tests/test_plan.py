@@ -1,0 +1,61 @@
+"""sgw_plan on the CPU: the dispatcher's whole decision -- kernel family, lanes per env, LDS layout, staging, walk window, the
+instances -- is a pure function of (config, options, CUs, LDS), enumerated here for every BASELINE config, the shapes measured in
+profiles/ and both sides of every threshold, and pinned by tests/golden/plans.json: a plan that changes unannounced fails."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_plans_match_the_pinned_ones(built):
+    import plan_cases
+
+    with open(plan_cases.GOLDEN) as fh:
+        want = json.load(fh)
+    got = plan_cases.plans()
+    assert sorted(got) == sorted(want), "cases added / removed: run `python tools/plan_cases.py --update` and commit the diff"
+    changed = {k: {f: (want[k][f], got[k][f]) for f in got[k] if got[k][f] != want[k].get(f)} for k in got if got[k] != want[k]}
+    assert not changed, ("the dispatcher's plan changed for these configurations (field: pinned -> now); if that is intended, run "
+                         "`python tools/plan_cases.py --update` and commit the diff: " + json.dumps(changed, indent=1)[:4000])
+
+
+def test_plan_is_pure_and_says_what_matters(built):
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+
+    c3 = treasurehunt_spec(32, 32, 8, 3).to_config(65536, 0)
+    a, b = N.plan(c3), N.plan(c3)
+    assert a == b and a["family"] == N.FAMILY_WAVE and a["kernel"] == "step_fast<true, 2, 6, 3, 32, 32>" and a["whole_env_burst"] == 1
+    assert a["lds_bytes"] == 4 * (512 + 2048 + 2352) and a["grid_blocks"] == 65536 // 4
+    c5 = treasurehunt_spec(128, 128, 64, 5).to_config(2048, 0)
+    p5 = N.plan(c5)
+    assert p5["family"] == N.FAMILY_WORKGROUP and p5["threads"] == 512 and p5["walk_blocks"] == 3 * 256 and p5["walk_min_envs"] < 2048 <= p5["walk_max_envs"]
+    assert N.plan(c5, num_cus=128)["walk_blocks"] == 3 * 128                       # a function of the device description it is given
+    own = treasurehunt_spec(32, 33, 8, 3).to_config(65536, 0)
+    assert N.plan(own)["kernel"] == "step_fast<true, 2, 6, 3, 32, 33>" and N.plan(own)["specialised"] == 1
+    with N.options(jit=0):                                                       # hipRTC absent: the prebuilt run-time-shape instance
+        p = N.plan(own)
+        assert p["specialised"] == 0 and p["kernel"] == p["kernel_prebuilt"] == "step_fast<true, 2, 6, 0, 0, 0, false, false, true>"
+    with pytest.raises(ValueError):
+        N.set_option("no_such_key", 1)
+    bad = treasurehunt_spec(32, 32, 8, 3).to_config(65536, 0)
+    bad.vision_radius = 40
+    with pytest.raises(ValueError):
+        N.plan(bad)
+
+
+def test_the_shipped_library_reads_one_environment_variable(built):
+    """sgw_set_option replaced ~30 getenv hooks: the library source asks for SGW_DEBUG and nothing else."""
+    import re
+
+    text = ""
+    for name in os.listdir(os.path.join(ROOT, "sorrel_amd", "csrc")):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(ROOT, "sorrel_amd", "csrc", name)) as fh:
+                text += fh.read()
+    calls = re.findall(r'getenv\("([A-Z_0-9]+)"\)', text)
+    assert calls == ["SGW_DEBUG"], calls

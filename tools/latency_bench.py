@@ -41,22 +41,29 @@ def time_turns(env, turns):
     return (time.perf_counter() - t0) / turns * 1e6
 
 
-def run(h, w, a, r, E, policy):
-    cfg = make_config(h, w, a, r, spawn_prob=0.005)
+def run(h, w, a, r, E, policy, spawn_prob=0.005):
+    cfg = make_config(h, w, a, r, spawn_prob=spawn_prob)
     world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0)
     env = TreasurehuntEnv(world, cfg, model_factory=policy_factory(E) if policy else None)
     env.write_obs_into_replay = os.environ.get("LAT_NO_DIRECT") != "1"      # A/B: windows through the observation tensor + a copy
+    label = {0: "device-random (1 launch)", 1: "policy (1+A launches)", 2: "policy, captured turn"}[policy]
+    if policy == 2 and env.capture_turn() is None:                          # round 4: the whole turn recorded once, replayed
+        label = f"policy, NOT capturable: {getattr(env, 'capture_error', None)!r}"[:60]
     turns = 2000 if E <= 4096 else 300
     us = time_turns(env, turns)
-    print(f"{h}x{w} A{a} r{r} E={E:6d} {'policy (1+A launches)' if policy else 'device-random (1 launch)':26s} "
-          f"{us:9.1f} us/turn  {E * a / us * 1e6:.3e} agent-steps/s")
+    env.raise_on_status()
+    print(f"{h}x{w} A{a} r{r} E={E:6d} {label:26s} {us:9.1f} us/turn  {E * a / us * 1e6:.3e} agent-steps/s", flush=True)
+    del env, world
+    torch.cuda.empty_cache()
 
 
 def main():
     for shape in ((21, 21, 2, 2), (32, 32, 8, 3)):
         for E in (1, 64, 1024, 16384, 65536):
-            for policy in (False, True):
+            for policy in (0, 1, 2):
                 run(*shape, E, policy)
+    for policy in (0, 1, 2):       # BASELINE config 5's per-GPU share
+        run(128, 128, 64, 5, 2048, policy, spawn_prob=0.05)
 
 
 if __name__ == "__main__":

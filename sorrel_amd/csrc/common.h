@@ -113,6 +113,11 @@ struct Params {
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int big_stage;    // step_big: bytes of LDS observation staging per wave (0: windows go straight to HBM, a dword store per lane and channel)
     int big_stage_off; // ... and where the first wave's area starts (behind the grid image)
+    // step_big<..., WALK>: the envs behind every workgroup's static share are handed out through a counter in device memory
+    // (whichever workgroup is free takes the next one: the XCDs of a chip do not run at the same speed)
+    uint32_t* walk_ctr;   // the counter (0 between launches: the workgroup that takes the last number resets it)
+    int walk_word;        // LDS byte offset of the word the next env's index is passed through
+    int walk_static;      // envs per workgroup that are assigned statically (blockIdx + k * gridDim, k < walk_static)
     int single_spawner;   // at most one type carries SGW_RULE_SPAWN: the byte-parallel sweep applies
     int rows_mode;        // phase_rows / observe_rows: how the staged windows leave (kRowsFlat / kRowsPair / kRowsSingle, phase.h)
     int rows_by_agent;    // observe_rows: a wave carries consecutive envs of ONE agent (per-agent destinations) instead of consecutive agents of an env

@@ -939,7 +939,7 @@ int resolve_kernel(sgw_engine* e, Kernel& k) {
     k.jit = jit_get(k.want, e->opt, e->arch.c_str(), e->dev, &err);
     if (!k.jit && !k.host) return fail(SGW_EHIP, "specialising %s failed and the library holds no prebuilt twin: %s", k.want.c_str(), err.c_str());
     if (k.jit && e->step_lds_bytes > 65536)   // (what hipFuncSetAttribute does for the prebuilt instances)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(e->lds_bytes, e->step_lds_bytes));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(e->lds_bytes, e->step_lds_bytes) + 16);
     return SGW_OK;
 }
 
@@ -1166,7 +1166,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         err = hipSuccess;
         for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk})
             if (err == hipSuccess && k->host)
-                err = hipFuncSetAttribute(k->host, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+                err = hipFuncSetAttribute(k->host, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes + 16);   // (+ the walking variant's hand-over word)
         if (err == hipSuccess && e->k_step.jit)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e->k_step.jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
         if (err == hipSuccess)
@@ -1256,8 +1256,14 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
     const bool walk = e->big && p.nturns == 1 && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
     p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
+    if (walk) {     // the walking workgroups: a static share each, the rest off a counter (step_big.h)
+        p.walk_ctr = reinterpret_cast<uint32_t*>(e->d_status) + 1;
+        p.walk_static = e->opt.big_walk_share > 0 ? e->opt.big_walk_share : (int)std::max<int64_t>(1, p.E / e->walk_blocks);
+        if (e->opt.big_walk_static) p.walk_static = 1 << 30;           // A/B hook: the purely static split of rounds 2-3
+    }
     if (e->big && p.nturns > 1 && e->big_threads != kBigThreads) p.big_stage = 0;   // (the rollout instance runs kBigThreads: the staging area is sized for this engine's waves)
     if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
+    if (walk) { p.walk_word = (int)lds; lds += 16; }   // (behind the grid image: the walking variant has no staging area there)
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
@@ -1589,8 +1595,7 @@ int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {
     const int A = e->cfg.num_agents;
     const int N = e->base.C * e->base.VV;
     if (e->turn_rows && obs) {   // this turn's windows -> the agents' replay rows
-        const int64_t total = (int64_t)e->cfg.num_envs * A * N;
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total / 2 + 1, kBlock), (int64_t)e->num_cus * 16));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div((int64_t)e->cfg.num_envs * A, kBlock / 64), (int64_t)e->num_cus * 32));   // a wave per window
         const bool even = (N & 1) == 0 && e->turn_rows_even && (reinterpret_cast<uintptr_t>(obs) & 7) == 0;
         if (e->obs_format == SGW_OBS_U8) {
             hipLaunchKernelGGL((turn_commit_kernel<uint8_t, 1>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, static_cast<const uint8_t*>(obs), (int64_t)e->cfg.num_envs, A, N);

@@ -159,6 +159,14 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
         if (t == 0 && p.do_move) ntot = p.total[e];
     };
     if constexpr (WALK) prefetch(env, tid0);
+    // WALK: every workgroup plays `walk_static` envs of its own (blockIdx + k * gridDim), then takes envs off a shared counter until
+    // they run out.  (Round 4: the eight XCDs of a chip finish the same share of config 5 up to 15 % apart -- stamps per XCD: a
+    // workgroup's life 27.5 ... 31.6 us -- and with a purely static split the launch waits for the slowest.)  Exactly
+    // (E - static part) + gridDim numbers are drawn per launch (every workgroup draws one that is out of range), so whoever draws the
+    // last one resets the counter for the next launch; no other draw is outstanding then.
+    [[maybe_unused]] int walk_k = 1;                 // envs of the static share this workgroup has started
+    [[maybe_unused]] int64_t next_env = 0;
+    [[maybe_unused]] volatile uint32_t* s_next = reinterpret_cast<volatile uint32_t*>(smem + p.walk_word);
     do {
     // WALK: the thread index is re-derived per env behind an opaque copy, so that nothing computed from it is hoisted
     // out of the env loop and kept in registers across it (the hoisted version needed 80 VGPRs + 27 spilled)
@@ -275,9 +283,29 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
         s_np[tid] = npos_v;      // packed (y, x) if the move succeeds
         s_ta[tid] = 0;           // journal: empty
     }
+    if constexpr (WALK) {
+        if (tid == 0) {          // which env this workgroup plays next
+            uint32_t nx;
+            if (walk_k < p.walk_static) {
+                nx = (uint32_t)(env + gridDim.x);
+            } else {
+                const uint32_t first = (uint32_t)p.walk_static * gridDim.x;      // the envs behind the static shares
+                const uint32_t tail = p.E > first ? (uint32_t)p.E - first : 0u;
+                const uint32_t got = atomicAdd(p.walk_ctr, 1u);
+                if (got == tail + gridDim.x - 1u) *p.walk_ctr = 0u;              // the last draw of the launch
+                nx = got < tail ? first + got : 0xFFFFFFFFu;
+            }
+            *s_next = nx;
+        }
+    }
     __syncthreads();             // grid (+ sweep patches) and tables visible to every wave
     STAMPB(1);                   // load + sweep done
-    if constexpr (WALK) prefetch(env + gridDim.x, tid);   // the next env's inputs: issued now, complete by the end of phase M (before any observation store)
+    if constexpr (WALK) {
+        const uint32_t nx = *s_next;
+        next_env = nx == 0xFFFFFFFFu ? p.E : (int64_t)nx;
+        ++walk_k;
+        prefetch(next_env, tid);   // the next env's inputs: issued now, complete by the end of phase M (before any observation store)
+    }
 
     // ---- phase M: the strictly sequential part, by wave 0 alone, entirely in registers.
     // All targets are read from the pre-move grid in ONE LDS round trip (lane a = agent a).  What
@@ -668,7 +696,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
         if (tid == 0) p.total[env] = tot;
     }
     if constexpr (!WALK) break;
-    env += gridDim.x;
+    env = next_env;
     if (env >= p.E) break;
     __syncthreads();             // the write-back has read this env's LDS image: the next env may overwrite it
     } while (true);

@@ -31,10 +31,10 @@ float run(int* out, int E, int block, int lds_per_wave, int iters) {
     return ms * 1000.f / iters;
 }
 
-int main() {
+int main(int argc, char** argv) {
     int* out;
     CK(hipMalloc(&out, 64));
-    const int E = 65536;
+    const int E = argc > 1 ? atoi(argv[1]) : 65536;      // (4 096: the launch floor next to BASELINE config 2)
     printf("empty waves, E = %d\n", E);
     for (int block : {64, 128, 256, 512, 1024})
         printf("  block %4d  lds/wave 2304: %.1f us   lds/wave 0: %.1f us\n", block, run<0>(out, E, block, 2304, 50), run<0>(out, E, block, 256, 50));

@@ -1,5 +1,6 @@
 """Diagnostic: per-segment share of a step_fast wave's lifetime, slot relaunch gaps and per-SIMD occupancy.
-Needs a -DSGW_STAMPS build of the library: SGW_LIB=<that .so> PYTHONPATH=. python tools/stamps.py [E]."""
+Needs a -DSGW_STAMPS build of the library (stamps exist in the PREBUILT instances only: jit = 0; group = 64 keeps small worlds on the
+wave-per-env kernel): SGW_LIB=<that .so> SGW_OPTIONS="jit=0;group=64" PYTHONPATH=. python tools/stamps.py [E [h w a r]]."""
 import ctypes as C
 import sys
 
@@ -10,14 +11,16 @@ from sorrel_amd.engine import GridEngine
 from sorrel_amd.spec import treasurehunt_spec
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-spec = treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005, seed=0)
+h, w, a, r = (int(x) for x in sys.argv[2:6]) if len(sys.argv) > 5 else (32, 32, 8, 3)
+spec = treasurehunt_spec(h, w, a, r, spawn_prob=0.005, seed=0)
 eng = GridEngine(spec, E, device="cuda:0")
 eng.reset(0)
+print(eng.launch_info())
 lib = N.load()
 import numpy as np
 
 buf = np.zeros((65536, 8), np.uint64)
-for _ in range(10):
+for _ in range(3000 if E <= 8192 else 10):
     eng.step(random_actions=True)
 torch.cuda.synchronize()
 lib.sgw_debug_stamps(buf.ctypes.data_as(C.c_void_p))
@@ -50,6 +53,9 @@ order = np.lexsort((start, slot))
 ss, st, en = slot[order], start[order], end[order]
 same = ss[1:] == ss[:-1]
 gap = (st[1:] - en[:-1])[same]
+if gap.size == 0:       # one round of waves (a small batch): no slot is reused, nothing more to say
+    print("every wave ran in its own slot (one round): no relaunch gaps, no convoys to look for")
+    sys.exit(0)
 print(f"slot relaunch gap: mean {gap.mean():.0f}  median {np.median(gap):.0f}  p90 {np.percentile(gap, 90):.0f}  max {gap.max()} ticks  (wave life mean {np.mean(en - st):.0f})")
 # per-SIMD occupancy over the kernel: sum(life) / (8 slots * span)
 occ = []

@@ -430,6 +430,11 @@ int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* s
 /* out6 = { instances compiled, loaded from the disk cache, reused in memory, refused, ms spent compiling, ms spent loading }
  * of this process so far. */
 int sgw_jit_stats(double* out6);
+/* Compile (or find in the disk cache) the code object of one template instance -- e.g. "step_fast<true, 2, 5, 3, 32, 32>", the
+ * `kernel` of an sgw_plan -- for `arch` ("gfx950") WITHOUT loading it: needs no device.  Fills a cache ahead of time (a build
+ * machine, a container without a GPU) and lets tools look at the code (registers, scratch).  path_out receives the cache file:
+ * "SGWJIT1\n", u32 name length, the lowered kernel name, the code object. */
+int sgw_jit_compile(const char* instance, const char* arch, char* path_out, int64_t capacity);
 
 const char* sgw_last_error(void);
 const char* sgw_version(void);

@@ -107,7 +107,7 @@ EXPORTS = (
     "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
-    "sgw_set_option", "sgw_plan", "sgw_jit_stats",
+    "sgw_set_option", "sgw_plan", "sgw_jit_stats", "sgw_jit_compile",
     "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state",
     "sgw_last_error", "sgw_version",
 )
@@ -204,6 +204,8 @@ def load():
     lib.sgw_set_option.restype = C.c_int
     lib.sgw_plan.argtypes = [cfgp, C.c_int32, C.c_int64, C.POINTER(SgwPlan)]
     lib.sgw_plan.restype = C.c_int
+    lib.sgw_jit_compile.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]
+    lib.sgw_jit_compile.restype = C.c_int
     lib.sgw_jit_stats.argtypes = [C.POINTER(C.c_double)]
     lib.sgw_jit_stats.restype = C.c_int
     lib.sgw_turn_bind.argtypes = [vp, C.POINTER(SgwTurnRows)]
@@ -262,6 +264,22 @@ def plan(cfg: "SgwConfig", num_cus: int = 256, lds_per_workgroup: int = 160 * 10
     out = SgwPlan()
     check(load().sgw_plan(C.byref(cfg), num_cus, lds_per_workgroup, C.byref(out)))
     return out.as_dict()
+
+
+def jit_compile(instance: str, arch: str = "gfx950") -> str:
+    """``sgw_jit_compile``: the cache file of one specialised instance, compiled now if the cache does not hold it (no device needed)."""
+    buf = C.create_string_buffer(1024)
+    check(load().sgw_jit_compile(instance.encode(), arch.encode(), buf, 1024))
+    return buf.value.decode()
+
+
+def jit_code_object(path: str):
+    """(lowered kernel name, code object bytes) of a cache file."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    assert data[:8] == b"SGWJIT1\n", path
+    n = int.from_bytes(data[8:12], "little")
+    return data[12:12 + n].decode(), data[12 + n:]
 
 
 def jit_stats() -> dict:

@@ -11,6 +11,8 @@ struct Options {
                               // 0: the prebuilt instances only (also what is used when hipRTC is absent or a compile fails)
     int jit_cache = 1;        // keep compiled code objects on disk (jit_cache_dir)
     int jit_verbose = 0;      // one line per compile / cache hit on stderr
+    int jit_own_rtc = 1;      // load /opt/rocm/lib/libhiprtc.so in a namespace of its own (the ROCm installation's compiler) rather than
+                              // the hipRTC the process has already mapped (PyTorch's wheel bundles an older one); read once per process
     std::string jit_cache_dir;   // "" = <directory of libsgw.so>/jit_cache
     int burst = 0;            // wave-per-env kernels with a compile-time shape: 0 auto, 1 whole-env burst whenever legal, 2 chunked (STAGE) always
     // ---- which prebuilt instance (A/B and test hooks of rounds 2-3; all default to "the rule decides")
@@ -55,6 +57,7 @@ const OptKey kOptKeys[] = {
     {"jit", &Options::jit, 0, 1, false},
     {"jit_cache", &Options::jit_cache, 0, 1, false},
     {"jit_verbose", &Options::jit_verbose, 0, 1, true},
+    {"jit_own_rtc", &Options::jit_own_rtc, 0, 1, false},
     {"burst", &Options::burst, 0, 2, false},
     {"static_radius", &Options::static_radius, 0, 2, false},
     {"pack3", &Options::pack3, 0, 1, false},

@@ -1085,6 +1085,28 @@ int sgw_plan(const sgw_config* cfg, int32_t num_cus, int64_t lds_per_workgroup, 
     return rc;
 }
 
+int sgw_jit_compile(const char* instance, const char* arch, char* path_out, int64_t capacity) {
+    if (!instance || !arch) return fail(SGW_EINVAL, "sgw_jit_compile: NULL argument");
+    Options o;
+    {
+        std::lock_guard<std::mutex> lock(g_opt_mu);
+        o = g_opts;
+    }
+    std::lock_guard<std::mutex> lock(g_jit_mu);
+    std::string lowered, code, path, err;
+    bool from_disk = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!jit_build(instance, o, arch, &lowered, &code, &path, &from_disk, &err)) return fail(SGW_EHIP, "sgw_jit_compile: %s", err.c_str());
+    if (!from_disk) {
+        g_jit_stats.compiled++;
+        g_jit_stats.compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        g_jit_stats.disk_hits++;
+    }
+    if (path_out && capacity > 0) snprintf(path_out, (size_t)capacity, "%s", path.c_str());
+    return SGW_OK;
+}
+
 int sgw_jit_stats(double* out6) {
     if (!out6) return fail(SGW_EINVAL, "sgw_jit_stats: NULL argument");
     std::lock_guard<std::mutex> lock(g_jit_mu);

@@ -389,6 +389,19 @@ typedef struct sgw_plan_info {
 } sgw_plan_info;
 int sgw_set_option(sgw_engine* eng, const char* key, const char* value);
 int sgw_plan(const sgw_config* cfg, int32_t num_cus, int64_t lds_per_workgroup, sgw_plan_info* out);
+/* ---- Row tails (round 4): what an agent's pov() appends to its flattened window, in-kernel ---------------------------------
+ * TagAgent.pov appends whether the agent is "it" (sorrel/examples/tag/agents.py:57-65), CleanupObservation.observe the
+ * positional code of the agent's cell (sorrel/examples/cleanup/agents.py:52-60, sorrel/observation/embedding.py:8-44).  With a
+ * tail bound, sgw_observe_rows writes it right behind the window in every row (element C*V*V onwards; env_stride must be
+ * >= C*V*V + tail_len) and sgw_act keeps it current (Tag: an agent tagged before its own pov reads 1), so the policy reads
+ * the finished row and nothing is concatenated on the host.  SGW_TAIL_AGENT_IS_IT: one element, 1.0 where the agent's current
+ * type is tag_it_type (needs sgw_bind_agent_state).  SGW_TAIL_POSITION_TABLE: tail_len elements table[(y*W + x)*tail_len ...]
+ * of the agent's cell; `table` is a DEVICE pointer to float [H][W][tail_len] owned by the caller.  float32 rows only. */
+#define SGW_TAIL_NONE 0
+#define SGW_TAIL_AGENT_IS_IT 1
+#define SGW_TAIL_POSITION_TABLE 2
+int sgw_bind_row_tail(sgw_engine* eng, int kind, int tail_len, const float* table);
+
 /* ---- A whole policy turn as ONE submission (round 4) ---------------------------------------------------------------
  * Agent.transition is pov -> get_action -> act, agent after agent (sorrel/agents/agent.py:155-173): 1 + A engine launches
  * with the policies' forward passes in between.  Three things change from turn to turn and used to arrive as kernel

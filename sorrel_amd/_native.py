@@ -19,6 +19,7 @@ OBS_F32, OBS_U8 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE, STATUS_BAD_POS = 1, 2, 4, 8
 CAP_OBSERVE_ROWS, CAP_ACT = 1, 2
 ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2
+TAIL_NONE, TAIL_AGENT_IS_IT, TAIL_POSITION_TABLE = 0, 1, 2
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
 
@@ -107,7 +108,7 @@ EXPORTS = (
     "sgw_random_actions", "sgw_set_obs_format", "sgw_bind_agent_state", "sgw_init_agent_state", "sgw_bind_agent_dir", "sgw_get_status", "sgw_obs_elems_per_env", "sgw_grid_bytes_per_env",
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
-    "sgw_set_option", "sgw_plan", "sgw_jit_stats", "sgw_jit_compile",
+    "sgw_set_option", "sgw_plan", "sgw_jit_stats", "sgw_jit_compile", "sgw_bind_row_tail",
     "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state",
     "sgw_last_error", "sgw_version",
 )
@@ -208,6 +209,8 @@ def load():
     lib.sgw_jit_compile.restype = C.c_int
     lib.sgw_jit_stats.argtypes = [C.POINTER(C.c_double)]
     lib.sgw_jit_stats.restype = C.c_int
+    lib.sgw_bind_row_tail.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.sgw_bind_row_tail.restype = C.c_int
     lib.sgw_turn_bind.argtypes = [vp, C.POINTER(SgwTurnRows)]
     lib.sgw_turn_bind.restype = C.c_int
     lib.sgw_turn_set.argtypes = [vp, C.c_uint32, C.c_uint32, vp]

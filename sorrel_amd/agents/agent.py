@@ -72,6 +72,12 @@ class Agent(Entity):
     def location(self, value):
         self._location = value
 
+    def row_tail(self, world):
+        """What ``pov`` appends behind the flattened window, as the engine can write it itself (``sgw_bind_row_tail``):
+        ``(N.TAIL_AGENT_IS_IT, None)``, ``(N.TAIL_POSITION_TABLE, float32 table [H, W, n])``, or None (``pov`` appends nothing, or
+        something only the host can compute)."""
+        return None
+
     def add_memory(self, state, action, reward, done) -> None:
         mem = getattr(self.model, "memory", None)
         if mem is not None:

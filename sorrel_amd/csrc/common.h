@@ -122,6 +122,11 @@ struct Params {
     int rows_mode;        // phase_rows / observe_rows: how the staged windows leave (kRowsFlat / kRowsPair / kRowsSingle, phase.h)
     int rows_by_agent;    // observe_rows: a wave carries consecutive envs of ONE agent (per-agent destinations) instead of consecutive agents of an env
     int onehot;           // every appearance row is a one-hot (or zero) vector and there is no post-processing: byte counters apply
+    // Row tails (sgw_bind_row_tail): what an agent's pov() appends to its flattened window, written behind the window in its row by
+    // sgw_observe_rows (and kept current by sgw_act): Tag's "it" flag (examples/tag/agents.py:57-65), Cleanup's positional code
+    // (examples/cleanup/agents.py:52-60, observation/embedding.py:8-44)
+    int tail_kind, tail_len;
+    const float* tail_table;   // SGW_TAIL_POSITION_TABLE: [H][W][tail_len]
     // Device-side turn state (sgw_turn_*): when set, the kernels take epoch and turn from here instead of the two fields above, so
     // that a launch recorded once (a hipGraph of a whole policy turn) plays the turn the engine has counted up to
     const TurnState* ts;

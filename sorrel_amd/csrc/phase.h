@@ -555,6 +555,15 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
     rows_index<L, R>(row, rowinb, x, W);
     float* o = reinterpret_cast<float*>(rp.p[a]) + env * rp.stride;
     rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, p.C, lane, live && gl < V, p.rows_mode);
+    if (p.tail_kind != SGW_TAIL_NONE && live) {      // what pov() appends behind the flattened window
+        float* t = o + p.C * VV;
+        if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {   // TagAgent.pov: [self.it]
+            if (gl == 0) t[0] = (p.agent_state && p.agent_state[env * p.A + a] == p.tag_it) ? 1.f : 0.f;
+        } else {                                     // CleanupObservation.observe: the positional code of the agent's cell
+            const float* src = p.tail_table + ((int64_t)y * W + x) * p.tail_len;
+            for (int k = gl; k < p.tail_len; k += G) t[k] = src[k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------- sgw_act: one agent acts, later agents' windows are repaired
@@ -834,8 +843,13 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
         if (RULE == SGW_AGENT_RULE_TAG && vy >= 0 && live) {
 #pragma unroll
             for (int n = 0; n < NJ; ++n)
-                if (j + n * G != a && pjv[n] == ((uint32_t)vy | ((uint32_t)vx << 8)))
-                    p.agent_state[env * p.A + j + n * G] = (uint8_t)p.tag_it;   // the agent standing on the victim's cell
+                if (j + n * G != a && pjv[n] == ((uint32_t)vy | ((uint32_t)vx << 8))) {
+                    const int jj = j + n * G;
+                    p.agent_state[env * p.A + jj] = (uint8_t)p.tag_it;   // the agent standing on the victim's cell
+                    // ... and, if it has yet to observe this turn, the "it" flag behind its window (TagAgent.pov reads self.it)
+                    if (jj > a && rp.p[jj] != nullptr && p.tail_kind == SGW_TAIL_AGENT_IS_IT && !p.obs_u8)
+                        reinterpret_cast<float*>(rp.p[jj])[env * rp.stride + (int64_t)C * VV] = 1.f;
+                }
         }
         if (pass) patch(y, x, p.zA, left, p.default_type);
         if (pass || mine_now != my_type) patch(ny, nx, p.zA, pass ? found : left, mine_now);

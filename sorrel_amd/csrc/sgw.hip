@@ -116,6 +116,8 @@ struct sgw_engine {
     uint8_t* agent_state = nullptr;    // caller-owned, bound with sgw_bind_agent_state
     uint8_t* state_at_pov = nullptr;
     uint8_t* agent_dir = nullptr;      // caller-owned, bound with sgw_bind_agent_dir
+    int tail_kind = SGW_TAIL_NONE, tail_len = 0;   // sgw_bind_row_tail
+    const float* tail_table = nullptr;
     int wpe = 1;          // waves per env
     int group = 64;       // generic step kernel: threads per env (16 / 32: several envs share a wave)
     bool onehot = true;
@@ -871,14 +873,16 @@ int plan_engine(sgw_engine* e, bool jit) {
     if (o.phase_kernel >= 0) e->phase_ok = plain_move && o.phase_kernel == 1;
     e->rows_epb = e->rows_wpb = 0;
     e->rows_lds = 0;
-    if (e->onehot && plain_move && p.cells >= 8 && o.phase_rows) {
+    if (e->onehot && p.cells >= 8 && o.phase_rows) {
+        // (observe_rows renders windows whatever the agents do when they act: every agent rule; phase_rows moves plain movers only)
         const int NW = (C + 3) / 4;
         e->k_rows.host = pick_rows(L, NW, r, &e->k_rows.host_name, &e->k_obs_rows.host, &e->k_obs_rows.host_name);
         if (jit && !e->k_rows.host && r >= 1 && r <= 7) {
             e->k_rows.want = rows_id("phase_rows", L, NW, r);
             e->k_obs_rows.want = rows_id("observe_rows", L, NW, r);
         }
-        if (e->k_rows.usable()) {
+        if (!plain_move) e->k_rows = Kernel();
+        if (e->k_obs_rows.usable()) {
             const int V = 2 * r + 1;
             e->rows_epb = e->rows_wpb = 4 * (64 / (V <= 4 ? 4 : (V <= 8 ? 8 : 16)));
             // per wave: counter words, the value table, the staging bytes of the windows it carries
@@ -1454,6 +1458,8 @@ static int fill_rows(const sgw_engine* e, void* const* rows, int64_t env_stride,
     const int64_t V = 2 * c.vision_radius + 1;
     if (!rows) return fail(SGW_EINVAL, "%s: rows is NULL", who);
     if (env_stride < (int64_t)c.num_channels * V * V) return fail(SGW_EINVAL, "%s: env_stride is smaller than one window", who);
+    if (e->tail_kind != SGW_TAIL_NONE && env_stride < (int64_t)c.num_channels * V * V + e->tail_len)
+        return fail(SGW_EINVAL, "%s: env_stride is smaller than one window + the bound row tail (%d elements)", who, e->tail_len);
     memset(rp, 0, sizeof(*rp));
     for (int a = a0; a < a1; ++a) {
         if (!rows[a] && need_all) return fail(SGW_EINVAL, "%s: rows[%d] is NULL", who, a);
@@ -1478,6 +1484,9 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
     Params p = e->base;
     p.grid = const_cast<uint8_t*>(grid); p.pos = const_cast<uint8_t*>(agent_pos);
     p.a0 = agent_begin; p.a1 = agent_end; p.flags = 0; p.do_move = 0;
+    p.agent_state = e->agent_state;
+    p.tail_kind = e->tail_kind; p.tail_len = e->tail_len; p.tail_table = e->tail_table;
+    if (p.tail_kind == SGW_TAIL_AGENT_IS_IT && !p.agent_state) return fail(SGW_EINVAL, "SGW_TAIL_AGENT_IS_IT needs sgw_bind_agent_state");
     {   // how the windows leave (phase.h, rows_emit)
         const int64_t N = (int64_t)p.C * p.VV;
         const int nA = agent_end - agent_begin;
@@ -1526,6 +1535,8 @@ static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* a
     p.state_at_pov = e->state_at_pov;
     p.agent_dir = e->agent_dir;
     p.obs_u8 = e->obs_format == SGW_OBS_U8 ? 1 : 0;
+    p.tail_kind = rows ? e->tail_kind : SGW_TAIL_NONE; p.tail_len = e->tail_len; p.tail_table = e->tail_table;
+    if (p.tail_kind != SGW_TAIL_NONE && env_stride < (int64_t)e->base.C * e->base.VV + e->tail_len) p.tail_kind = SGW_TAIL_NONE;   // (windows in the observation tensor: no room for tails)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = time_begin(e, s)) return rc;
     const int A = e->cfg.num_agents;
@@ -1658,6 +1669,20 @@ int sgw_bind_agent_state(sgw_engine* e, uint8_t* agent_state, uint8_t* state_at_
     if (!agent_state && state_at_pov) return fail(SGW_EINVAL, "sgw_bind_agent_state: state_at_pov without agent_state");
     e->agent_state = agent_state;
     e->state_at_pov = state_at_pov;
+    return SGW_OK;
+}
+
+int sgw_bind_row_tail(sgw_engine* e, int kind, int tail_len, const float* table) {
+    if (!e) return fail(SGW_EINVAL, "sgw_bind_row_tail: NULL engine");
+    if (kind == SGW_TAIL_NONE) { e->tail_kind = SGW_TAIL_NONE; e->tail_len = 0; e->tail_table = nullptr; return SGW_OK; }
+    if (kind == SGW_TAIL_AGENT_IS_IT) {
+        if (e->cfg.agent_rule != SGW_AGENT_RULE_TAG) return fail(SGW_EINVAL, "SGW_TAIL_AGENT_IS_IT is the tail of SGW_AGENT_RULE_TAG agents");
+        e->tail_kind = kind; e->tail_len = 1; e->tail_table = nullptr;
+        return SGW_OK;
+    }
+    if (kind != SGW_TAIL_POSITION_TABLE) return fail(SGW_EINVAL, "sgw_bind_row_tail: unknown kind %d", kind);
+    if (tail_len < 1 || tail_len > 4096 || !table) return fail(SGW_EINVAL, "SGW_TAIL_POSITION_TABLE needs a device table of [H][W][tail_len] floats, 1 <= tail_len <= 4096");
+    e->tail_kind = kind; e->tail_len = tail_len; e->tail_table = table;
     return SGW_OK;
 }
 

@@ -164,9 +164,8 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
     // workgroup's life 27.5 ... 31.6 us -- and with a purely static split the launch waits for the slowest.)  Exactly
     // (E - static part) + gridDim numbers are drawn per launch (every workgroup draws one that is out of range), so whoever draws the
     // last one resets the counter for the next launch; no other draw is outstanding then.
-    [[maybe_unused]] int walk_k = 1;                 // envs of the static share this workgroup has started
-    [[maybe_unused]] int64_t next_env = 0;
-    [[maybe_unused]] volatile uint32_t* s_next = reinterpret_cast<volatile uint32_t*>(smem + p.walk_word);
+    [[maybe_unused]] int walk_k = 1;                 // envs of the static share this workgroup has started (wave-uniform: a scalar register)
+    [[maybe_unused]] uint32_t next_u = 0;            // the env this workgroup plays next (0xFFFFFFFF: none), wave-uniform
     do {
     // WALK: the thread index is re-derived per env behind an opaque copy, so that nothing computed from it is hoisted
     // out of the env loop and kept in registers across it (the hoisted version needed 80 VGPRs + 27 spilled)
@@ -295,16 +294,15 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
                 if (got == tail + gridDim.x - 1u) *p.walk_ctr = 0u;              // the last draw of the launch
                 nx = got < tail ? first + got : 0xFFFFFFFFu;
             }
-            *s_next = nx;
+            *reinterpret_cast<volatile uint32_t*>(smem + p.walk_word) = nx;
         }
     }
     __syncthreads();             // grid (+ sweep patches) and tables visible to every wave
     STAMPB(1);                   // load + sweep done
     if constexpr (WALK) {
-        const uint32_t nx = *s_next;
-        next_env = nx == 0xFFFFFFFFu ? p.E : (int64_t)nx;
+        next_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile uint32_t*>(smem + p.walk_word));
         ++walk_k;
-        prefetch(next_env, tid);   // the next env's inputs: issued now, complete by the end of phase M (before any observation store)
+        prefetch(next_u == 0xFFFFFFFFu ? p.E : (int64_t)next_u, tid);   // the next env's inputs: issued now, complete by the end of phase M (before any observation store)
     }
 
     // ---- phase M: the strictly sequential part, by wave 0 alone, entirely in registers.
@@ -696,7 +694,8 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
         if (tid == 0) p.total[env] = tot;
     }
     if constexpr (!WALK) break;
-    env = next_env;
+    if (next_u == 0xFFFFFFFFu) break;
+    env = (int64_t)next_u;
     if (env >= p.E) break;
     __syncthreads();             // the write-back has read this env's LDS image: the next env may overwrite it
     } while (true);

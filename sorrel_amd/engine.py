@@ -99,6 +99,8 @@ class GridEngine:
         self.obs = (torch.zeros((E,) + spec.obs_shape, dtype=obs_dtype, device=dev) if allocate_obs else None)
         self.epoch = 0
         self.turn = 0
+        self.row_tail = 0               # elements bind_row_tail appends behind every window of a row
+        self._tail_table = None
         self._scratch_obs = None
         self.max_turns = 0              # set_auto_reset: epoch length (0 = no auto-reset)
         self.episode_return = None      # [E] float64: total_reward of the epoch that just ended
@@ -152,12 +154,13 @@ class GridEngine:
                              f"(got {got}); the step kernel writes exactly that many bytes")
         return t
 
-    def _check_window(self, t: torch.Tensor, name: str) -> torch.Tensor:
+    def _check_window(self, t: torch.Tensor, name: str, tail: int = 0) -> torch.Tensor:
         """One window per env (``SGW_STEP_OBS_NEXT_PACKED``): exactly ``E * C * V * V`` contiguous elements of the engine's
         observation dtype on its device, whatever the trailing shape (``[E, C, V, V]`` or a replay row ``[E, C*V*V]``)."""
         per_env = 1
         for d in self.spec.obs_shape[1:]:
             per_env *= int(d)
+        per_env += tail
         if not torch.is_tensor(t) or t.dtype != self.obs_dtype or t.device != self.device or not t.is_contiguous() \
                 or t.dim() < 2 or t.shape[0] != self.num_envs or t.numel() != self.num_envs * per_env:
             got = (tuple(t.shape), t.dtype, t.device) if torch.is_tensor(t) else type(t)
@@ -232,8 +235,8 @@ class GridEngine:
         if len(dests) != A:
             raise ValueError(f"need one destination per agent ({A}), got {len(dests)}")
         for a, t in enumerate(dests):
-            arr[a] = self._check_window(t, f"dests[{a}]").data_ptr()
-        return arr, per_env, list(dests)
+            arr[a] = self._check_window(t, f"dests[{a}]", self.row_tail).data_ptr()
+        return arr, per_env + self.row_tail, list(dests)
 
     def observe_rows(self, rows, agent_begin: int = 0, agent_end: Optional[int] = None):
         """Every agent's window, once, into its own destination (``rows`` from ``window_rows``): step 2 of a policy-driven
@@ -280,6 +283,25 @@ class GridEngine:
         if rc:
             N.check(rc)
         return self.rewards[:, agent] if reward_row is None else reward_row
+
+    def bind_row_tail(self, kind: int, table: Optional[torch.Tensor] = None):
+        """``sgw_bind_row_tail``: what the agents' ``pov`` appends behind the flattened window, written by ``observe_rows`` (and kept
+        current by ``act``) instead of a ``torch.cat`` on the host: ``N.TAIL_AGENT_IS_IT`` (Tag: one element) or
+        ``N.TAIL_POSITION_TABLE`` with ``table`` float32 ``[H, W, tail_len]`` on the device (Cleanup's positional code).  Rows passed
+        to ``window_rows`` then hold ``C*V*V + tail`` elements per env."""
+        n = 0
+        if kind == N.TAIL_POSITION_TABLE:
+            if not torch.is_tensor(table) or table.dtype != torch.float32 or table.device != self.device or not table.is_contiguous() \
+                    or table.dim() != 3 or tuple(table.shape[:2]) != (self.spec.height, self.spec.width):
+                raise ValueError(f"table must be a contiguous float32 [H, W, tail_len] tensor on {self.device}")
+            n = int(table.shape[2])
+        elif kind == N.TAIL_AGENT_IS_IT:
+            n = 1
+        if self.obs_dtype != torch.float32 and kind != N.TAIL_NONE:
+            raise ValueError("row tails are float32 (the observation format must be float32)")
+        with self._on_device():
+            N.check(self._lib.sgw_bind_row_tail(self._h, int(kind), n, self._ptr(table) if kind == N.TAIL_POSITION_TABLE else None))
+        self.row_tail, self._tail_table = n, table
 
     # ------------------------------------------------------------------ a whole policy turn as one capturable submission
     def turn_bind(self, rings=None):

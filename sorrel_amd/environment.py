@@ -122,6 +122,7 @@ class Environment:
         self._fresh_obs = None       # (slot, world mutation count): eng.obs[:, slot] was rendered by the last launch
         self._turn_windows = None    # [world mutation count, rows, first agent whose window is still current, replay slots]: this turn's windows
         self._replay_slots = None
+        self._tail_rows = None
         self._captured = None        # CapturedTurn: a whole policy turn recorded as one graph (capture_turn)
         self._turn_capture = False   # the turn protocol with device-side counters is in charge of this turn (recording or warming up)
         self._engine = None
@@ -289,8 +290,43 @@ class Environment:
         w.agent_state = self._engine.agent_state
         w.agent_dir = self._engine.agent_dir
         self._engine_version = w.registry.version
+        self._bind_row_tail()
         self._validate_border()
         return self._engine
+
+    def _bind_row_tail(self):
+        """What the agents' ``pov`` appends behind the flattened window (``Agent.row_tail``: Tag's "it" flag, Cleanup's positional
+        code) is written by the engine behind the window in every row (``sgw_bind_row_tail``) -- when every agent declares the same
+        tail and the engine renders float32 windows into rows; otherwise the agents concatenate on the host as before."""
+        from sorrel_amd import _native as N
+
+        eng = self._engine
+        self._tail_rows = None
+        self._turn_windows = None
+        if eng is None:          # (nothing built yet: _ensure_engine binds)
+            return
+        if eng.row_tail:
+            eng.bind_row_tail(N.TAIL_NONE)
+        tails = [a.row_tail(self.world) for a in self.agents]
+        if any(t is None for t in tails) or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_OBSERVE_ROWS) or not self.row_tails_in_kernel:
+            return
+        kind, table = tails[0]
+        for k, t in tails[1:]:
+            if k != kind or (t is None) != (table is None) or (t is not None and (t.shape != table.shape or not torch.equal(t, table))):
+                return
+        eng.bind_row_tail(kind, table)
+
+    #: Tag / Cleanup agents: let the engine write what ``pov`` appends behind the window (False = ``torch.cat`` on the host: A/B and tests)
+    row_tails_in_kernel = True
+
+    def _pov_row(self, slot: int):
+        """``[E, C*V*V + tail]``: this turn's finished row of agent ``slot`` -- window and tail, both written by the engine -- or None
+        when the turn's windows were not rendered into tailed rows (then ``pov`` concatenates on the host)."""
+        tw = self._turn_windows
+        eng = self._engine
+        if tw is None or eng is None or eng.row_tail == 0 or tw[0] != self.world.mutations or slot < tw[2] or tw[1][2] is None:
+            return None
+        return tw[1][2][slot].view(eng.num_envs, -1)
 
     def _validate_border(self):
         """Engine precondition: the reference has no bounds check in ``move`` --
@@ -366,6 +402,11 @@ class Environment:
             return False
         dests = self._replay_rows() if caps & N.CAP_OBSERVE_ROWS else None
         slots = self._replay_slots if dests is not None else None      # (buffer, row) per agent
+        if dests is None and eng.row_tail:      # tailed rows without replay buffers to put them in: the environment's own
+            if self._tail_rows is None:
+                per_env = int(np.prod(eng.spec.obs_shape[1:])) + eng.row_tail
+                self._tail_rows = [torch.zeros((eng.num_envs, per_env), dtype=torch.float32, device=eng.device) for _ in self.agents]
+            dests = self._tail_rows
         rows = eng.window_rows(dests)
         if dests is not None:                   # the sweep alone, then every window into its agent's replay row
             eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
@@ -407,7 +448,7 @@ class Environment:
             i = (mem.idx + k) % mem.capacity
             row = mem.states[i]
             if row.dtype != eng.obs_dtype or row.device != eng.device or not row.is_contiguous() or row.dim() < 2 \
-                    or row.shape[0] != eng.num_envs or row.numel() != eng.num_envs * per_env:
+                    or row.shape[0] != eng.num_envs or row.numel() != eng.num_envs * (per_env + eng.row_tail):
                 return None
             rows.append(row)
             self._replay_slots.append((mem, i))

@@ -22,15 +22,24 @@ class CleanupObservation(OneHotObservationSpec):
         self.input_size = (1, n + 4 * embedding_size)
         self._table = None
 
-    def pos_code(self, world, agent) -> torch.Tensor:
+    def table(self, world) -> torch.Tensor:
+        """``[H, W, 4 * embedding_size]`` float32: the positional code of every cell (what the engine gathers by agent position)."""
         if self._table is None or self._table.device != world.device or self._table.shape[:2] != (world.height, world.width):
-            self._table = embedding.positional_embedding_table(world, (self.embedding_size, self.embedding_size))
+            self._table = embedding.positional_embedding_table(world, (self.embedding_size, self.embedding_size)).contiguous()
+        return self._table
+
+    def pos_code(self, world, agent) -> torch.Tensor:
         yx = world.agent_pos[:, agent.slot].long()
-        return self._table[yx[:, 0], yx[:, 1]]
+        return self.table(world)[yx[:, 0], yx[:, 1]]
 
     def observe(self, world, location=None):
         if location is None:
             raise ValueError("Location must not be None for CleanupObservation.")
+        slot = getattr(location, "slot", None)
+        if slot is not None:          # an agent's own pov in a policy-driven turn: window and positional code are in its row already
+            row = world._environment._pov_row(slot)
+            if row is not None:
+                return row
         image = super().observe(world, location)
         flat = image.reshape(image.shape[0], -1)
         return torch.cat([flat, self.pos_code(world, location).to(flat.dtype)], dim=1)
@@ -59,6 +68,12 @@ class CleanupAgent(MovingAgent):
 
     def reset(self) -> None:
         self.model.reset()
+
+    def row_tail(self, world):
+        from sorrel_amd import _native as N
+
+        table = getattr(self.observation_spec, "table", None)
+        return (N.TAIL_POSITION_TABLE, table(world)) if callable(table) else None
 
     def pov(self, world) -> torch.Tensor:
         return self.observation_spec.observe(world, self)

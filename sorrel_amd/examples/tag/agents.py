@@ -39,8 +39,17 @@ class TagAgent(MovingAgent):
     def reset(self) -> None:
         self.model.reset()
 
+    def row_tail(self, world):
+        from sorrel_amd import _native as N
+
+        return (N.TAIL_AGENT_IS_IT, None)        # pov appends [self.it]: the engine writes it behind the window itself
+
     def pov(self, world) -> torch.Tensor:
-        """Flattened visual field + the it flag: ``[E, C*V*V + 1]`` (agents.py:57-65)."""
+        """Flattened visual field + the it flag: ``[E, C*V*V + 1]`` (agents.py:57-65).  In a policy-driven turn the engine has
+        written both into this agent's row already (``sgw_bind_row_tail``: no concatenation on the host)."""
+        row = world._environment._pov_row(self.slot)
+        if row is not None:
+            return row
         image = self.observation_spec.observe(world, self)
         flat = image.reshape(image.shape[0], -1)
         return torch.cat([flat, self.its.to(flat.dtype)[:, None]], dim=1)

@@ -241,10 +241,12 @@ def test_sgw_act_and_observe_rows_reject_what_they_cannot_serve(torch_cuda):
 
     d, spec = H.load_golden("tag_9x9")
     tag = make_engine(H.world_spec(spec), 8)
-    assert tag.capabilities() == N.CAP_ACT                # sgw_act serves TagAgent.act; there is no row-load instance for Tag worlds
-    with pytest.raises(ValueError):
-        tag.observe_rows(tag.window_rows(None))
+    assert tag.capabilities() == N.CAP_ACT | N.CAP_OBSERVE_ROWS   # (round 4: observe_rows renders windows whatever the agents' act rule is)
     ws = _move_world(16, 16, 2, 6, 4, 2, seed=1)
+    u8 = make_engine(ws, 8, obs_dtype=torch.uint8)
+    assert u8.capabilities() == N.CAP_ACT                # the row-load kernels write float32 windows only
+    with pytest.raises(ValueError):
+        u8.observe_rows(u8.window_rows(None))
     eng = make_engine(ws, 8)
     per_env = int(np.prod(ws.obs_shape[1:]))
     with pytest.raises(ValueError):                       # a destination that is not exactly one window per env

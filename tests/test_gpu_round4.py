@@ -290,3 +290,75 @@ def test_long_horizon_treasurehunt_packed_and_own_entities(torch_cuda):
     _long_horizon(torch_cuda, treasurehunt_spec(21, 21, 2, 2, spawn_prob=0.02, seed=9), 64, 500, expect="step_kernel<16, true, 2, 6, 0, 2, 21, 21>")
     N.set_option("group", None)
     _long_horizon(torch_cuda, _move_world(26, 30, 3, 5, 7, 3, seed=11), 48, 500, expect="step_fast<true, 3, 5, 3, 26, 30")
+
+
+# ------------------------------------------------------------------ row tails: what pov() appends, written by the engine
+@pytest.mark.parametrize("which", ["tag", "cleanup"])
+@pytest.mark.parametrize("memory", [0, 5], ids=["no_buffers", "replay_rows"])
+def test_row_tails_written_by_the_engine_equal_the_host_concatenation(torch_cuda, which, memory):
+    """TagAgent.pov appends the "it" flag, CleanupObservation.observe the positional code (sorrel/examples/tag/agents.py:57-65,
+    sorrel/examples/cleanup/agents.py:52-60).  With sgw_bind_row_tail the engine writes them behind the window in each agent's row
+    (its replay row where it has one) and sgw_act keeps Tag's flag current; the policy reads the finished row.  Everything a policy
+    saw, every replay row and the state equal the host-concatenation path, turn after turn; Tag's flag equals the oracle's
+    state_at_pov; the windows equal the oracle's."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+
+    E = 29
+
+    def factory():
+        class Policy(BaseModel):
+            def __init__(self, input_size, n_actions):
+                super().__init__((int(np.prod(input_size)),), n_actions, memory_size=memory, num_envs=E, device="cuda:0")
+                self.seen = []
+
+            def take_action(self, state):
+                self.seen.append(state.clone())
+                s = state.reshape(state.shape[0], -1)
+                return (s[:, ::3].sum(dim=1).long() * 7 + (s[:, -1] * 3).long() + (s > 0).sum(dim=1)) % self.action_space
+
+        return Policy
+
+    def make(in_kernel):
+        if which == "tag":
+            from sorrel_amd.entities import EmptyEntity
+            from sorrel_amd.examples.tag.env import TagEnv
+            from sorrel_amd.worlds import Gridworld
+
+            cfg = {"agent": {"num_agents": 6, "vision_radius": 2, "reward_per_turn": 10}, "experiment": {"epochs": 1, "max_turns": 50}}
+            env = TagEnv(Gridworld(8, 9, 1, EmptyEntity(), num_envs=E, device="cuda:0", seed=31), cfg, model_factory=factory())
+        else:
+            from tests.test_api_host import make_cleanup_env
+
+            env = make_cleanup_env(E=E, seed=7, device="cuda:0", model_factory=factory())
+        env.row_tails_in_kernel = in_kernel
+        env._bind_row_tail()              # (the constructor has built the engine already)
+        return env
+
+    a, b = make(True), make(False)
+    eng = a._ensure_engine()
+    assert eng.row_tail == (1 if which == "tag" else 12) and b._ensure_engine().row_tail == 0
+    co = H.COracle(a.compile_spec(), E)
+    co.grid[...] = a.world.grid.cpu().numpy()
+    co.pos[...] = a.world.agent_pos.cpu().numpy()
+    if which == "tag":
+        co.agent_state[...] = a.world.agent_state.cpu().numpy()
+    nwin = int(np.prod(eng.spec.obs_shape[1:]))
+    for t in range(1, 15):
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        assert co.step(0, t, actions=a.actions.cpu().numpy()) == 0
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.rewards, b.rewards), t
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert np.array_equal(a.world.grid.cpu().numpy(), co.grid) and np.array_equal(a.rewards.cpu().numpy(), co.rewards), t
+        for k, (x, y) in enumerate(zip(a.agents, b.agents)):
+            sx, sy = x.model.seen[-1], y.model.seen[-1]
+            assert sx.shape == sy.shape == (E, nwin + eng.row_tail) and torch.equal(sx, sy), (t, k)
+            assert np.array_equal(sx[:, :nwin].cpu().numpy(), co.obs[:, k].reshape(E, -1)), (t, k)
+            if which == "tag":
+                assert np.array_equal(sx[:, -1].cpu().numpy() != 0, co.state_at_pov[:, k] == eng.spec.tag_it_type), (t, k)
+            if memory:
+                assert torch.equal(x.model.memory.states, y.model.memory.states) and torch.equal(x.model.memory.actions, y.model.memory.actions), (t, k)
+    a.raise_on_status()

@@ -39,7 +39,18 @@ print('us per launch', ['%.1f' % u for u in us], ' %.3f of 8 TB/s' % (by / min(u
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r04_c5 -- python3 $REPO/bench.py --config c5 --steps 300 --warmup 10 --prewarm-steps 700 --no-cpu-baseline --no-series --no-side-configs --turns-per-launch 0 > $OUT/prof_r04_c5.json 2> $OUT/prof_r04_c5.err) || exit 1
   timeout -k 10 700 bash tools/pmc_pass.sh r04_c5 "--config c5" "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" > $OUT/r04_c5_pmc.txt 2>&1 || exit 1
   rocm-smi --showclocks --showpower > $OUT/r04_c5_smi.txt 2>&1
+elif [ "$PART" = "jit" ]; then
+  # the specialised instances: us per turn next to the prebuilt ones, create-time cost cold / from the disk cache / in memory, and a
+  # kernel trace that names them
+  rm -rf $REPO/sorrel_amd/csrc/jit_cache
+  timeout -k 10 600 python3 tools/jit_probe.py > $OUT/r04_jit_probe.txt 2>&1 || exit 1
+  timeout -k 10 300 python3 tools/generic_tables_probe.py > $OUT/r04_generic_tables.txt 2>&1 || exit 1
+  PROBE_SMALL=1 timeout -k 10 300 python3 tools/generic_tables_probe.py >> $OUT/r04_generic_tables.txt 2>&1 || exit 1
+  timeout -k 10 300 python3 tools/rt_shape_probe.py >> $OUT/r04_generic_tables.txt 2>&1 || exit 1
+  timeout -k 10 300 python3 tools/jit_create_cost.py > $OUT/r04_jit_create_cost.txt 2>&1 || exit 1
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r04_jit -- python3 $REPO/tools/generic_tables_probe.py > $OUT/prof_r04_jit.out 2>&1) || exit 1
 else
   timeout -k 10 600 python3 tools/latency_bench.py > $OUT/r04_api_latency.txt 2>&1 || exit 1
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r04_captured -- python3 $REPO/tools/profile_captured_turn.py 1024 > $OUT/prof_r04_captured.out 2>&1) || exit 1
 fi
 echo "part $PART done"

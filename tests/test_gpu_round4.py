@@ -362,3 +362,22 @@ def test_row_tails_written_by_the_engine_equal_the_host_concatenation(torch_cuda
             if memory:
                 assert torch.equal(x.model.memory.states, y.model.memory.states) and torch.equal(x.model.memory.actions, y.model.memory.actions), (t, k)
     a.raise_on_status()
+
+
+def test_specialised_step_big_with_more_than_64_kib_of_lds(torch_cuda):
+    """A 180x200x2 world keeps 72 KB per env in LDS: the specialised step_big instance (loaded as a module function) gets that much
+    dynamic LDS, and agrees with the oracle and with the prebuilt instance."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(180, 200, 6, 4, spawn_prob=0.03, seed=12, dense_prob=0.1)
+    for jit in (1, 0):
+        N.set_option("jit", jit)
+        eng, co = make_engine(ws, 6, first=1), H.COracle(ws, 6, first_env_id=1)
+        assert "step_big<" in eng.launch_info() and f"specialised={jit}" in eng.launch_info() and int(eng.launch_info().split("lds=")[1].split()[0]) > 65536, eng.launch_info()
+        eng.reset(0)
+        co.reset(0)
+        for t in range(1, 4):
+            eng.step(random_actions=True)
+            assert co.step(0, t, random_actions=True) == 0
+            assert_same(eng, co, ctx=f"jit={jit} turn {t}")
+        assert eng.status() == 0

@@ -58,3 +58,30 @@ def patched_turn():         # round 3: sweep + every window in ONE launch, then 
 
 print(f"  policy-driven, 1 + A launches (round 3: NO_MOVE + sgw_act)   {timed(lambda: [patched_turn() for _ in range(20)], 3) / 20:8.1f} us/turn")
 assert eng.status() == 0
+
+# round 4: every agent's window + its positional code into a row of its own (what its replay buffer row is) -- sweep alone, observe_rows
+# with the row tail bound, then per agent sgw_act; no torch.cat of the window on the host
+import torch as _t
+from sorrel_amd import _native as N
+if eng.capabilities() & N.CAP_OBSERVE_ROWS:
+    table = _t.rand((21, 31, 12), device="cuda:0")
+    eng.bind_row_tail(N.TAIL_POSITION_TABLE, table)
+    nwin = int(np.prod(spec.obs_shape[1:]))
+    dests = [_t.zeros((E, nwin + 12), device="cuda:0") for _ in range(10)]
+    TROWS = eng.window_rows(dests)
+
+    def tailed_turn():
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, advance_turn=False)
+        eng.observe_rows(TROWS)
+        for a in range(10):
+            eng.act(a, TROWS)
+        eng.turn += 1
+
+    def parts():
+        t_sweep = timed(lambda: eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, advance_turn=False), 20)
+        t_rows = timed(lambda: eng.observe_rows(TROWS), 20)
+        return t_sweep, t_rows
+
+    print(f"  policy-driven, 2 + A launches (round 4: sweep, observe_rows into tailed rows, sgw_act) {timed(lambda: [tailed_turn() for _ in range(20)], 3) / 20:8.1f} us/turn"
+          f"   (sweep alone {parts()[0]:.1f} us, observe_rows {parts()[1]:.1f} us)")
+    assert eng.status() == 0

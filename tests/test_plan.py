@@ -59,3 +59,36 @@ def test_the_shipped_library_reads_one_environment_variable(built):
                 text += fh.read()
     calls = re.findall(r'getenv\("([A-Z_0-9]+)"\)', text)
     assert calls == ["SGW_DEBUG"], calls
+
+
+def test_a_specialised_instance_compiles_without_a_device(built, tmp_path):
+    """sgw_jit_compile: the library's embedded kernel sources + hipRTC produce the code object of a plan's kernel with no GPU in the
+    machine (pre-filling a cache on a build host; tools/jit_regs.py).  The file carries the lowered name and an ELF; a second call is a
+    cache hit; the instance uses no scratch."""
+    import re
+    import subprocess
+
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+
+    plan = N.plan(treasurehunt_spec(14, 18, 3, 2).to_config(1000, 0))
+    assert plan["specialised"] == 1 and plan["kernel"].startswith("step_")
+    with N.options(jit_cache_dir=str(tmp_path)):
+        s0 = N.jit_stats()
+        path = N.jit_compile(plan["kernel"])
+        s1 = N.jit_stats()
+        again = N.jit_compile(plan["kernel"])
+        s2 = N.jit_stats()
+    assert path == again and os.path.dirname(path) == str(tmp_path)
+    assert s1["compiled"] == s0["compiled"] + 1 and s2["compiled"] == s1["compiled"] and s2["disk_hits"] == s1["disk_hits"] + 1
+    lowered, code = N.jit_code_object(path)
+    assert lowered.startswith("_Z") and code[:4] == b"\x7fELF"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if os.path.exists(readelf):
+        obj = tmp_path / "k.hsaco"
+        obj.write_bytes(code)
+        notes = subprocess.run([readelf, "--notes", str(obj)], capture_output=True, text=True).stdout
+        meta = next(b for b in notes.split("- .agpr_count") if lowered in b)
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta)[1]) == 0, "the specialised instance spills to scratch"
+    with pytest.raises(N.SgwError):
+        N.jit_compile("step_fast<true, 2, 6, 3, 32>")          # not an instance of the template: hipRTC's error comes back

@@ -43,7 +43,7 @@ struct Options {
     int big_walk_static = 0;  // ... 1: every env assigned statically (blockIdx + k * gridDim), as in rounds 2-3 (A/B)
     int big_walk_share = 0;   // ... envs per workgroup assigned statically before the shared counter takes over (0 auto)
     // ---- live (also settable on an engine after sgw_create)
-    int rows_mode = 0;        // sgw_observe_rows emit: 0 auto, 1 single floats, 2 float2 runs where legal
+    int rows_mode = 0;        // sgw_observe_rows emit: 0 auto, 1 single floats, 2 float2 runs where legal, 3 aligned float4 runs
 };
 
 struct OptKey {
@@ -83,7 +83,7 @@ const OptKey kOptKeys[] = {
     {"big_walk_blocks", &Options::big_walk_blocks, 0, 1 << 20, false},
     {"big_walk_static", &Options::big_walk_static, 0, 1, false},
     {"big_walk_share", &Options::big_walk_share, 0, 1 << 20, false},
-    {"rows_mode", &Options::rows_mode, 0, 2, true},
+    {"rows_mode", &Options::rows_mode, 0, 3, true},
 };
 
 std::mutex g_opt_mu;

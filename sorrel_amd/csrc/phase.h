@@ -275,12 +275,15 @@ __device__ __forceinline__ void rows_index(uint64_t (&row)[L][(2 * R + 1 + 7) / 
 //                 one agent in that agent's own [E][C][V][V] destination): streaming float4 stores of whole lines, as the
 //                 headline kernel's emit -- observe_rows at config 3: 188 us with per-lane 16-byte pieces, 145 with
 //                 per-window float2 runs, ... flat;
-//   kRowsPair     every destination 8-byte aligned and C*V*V even: per window, float2 runs;
-//   kRowsSingle   anything else: per window, single floats.
+//   kRowsRun      (round 4) any other destination: per window, the elements up to the first 16-byte boundary one by one, then
+//                 float4 streaming stores on 16-byte boundaries (the staged bytes re-aligned with v_alignbyte), then the rest one by
+//                 one -- rows with a tail behind the window (Cleanup: 1 089 + 12 elements per env) have no common alignment;
+//   kRowsPair     every destination 8-byte aligned and C*V*V even: per window, float2 runs (kept as a test / A-B path);
+//   kRowsSingle   per window, single floats (likewise).
 //   idx     this lane's row (rows_index)          o       the window's destination (the same in every lane of a group)
 //   wd      the wave's counter words              stage   the wave's staging area, WPW * C*V*V bytes (+ 3)
 //   act     this lane renders a row of a live window
-constexpr int kRowsSingle = 1, kRowsPair = 2, kRowsFlat = 4;
+constexpr int kRowsSingle = 1, kRowsPair = 2, kRowsRun = 3, kRowsFlat = 4;
 template <int L, int NW, int R>
 __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 7) / 8], const uint32_t* wd, uint8_t* stage, float* o,
                                           const int C, const int lane, const bool act, const int mode) {
@@ -346,7 +349,27 @@ __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 
         float* ow = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)o_hi, w * G) << 32) |
                                              (uint32_t)__builtin_amdgcn_readlane((int)o_lo, w * G));
         const uint8_t* sw = stage + w * N;
-        if (mode == kRowsPair) {
+        if (mode == kRowsRun) {
+            typedef float vfloat4 __attribute__((ext_vector_type(4)));
+            const int h = min((int)(((16u - ((uint32_t)reinterpret_cast<uintptr_t>(ow) & 15u)) & 15u) >> 2), N);   // elements before the first 16-byte boundary
+            if (lane < h) ow[lane] = (float)sw[lane];
+            const int nb = (N - h) >> 2;
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(stage);
+            const int base = w * N + h;                                       // staging byte of the body's first element
+            for (int k = lane; k < nb; k += 64) {
+                const int off = base + 4 * k;
+                const uint32_t lo = s4[off >> 2], hi = (off & 3) ? s4[(off >> 2) + 1] : 0u;
+                const uint32_t b = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(off & 3));
+                vfloat4 v;
+                v.x = (float)(b & 0xFFu);
+                v.y = (float)((b >> 8) & 0xFFu);
+                v.z = (float)((b >> 16) & 0xFFu);
+                v.w = (float)(b >> 24);
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(ow + h) + k);
+            }
+            const int done = h + 4 * nb;
+            if (lane < N - done) ow[done + lane] = (float)sw[done + lane];
+        } else if (mode == kRowsPair) {
             for (int k = lane; 2 * k < N; k += 64) {
                 const uint32_t b2 = (uint32_t)sw[2 * k] | ((uint32_t)sw[2 * k + 1] << 8);
                 vf2u v2 = {(float)(b2 & 0xFFu), (float)(b2 >> 8)};

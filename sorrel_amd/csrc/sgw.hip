@@ -1297,7 +1297,8 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
         const int64_t N = (int64_t)p.C * p.VV;
         const uintptr_t dst = reinterpret_cast<uintptr_t>(p.obs);
-        p.rows_mode = (p.obs_A == 1 && (dst & 15) == 0) ? kRowsFlat : (((dst & 7) == 0 && (N & 1) == 0) ? kRowsPair : kRowsSingle);
+        p.rows_mode = (p.obs_A == 1 && (dst & 15) == 0) ? kRowsFlat : kRowsRun;
+        (void)N;
         if (int rc = launch_kernel(e, e->k_rows, (unsigned)ceil_div(p.E, e->rows_epb), kBlock, e->rows_lds, s, p, nullptr)) return rc;
         return time_end(e, s);
     }
@@ -1501,9 +1502,9 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
         const bool pair_ok = al8 && (N & 1) == 0 && (env_stride & 1) == 0;
         if (slots && (reinterpret_cast<uintptr_t>(rows[agent_begin]) & 15) == 0) p.rows_mode = kRowsFlat;
         else if (env_stride == N && al16) { p.rows_mode = kRowsFlat; p.rows_by_agent = 1; }
-        else p.rows_mode = pair_ok ? kRowsPair : kRowsSingle;
-        const int m = e->opt.rows_mode;   // test hook: force a slower emit (1 = single floats, 2 = float2 runs where legal)
-        if (m == kRowsSingle || (m == kRowsPair && pair_ok)) { p.rows_mode = m; p.rows_by_agent = 0; }
+        else p.rows_mode = kRowsRun;      // per window: aligned float4 runs, the ends element by element
+        const int m = e->opt.rows_mode;   // test hook: force another emit (1 = single floats, 2 = float2 runs where legal, 3 = aligned runs)
+        if (m == kRowsSingle || m == kRowsRun || (m == kRowsPair && pair_ok)) { p.rows_mode = m; p.rows_by_agent = 0; }
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = time_begin(e, s)) return rc;

@@ -332,7 +332,7 @@ def test_environment_policy_turn_protocols_agree_and_overridden_take_turn_is_cal
     assert len(calls) == 2 * 7, calls
 
 
-@pytest.mark.parametrize("mode", ["flat", "pairs", "singles", "offset_rows", "agent_range"])
+@pytest.mark.parametrize("mode", ["flat", "pairs", "singles", "runs", "offset_rows", "agent_range"])
 def test_observe_rows_emit_modes(torch_cuda, mode, monkeypatch):
     """The staged windows leave as one contiguous aligned run per wave (tensor slots: agents of consecutive envs; per-agent
     rows: consecutive envs of one agent), as float2 runs per window, or as single floats -- whatever the alignment of the
@@ -342,6 +342,8 @@ def test_observe_rows_emit_modes(torch_cuda, mode, monkeypatch):
         N.set_option("rows_mode", 2)
     if mode == "singles":
         N.set_option("rows_mode", 1)
+    if mode == "runs":        # (round 4: what unaligned destinations take by default -- aligned float4 runs, the ends element by element)
+        N.set_option("rows_mode", 3)
     for (h, w, layers, channels, a_, r_, E) in [(32, 32, 2, 6, 8, 3, 77), (16, 16, 2, 6, 4, 2, 201), (9, 13, 1, 3, 5, 1, 50), (40, 36, 2, 8, 3, 5, 13)]:
         ws = _move_world(h, w, layers, channels, a_, r_, seed=3)
         A = ws.num_agents

@@ -438,6 +438,15 @@ int sgw_turn_begin(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
 int sgw_turn_act(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* obs, float* rewards,
                  double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream);
 int sgw_turn_end(sgw_engine* eng, const void* obs, void* stream);
+/* The same protocol with the windows in PER-AGENT rows (`rows[a]` + env * env_stride, as sgw_observe_rows / sgw_act take them; needs
+ * SGW_CAP_OBSERVE_ROWS): sgw_turn_begin_rows = the sweep alone + every agent's window into its row AND -- by the device's row count --
+ * into its replay row of the turn in flight; sgw_turn_act_rows repairs both copies; sgw_turn_end(eng, NULL, stream) then only
+ * advances the rings.  No copy of the windows at the end of the turn (617 MB read + written at config 3's 65 536 envs), and each
+ * policy reads a contiguous [E][C*V*V] row at a fixed address. */
+int sgw_turn_begin_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rewards, double* total_reward,
+                        void* const* rows, int64_t env_stride, uint32_t flags, void* stream);
+int sgw_turn_act_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
+                      float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream);
 int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* stream);
 
 /* out6 = { instances compiled, loaded from the disk cache, reused in memory, refused, ms spent compiling, ms spent loading }

@@ -206,6 +206,8 @@ struct RowPtrs {
     float* reward_row;          // [E]: a second copy of the rewards (the row of the agent's replay buffer)
     int64_t* action_row;        // [E]: the actions as int64 (the row of the agent's replay buffer)
     const TurnState* ts;        // sgw_turn_act: reward_row / action_row are the acting agent's ring rows of the turn the engine has counted up to
+    int dual;                   // sgw_turn_*_rows: every window (and every repair) is ALSO written to the agent's ring row of the turn in flight
+    int rows_mode2;             // ... how those second copies leave (kRowsFlat where the rings allow it, else kRowsRun)
 };
 
 __device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* q) {
@@ -286,14 +288,14 @@ __device__ __forceinline__ void rows_index(uint64_t (&row)[L][(2 * R + 1 + 7) / 
 constexpr int kRowsSingle = 1, kRowsPair = 2, kRowsRun = 3, kRowsFlat = 4;
 template <int L, int NW, int R>
 __device__ __forceinline__ void rows_emit(const uint64_t (&idx)[L][(2 * R + 1 + 7) / 8], const uint32_t* wd, uint8_t* stage, float* o,
-                                          const int C, const int lane, const bool act, const int mode) {
+                                          const int C, const int lane, const bool act, const int mode, const bool staged = false) {   // staged: the bytes are in the staging area already (a second destination)
     constexpr int V = 2 * R + 1, VV = V * V, kTabW = RowsTab<NW>::kTabW;
     constexpr int G = V <= 4 ? 4 : (V <= 8 ? 8 : 16), WPW = 64 / G;
     const int N = C * VV;
     const uint8_t* wdb = reinterpret_cast<const uint8_t*>(wd);
     const int gl = lane & (G - 1);
     uint8_t* mine = stage + (lane / G) * N + gl * V;
-    if (act) {
+    if (act && !staged) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             uint32_t cnt[NW];
@@ -578,6 +580,15 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
     rows_index<L, R>(row, rowinb, x, W);
     float* o = reinterpret_cast<float*>(rp.p[a]) + env * rp.stride;
     rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o, p.C, lane, live && gl < V, p.rows_mode);
+    if (rp.dual && rp.ts) {      // the same windows into the agents' replay rows of the turn in flight (by the device's row count): a recorded turn
+        const TurnState* ts = rp.ts;   // needs no copy of the windows afterwards
+        const bool keep = ts->cap[a] > 0 && ts->states[a] != nullptr;
+        float* o2 = keep ? static_cast<float*>(ts->states[a]) + (ts->row[a] * p.E + env) * ts->row_elems[a] : o;
+        if (keep && live && gl == 0 && ts->dones[a]) ts->dones[a][ts->row[a] * p.E + env] = 0.f;   // done is False inside an epoch
+        // (flat mode: a wave carries consecutive envs of ONE agent, so `keep` is wave-uniform; otherwise dead windows are masked below)
+        if (__ballot(keep) != 0ull)
+            rows_emit<L, NW, R>(row, wd, smem + sub * kWaveLds + RowsTab<NW>::kBytes + SGW_MAX_TYPES * 8, o2, p.C, lane, live && gl < V && keep, rp.rows_mode2, true);
+    }
     if (p.tail_kind != SGW_TAIL_NONE && live) {      // what pov() appends behind the flattened window
         float* t = o + p.C * VV;
         if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {   // TagAgent.pov: [self.it]
@@ -678,6 +689,8 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                         const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
                         if (p.obs_u8) reinterpret_cast<uint8_t*>(rp.p[jj])[o + (int64_t)c * VV] = (uint8_t)v;
                         else reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = (float)v;
+                        if (rp.dual && rp.ts && rp.ts->cap[jj] > 0 && rp.ts->states[jj])      // ... and in the agent's replay row of this turn
+                            static_cast<float*>(rp.ts->states[jj])[(rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj] + di * V + dj + (int64_t)c * VV] = (float)v;
                     }
                 }
             }
@@ -689,6 +702,8 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                 for (int z = 1; z < SGW_MAX_LAYERS; ++z)
                     if (z < L) acc += s_app[tz[z] * SGW_MAX_CHANNELS + c];
                 reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
+                if (rp.dual && rp.ts && rp.ts->cap[jj] > 0 && rp.ts->states[jj])
+                    static_cast<float*>(rp.ts->states[jj])[(rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj] + di * V + dj + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
             }
         }
       }

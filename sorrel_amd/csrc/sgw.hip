@@ -112,6 +112,7 @@ struct sgw_engine {
     TurnState* d_turn = nullptr;   // device-side turn state (sgw_turn_*): a whole policy turn as one capturable submission
     bool turn_rows = false;        // sgw_turn_bind gave replay rows
     bool turn_rows_even = false;   // ... all of them 8-byte aligned with an even row stride (float2 copies)
+    bool turn_rows_flat = false;   // ... all of them 16-byte aligned rows of exactly one window per env, E * N * 4 a multiple of 16 (flat second copies)
     int obs_format = SGW_OBS_F32;
     uint8_t* agent_state = nullptr;    // caller-owned, bound with sgw_bind_agent_state
     uint8_t* state_at_pov = nullptr;
@@ -1472,8 +1473,8 @@ static int fill_rows(const sgw_engine* e, void* const* rows, int64_t env_stride,
     return SGW_OK;
 }
 
-int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
-                     int32_t agent_begin, int32_t agent_end, void* stream) {
+static int observe_rows_impl(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
+                             int32_t agent_begin, int32_t agent_end, const TurnState* ts, void* stream) {
     if (!e || !grid || !agent_pos) return fail(SGW_EINVAL, "sgw_observe_rows: NULL argument");
     if (agent_begin < 0 || agent_end > e->cfg.num_agents || agent_begin >= agent_end)
         return fail(SGW_EINVAL, "sgw_observe_rows: agent range [%d, %d) invalid", agent_begin, agent_end);
@@ -1482,6 +1483,11 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
                                 "see sgw_capabilities) -- use sgw_observe");
     RowPtrs rp;
     if (int rc = fill_rows(e, rows, env_stride, agent_begin, agent_end, true, &rp, "sgw_observe_rows")) return rc;
+    if (ts && e->turn_rows) {   // a recorded turn: the windows also go to the replay rows of the turn in flight
+        rp.ts = ts;
+        rp.dual = 1;
+        rp.rows_mode2 = e->turn_rows_flat ? kRowsFlat : kRowsRun;
+    }
     Params p = e->base;
     p.grid = const_cast<uint8_t*>(grid); p.pos = const_cast<uint8_t*>(agent_pos);
     p.a0 = agent_begin; p.a1 = agent_end; p.flags = 0; p.do_move = 0;
@@ -1510,13 +1516,19 @@ int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_po
     if (int rc = time_begin(e, s)) return rc;
     const int wpw = e->rows_wpb / 4;                                   // windows per wave
     const int64_t waves = p.rows_by_agent ? ceil_div(p.E, wpw) * (agent_end - agent_begin) : ceil_div(p.E * (agent_end - agent_begin), wpw);
+    if (rp.dual && rp.rows_mode2 == kRowsFlat && !p.rows_by_agent) rp.rows_mode2 = kRowsRun;   // (flat second copies need a wave = consecutive envs of ONE agent)
     if (int rc = launch_kernel(e, e->k_obs_rows, (unsigned)ceil_div(waves, 4), kBlock, e->rows_lds, s, p, &rp)) return rc;
     return time_end(e, s);
 }
 
+int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
+                     int32_t agent_begin, int32_t agent_end, void* stream) {
+    return observe_rows_impl(e, grid, agent_pos, rows, env_stride, agent_begin, agent_end, nullptr, stream);
+}
+
 static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
                     float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
-                    float* reward_row, int64_t* action_row, const TurnState* ts, void* stream) {
+                    float* reward_row, int64_t* action_row, const TurnState* ts, void* stream, int dual = 0) {
     if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward) return fail(SGW_EINVAL, "sgw_act: NULL argument");
     if (agent < 0 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_act: agent %d out of range", agent);
     if (e->cfg.agent_rule == SGW_AGENT_RULE_TAG && !e->agent_state) return fail(SGW_EINVAL, "SGW_AGENT_RULE_TAG needs sgw_bind_agent_state");
@@ -1529,6 +1541,7 @@ static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* a
         return fail(SGW_EINVAL, "sgw_act: unknown action_kind %d", action_kind);
     rp.agent_action = agent_action; rp.action_kind = action_kind; rp.reward_row = reward_row; rp.action_row = action_row;
     rp.ts = ts;
+    rp.dual = (dual && ts && e->turn_rows) ? 1 : 0;
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.rewards = rewards; p.total = total_reward;
     p.a0 = agent; p.a1 = agent + 1; p.flags = SGW_STEP_NO_OBS; p.do_move = 1;
@@ -1582,8 +1595,10 @@ int sgw_turn_bind(sgw_engine* e, const sgw_turn_rows* rows) {
             h.row[a] = rows->row[a]; h.cap[a] = rows->capacity[a]; h.step[a] = rows->step[a]; h.row_elems[a] = rows->row_elems[a];
             h.states[a] = rows->states[a]; h.rewards[a] = rows->rewards[a]; h.actions[a] = rows->actions[a];
             h.dones[a] = rows->states[a] ? rows->dones[a] : nullptr;   // (zeroed by the window copy)
-            if (!e->turn_rows) e->turn_rows_even = true;
+            if (!e->turn_rows) e->turn_rows_even = e->turn_rows_flat = true;
             e->turn_rows = true;
+            if (rows->states[a] && ((reinterpret_cast<uintptr_t>(rows->states[a]) & 15) || rows->row_elems[a] != N || (((int64_t)e->cfg.num_envs * N * 4) & 15)))
+                e->turn_rows_flat = false;
             if (rows->states[a] && ((reinterpret_cast<uintptr_t>(rows->states[a]) & 7) || (rows->row_elems[a] & 1))) e->turn_rows_even = false;
         }
     }
@@ -1621,6 +1636,29 @@ int sgw_turn_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* acti
     for (int a = 0; a < A; ++a) rows[a] = static_cast<uint8_t*>(obs) + (int64_t)a * N * esz;   // slot a of the [E][A][C][V][V] tensor
     return act_impl(e, grid, agent_pos, actions, rows, (int64_t)A * N, rewards, total_reward, agent, agent_action, action_kind, nullptr, nullptr,
                     e->d_turn, stream);
+}
+
+int sgw_turn_begin_rows(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rewards, double* total_reward,
+                        void* const* rows, int64_t env_stride, uint32_t flags, void* stream) {
+    if (!e || !grid || !agent_pos || !actions || !rewards || !total_reward || !rows) return fail(SGW_EINVAL, "sgw_turn_begin_rows: NULL argument");
+    if (flags & ~(SGW_STEP_SWEEP)) return fail(SGW_EINVAL, "sgw_turn_begin_rows: only SGW_STEP_SWEEP may be set");
+    if (!(sgw_capabilities(e) & SGW_CAP_OBSERVE_ROWS)) return fail(SGW_EINVAL, "sgw_turn_begin_rows needs SGW_CAP_OBSERVE_ROWS (one-hot float32 windows); use sgw_turn_begin");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & SGW_STEP_SWEEP) {     // the entity sweep alone, at the device's turn
+        Params p = e->base;
+        p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = nullptr; p.rewards = rewards; p.total = total_reward;
+        p.ts = e->d_turn;
+        p.a0 = 0; p.a1 = 0; p.flags = SGW_STEP_SWEEP | SGW_STEP_NO_OBS; p.do_move = 1;
+        if (int rc = launch_step(e, p, s)) return rc;
+    }
+    return observe_rows_impl(e, grid, agent_pos, rows, env_stride, 0, e->cfg.num_agents, e->d_turn, stream);
+}
+
+int sgw_turn_act_rows(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride, float* rewards,
+                      double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream) {
+    if (!e || !rows) return fail(SGW_EINVAL, "sgw_turn_act_rows: NULL argument");
+    return act_impl(e, grid, agent_pos, actions, rows, env_stride, rewards, total_reward, agent, agent_action, action_kind, nullptr, nullptr,
+                    e->d_turn, stream, 1);
 }
 
 int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {

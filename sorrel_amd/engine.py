@@ -390,6 +390,32 @@ class GridEngine:
             N.check(rc)
         return self.rewards[:, agent]
 
+    def turn_begin_rows(self, rows, sweep: bool = True):
+        """``sgw_turn_begin_rows``: the sweep alone, then every agent's window into its row of ``rows`` (``window_rows(dests)``) AND -- by
+        the device's row count -- into its replay row of the turn in flight."""
+        arr, stride, _ = rows
+        with self._on_device():
+            rc = self._lib.sgw_turn_begin_rows(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(),
+                                               self.total_reward.data_ptr(), arr, stride, N.STEP_SWEEP if sweep else 0, self._stream())
+        if rc:
+            N.check(rc)
+
+    def turn_act_rows(self, agent: int, rows, action: Optional[torch.Tensor] = None):
+        """``sgw_turn_act_rows``: ``act`` of one agent, the repairs written to the later agents' rows of ``rows`` and to their replay rows."""
+        arr, stride, _ = rows
+        kind = pa = 0
+        if action is not None:
+            kind = self._ACTION_KINDS.get(action.dtype)
+            if kind is None or action.device != self.device or action.numel() != self.num_envs or not action.is_contiguous():
+                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {self.num_envs} elements on {self.device}")
+            pa = action.data_ptr()
+        with self._on_device():
+            rc = self._lib.sgw_turn_act_rows(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), arr, stride,
+                                             self.rewards.data_ptr(), self.total_reward.data_ptr(), int(agent), pa or None, kind, self._stream())
+        if rc:
+            N.check(rc)
+        return self.rewards[:, agent]
+
     def turn_end(self, commit_windows: bool = True):
         """``sgw_turn_end``: the turn's windows -> the agents' ring rows, every ring advances."""
         with self._on_device():

@@ -123,6 +123,7 @@ class Environment:
         self._turn_windows = None    # [world mutation count, rows, first agent whose window is still current, replay slots]: this turn's windows
         self._replay_slots = None
         self._tail_rows = None
+        self._capture_rows = None    # recorded turns: (pointer array, stride, per-agent [E, C*V*V] tensors) the policies read their windows from
         self._captured = None        # CapturedTurn: a whole policy turn recorded as one graph (capture_turn)
         self._turn_capture = False   # the turn protocol with device-side counters is in charge of this turn (recording or warming up)
         self._engine = None
@@ -316,6 +317,10 @@ class Environment:
                 return
         eng.bind_row_tail(kind, table)
 
+    #: recorded turns: "rows" (default where the engine can: per-agent window rows, replay rows written alongside) or "tensor" (the
+    #: observation tensor + a copy into the replay rows at the end of the turn) -- A/B and tests
+    capture_layout = "rows"
+
     #: Tag / Cleanup agents: let the engine write what ``pov`` appends behind the window (False = ``torch.cat`` on the host: A/B and tests)
     row_tails_in_kernel = True
 
@@ -458,16 +463,21 @@ class Environment:
     def _turn_protocol_body(self, eng) -> None:
         """One policy-driven take_turn through the device-counted protocol (include/sgw.h, sgw_turn_*): the same calls with the same
         arguments every turn -- what a graph can record."""
-        eng.turn_begin(sweep=True)
-        self._turn_windows = [self.world.mutations, eng.window_rows(None), 0, None]
+        rows = self._capture_rows
+        if rows is not None:       # windows in per-agent rows at fixed addresses; the kernels write the replay rows alongside (no copy at the end)
+            eng.turn_begin_rows(rows, sweep=True)
+        else:                      # windows in the observation tensor; sgw_turn_end copies them into the replay rows
+            rows = eng.window_rows(None)
+            eng.turn_begin(sweep=True)
+        self._turn_windows = [self.world.mutations, rows, 0, None]
         self._turn_capture = True
         try:
             for agent in self.agents:
-                agent.transition(self.world)          # pov (a view of eng.obs) -> get_action -> act (sgw_turn_act) -> add_memory (deferred)
+                agent.transition(self.world)          # pov (a view of the window at its fixed address) -> get_action -> act -> add_memory (deferred)
         finally:
             self._turn_capture = False
             self._turn_windows = None
-        eng.turn_end()
+        eng.turn_end(commit_windows=self._capture_rows is None)
 
     def capture_turn(self, warmup: int = 2):
         """Record ONE whole policy-driven ``take_turn`` -- sweep + every agent's window, then per agent the policy's forward pass
@@ -485,6 +495,7 @@ class Environment:
         recorded: an agent class overrides ``transition`` / ``add_memory``, a model's memory is not a ``sorrel_amd.buffers.Buffer``
         of plain windows with ``n_frames == 1`` (frame stacks and appended features index the ring from the host), the engine has
         no observation tensor, or a model's forward pass does something a capture forbids (a host synchronisation)."""
+        from sorrel_amd import _native as N
         from sorrel_amd.buffers import Buffer
 
         self._captured = None
@@ -515,6 +526,11 @@ class Environment:
                               (mem.idx + k) % mem.capacity, len(slots))
             return out
 
+        # where the policies read their windows: per-agent rows the row kernels fill (and, alongside, the replay rows) where the engine
+        # has them -- one-hot float32 windows --, else the observation tensor + a copy at the end of the turn
+        self._capture_rows = None
+        if self.capture_layout != "tensor" and (eng.capabilities() & N.CAP_OBSERVE_ROWS) and eng.row_tail == 0:
+            self._capture_rows = eng.window_rows([torch.zeros((eng.num_envs, per_env), dtype=torch.float32, device=eng.device) for _ in self.agents])
         cap = CapturedTurn(self, eng, buffers, [len(v[1]) for v in sharers.values()], rings)
         try:
             cap.record(max(1, int(warmup)))
@@ -707,6 +723,8 @@ class Environment:
                 and action.shape[0] == eng.num_envs and action.is_contiguous()
             if not direct:
                 eng.actions[:, a].copy_(action)
+            if self._capture_rows is not None:
+                return eng.turn_act_rows(a, tw[1], action if direct else None)
             return eng.turn_act(a, action if direct else None)
         if tw is not None:
             if tw[0] == self.world.mutations and a >= tw[2]:
@@ -1011,6 +1029,7 @@ class CapturedTurn:
         for mem in self.buffers:
             mem._deferred = False
         self.graph = None
+        self.env._capture_rows = None
         try:
             self.eng.turn_bind(None)
         except Exception:

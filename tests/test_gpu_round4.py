@@ -13,8 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------ sgw_turn_*: the device counts turns and replay rows
-def test_turn_protocol_counts_on_the_device_vs_oracle(torch_cuda):
-    """sgw_turn_begin / sgw_turn_act / sgw_turn_end with the SAME arguments every turn: the turn number, the epoch and each agent's
+@pytest.mark.parametrize("layout", ["tensor", "rows"])
+def test_turn_protocol_counts_on_the_device_vs_oracle(torch_cuda, layout):
+    """sgw_turn_begin / sgw_turn_act / sgw_turn_end (windows in the observation tensor, copied into the replay rows at the end of the turn)
+    and sgw_turn_begin_rows / sgw_turn_act_rows (windows in per-agent rows, the replay rows written alongside) with the SAME arguments every turn: the turn number, the epoch and each agent's
     replay row come from device memory the engine advances itself.  Every window an agent's policy would read, the rewards, the
     state and the rows of the rings (windows, int64 actions, float32 rewards, zeroed dones) against the C oracle, across a ring
     wrap-around and an epoch change."""
@@ -34,6 +36,8 @@ def test_turn_protocol_counts_on_the_device_vs_oracle(torch_cuda):
     rings = [(r["states"], r["rewards"], r["actions"], r["dones"], 1, 1) for r in own] + \
             [(shared["states"], shared["rewards"], shared["actions"], shared["dones"], 2 + k, 2) for k in range(2)]
     eng.turn_bind(rings)
+    dests = [torch.zeros((E, N_), device="cuda:0") for _ in range(A)]
+    rows = eng.window_rows(dests)
     rng = np.random.default_rng(3)
     epoch = 4
     eng.reset(epoch)
@@ -50,13 +54,22 @@ def test_turn_protocol_counts_on_the_device_vs_oracle(torch_cuda):
         acts = rng.integers(0, len(ws.action_dy), size=(E, A), dtype=np.uint8)
         assert co.step(epoch, turn, actions=acts) == 0
         policy = torch.from_numpy(acts.astype(np.int64)).cuda()
-        eng.obs.fill_(-9.0)
-        eng.turn_begin()
         seen = torch.zeros_like(eng.obs)
-        for a in range(A):
-            seen[:, a] = eng.obs[:, a]
-            eng.turn_act(a, policy[:, a].contiguous())
-        eng.turn_end()
+        if layout == "tensor":
+            eng.obs.fill_(-9.0)
+            eng.turn_begin()
+            for a in range(A):
+                seen[:, a] = eng.obs[:, a]
+                eng.turn_act(a, policy[:, a].contiguous())
+            eng.turn_end()
+        else:
+            for d in dests:
+                d.fill_(-9.0)
+            eng.turn_begin_rows(rows)
+            for a in range(A):
+                seen[:, a] = dests[a].view(E, *ws.obs_shape[1:])
+                eng.turn_act_rows(a, rows, policy[:, a].contiguous())
+            eng.turn_end(commit_windows=False)
         torch.cuda.synchronize()
         assert eng.turn_state()[:2] == (epoch, turn)
         assert np.array_equal(seen.cpu().numpy(), co.obs), f"turn {t}: windows at pov time"
@@ -94,15 +107,18 @@ def _policy_env(E, shape=(13, 15, 5, 2), memory=6, seed=5):
     return make_env(h, w, a, r, E, p=0.05, seed=seed, model_factory=Policy)
 
 
-def test_captured_turn_equals_the_eager_turn_and_the_oracle(torch_cuda):
+@pytest.mark.parametrize("layout", ["rows", "tensor"])
+def test_captured_turn_equals_the_eager_turn_and_the_oracle(torch_cuda, layout):
     """Environment.capture_turn(): sweep + every window + A x (policy forward, act) + the copy into the replay rows recorded ONCE and
     replayed -- 60 turns across two epoch resets and several wrap-arounds of the 6-row rings equal the eager loop (state, step
     outputs, every buffer row, the buffers' idx / size), and the C oracle stepping the actions the policies chose."""
     torch = torch_cuda
     E = 37
     a, b = _policy_env(E), _policy_env(E)
+    b.capture_layout = layout
     cap = b.capture_turn(warmup=2)
     assert cap is not None, getattr(b, "capture_error", None)
+    assert (b._capture_rows is not None) == (layout == "rows")
     for _ in range(2):                      # the warm-up turns were real turns
         a.take_turn()
     ws = a._engine.spec

@@ -85,3 +85,18 @@ if eng.capabilities() & N.CAP_OBSERVE_ROWS:
     print(f"  policy-driven, 2 + A launches (round 4: sweep, observe_rows into tailed rows, sgw_act) {timed(lambda: [tailed_turn() for _ in range(20)], 3) / 20:8.1f} us/turn"
           f"   (sweep alone {parts()[0]:.1f} us, observe_rows {parts()[1]:.1f} us)")
     assert eng.status() == 0
+
+    # round 4, "lazy windows": the sweep alone, then per agent its OWN window rendered right before its policy reads it (observe_rows of
+    # one agent: what earlier agents' beams and moves did is simply in the grid by then) and its act WITHOUT repairs.  2 A + 1 launches;
+    # pays where an act changes many cells that many later windows contain (Cleanup's beams: 3 R cells x ~5 later windows x 2 channels
+    # of lone 4-byte stores per env and act)
+    def lazy_turn():
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, advance_turn=False)
+        for a in range(10):
+            eng.observe_rows(TROWS, a, a + 1)
+            eng.act(a, None)
+        eng.turn += 1
+
+    print(f"  policy-driven, 1 + 2 A launches (round 4: sweep, then per agent observe_rows of ONE agent + sgw_act without repairs) {timed(lambda: [lazy_turn() for _ in range(20)], 3) / 20:8.1f} us/turn"
+          f"   (one agent's window {timed(lambda: eng.observe_rows(TROWS, 3, 4), 20):.1f} us, an act without repairs {timed(lambda: eng.act(3, None), 20):.1f} us)")
+    assert eng.status() == 0

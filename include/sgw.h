@@ -103,6 +103,7 @@ extern "C" {
 #define SGW_STREAM_DENSE 4
 #define SGW_STREAM_DENSE_KIND 5
 #define SGW_STREAM_TAG_INIT 6
+#define SGW_STREAM_EXPLORE 7           /* index = agent: the epsilon test of SGW_ACT_QF32 (sgw_turn_epsilon) */
 
 /* what Agent.act does (sgw_config.agent_rule) */
 #define SGW_AGENT_RULE_MOVE 0 /* MovingAgent.act: reward = value of the target, then move (sorrel/agents/agent.py:215-225) */
@@ -252,6 +253,17 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
 #define SGW_ACT_U8 0
 #define SGW_ACT_I32 1
 #define SGW_ACT_I64 2
+/* SGW_ACT_QF32: `agent_action` is the policy's VALUE output, float32 [E][num_actions] (contiguous): the act takes the first index
+ * of the row's maximum itself (np.argmax / torch.argmax; a NaN counts as the maximum, as in both) -- the greedy half of the
+ * reference's take_action (sorrel/models/pytorch/iqn.py:294-309: `random.random() > epsilon` -> argmax of the action values, else a
+ * uniform action), one launch less per agent in a recorded turn.  The other half under the turn protocol (sgw_turn_act /
+ * sgw_turn_act_rows): with probability epsilon[agent] (sgw_turn_epsilon; 0 until set) the action is the engine's own uniform draw
+ * for (env, turn, agent) -- the action SGW_STEP_RANDOM_ACTIONS would take, stream SGW_STREAM_ACTION -- decided by
+ * u32(SGW_STREAM_EXPLORE, index = agent) < floor(epsilon * 2^32).  sgw_act has no turn of its own: it reads epoch, turn in flight
+ * (= completed + 1) and epsilon from the same device state, which its caller keeps current with sgw_turn_set (epsilon 0, the
+ * default, needs neither).  The action taken is recorded in actions[:, agent] (uint8) and the replay row (int64) as for the
+ * other kinds. */
+#define SGW_ACT_QF32 3
 int sgw_capabilities(sgw_engine* eng);
 int sgw_observe_rows(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
                      int32_t agent_begin, int32_t agent_end, void* stream);
@@ -448,6 +460,9 @@ int sgw_turn_begin_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint
 int sgw_turn_act_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
                       float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream);
 int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* stream);
+/* Exploration rate of SGW_ACT_QF32 acts under the turn protocol: `agent` in [0, A) or -1 for every agent; epsilon in [0, 1].
+ * Stream-ordered and kept in the device's turn state, so a recorded turn follows a decaying epsilon without being recorded again. */
+int sgw_turn_epsilon(sgw_engine* eng, int32_t agent, double epsilon, void* stream);
 
 /* out6 = { instances compiled, loaded from the disk cache, reused in memory, refused, ms spent compiling, ms spent loading }
  * of this process so far. */

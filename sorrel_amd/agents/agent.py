@@ -92,8 +92,17 @@ class Agent(Entity):
         state = self.pov(world)
         action = self.get_action(state)
         reward = self.act(world, action)
+        if torch.is_tensor(action) and action.dim() == 2:
+            # get_action returned action VALUES ([E, n_actions]): the act chose -- argmax, or the engine's uniform draw with
+            # probability ``epsilon`` (iqn.py:294-309, in-kernel) -- and what it took is on record
+            action = world._environment.actions[:, self.slot]
         done = self.is_done(world)
         self.add_memory(state, action, reward, done)
+
+    @property
+    def epsilon(self) -> float:
+        """Exploration rate of an agent whose ``get_action`` returns action values: the model's (``iqn.py:305-309``), 0 without one."""
+        return float(getattr(self.model, "epsilon", 0.0) or 0.0)
 
 
 class MovingAgent(Agent):

@@ -51,6 +51,7 @@ struct TurnState {
     int64_t* actions[SGW_MAX_AGENTS];     // [cap][E]
     float* dones[SGW_MAX_AGENTS];         // [cap][E]: zeroed for the turn's row (done is False inside an epoch); NULL: rows are all zero already
     int64_t row_elems[SGW_MAX_AGENTS];    // elements per env of a states row (>= C*V*V; the tail is the caller's)
+    uint64_t eps_thr[SGW_MAX_AGENTS];     // SGW_ACT_QF32: explore when u32 < eps_thr (floor(epsilon * 2^32): 2^32 = always)
 };
 
 struct Params {

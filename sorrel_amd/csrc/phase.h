@@ -202,10 +202,11 @@ struct RowPtrs {
     int64_t stride;
     // sgw_act only: where the acting agent's action comes from and where else its outputs go (all optional)
     const void* agent_action;   // [E] of the agent's own actions (the policy's output tensor as it is); NULL: actions[E][A]
-    int action_kind;            // SGW_ACT_U8 / _I32 / _I64
+    int action_kind;            // SGW_ACT_U8 / _I32 / _I64 / _QF32 (agent_action: [E][nact] action values)
     float* reward_row;          // [E]: a second copy of the rewards (the row of the agent's replay buffer)
     int64_t* action_row;        // [E]: the actions as int64 (the row of the agent's replay buffer)
     const TurnState* ts;        // sgw_turn_act: reward_row / action_row are the acting agent's ring rows of the turn the engine has counted up to
+    const TurnState* ets;       // SGW_ACT_QF32: where the exploration reads epsilon, epoch and turn (= ts under the turn protocol)
     int dual;                   // sgw_turn_*_rows: every window (and every repair) is ALSO written to the agent's ring row of the turn in flight
     int rows_mode2;             // ... how those second copies leave (kRowsFlat where the rings allow it, else kRowsRun)
 };
@@ -399,7 +400,36 @@ struct ActIO {                   // sgw_act's optional extras (see RowPtrs), pas
     int action_kind = 0;
     float* reward_row = nullptr;
     int64_t* action_row = nullptr;
+    const TurnState* ts = nullptr;
 };
+// The caller's action of agent a in env: its tensor's element, or for SGW_ACT_QF32 the first index of the maximum of the env's row of
+// action values (np.argmax; NaN = maximum, as np / torch have it) -- and, under the turn protocol, with probability epsilon[a] the
+// engine's own uniform draw for (env, turn, agent) instead, the action SGW_STEP_RANDOM_ACTIONS takes (sorrel/models/pytorch/iqn.py:294-309: the two branches of take_action_from_policy).
+__device__ __forceinline__ int64_t read_action(const Params& p, const void* agent_action, const int kind, const TurnState* ts,
+                                               const int64_t env, const int a) {
+    if (kind == SGW_ACT_I64) return reinterpret_cast<const int64_t*>(agent_action)[env];
+    if (kind == SGW_ACT_I32) return (int64_t)reinterpret_cast<const int32_t*>(agent_action)[env];
+    if (kind == SGW_ACT_U8) return (int64_t)reinterpret_cast<const uint8_t*>(agent_action)[env];
+    const float* q = reinterpret_cast<const float*>(agent_action) + env * p.nact;
+    float best = q[0];
+    int arg = 0;
+    for (int i = 1; i < p.nact; ++i) {
+        const float v = q[i];
+        if (best == best && (v > best || v != v)) { best = v; arg = i; }
+    }
+    if (ts) {
+        const uint64_t thr = ts->eps_thr[a];
+        if (thr) {
+            const uint32_t env_id = p.first_env + (uint32_t)env, turn = ts->turn + 1u, ep4 = ts->epoch << 4;
+            const U4 u = philox4x32_10((uint32_t)a >> 2, turn, env_id, ep4 | SGW_STREAM_EXPLORE, p.seed_lo, p.seed_hi);
+            if ((uint64_t)word_of(u, a & 3) < thr) {
+                const U4 w = philox4x32_10((uint32_t)a >> 2, turn, env_id, ep4 | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
+                arg = (int)(((uint64_t)word_of(w, a & 3) * (uint32_t)p.nact) >> 32);
+            }
+        }
+    }
+    return (int64_t)arg;
+}
 __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, uint8_t* g, const int64_t env, const int a,
                                         const double* wval, const bool writer, MoveOut& mo, const ActIO io = ActIO{}) {
     const int H = p.H, W = p.W, HW = H * W;
@@ -408,9 +438,7 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
     uint32_t act;
     int64_t act_raw;
     if (io.agent_action) {                               // the policy's own output tensor: one action per env
-        act_raw = io.action_kind == SGW_ACT_I64 ? reinterpret_cast<const int64_t*>(io.agent_action)[env]
-                : io.action_kind == SGW_ACT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(io.agent_action)[env]
-                                                   : (int64_t)reinterpret_cast<const uint8_t*>(io.agent_action)[env];
+        act_raw = read_action(p, io.agent_action, io.action_kind, io.ts, env, a);
         act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;     // out of range either way: SGW_STATUS_BAD_ACTION
     } else {
         act = p.actions[env * p.A + a];
@@ -711,7 +739,7 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
 
     if constexpr (RULE == SGW_AGENT_RULE_MOVE) {
         MoveOut mo;
-        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, reward_row, action_row});
+        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, reward_row, action_row, rp.ets});
         if (st && writer) atomicOr(p.status, st);
         if (mo.old_y < 0) return;
         patch(mo.old_y, mo.old_x, p.zA, mo.left, p.default_type);
@@ -724,9 +752,7 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
         uint32_t act;
         int64_t act_raw;
         if (rp.agent_action) {
-            act_raw = rp.action_kind == SGW_ACT_I64 ? reinterpret_cast<const int64_t*>(rp.agent_action)[env]
-                    : rp.action_kind == SGW_ACT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(rp.agent_action)[env]
-                                                    : (int64_t)reinterpret_cast<const uint8_t*>(rp.agent_action)[env];
+            act_raw = read_action(p, rp.agent_action, rp.action_kind, rp.ets, env, a);
             act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;
         } else {
             act = p.actions[env * p.A + a];

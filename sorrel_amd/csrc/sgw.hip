@@ -1537,10 +1537,13 @@ static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* a
     memset(&rp, 0, sizeof(rp));
     if (rows)
         if (int rc = fill_rows(e, rows, env_stride, agent + 1, e->cfg.num_agents, false, &rp, "sgw_act")) return rc;
-    if (agent_action && action_kind != SGW_ACT_U8 && action_kind != SGW_ACT_I32 && action_kind != SGW_ACT_I64)
+    if (agent_action && action_kind != SGW_ACT_U8 && action_kind != SGW_ACT_I32 && action_kind != SGW_ACT_I64 && action_kind != SGW_ACT_QF32)
         return fail(SGW_EINVAL, "sgw_act: unknown action_kind %d", action_kind);
+    if (agent_action && action_kind == SGW_ACT_QF32 && (reinterpret_cast<uintptr_t>(agent_action) & 3))
+        return fail(SGW_EINVAL, "sgw_act: SGW_ACT_QF32 action values must be 4-byte aligned");
     rp.agent_action = agent_action; rp.action_kind = action_kind; rp.reward_row = reward_row; rp.action_row = action_row;
     rp.ts = ts;
+    rp.ets = (agent_action && action_kind == SGW_ACT_QF32) ? e->d_turn : nullptr;
     rp.dual = (dual && ts && e->turn_rows) ? 1 : 0;
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.rewards = rewards; p.total = total_reward;
@@ -1610,6 +1613,17 @@ int sgw_turn_set(sgw_engine* e, uint32_t epoch, uint32_t turn, void* stream) {
     if (!e) return fail(SGW_EINVAL, "sgw_turn_set: NULL engine");
     if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
     hipLaunchKernelGGL(turn_set_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), e->d_turn, epoch, turn);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_turn_epsilon(sgw_engine* e, int32_t agent, double epsilon, void* stream) {
+    if (!e) return fail(SGW_EINVAL, "sgw_turn_epsilon: NULL engine");
+    if (agent < -1 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_turn_epsilon: agent %d out of range", agent);
+    if (!(epsilon >= 0.0 && epsilon <= 1.0)) return fail(SGW_EINVAL, "sgw_turn_epsilon: epsilon must be in [0, 1]");
+    const double t = std::floor(epsilon * 4294967296.0);
+    const uint64_t thr = t >= 4294967296.0 ? 4294967296ull : (uint64_t)t;
+    hipLaunchKernelGGL(turn_epsilon_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), e->d_turn, agent, e->cfg.num_agents, thr);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
 }

@@ -202,6 +202,10 @@ __global__ __launch_bounds__(kBlock) void observe_full_kernel(const Params p, vo
 }
 
 // ---------------------------------------------------------------- device-side turn state (sgw_turn_*)
+__global__ void turn_epsilon_kernel(TurnState* ts, const int agent, const int A, const uint64_t thr) {
+    const int a = threadIdx.x;
+    if (a < A && (agent < 0 || a == agent)) ts->eps_thr[a] = thr;
+}
 __global__ void turn_set_kernel(TurnState* ts, const uint32_t epoch, const uint32_t turn) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { ts->epoch = epoch; ts->turn = turn; }
 }

@@ -249,6 +249,24 @@ class GridEngine:
 
     _ACTION_KINDS = {torch.uint8: N.ACT_U8, torch.int32: N.ACT_I32, torch.int64: N.ACT_I64}
 
+    def is_action_values(self, action) -> bool:
+        """A policy's VALUE output -- float32 ``[E, n_actions]`` -- which ``act`` / ``turn_act`` take as it is (``SGW_ACT_QF32``: the
+        kernel picks the first index of each row's maximum, and explores by ``turn_epsilon`` under the turn protocol)."""
+        return torch.is_tensor(action) and action.dim() == 2 and action.dtype == torch.float32 and action.device == self.device \
+            and tuple(action.shape) == (self.num_envs, self.spec.num_actions) and action.is_contiguous()
+
+    def _action_arg(self, action):
+        """(pointer, SGW_ACT_* kind) of a caller's action tensor: ``[E]`` uint8 / int32 / int64, or float32 ``[E, n_actions]`` action values."""
+        if action is None:
+            return 0, 0
+        if self.is_action_values(action):
+            return action.data_ptr(), N.ACT_QF32
+        kind = self._ACTION_KINDS.get(action.dtype)
+        if kind is None or action.device != self.device or action.numel() != self.num_envs or not action.is_contiguous():
+            raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {self.num_envs} elements -- or float32 action values "
+                             f"[{self.num_envs}, {self.spec.num_actions}] -- on {self.device}")
+        return action.data_ptr(), kind
+
     def act(self, agent: int, rows=None, action: Optional[torch.Tensor] = None, reward_row: Optional[torch.Tensor] = None,
             action_row: Optional[torch.Tensor] = None):
         """``MovingAgent.act`` of ONE agent for every env; the at most two cells the move changes are rewritten in the
@@ -260,12 +278,8 @@ class GridEngine:
         time in those rows -- e.g. the rows of the agent's replay buffer."""
         arr, stride = (None, 0) if rows is None else (rows[0], rows[1])
         E, dev = self.num_envs, self.device
-        kind = pa = prr = par = 0
-        if action is not None:
-            kind = self._ACTION_KINDS.get(action.dtype)
-            if kind is None or action.device != dev or action.numel() != E or not action.is_contiguous():
-                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {E} elements on {dev}")
-            pa = action.data_ptr()
+        prr = par = 0
+        pa, kind = self._action_arg(action)
         if reward_row is not None:
             if reward_row.dtype != torch.float32 or reward_row.device != dev or reward_row.numel() != E or not reward_row.is_contiguous():
                 raise ValueError(f"reward_row must be a contiguous float32 tensor of {E} elements on {dev}")
@@ -377,12 +391,7 @@ class GridEngine:
     def turn_act(self, agent: int, action: Optional[torch.Tensor] = None):
         """``sgw_turn_act``: ``act`` of one agent with the windows in ``self.obs``; reward and int64 action also go to the agent's ring
         row of the turn in flight (by the device's own row count)."""
-        kind = pa = 0
-        if action is not None:
-            kind = self._ACTION_KINDS.get(action.dtype)
-            if kind is None or action.device != self.device or action.numel() != self.num_envs or not action.is_contiguous():
-                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {self.num_envs} elements on {self.device}")
-            pa = action.data_ptr()
+        pa, kind = self._action_arg(action)
         with self._on_device():
             rc = self._lib.sgw_turn_act(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), self.obs.data_ptr(),
                                         self.rewards.data_ptr(), self.total_reward.data_ptr(), int(agent), pa or None, kind, self._stream())
@@ -403,12 +412,7 @@ class GridEngine:
     def turn_act_rows(self, agent: int, rows, action: Optional[torch.Tensor] = None):
         """``sgw_turn_act_rows``: ``act`` of one agent, the repairs written to the later agents' rows of ``rows`` and to their replay rows."""
         arr, stride, _ = rows
-        kind = pa = 0
-        if action is not None:
-            kind = self._ACTION_KINDS.get(action.dtype)
-            if kind is None or action.device != self.device or action.numel() != self.num_envs or not action.is_contiguous():
-                raise ValueError(f"action must be a contiguous uint8 / int32 / int64 tensor of {self.num_envs} elements on {self.device}")
-            pa = action.data_ptr()
+        pa, kind = self._action_arg(action)
         with self._on_device():
             rc = self._lib.sgw_turn_act_rows(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), arr, stride,
                                              self.rewards.data_ptr(), self.total_reward.data_ptr(), int(agent), pa or None, kind, self._stream())
@@ -422,6 +426,13 @@ class GridEngine:
             rc = self._lib.sgw_turn_end(self._h, self.obs.data_ptr() if (commit_windows and self.obs is not None) else None, self._stream())
         if rc:
             N.check(rc)
+
+    def turn_epsilon(self, epsilon: float, agent: int = -1):
+        """``sgw_turn_epsilon``: the exploration rate of action-value acts (``turn_act*`` with float32 ``[E, n_actions]``) of one agent, or of
+        every agent (``-1``): with that probability the act takes the engine's own uniform draw for (env, turn, agent) instead of the
+        row's argmax.  Stream-ordered, kept on the device: a recorded turn follows it."""
+        with self._on_device():
+            N.check(self._lib.sgw_turn_epsilon(self._h, int(agent), float(epsilon), self._stream()))
 
     def turn_state(self):
         """(epoch, turn, [row per agent]) as the device has counted them (synchronising)."""

@@ -126,6 +126,9 @@ class Environment:
         self._capture_rows = None    # recorded turns: (pointer array, stride, per-agent [E, C*V*V] tensors) the policies read their windows from
         self._captured = None        # CapturedTurn: a whole policy turn recorded as one graph (capture_turn)
         self._turn_capture = False   # the turn protocol with device-side counters is in charge of this turn (recording or warming up)
+        self._value_agents = set()   # slots whose get_action returns action values: the act launch takes the argmax / explores (SGW_ACT_QF32)
+        self._eps_pushed = {}        # slot -> (engine id, epsilon) last sent to the device's turn state
+        self._turn_state_at = None   # (engine id, epoch, turn) the device's turn state was last set for by the eager loop
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
@@ -320,6 +323,12 @@ class Environment:
     #: recorded turns: "rows" (default where the engine can: per-agent window rows, replay rows written alongside) or "tensor" (the
     #: observation tensor + a copy into the replay rows at the end of the turn) -- A/B and tests
     capture_layout = "rows"
+
+    #: ``run_experiment``: record the policy turn once (``capture_turn``) and replay it for every later turn of every epoch; the eager
+    #: loop stays in charge where a turn cannot be recorded (``capture_error`` says why) or ``stop_if_done`` is set.  Also read from
+    #: ``config.experiment.capture_turns``.  Off by default: a recorded turn freezes the Python inside the agent loop (a policy
+    #: that branches on host state must stay eager).
+    capture_turns = False
 
     #: Tag / Cleanup agents: let the engine write what ``pov`` appends behind the window (False = ``torch.cat`` on the host: A/B and tests)
     row_tails_in_kernel = True
@@ -709,18 +718,42 @@ class Environment:
             return None
         return row
 
+    def _push_epsilon(self, eng, slots=None) -> None:
+        """The exploration rates of the agents that act through action values, to the device's turn state when they change."""
+        for a in (self._value_agents if slots is None else slots):
+            eps = min(1.0, max(0.0, self.agents[a].epsilon))
+            if self._eps_pushed.get(a) != (id(eng), eps):
+                eng.turn_epsilon(eps, a)
+                self._eps_pushed[a] = (id(eng), eps)
+
     def _act(self, agent: Agent, action) -> torch.Tensor:
         eng = self._ensure_engine()
         a = agent.slot
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
+        values = action.dim() == 2
+        if values:
+            # the policy's action VALUES [E, n_actions]: the act launch takes the argmax itself (one launch less per agent) and, with
+            # probability agent.epsilon, the engine's own uniform draw for (env, turn, agent) instead (iqn.py:294-309)
+            if tuple(action.shape) != (self.num_envs, eng.spec.num_actions) or not action.is_floating_point():
+                raise ValueError(f"action values must be floating point [{self.num_envs}, {eng.spec.num_actions}]; got {action.dtype} {tuple(action.shape)}")
+            action = action.to(device=eng.device, dtype=torch.float32).contiguous()
+            if a not in self._value_agents:
+                if self._captured is not None and self._captured.graph is not None:
+                    raise RuntimeError("an agent switched to action values after its turn was recorded: capture_turn() again")
+                self._value_agents.add(a)
+            if not self._turn_capture and self._turn_state_at != (id(eng), self.epoch, self.turn):
+                eng.turn_set(self.epoch, self.turn - 1)               # the exploration draws are keyed by the turn in flight
+                self._turn_state_at = (id(eng), self.epoch, self.turn)
+            if not (self._turn_capture and torch.cuda.is_current_stream_capturing()):
+                self._push_epsilon(eng, (a,))                         # (a recorded turn gets its epsilons before each replay)
         tw = self._turn_windows
         if self._turn_capture:                   # the turn protocol with device-side counters (capture_turn): rows by the device's count
             if tw is None or tw[0] != self.world.mutations or a < tw[2]:
                 raise RuntimeError("a captured policy turn cannot be recorded while host code edits the world between pov and act")
             tw[2] = a + 1
-            direct = action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1 \
-                and action.shape[0] == eng.num_envs and action.is_contiguous()
+            direct = values or (action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1
+                                and action.shape[0] == eng.num_envs and action.is_contiguous())
             if not direct:
                 eng.actions[:, a].copy_(action)
             if self._capture_rows is not None:
@@ -731,8 +764,8 @@ class Environment:
                 tw[2] = a + 1                    # the windows of the agents after a stay current: sgw_act repairs them
                 # the policy's output goes to the kernel as it is (no narrowing copy); rewards and actions are also written
                 # where the agent's add_memory would copy them to
-                direct = action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1 \
-                    and action.shape[0] == eng.num_envs and action.is_contiguous()
+                direct = values or (action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1
+                                    and action.shape[0] == eng.num_envs and action.is_contiguous())
                 if not direct:
                     eng.actions[:, a].copy_(action)
                 rr = ar = None
@@ -740,9 +773,14 @@ class Environment:
                     mem, i = tw[3][a]
                     if mem.idx == i:             # (still the row this agent's add_memory fills)
                         rr, ar = mem.rewards[i], mem.actions[i]
-                        mem._prefilled = (i, action.data_ptr())
+                        mem._prefilled = (i, (eng.actions[:, a] if values else action).data_ptr())     # (values: Agent.transition hands add_memory the record of what was taken)
                 return eng.act(a, tw[1], action=action if direct else None, reward_row=rr, action_row=ar)
             self._turn_windows = None            # host code changed the world mid-turn: render on demand from here on
+        if values:                               # (the older per-launch protocol has no action-value input: greedy, on the host)
+            if agent.epsilon > 0.0:
+                raise ValueError("in-kernel exploration (action values with epsilon > 0) needs the patched-window turn protocol "
+                                 "(Environment.patch_windows = True and an observation tensor)")
+            action = action.argmax(dim=1)
         eng.actions[:, a].copy_(action)          # one strided copy that also narrows int64 -> uint8
         nxt = a + 1 < len(self.agents) and eng.obs is not None
         slot = self._replay_slot(a + 1, a) if nxt else None
@@ -820,6 +858,7 @@ class Environment:
         save_weights = bool(self._cfg_model("save_weights", False))
         decay = self._cfg_model("epsilon_decay", None)
         out_dir = self._output_dir(output_dir) if save_weights else None
+        capture = bool(self.capture_turns or (exp.get("capture_turns", False) if hasattr(exp, "get") else getattr(exp, "capture_turns", False)))
         history = []
         for epoch in range(epochs + 1):
             self.reset()
@@ -829,6 +868,9 @@ class Environment:
                     and type(self).take_turn is Environment.take_turn:
                 self.rollout(max_turns - self.turn)        # the whole epoch in one engine call (a subclass that overrides
                                                            # take_turn gets its per-turn loop below, as in the reference)
+            elif capture and self._captured is None and not self.stop_if_done and type(self).take_turn is Environment.take_turn \
+                    and max_turns - self.turn > 2:
+                capture = self.capture_turn(warmup=2) is not None      # (two real turns of this epoch; not tried again when it fails)
             while self.turn < max_turns:
                 self.take_turn()
                 if self.world.is_done and self.stop_if_done:
@@ -986,6 +1028,7 @@ class CapturedTurn:
         self.env, self.eng, self.buffers, self.adds, self._rings = env, eng, buffers, adds_per_turn, rings
         self.graph = None
         self.turns_replayed = 0
+        self._expect, self._at = None, None    # the rings' rows and (epoch, turn) the device's turn state stands at, as the host last knew them
 
     def valid(self, eng) -> bool:
         return self.graph is not None and eng is self.eng
@@ -994,6 +1037,7 @@ class CapturedTurn:
         """After ``Environment.reset`` (or any host-side change of the counters): the device's turn state follows the host's."""
         self.eng.turn_bind(self._rings())
         self.eng.turn_set(self.env.epoch, self.env.turn)
+        self._expect, self._at = [mem.idx for mem in self.buffers], (self.env.epoch, self.env.turn)
 
     def _host_step(self) -> None:
         env = self.env
@@ -1024,6 +1068,7 @@ class CapturedTurn:
         for mem, (idx, size) in zip(self.buffers, before):
             mem.idx, mem.size = idx, size
         self.graph = g
+        self._expect, self._at = [mem.idx for mem in self.buffers], (env.epoch, env.turn)
 
     def abort(self) -> None:
         for mem in self.buffers:
@@ -1036,11 +1081,16 @@ class CapturedTurn:
             pass
 
     def replay(self) -> None:
+        if self._expect != [mem.idx for mem in self.buffers] or self._at != (self.env.epoch, self.env.turn):
+            self.resync()                                 # host code moved a ring (Buffer.clear at the start of an epoch) or the counters
         self._host_step()
+        if self.env._value_agents:
+            self.env._push_epsilon(self.eng)              # a decaying epsilon reaches the recorded acts through the device's turn state
         self.graph.replay()
         for mem, n in zip(self.buffers, self.adds):
             mem.idx = (mem.idx + n) % mem.capacity
             mem.size = min(mem.size + n, mem.capacity)
+        self._expect, self._at = [mem.idx for mem in self.buffers], (self.env.epoch, self.env.turn)
         self.turns_replayed += 1
 
     def release(self) -> None:

@@ -397,3 +397,219 @@ def test_specialised_step_big_with_more_than_64_kib_of_lds(torch_cuda):
             assert co.step(0, t, random_actions=True) == 0
             assert_same(eng, co, ctx=f"jit={jit} turn {t}")
         assert eng.status() == 0
+
+
+# ------------------------------------------------------------------ SGW_ACT_QF32: the act takes the argmax of the policy's action values / explores
+def _values_and_expected(rng, ws, E, A, first, epoch, turn, eps):
+    """Random action values with ties, NaNs and infinities in some rows, and the actions the oracle's value_action takes from them."""
+    from oracle import gridstep_oracle as O
+
+    nact = len(ws.action_dy)
+    q = rng.standard_normal((A, E, nact)).astype(np.float32)
+    q[:, 0::7] = np.round(q[:, 0::7])                        # ties: the FIRST maximum wins
+    q[:, 3::11, 1] = np.nan                                  # NaN counts as the maximum (np.argmax / torch.argmax)
+    q[:, 5::13, nact - 1] = np.inf
+    q[:, 6::17] = -np.inf
+    spec = H.oracle_spec(ws)
+    acts = np.zeros((E, A), dtype=np.uint8)
+    for a in range(A):
+        for e in range(E):
+            acts[e, a] = O.value_action(spec, first + e, epoch, turn, a, q[a, e], eps[a])
+    return q, acts
+
+
+@pytest.mark.parametrize("world", ["treasurehunt", "tag"])
+def test_action_values_argmax_and_exploration_in_the_act_vs_oracle(torch_cuda, world):
+    """``agent_action`` = the policy's action values (float32 [E][num_actions], SGW_ACT_QF32): the act takes np.argmax of each row --
+    ties, NaN, +-inf -- or, with probability epsilon[agent] (sgw_turn_epsilon: 0, 0.3, 1, ...), the engine's own uniform action for
+    (env, turn, agent), as oracle.value_action (iqn.py:294-309 with the counter RNG) says; through sgw_turn_act (rings get the int64
+    action taken) across an epoch change, and through sgw_act with the turn state set by the caller."""
+    torch = torch_cuda
+    from sorrel_amd.spec import treasurehunt_spec
+
+    ws = treasurehunt_spec(14, 17, 5, 2, spawn_prob=0.05, seed=8, dense_prob=0.1) if world == "treasurehunt" else _tag_spec(12, 12, 5, 3)
+    E, A, first, CAP = 45, 5, 11, 3
+    eng, co = make_engine(ws, E, first=first), H.COracle(ws, E, first_env_id=first)
+    nact = len(ws.action_dy)
+    rings = [(None, torch.zeros((CAP, E), device="cuda:0"), torch.full((CAP, E), -1, dtype=torch.int64, device="cuda:0"), None, 0, 1) for _ in range(A)]
+    eng.turn_bind(rings)
+    eps = [0.0, 0.3, 1.0, 0.05, 0.7]
+    for a in range(A):
+        eng.turn_epsilon(eps[a], a)
+    rng = np.random.default_rng(17)
+    epoch = 2
+    eng.reset(epoch); co.reset(epoch)
+    eng.turn_set(epoch, 0)
+    explored = 0
+    for t in range(1, 11):
+        if t == 6:
+            epoch += 1
+            eng.reset(epoch); co.reset(epoch)
+            eng.turn_set(epoch, 0)
+            eng.turn_epsilon(0.5)                    # every agent at once
+            eps = [0.5] * A
+        turn = t if t < 6 else t - 5
+        q, acts = _values_and_expected(rng, ws, E, A, first, epoch, turn, eps)
+        explored += int((acts != np.nanargmax(np.where(np.isnan(q), np.inf, q), axis=2).T).sum())
+        assert co.step(epoch, turn, actions=acts) == 0
+        qd = torch.from_numpy(q).cuda()
+        row = eng.turn_state()[2][0]
+        eng.turn_begin()
+        for a in range(A):
+            eng.turn_act(a, qd[a])
+        eng.turn_end(commit_windows=False)
+        assert_same(eng, co, ("grid", "pos", "actions", "rewards", "total"), ctx=f"{world} turn {t}")
+        if eng.agent_state is not None:
+            assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), t
+        for a in range(A):
+            assert np.array_equal(rings[a][2][row].cpu().numpy(), acts[:, a].astype(np.int64)), (t, a)
+    assert explored > 50                              # (the epsilon branch was taken, and differs from the argmax, often)
+    # sgw_act: no turn of its own -- the caller sets the device's turn state; epsilon 0 = plain argmax
+    eng.turn_bind(None)
+    for turn in (6, 7):
+        for mode in ("explore", "greedy"):
+            eps = [0.4] * A if mode == "explore" else [0.0] * A
+            eng.turn_epsilon(eps[0])
+            q, acts = _values_and_expected(rng, ws, E, A, first, epoch, turn, eps)
+            if mode == "greedy":
+                assert np.array_equal(acts, np.nanargmax(np.where(np.isnan(q), np.inf, q), axis=2).T.astype(np.uint8))
+            assert co.step(epoch, turn, actions=acts, sweep=False) == 0
+            qd = torch.from_numpy(q).cuda()
+            eng.turn_set(epoch, turn - 1)
+            eng.step(sweep=False, no_move=True, turn=turn)
+            for a in range(A):
+                eng.act(a, eng.window_rows(None), action=qd[a])
+            assert_same(eng, co, ("grid", "pos", "actions", "rewards", "total"), ctx=f"{world} sgw_act turn {turn} {mode}")
+    assert eng.status() == 0
+    with pytest.raises(ValueError):
+        eng.turn_act(0, torch.zeros((E, nact + 1), device="cuda:0"))
+    with pytest.raises(ValueError):
+        eng.turn_epsilon(1.5)
+
+
+def test_captured_turn_with_action_values_follows_a_decaying_epsilon(torch_cuda):
+    """Agents whose get_action returns the model's action VALUES: Environment hands them to the act launch (no argmax launch, exploration
+    in-kernel at the model's epsilon).  A recorded turn -- one node less per agent -- equals the eager loop and the oracle over 40 turns
+    while epsilon decays every few turns and across an epoch reset; the buffers hold the actions TAKEN."""
+    torch = torch_cuda
+    from oracle import gridstep_oracle as O
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E = 29
+
+    class ValuePolicy(BaseModel):
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=5, num_envs=E, device="cuda:0")
+            n = int(np.prod(input_size))
+            self.weight = torch.randn((n, action_space), generator=torch.Generator().manual_seed(99 + n)).cuda()
+            self.epsilon = 0.6
+
+        def take_action(self, state):
+            return state.reshape(state.shape[0], -1) @ self.weight          # [E, n_actions] float32: values, not actions
+
+    a, b = (make_env(12, 16, 4, 2, E, p=0.05, seed=3, model_factory=ValuePolicy) for _ in range(2))
+    cap = b.capture_turn(warmup=2)
+    assert cap is not None, getattr(b, "capture_error", None)
+    for _ in range(2):
+        a.take_turn()
+    ws = a._engine.spec
+    spec = H.oracle_spec(ws)
+    co = H.COracle(ws, E, first_env_id=0)
+
+    def sync_oracle():
+        co.grid[...] = a.world.grid.cpu().numpy()
+        co.pos[...] = a.world.agent_pos.cpu().numpy()
+        co.total[...] = a.world.total_reward.cpu().numpy()
+
+    sync_oracle()
+    took_random = 0
+    for t in range(40):
+        if t == 25:
+            a.reset(); b.reset()
+            sync_oracle()
+        if t % 4 == 0:
+            for env in (a, b):
+                for ag in env.agents:
+                    ag.model.epsilon *= 0.8
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        # the oracle, agent by agent: the window -> the same linear values (float32 on the host) -> value_action -> act
+        assert co.step(a.epoch, a.turn, actions=b.actions.cpu().numpy()) == 0
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.rewards, b.rewards), t
+        assert np.array_equal(b.world.grid.cpu().numpy(), co.grid) and np.array_equal(b.rewards.cpu().numpy(), co.rewards), t
+        for k, (x, y) in enumerate(zip(a.agents, b.agents)):
+            mx, my = x.model.memory, y.model.memory
+            assert (mx.idx, mx.size) == (my.idx, my.size), t
+            for name in ("states", "actions", "rewards", "dones"):
+                assert torch.equal(getattr(mx, name), getattr(my, name)), (t, k, name)
+            last = (my.idx - 1) % my.capacity
+            taken = my.actions[last].cpu().numpy().reshape(-1)
+            assert np.array_equal(taken, b.actions[:, k].cpu().numpy().astype(np.int64)), (t, k)
+            # ... and they are what value_action takes from the values of the window the agent saw
+            q = (my.states[last].reshape(E, -1) @ y.model.weight).cpu().numpy()
+            want = np.array([O.value_action(spec, e, b.epoch, b.turn, k, q[e], y.model.epsilon) for e in range(E)])
+            greedy = q.argmax(axis=1)
+            margin = np.sort(q, axis=1)
+            sure = (margin[:, -1] - margin[:, -2]) > 1e-3          # (the host's matmul may round differently from the device's: skip near-ties)
+            assert np.array_equal(taken[sure], want[sure]), (t, k)
+            took_random += int((taken[sure] != greedy[sure]).sum())
+    assert took_random > 20
+    assert cap.turns_replayed == 40
+    b.raise_on_status()
+
+
+def test_run_experiment_with_recorded_turns_equals_the_eager_loop(torch_cuda):
+    """``Environment.capture_turns = True``: run_experiment records the policy turn in its first epoch and replays it for every later
+    turn of every epoch -- across resets, a model that clears its memory at the start of some epochs (the rings are bound again) and an
+    epsilon that decays per epoch (in-kernel exploration follows it) -- with the history, world and buffers of the eager loop."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E = 21
+
+    class Model(BaseModel):
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=7, num_envs=E, device="cuda:0")
+            n = int(np.prod(input_size))
+            self.weight = torch.randn((n, action_space), generator=torch.Generator().manual_seed(5 + n)).cuda()
+            self.epsilon = 0.5
+            self.trained = 0
+
+        def take_action(self, state):
+            return state.reshape(state.shape[0], -1) @ self.weight
+
+        def start_epoch_action(self, epoch=0, **kw):
+            if epoch % 2 == 1:
+                self.memory.clear()
+
+        def train_step(self):
+            self.trained += 1
+            self.weight.mul_(0.97)            # in place: the recorded forward pass reads the same storage
+            return float(self.memory.rewards.sum())
+
+    envs = []
+    for capture in (False, True):
+        env = make_env(13, 12, 3, 2, E, p=0.06, seed=9, model_factory=Model, max_turns=11, extra_model={"epsilon_decay": 0.2})
+        env.capture_turns = capture
+        hist = env.run_experiment(epochs=3, logging=False, all_reduce=False)
+        torch.cuda.synchronize()
+        envs.append((env, hist))
+    (a, ha), (b, hb) = envs
+    assert b._captured is not None and b._captured.turns_replayed == 4 * 11 - 2, getattr(b, "capture_error", None)
+    assert a._captured is None
+    assert ha == hb
+    for name in ("grid", "agent_pos", "total_reward"):
+        assert torch.equal(getattr(a.world, name), getattr(b.world, name)), name
+    assert torch.equal(a.actions, b.actions) and torch.equal(a.rewards, b.rewards)
+    for x, y in zip(a.agents, b.agents):
+        assert x.model.trained == y.model.trained == 4 and x.model.epsilon == y.model.epsilon < 0.5
+        mx, my = x.model.memory, y.model.memory
+        assert (mx.idx, mx.size) == (my.idx, my.size)
+        for name in ("states", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(mx, name), getattr(my, name)), name
+    b.raise_on_status()

@@ -15,7 +15,7 @@ from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
 from sorrel_amd.models import BaseModel
 
 
-def policy_factory(E):
+def policy_factory(E, values=False):
     class LinearPolicy(BaseModel):
         """obs [E, F] -> argmax of one linear layer: the cheapest model that really reads the observation."""
 
@@ -24,8 +24,11 @@ def policy_factory(E):
             g = torch.Generator(device="cpu").manual_seed(1)
             self.w = torch.randn(int(input_size[0]), action_space, generator=g).cuda()
 
+            self.epsilon = 0.05 if values else 0.0
+
         def take_action(self, state):
-            return (state.reshape(state.shape[0], -1) @ self.w).argmax(dim=1)
+            q = state.reshape(state.shape[0], -1) @ self.w
+            return q if values else q.argmax(dim=1)     # values: the act launch takes the argmax / explores (SGW_ACT_QF32)
 
     return LinearPolicy
 
@@ -44,10 +47,10 @@ def time_turns(env, turns):
 def run(h, w, a, r, E, policy, spawn_prob=0.005):
     cfg = make_config(h, w, a, r, spawn_prob=spawn_prob)
     world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0)
-    env = TreasurehuntEnv(world, cfg, model_factory=policy_factory(E) if policy else None)
+    env = TreasurehuntEnv(world, cfg, model_factory=policy_factory(E, values=policy >= 3) if policy else None)
     env.write_obs_into_replay = os.environ.get("LAT_NO_DIRECT") != "1"      # A/B: windows through the observation tensor + a copy
-    label = {0: "device-random (1 launch)", 1: "policy (1+A launches)", 2: "policy, captured turn"}[policy]
-    if policy == 2 and env.capture_turn() is None:                          # round 4: the whole turn recorded once, replayed
+    label = {0: "device-random (1 launch)", 1: "policy (1+A launches)", 2: "policy, captured turn", 3: "values -> act, eager", 4: "values -> act, captured"}[policy]
+    if policy in (2, 4) and env.capture_turn() is None:                          # round 4: the whole turn recorded once, replayed
         label = f"policy, NOT capturable: {getattr(env, 'capture_error', None)!r}"[:60]
     turns = 2000 if E <= 4096 else 300
     us = time_turns(env, turns)
@@ -60,9 +63,9 @@ def run(h, w, a, r, E, policy, spawn_prob=0.005):
 def main():
     for shape in ((21, 21, 2, 2), (32, 32, 8, 3)):
         for E in (1, 64, 1024, 16384, 65536):
-            for policy in (0, 1, 2):
+            for policy in (0, 1, 2, 3, 4):
                 run(*shape, E, policy)
-    for policy in (0, 1, 2):       # BASELINE config 5's per-GPU share
+    for policy in (0, 1, 2, 3, 4):       # BASELINE config 5's per-GPU share
         run(128, 128, 64, 5, 2048, policy, spawn_prob=0.05)
 
 

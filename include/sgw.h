@@ -460,6 +460,11 @@ int sgw_turn_begin_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint
 int sgw_turn_act_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
                       float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream);
 int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* stream);
+/* Buffer.current_state (sorrel/buffers.py:143-154) for a recorded turn -- the frames a frame-stacking policy reads in front of its
+ * window: the `count` rows of agent `agent`'s replay states BEFORE the row the turn in flight fills, oldest first, wrapping around
+ * the ring, by the device's own row count -> out [count][E][row_elems] (device, element type = sgw_set_obs_format's).  Same
+ * arguments every turn: recordable.  The ring must be bound with states (sgw_turn_bind); 1 <= count <= capacity. */
+int sgw_turn_prev_rows(sgw_engine* eng, int32_t agent, int32_t count, void* out, void* stream);
 /* Exploration rate of SGW_ACT_QF32 acts under the turn protocol: `agent` in [0, A) or -1 for every agent; epsilon in [0, 1].
  * Stream-ordered and kept in the device's turn state, so a recorded turn follows a decaying epsilon without being recorded again. */
 int sgw_turn_epsilon(sgw_engine* eng, int32_t agent, double epsilon, void* stream);

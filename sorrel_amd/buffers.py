@@ -37,6 +37,7 @@ class Buffer:
                                       # the rows are all zero already and add(done=False) has nothing to write
         self._deferred = False        # a captured policy turn is being recorded / replayed: the engine's own kernels fill the row
         self._deferred_adds = 0       # (device-side row count, sgw_turn_end) -- add() only keeps the host's idx / size in step
+        self._prev_rows = None        # ... and current_state() is gathered on the device by that same count (sgw_turn_prev_rows)
         self.extra_data = {}
         for key, value in extra.items():
             shape = (capacity, E, *value) if isinstance(value, tuple) else (capacity, E)
@@ -167,6 +168,8 @@ class Buffer:
         k = self.n_frames - 1
         if k == 0:
             return self.states[0:0]
+        if self._deferred and self._prev_rows is not None:       # a recorded turn: the engine gathers by its own row count
+            return self._prev_rows()
         sel = [(self.idx - k + j) % self.capacity for j in range(k)]
         return self.states[sel]
 

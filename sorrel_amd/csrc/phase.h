@@ -619,11 +619,22 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
     }
     if (p.tail_kind != SGW_TAIL_NONE && live) {      // what pov() appends behind the flattened window
         float* t = o + p.C * VV;
+        float* t2 = nullptr;                         // ... and behind its second copy in the replay row (a recorded turn), where the row has room
+        if (rp.dual && rp.ts && rp.ts->cap[a] > 0 && rp.ts->states[a] && rp.ts->row_elems[a] >= p.C * VV + p.tail_len)
+            t2 = static_cast<float*>(rp.ts->states[a]) + (rp.ts->row[a] * p.E + env) * rp.ts->row_elems[a] + p.C * VV;
         if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {   // TagAgent.pov: [self.it]
-            if (gl == 0) t[0] = (p.agent_state && p.agent_state[env * p.A + a] == p.tag_it) ? 1.f : 0.f;
+            if (gl == 0) {
+                const float it = (p.agent_state && p.agent_state[env * p.A + a] == p.tag_it) ? 1.f : 0.f;
+                t[0] = it;
+                if (t2) t2[0] = it;
+            }
         } else {                                     // CleanupObservation.observe: the positional code of the agent's cell
             const float* src = p.tail_table + ((int64_t)y * W + x) * p.tail_len;
-            for (int k = gl; k < p.tail_len; k += G) t[k] = src[k];
+            for (int k = gl; k < p.tail_len; k += G) {
+                const float f = src[k];
+                t[k] = f;
+                if (t2) t2[k] = f;
+            }
         }
     }
 }
@@ -911,8 +922,11 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                     const int jj = j + n * G;
                     p.agent_state[env * p.A + jj] = (uint8_t)p.tag_it;   // the agent standing on the victim's cell
                     // ... and, if it has yet to observe this turn, the "it" flag behind its window (TagAgent.pov reads self.it)
-                    if (jj > a && rp.p[jj] != nullptr && p.tail_kind == SGW_TAIL_AGENT_IS_IT && !p.obs_u8)
+                    if (jj > a && rp.p[jj] != nullptr && p.tail_kind == SGW_TAIL_AGENT_IS_IT && !p.obs_u8) {
                         reinterpret_cast<float*>(rp.p[jj])[env * rp.stride + (int64_t)C * VV] = 1.f;
+                        if (rp.dual && rp.ts && rp.ts->cap[jj] > 0 && rp.ts->states[jj] && rp.ts->row_elems[jj] > (int64_t)C * VV)
+                            static_cast<float*>(rp.ts->states[jj])[(rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj] + (int64_t)C * VV] = 1.f;
+                    }
                 }
         }
         if (pass) patch(y, x, p.zA, left, p.default_type);

@@ -111,6 +111,9 @@ struct sgw_engine {
     double* d_part = nullptr;
     TurnState* d_turn = nullptr;   // device-side turn state (sgw_turn_*): a whole policy turn as one capturable submission
     bool turn_rows = false;        // sgw_turn_bind gave replay rows
+    int64_t turn_cap[SGW_MAX_AGENTS] = {};        // ... host mirror: rows of agent a's ring (0: none, or no states)
+    int64_t turn_row_bytes[SGW_MAX_AGENTS] = {};  // ... bytes of one of its rows (E * row_elems * element size)
+    const void* turn_states[SGW_MAX_AGENTS] = {};
     bool turn_rows_even = false;   // ... all of them 8-byte aligned with an even row stride (float2 copies)
     bool turn_rows_flat = false;   // ... all of them 16-byte aligned rows of exactly one window per env, E * N * 4 a multiple of 16 (flat second copies)
     int obs_format = SGW_OBS_F32;
@@ -1587,6 +1590,7 @@ int sgw_turn_bind(sgw_engine* e, const sgw_turn_rows* rows) {
         h.states[a] = nullptr; h.rewards[a] = nullptr; h.actions[a] = nullptr; h.dones[a] = nullptr;
     }
     e->turn_rows = false;
+    for (int a = 0; a < SGW_MAX_AGENTS; ++a) { e->turn_cap[a] = 0; e->turn_row_bytes[a] = 0; e->turn_states[a] = nullptr; }
     if (rows) {
         for (int a = 0; a < A; ++a) {
             if (rows->capacity[a] <= 0) continue;
@@ -1598,6 +1602,11 @@ int sgw_turn_bind(sgw_engine* e, const sgw_turn_rows* rows) {
             h.row[a] = rows->row[a]; h.cap[a] = rows->capacity[a]; h.step[a] = rows->step[a]; h.row_elems[a] = rows->row_elems[a];
             h.states[a] = rows->states[a]; h.rewards[a] = rows->rewards[a]; h.actions[a] = rows->actions[a];
             h.dones[a] = rows->states[a] ? rows->dones[a] : nullptr;   // (zeroed by the window copy)
+            if (rows->states[a]) {
+                e->turn_cap[a] = rows->capacity[a];
+                e->turn_row_bytes[a] = (int64_t)e->cfg.num_envs * rows->row_elems[a] * esz;
+                e->turn_states[a] = rows->states[a];
+            }
             if (!e->turn_rows) e->turn_rows_even = e->turn_rows_flat = true;
             e->turn_rows = true;
             if (rows->states[a] && ((reinterpret_cast<uintptr_t>(rows->states[a]) & 15) || rows->row_elems[a] != N || (((int64_t)e->cfg.num_envs * N * 4) & 15)))
@@ -1673,6 +1682,25 @@ int sgw_turn_act_rows(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t*
     if (!e || !rows) return fail(SGW_EINVAL, "sgw_turn_act_rows: NULL argument");
     return act_impl(e, grid, agent_pos, actions, rows, env_stride, rewards, total_reward, agent, agent_action, action_kind, nullptr, nullptr,
                     e->d_turn, stream, 1);
+}
+
+int sgw_turn_prev_rows(sgw_engine* e, int32_t agent, int32_t count, void* out, void* stream) {
+    if (!e || !out) return fail(SGW_EINVAL, "sgw_turn_prev_rows: NULL argument");
+    if (agent < 0 || agent >= e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_turn_prev_rows: agent %d out of range", agent);
+    if (e->turn_cap[agent] <= 0) return fail(SGW_EINVAL, "sgw_turn_prev_rows: agent %d has no replay states bound (sgw_turn_bind)", agent);
+    if (count < 1 || count > e->turn_cap[agent]) return fail(SGW_EINVAL, "sgw_turn_prev_rows: count must be in [1, capacity = %lld]", (long long)e->turn_cap[agent]);
+    const int64_t rb = e->turn_row_bytes[agent];
+    const bool v16 = (rb & 15) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(e->turn_states[agent])) & 15) == 0;
+    const bool v4 = (rb & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(e->turn_states[agent])) & 3) == 0;
+    const int vec = v16 ? 16 : (v4 ? 4 : 1);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(rb / vec * count, kBlock), (int64_t)e->num_cus * 16));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t* o = static_cast<uint8_t*>(out);
+    if (vec == 16) hipLaunchKernelGGL((turn_prev_rows_kernel<16>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, agent, count, o, rb);
+    else if (vec == 4) hipLaunchKernelGGL((turn_prev_rows_kernel<4>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, agent, count, o, rb);
+    else hipLaunchKernelGGL((turn_prev_rows_kernel<1>), dim3(blocks), dim3(kBlock), 0, s, e->d_turn, agent, count, o, rb);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
 }
 
 int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {

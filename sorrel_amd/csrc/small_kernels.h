@@ -219,6 +219,22 @@ __global__ void turn_advance_kernel(TurnState* ts, const int A) {
 }
 // The windows of the turn (the [E][A][N] tensor the policies read) into each agent's replay row of the turn in flight
 // (Agent.add_memory -> Buffer.add, sorrel/agents/agent.py:127-130, sorrel/buffers.py:46-63), VEC elements per thread and step.
+// Buffer.current_state (sorrel/buffers.py:143-154) by the device's row count: the `count` rows before the one the turn in flight
+// fills, oldest first, wrapping around the ring -- out[j] = states[(row - count + j) mod capacity], each row_bytes long.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void turn_prev_rows_kernel(const TurnState* __restrict__ ts, const int a, const int count, uint8_t* __restrict__ out,
+                                                                const int64_t row_bytes) {
+    struct alignas(VEC) Pack { uint8_t v[VEC]; };
+    const int64_t cap = ts->cap[a], row = ts->row[a];
+    if (cap <= 0 || !ts->states[a]) return;
+    const int64_t per = row_bytes / VEC, n = per * count;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = i / per, k = i - j * per;
+        const int64_t src_row = (((row - count + j) % cap) + cap) % cap;
+        reinterpret_cast<Pack*>(out + j * row_bytes)[k] = reinterpret_cast<const Pack*>(static_cast<const uint8_t*>(ts->states[a]) + src_row * row_bytes)[k];
+    }
+}
+
 // (Letting the workgroup that finishes last advance the state -- one launch instead of two -- was measured: 4 096 same-address
 // atomics cost more than the ~4 us of a dependent launch, 149 -> 328 us per recorded turn at 1 024 envs.)
 template <typename T, int VEC>

@@ -427,6 +427,17 @@ class GridEngine:
         if rc:
             N.check(rc)
 
+    def turn_prev_rows(self, agent: int, count: int, out: torch.Tensor) -> torch.Tensor:
+        """``sgw_turn_prev_rows``: ``Buffer.current_state`` by the device's row count -- the ``count`` rows of the agent's bound replay
+        states before the row the turn in flight fills, oldest first, into ``out`` ``[count, E, row_elems]`` (contiguous, the engine's
+        observation dtype, on the device)."""
+        if not torch.is_tensor(out) or out.dtype != self.obs_dtype or out.device != self.device or not out.is_contiguous() \
+                or out.dim() < 2 or out.shape[0] != count or out.shape[1] != self.num_envs:
+            raise ValueError(f"out must be a contiguous {self.obs_dtype} tensor [{count}, {self.num_envs}, ...] on {self.device}")
+        with self._on_device():
+            N.check(self._lib.sgw_turn_prev_rows(self._h, int(agent), int(count), out.data_ptr(), self._stream()))
+        return out
+
     def turn_epsilon(self, epsilon: float, agent: int = -1):
         """``sgw_turn_epsilon``: the exploration rate of action-value acts (``turn_act*`` with float32 ``[E, n_actions]``) of one agent, or of
         every agent (``-1``): with that probability the act takes the engine's own uniform draw for (env, turn, agent) instead of the

@@ -502,7 +502,8 @@ class Environment:
         ``warmup`` real turns are played through the same protocol first (lazy initialisation must not happen inside a
         capture).  Returns the ``CapturedTurn``, or ``None`` -- and the eager loop stays in charge -- when the turn cannot be
         recorded: an agent class overrides ``transition`` / ``add_memory``, a model's memory is not a ``sorrel_amd.buffers.Buffer``
-        of plain windows with ``n_frames == 1`` (frame stacks and appended features index the ring from the host), the engine has
+        of plain windows (appended features index the ring from the host; frame stacks -- ``n_frames > 1`` -- are recorded: ``current_state()``
+        becomes a gather by the device's row count, ``sgw_turn_prev_rows``, unless agents share the ring), the engine has
         no observation tensor, or a model's forward pass does something a capture forbids (a host synchronisation)."""
         from sorrel_amd import _native as N
         from sorrel_amd.buffers import Buffer
@@ -514,6 +515,12 @@ class Environment:
         per_env = 1
         for d in eng.spec.obs_shape[1:]:
             per_env *= int(d)
+        # what pov appends behind the window (Tag's "it" flag, Cleanup's positional code) is the engine's to write (_bind_row_tail): the
+        # rows the policies read and the replay rows then hold window + tail
+        use_rows = self.capture_layout != "tensor" and bool(eng.capabilities() & N.CAP_OBSERVE_ROWS)
+        if eng.row_tail and not use_rows:
+            return None
+        per_row = per_env + eng.row_tail
         sharers = {}
         for agent in self.agents:
             mem = getattr(agent.model, "memory", None)
@@ -521,10 +528,12 @@ class Environment:
                 return None
             if mem is None:
                 continue
-            if not isinstance(mem, Buffer) or mem.n_frames != 1 or mem.extra_data or mem.num_envs != eng.num_envs or mem.device != eng.device \
-                    or mem.states.dtype != eng.obs_dtype or mem.states[0, 0].numel() != per_env:
+            if not isinstance(mem, Buffer) or mem.extra_data or mem.num_envs != eng.num_envs or mem.device != eng.device \
+                    or mem.states.dtype != eng.obs_dtype or mem.states[0, 0].numel() != per_row or mem.n_frames - 1 > mem.capacity:
                 return None
             sharers.setdefault(id(mem), [mem, []])[1].append(agent.slot)
+        if any(v[0].n_frames > 1 and len(v[1]) > 1 for v in sharers.values()):
+            return None        # (frame stacks of agents that share one ring interleave their rows: left to the eager loop)
         buffers = [v[0] for v in sharers.values()]
 
         def rings():
@@ -538,9 +547,10 @@ class Environment:
         # where the policies read their windows: per-agent rows the row kernels fill (and, alongside, the replay rows) where the engine
         # has them -- one-hot float32 windows --, else the observation tensor + a copy at the end of the turn
         self._capture_rows = None
-        if self.capture_layout != "tensor" and (eng.capabilities() & N.CAP_OBSERVE_ROWS) and eng.row_tail == 0:
-            self._capture_rows = eng.window_rows([torch.zeros((eng.num_envs, per_env), dtype=torch.float32, device=eng.device) for _ in self.agents])
+        if use_rows:
+            self._capture_rows = eng.window_rows([torch.zeros((eng.num_envs, per_row), dtype=torch.float32, device=eng.device) for _ in self.agents])
         cap = CapturedTurn(self, eng, buffers, [len(v[1]) for v in sharers.values()], rings)
+        cap._stacked = [(v[0], v[1]) for v in sharers.values() if v[0].n_frames > 1]
         try:
             cap.record(max(1, int(warmup)))
         except Exception as exc:                                   # not capturable: leave everything consistent and say why
@@ -1028,6 +1038,7 @@ class CapturedTurn:
         self.env, self.eng, self.buffers, self.adds, self._rings = env, eng, buffers, adds_per_turn, rings
         self.graph = None
         self.turns_replayed = 0
+        self._stacked = []                     # (buffer, [slot]) of the frame-stacking memories
         self._expect, self._at = None, None    # the rings' rows and (epoch, turn) the device's turn state stands at, as the host last knew them
 
     def valid(self, eng) -> bool:
@@ -1050,6 +1061,10 @@ class CapturedTurn:
         self.resync()
         for mem in self.buffers:
             mem._deferred, mem._deferred_adds = True, 0
+        for mem, slots in self._stacked:
+            # Buffer.current_state (frame stacks, n_frames > 1): gathered by the device's row count into a fixed tensor
+            out = torch.zeros((mem.n_frames - 1,) + tuple(mem.states.shape[1:]), dtype=mem.states.dtype, device=mem.device)
+            mem._prev_rows = (lambda a=slots[0], k=mem.n_frames - 1, out=out: eng.turn_prev_rows(a, k, out))
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(torch.cuda.current_stream(eng.device))
         with torch.cuda.stream(side):
@@ -1073,6 +1088,7 @@ class CapturedTurn:
     def abort(self) -> None:
         for mem in self.buffers:
             mem._deferred = False
+            mem._prev_rows = None
         self.graph = None
         self.env._capture_rows = None
         try:

@@ -613,3 +613,149 @@ def test_run_experiment_with_recorded_turns_equals_the_eager_loop(torch_cuda):
         for name in ("states", "actions", "rewards", "dones"):
             assert torch.equal(getattr(mx, name), getattr(my, name)), name
     b.raise_on_status()
+
+
+def test_captured_turn_with_frame_stacks(torch_cuda):
+    """Memories with ``n_frames = 3`` (the reference's Cleanup / IQN configs stack frames: ``Buffer.current_state``,
+    sorrel/buffers.py:143-154, in front of the window): in a recorded turn the previous frames are gathered by the device's own row
+    count (sgw_turn_prev_rows) -- 30 turns with wrap-arounds of the 5-row rings, an epoch reset and an ``add_empty`` at its start equal
+    the eager loop; the gather itself against the ring for every position of the row counter."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E = 19
+
+    class Stacked(BaseModel):
+        n_frames = 3
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=0, num_envs=E, device="cuda:0")
+            n = int(np.prod(input_size))
+            self.memory = Buffer(capacity=5, obs_shape=(n,), n_frames=3, num_envs=E, device="cuda:0")
+            self.weight = torch.randn((3 * n, action_space), generator=torch.Generator().manual_seed(7 + n)).cuda()
+
+        def take_action(self, state):
+            assert state.shape[1] == self.weight.shape[0]
+            return (state @ self.weight).argmax(dim=1)
+
+        def start_epoch_action(self, **kw):
+            self.memory.add_empty()
+
+    a, b = (make_env(12, 13, 3, 2, E, p=0.05, seed=4, model_factory=Stacked) for _ in range(2))
+    cap = b.capture_turn(warmup=2)
+    assert cap is not None, getattr(b, "capture_error", None)
+    for _ in range(2):
+        a.take_turn()
+    for t in range(30):
+        if t == 17:
+            for env in (a, b):
+                env.reset()
+                for ag in env.agents:
+                    ag.model.start_epoch_action()
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.rewards, b.rewards), t
+        for k, (x, y) in enumerate(zip(a.agents, b.agents)):
+            mx, my = x.model.memory, y.model.memory
+            assert (mx.idx, mx.size) == (my.idx, my.size), t
+            for name in ("states", "actions", "rewards", "dones"):
+                assert torch.equal(getattr(mx, name), getattr(my, name)), (t, k, name)
+            # the gather, against the host's indices
+            got = b._engine.turn_prev_rows(k, 2, torch.empty_like(my.states[:2]))
+            assert torch.equal(got, my.states[[(my.idx - 2) % 5, (my.idx - 1) % 5]]), (t, k)
+    assert cap.turns_replayed == 30
+    b.raise_on_status()
+    eng = b._engine
+    with pytest.raises(ValueError):
+        eng.turn_prev_rows(0, 6, torch.empty((6, E, my.states.shape[2]), device="cuda:0"))      # more rows than the ring has
+    # agents that SHARE a frame-stacking ring: not recorded
+    c = make_env(12, 13, 3, 2, E, p=0.05, seed=4, model_factory=Stacked)
+    for ag in c.agents[1:]:
+        ag.model.memory = c.agents[0].model.memory
+    assert c.capture_turn() is None
+    c.take_turn()
+
+
+@pytest.mark.parametrize("which", ["tag", "cleanup"])
+def test_captured_turn_of_the_tag_and_cleanup_examples(torch_cuda, which):
+    """The shipped Tag and Cleanup agents -- whose pov appends to the window -- in a recorded turn: the engine writes window + tail into
+    the row each policy reads AND into its replay row (the "it" flag of an agent tagged before its own pov in both), so nothing is
+    concatenated or copied on the host.  35 turns across ring wrap-arounds and a reset equal the eager loop; the rows a policy read
+    equal the oracle's windows, Tag's flag the oracle's state_at_pov."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+
+    E = 23
+
+    class Policy(BaseModel):
+        def __init__(self, input_size, n_actions):
+            n = int(np.prod(input_size))
+            super().__init__((n,), n_actions, memory_size=6, num_envs=E, device="cuda:0")
+            self.weight = torch.randn((n, n_actions), generator=torch.Generator().manual_seed(3 + n)).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.weight).argmax(dim=1)
+
+    def make():
+        if which == "tag":
+            from sorrel_amd.entities import EmptyEntity
+            from sorrel_amd.examples.tag.env import TagEnv
+            from sorrel_amd.worlds import Gridworld
+
+            cfg = {"agent": {"num_agents": 6, "vision_radius": 2, "reward_per_turn": 10}, "experiment": {"epochs": 1, "max_turns": 50}}
+            return TagEnv(Gridworld(8, 9, 1, EmptyEntity(), num_envs=E, device="cuda:0", seed=31), cfg, model_factory=Policy)
+        from tests.test_api_host import make_cleanup_env
+
+        return make_cleanup_env(E=E, seed=7, device="cuda:0", model_factory=Policy)
+
+    a, b = make(), make()
+    eng = b._ensure_engine()
+    tail = 1 if which == "tag" else 12
+    assert eng.row_tail == tail
+    cap = b.capture_turn(warmup=2)
+    assert cap is not None, getattr(b, "capture_error", None)
+    assert b._capture_rows is not None
+    for _ in range(2):
+        a.take_turn()
+    co = H.COracle(a.compile_spec(), E)
+
+    def sync_oracle():
+        co.grid[...] = a.world.grid.cpu().numpy()
+        co.pos[...] = a.world.agent_pos.cpu().numpy()
+        co.total[...] = a.world.total_reward.cpu().numpy()
+        if which == "tag":
+            co.agent_state[...] = a.world.agent_state.cpu().numpy()
+        else:
+            co.agent_dir[...] = a.world.agent_dir.cpu().numpy()
+
+    sync_oracle()
+    nwin = int(np.prod(eng.spec.obs_shape[1:]))
+    for t in range(35):
+        if t == 20:
+            a.reset(); b.reset()
+            sync_oracle()
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        assert co.step(a.epoch, a.turn, actions=a.actions.cpu().numpy()) == 0
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.rewards, b.rewards), t
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert np.array_equal(b.world.grid.cpu().numpy(), co.grid) and np.array_equal(b.rewards.cpu().numpy(), co.rewards), t
+        for k, (x, y) in enumerate(zip(a.agents, b.agents)):
+            mx, my = x.model.memory, y.model.memory
+            assert (mx.idx, mx.size) == (my.idx, my.size), t
+            for name in ("states", "actions", "rewards", "dones"):
+                assert torch.equal(getattr(mx, name), getattr(my, name)), (t, k, name)
+            row = my.states[(my.idx - 1) % my.capacity].reshape(E, -1)
+            assert row.shape[1] == nwin + tail
+            assert np.array_equal(row[:, :nwin].cpu().numpy(), co.obs[:, k].reshape(E, -1)), (t, k)
+            if which == "tag":
+                assert np.array_equal(row[:, -1].cpu().numpy() != 0, co.state_at_pov[:, k] == eng.spec.tag_it_type), (t, k)
+    assert cap.turns_replayed == 35
+    b.raise_on_status()

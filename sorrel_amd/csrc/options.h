@@ -44,6 +44,7 @@ struct Options {
     int big_walk_share = 0;   // ... envs per workgroup assigned statically before the shared counter takes over (0 auto)
     // ---- live (also settable on an engine after sgw_create)
     int rows_mode = 0;        // sgw_observe_rows emit: 0 auto, 1 single floats, 2 float2 runs where legal, 3 aligned float4 runs
+    int act_lanes = 0;        // sgw_act with 9..16 agents: lanes per env -- 0 auto, 8 (two agents per lane), 16 (one)
 };
 
 struct OptKey {
@@ -84,6 +85,7 @@ const OptKey kOptKeys[] = {
     {"big_walk_static", &Options::big_walk_static, 0, 1, false},
     {"big_walk_share", &Options::big_walk_share, 0, 1 << 20, false},
     {"rows_mode", &Options::rows_mode, 0, 3, true},
+    {"act_lanes", &Options::act_lanes, 0, 16, true},
 };
 
 std::mutex g_opt_mu;

@@ -394,6 +394,7 @@ struct MoveOut {
     uint32_t my_type;
     uint32_t found;      // what the target cell held before the agent entered it
     uint32_t left;       // what the agent's own cell held (its type, unless the caller's grid and agent types disagree)
+    uint64_t col_old, col_new;   // ActIO.want_cols: every layer's byte of the two cells (byte z = layer z), loaded with the rest
 };
 struct ActIO {                   // sgw_act's optional extras (see RowPtrs), passed by value
     const void* agent_action = nullptr;
@@ -401,6 +402,7 @@ struct ActIO {                   // sgw_act's optional extras (see RowPtrs), pas
     float* reward_row = nullptr;
     int64_t* action_row = nullptr;
     const TurnState* ts = nullptr;
+    bool want_cols = false;      // sgw_act: the whole columns of the mover's two cells (window repairs need the other layers)
 };
 // The caller's action of agent a in env: its tensor's element, or for SGW_ACT_QF32 the first index of the maximum of the env's row of
 // action values (np.argmax; NaN = maximum, as np / torch have it) -- and, under the turn protocol, with probability epsilon[a] the
@@ -455,6 +457,15 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
     const bool tinb = act_ok && (unsigned)ty < (unsigned)H && (unsigned)tx < (unsigned)W;
     const uint32_t t = tinb ? (uint32_t)g[p.zA * HW + ty * W + tx] : 0xFFu;
     const uint32_t here = g[p.zA * HW + my * W + mx];                               // (issued with the target's byte)
+    mo.col_old = mo.col_new = 0ull;
+    if (io.want_cols) {                                                             // (... and so are the other layers of both cells)
+#pragma unroll
+        for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+            if (z < p.L) {
+                mo.col_old |= (uint64_t)g[z * HW + my * W + mx] << (8 * z);
+                if (tinb) mo.col_new |= (uint64_t)g[z * HW + ty * W + tx] << (8 * z);
+            }
+    }
     const bool tok = tinb && t < (uint32_t)p.T;
     const double val = tok ? (wval ? wval[t & 31u] : gtab->value[t & 31u]) : 0.0;   // reward read BEFORE the move
     const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
@@ -651,53 +662,95 @@ __global__ __launch_bounds__(kBlock, 8) void observe_rows(const Params p, const 
 // 23 -> ... us at 65 536 envs); every lane of a group evaluates the act from same-address loads (vector instructions
 // cost the same for 1 or 64 lanes), lane 0 of the group stores.  A changed cell is recomputed from the grid column with the changed layer's NEW type substituted (the
 // stores of this launch are never read back by it).
-template <int G, int NJ, int RULE>
-__global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) void act_patch(const Params p, const RowPtrs rp) {   // (Cleanup: 27 registers spilled at 64)
+template <int G, int NJ, int RULE, bool ONEHOT>
+__global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 4 : 8) void act_patch(const Params p, const RowPtrs rp) {   // (Cleanup: registers spilled at 64 and at 96)
     constexpr int EPW = 64 / G;
     // the appearance tables a repair looks up: in LDS (a repair is then ONE global round trip -- the cell's other layers --
     // instead of a chain of dependent table loads from global memory: Cleanup's crowded 11x11 windows made an act 35-90 us)
-    __shared__ uint32_t s_delta[4 * SGW_MAX_TYPES];
-    __shared__ double s_app[SGW_MAX_TYPES * SGW_MAX_CHANNELS];
+    __shared__ uint8_t s_chan[SGW_MAX_TYPES];             // one-hot tables: the channel a type lights (0xFF: none -- EmptyEntity's all-zero row)
+    __shared__ double s_app[ONEHOT ? 1 : SGW_MAX_TYPES * SGW_MAX_CHANNELS];
     __shared__ double s_value[SGW_MAX_TYPES];            // Entity.value: keeps a dependent global load out of every act
     const int tid = threadIdx.x;
     const DevTables* gtab = p.tab;
-    if (tid >= 128 && tid < 128 + SGW_MAX_TYPES) s_value[tid - 128] = gtab->value[tid - 128];
-    if (p.onehot) {
-        if (tid < 4 * SGW_MAX_TYPES) s_delta[tid] = reinterpret_cast<const uint32_t*>(gtab->delta)[tid];
-    } else {
-        for (int i = tid; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBlock) s_app[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
-    }
-    __syncthreads();
     const int lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t env0 = ((int64_t)blockIdx.x * 4 + sub) * EPW;
-    if (env0 >= p.E) return;
+    const bool wave_live = env0 < p.E;
     const int j = lane & (G - 1);
     int64_t env = env0 + (lane / G);
-    const bool live = env < p.E;
+    const bool live = wave_live && env < p.E;
     if (!live) env = p.E - 1;
     const int H = p.H, W = p.W, HW = H * W, C = p.C, V = p.V, VV = p.VV, r = p.r, L = p.L, a = p.a0;
-    uint8_t* g = p.grid + env * p.env_stride;
-    const bool writer = live && j == 0;
+    // Everything below up to the barrier is loads whose addresses need nothing but the launch arguments: they fly while the tables
+    // travel to LDS (a recorded turn at <= 1 024 envs is a chain of such launches, each as long as its dependent round trips).
+    uint32_t pjv[NJ];                                                        // where this lane's agents stand (0xFFFFFFFF: no such agent)
+    float* ring[NJ];                                                         // a recorded turn: this lane's agents' replay rows of the turn in flight
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) {
+        const int jj = j + n * G;
+        pjv[n] = (live && jj < p.A) ? (uint32_t)reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + jj] : 0xFFFFFFFFu;
+        ring[n] = nullptr;
+        if (rp.dual && rp.ts && live && jj > a && jj < p.A && rp.ts->cap[jj] > 0 && rp.ts->states[jj])
+            ring[n] = static_cast<float*>(rp.ts->states[jj]) + (rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj];
+    }
     float* reward_row = rp.reward_row;
     int64_t* action_row = rp.action_row;
     if (rp.ts && rp.ts->cap[a] > 0) {        // the replay rows of the turn in flight, by the engine's own count
         if (rp.ts->rewards[a]) reward_row = rp.ts->rewards[a] + rp.ts->row[a] * p.E;
         if (rp.ts->actions[a]) action_row = rp.ts->actions[a] + rp.ts->row[a] * p.E;
     }
-    uint32_t pjv[NJ];                                                        // where this lane's agents stand (0xFFFFFFFF: no such agent)
+    if (tid >= 128 && tid < 128 + SGW_MAX_TYPES) s_value[tid - 128] = gtab->value[tid - 128];
+    if constexpr (ONEHOT) {
+        if (tid < SGW_MAX_TYPES) {
+            uint32_t ch = 0xFFu;
 #pragma unroll
-    for (int n = 0; n < NJ; ++n) {
-        const int jj = j + n * G;
-        pjv[n] = (live && jj < p.A) ? (uint32_t)reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + jj] : 0xFFFFFFFFu;
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w = gtab->delta[q][tid];
+                if (w) ch = 4u * q + ((uint32_t)__builtin_ctz(w) >> 3);
+            }
+            s_chan[tid] = (uint8_t)ch;
+        }
+    } else {
+        for (int i = tid; i < SGW_MAX_TYPES * SGW_MAX_CHANNELS; i += kBlock) s_app[i] = reinterpret_cast<const double*>(gtab->appearance)[i];
     }
+    __syncthreads();
+    if (!wave_live) return;
+    uint8_t* g = p.grid + env * p.env_stride;
+    const bool writer = live && j == 0;
 
-    // cell (cy, cx) held type `ot` on layer `zc` and now holds `nt`: rewrite it in this lane's window if the window contains
-    // it -- only the channels whose value changes (a one-hot type change touches at most two of the C channel planes; every
-    // store here is a lone 4-byte write into a tensor far bigger than the caches, so they are what a repair costs:
-    // Cleanup 21x31x3, 65 536 envs, an act with every agent firing 152 -> ... us)
-    auto patch = [&](const int cy, const int cx, const int zc, const uint32_t ot, const uint32_t nt) {
-      if (ot == nt) return;
+    // Cell (cy, cx) held type `ot` on layer `zc` and now holds `nt`: it is rewritten in the window of every later agent that
+    // contains it -- only the channels whose value changes (every store here is a lone 4-byte write into a tensor far bigger than
+    // the caches: they are what a repair costs).  `col`: the cell's bytes on every layer (byte z = layer z) as they were before
+    // this act, where the caller has them in registers already; kNoCol: the other layers are read here.
+    // One-hot tables (a type lights one channel or none): WHAT changes is a property of the cell, not of the window -- at most
+    // two (channel, new value) pairs, `cell_update` packs them into one dword (channel 0xFF: nothing) -- so it is computed once
+    // per cell (for Cleanup's beams by the lane that placed the beam, in parallel) and `apply` is a window test + <= 2 stores.
+    // The per-window form -- s_delta counters for every channel group, 81 (cell, agent) pairs deep in a serial loop -- made a
+    // Cleanup act with every agent firing 28 us at 1 024 envs.
+    constexpr uint64_t kNoCol = ~0ull;
+    constexpr uint32_t kNoUpdate = 0x00FF00FFu;
+    auto load_col = [&](const int cy, const int cx) {
+        uint64_t col = 0ull;
+#pragma unroll
+        for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+            if (z < L) col |= (uint64_t)g[z * HW + cy * W + cx] << (8 * z);
+        return col;
+    };
+    auto cell_update = [&](const int zc, const uint32_t ot, const uint32_t nt, const uint64_t col) -> uint32_t {
+        const uint32_t co = s_chan[ot & 31u], cn = s_chan[nt & 31u];
+        if (ot == nt || co == cn) return kNoUpdate;
+        uint32_t vo = 0u, vn = 1u;
+#pragma unroll
+        for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+            if (z < L && z != zc) {
+                const uint32_t c = s_chan[(uint32_t)(col >> (8 * z)) & 31u];
+                vo += c == co ? 1u : 0u;
+                vn += c == cn ? 1u : 0u;
+            }
+        return co | (vo << 8) | (cn << 16) | (vn << 24);
+    };
+    auto apply = [&](const int cy, const int cx, const uint32_t u) {
+      if (u == kNoUpdate) return;
 #pragma unroll
       for (int n = 0; n < NJ; ++n) {
         const int jj = j + n * G;
@@ -705,56 +758,57 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
         const int di = cy - (int)(pjv[n] & 0xFFu) + r, dj = cx - (int)((pjv[n] >> 8) & 0xFFu) + r;
         if ((unsigned)di >= (unsigned)V || (unsigned)dj >= (unsigned)V) continue;
         const int64_t o = env * rp.stride + di * V + dj;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t c = (u >> (16 * h)) & 0xFFu, v = (u >> (16 * h + 8)) & 0xFFu;
+            if (c == 0xFFu) continue;
+            if (p.obs_u8) reinterpret_cast<uint8_t*>(rp.p[jj])[o + (int64_t)c * VV] = (uint8_t)v;
+            else reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = (float)v;
+            if (ring[n]) ring[n][di * V + dj + (int64_t)c * VV] = (float)v;       // ... and in the agent's replay row of this turn
+        }
+      }
+    };
+    // any appearance table: np.sum over layers, left to right, float64 (visual_field.py:51), per window
+    auto patch_general = [&](const int cy, const int cx, const int zc, const uint32_t ot, const uint32_t nt, const uint64_t col) {
+      if (ot == nt) return;
+#pragma unroll
+      for (int n = 0; n < NJ; ++n) {
+        const int jj = j + n * G;
+        if (!(live && jj > a && jj < p.A) || rp.p[jj] == nullptr) continue;
+        const int di = cy - (int)(pjv[n] & 0xFFu) + r, dj = cx - (int)((pjv[n] >> 8) & 0xFFu) + r;
+        if ((unsigned)di >= (unsigned)V || (unsigned)dj >= (unsigned)V) continue;
+        const int64_t o = env * rp.stride + di * V + dj;
         uint32_t tz[SGW_MAX_LAYERS];
 #pragma unroll
         for (int z = 0; z < SGW_MAX_LAYERS; ++z)                             // the column's other layers: loads issued together
-            tz[z] = z < L ? ((z == zc ? nt : (uint32_t)g[z * HW + cy * W + cx]) & 31u) : 0u;
-        if (p.onehot) {                                   // one-hot tables: byte counters
-            uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+            tz[z] = z < L ? ((z == zc ? nt : (col != kNoCol ? (uint32_t)(col >> (8 * z)) : (uint32_t)g[z * HW + cy * W + cx])) & 31u) : 0u;
+        for (int c = 0; c < C; ++c) {
+            if (s_app[(ot & 31u) * SGW_MAX_CHANNELS + c] == s_app[(nt & 31u) * SGW_MAX_CHANNELS + c]) continue;
+            double acc = s_app[tz[0] * SGW_MAX_CHANNELS + c];
 #pragma unroll
-            for (int z = 0; z < SGW_MAX_LAYERS; ++z)
-                if (z < L) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cnt[q] += s_delta[q * SGW_MAX_TYPES + tz[z]];
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t diff = s_delta[q * SGW_MAX_TYPES + (ot & 31u)] ^ s_delta[q * SGW_MAX_TYPES + (nt & 31u)];
-                if (!diff) continue;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int c = 4 * q + b;
-                    if (c < C && ((diff >> (8 * b)) & 0xFFu)) {
-                        const uint32_t v = (cnt[q] >> (8 * b)) & 0xFFu;
-                        if (p.obs_u8) reinterpret_cast<uint8_t*>(rp.p[jj])[o + (int64_t)c * VV] = (uint8_t)v;
-                        else reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = (float)v;
-                        if (rp.dual && rp.ts && rp.ts->cap[jj] > 0 && rp.ts->states[jj])      // ... and in the agent's replay row of this turn
-                            static_cast<float*>(rp.ts->states[jj])[(rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj] + di * V + dj + (int64_t)c * VV] = (float)v;
-                    }
-                }
-            }
-        } else {                                          // np.sum over layers: left to right, float64 (visual_field.py:51)
-            for (int c = 0; c < C; ++c) {
-                if (s_app[(ot & 31u) * SGW_MAX_CHANNELS + c] == s_app[(nt & 31u) * SGW_MAX_CHANNELS + c]) continue;
-                double acc = s_app[tz[0] * SGW_MAX_CHANNELS + c];
-#pragma unroll
-                for (int z = 1; z < SGW_MAX_LAYERS; ++z)
-                    if (z < L) acc += s_app[tz[z] * SGW_MAX_CHANNELS + c];
-                reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
-                if (rp.dual && rp.ts && rp.ts->cap[jj] > 0 && rp.ts->states[jj])
-                    static_cast<float*>(rp.ts->states[jj])[(rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj] + di * V + dj + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
-            }
+            for (int z = 1; z < SGW_MAX_LAYERS; ++z)
+                if (z < L) acc += s_app[tz[z] * SGW_MAX_CHANNELS + c];
+            reinterpret_cast<float*>(rp.p[jj])[o + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
+            if (ring[n]) ring[n][di * V + dj + (int64_t)c * VV] = obs_finish(acc, p.obs_post);
         }
       }
+    };
+    auto patch = [&](const int cy, const int cx, const int zc, const uint32_t ot, const uint32_t nt, const uint64_t col) {
+        if constexpr (ONEHOT) {
+            if (ot == nt) return;
+            apply(cy, cx, cell_update(zc, ot, nt, col != kNoCol ? col : load_col(cy, cx)));
+        } else {
+            patch_general(cy, cx, zc, ot, nt, col);
+        }
     };
 
     if constexpr (RULE == SGW_AGENT_RULE_MOVE) {
         MoveOut mo;
-        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, reward_row, action_row, rp.ets});
+        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, reward_row, action_row, rp.ets, true});
         if (st && writer) atomicOr(p.status, st);
         if (mo.old_y < 0) return;
-        patch(mo.old_y, mo.old_x, p.zA, mo.left, p.default_type);
-        patch(mo.new_y, mo.new_x, p.zA, mo.found, mo.my_type);
+        patch(mo.old_y, mo.old_x, p.zA, mo.left, p.default_type, mo.col_old);
+        patch(mo.new_y, mo.new_x, p.zA, mo.found, mo.my_type, mo.col_new);
         return;
     } else {
         // ---- inputs of the act (same-address loads in every lane of the group)
@@ -774,11 +828,15 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
         if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
         const int y = (int)(yx & 0xFFu), x = (int)(yx >> 8);
         const bool act_ok = act < (uint32_t)p.nact;
-        const uint32_t left = g[p.zA * HW + y * W + x];      // what the agent's own cell holds (its type, unless the caller's grid and agent types disagree)
+        uint64_t col_own = 0ull;             // every layer of the agent's own cell (its type on the agent layer, unless the caller's grid and agent types disagree)
+#pragma unroll
+        for (int zl = 0; zl < SGW_MAX_LAYERS; ++zl)
+            if (zl < L) col_own |= (uint64_t)g[zl * HW + y * W + x] << (8 * zl);
         double reward = 0.0, total_add = 0.0;
         bool pass = false;
         int ny = y, nx = x;
         uint32_t found = 0u;                 // what the cell the agent moved onto held
+        uint64_t col_new = kNoCol;           // ... and that cell's column
         if constexpr (RULE == SGW_AGENT_RULE_CLEANUP) {
             // CleanupAgent.act: a move action turns the agent (even if the move fails) and moves it; clean / zap place a
             // beam on the layer above; the reward is the value summed over ALL layers of the target, read before the move
@@ -800,8 +858,9 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                 for (int zl = 0; zl < SGW_MAX_LAYERS; ++zl) tl[zl] = (tin && zl < L) ? (uint32_t)g[zl * HW + ny * W + nx] : 0u;
                 if (kind != SGW_ACTION_MOVE && p.zA + 1 < L) {
                     // The beam cells (1..R ahead; 0..R-1 ahead of the right / left neighbours) are spread over the lanes of the
-                    // group: lane k tests and writes cells k, k + G, ... (independent loads, one wait), a ballot tells every
-                    // lane which cells took a beam, and each later agent's lane repairs those inside its window.
+                    // group: lane k tests and writes cells k, k + G, ... (independent loads, one wait) and reads the cell's other
+                    // layers in the same round trip; a ballot tells every lane which cells took a beam, and each later agent's lane
+                    // repairs those inside its window from the placing lane's registers (no load in the repair loop).
                     const int fy = dir == 0 ? -1 : dir == 2 ? 1 : 0, fx = dir == 1 ? 1 : dir == 3 ? -1 : 0;
                     const int ry = dir == 1 ? 1 : dir == 3 ? -1 : 0, rx = dir == 0 ? 1 : dir == 2 ? -1 : 0;
                     const uint32_t beam = kind == SGW_ACTION_CLEAN ? p.clean_beam : p.zap_beam;
@@ -818,30 +877,51 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                         const int b = b0 + j;
                         bool placed = false;
                         uint32_t was = 0u;                                      // what the beam cell held
+                        uint32_t col_lo = 0u, col_hi = 0u;                      // the cell's column (SGW_MAX_LAYERS = 7 bytes: two dwords for the shuffles)
+                        uint32_t upd = kNoUpdate, cyx = 0u;                     // one-hot: what changes in the cell, and where it is
                         if (b < nb && beam_cell(b, by, bx)) {
                             const int boff = (p.zA + 1) * HW + by * W + bx;
-                            was = g[boff] & 31u;
+                            const uint64_t col = load_col(by, bx);
+                            was = (uint32_t)(col >> (8 * (p.zA + 1))) & 31u;
+                            col_lo = (uint32_t)col; col_hi = (uint32_t)(col >> 32);
                             placed = !((p.beam_block_mask >> was) & 1u);
                             if (placed && live) g[boff] = (uint8_t)beam;        // (a cell is visited at most once per act)
+                            if constexpr (ONEHOT) {
+                                if (placed) upd = cell_update(p.zA + 1, was, beam, col);
+                                cyx = (uint32_t)by | ((uint32_t)bx << 8);
+                            }
                         }
-                        const unsigned long long all = __ballot(placed);
+                        const unsigned long long all = __ballot(ONEHOT ? (placed && upd != kNoUpdate) : placed);
                         uint32_t mine_grp = (uint32_t)(all >> (lane & ~(G - 1))) & (G == 64 ? 0xFFFFFFFFu : ((1u << (G & 31)) - 1u));
                         if constexpr (G == 64) {
                             unsigned long long m = all;
                             while (m) {
                                 const int k = __builtin_ctzll(m);
                                 m &= m - 1ull;
-                                int cy, cx;
-                                beam_cell(b0 + k, cy, cx);
-                                patch(cy, cx, p.zA + 1, (uint32_t)__builtin_amdgcn_readlane((int)was, k), beam);
+                                if constexpr (ONEHOT) {
+                                    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)cyx, k);
+                                    apply((int)(at & 0xFFu), (int)(at >> 8), (uint32_t)__builtin_amdgcn_readlane((int)upd, k));
+                                } else {
+                                    int cy, cx;
+                                    beam_cell(b0 + k, cy, cx);
+                                    const uint64_t ck = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)col_lo, k) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)col_hi, k) << 32);
+                                    patch_general(cy, cx, p.zA + 1, (uint32_t)__builtin_amdgcn_readlane((int)was, k), beam, ck);
+                                }
                             }
                         } else {
                             while (mine_grp) {                                  // (divergent across the envs of a wave: each lane walks its own group's bits)
                                 const int k = __ffs(mine_grp) - 1;
                                 mine_grp &= mine_grp - 1u;
-                                int cy, cx;
-                                beam_cell(b0 + k, cy, cx);
-                                patch(cy, cx, p.zA + 1, (uint32_t)__shfl((int)was, (lane & ~(G - 1)) + k), beam);
+                                const int src = (lane & ~(G - 1)) + k;
+                                if constexpr (ONEHOT) {
+                                    const uint32_t at = (uint32_t)__shfl((int)cyx, src);
+                                    apply((int)(at & 0xFFu), (int)(at >> 8), (uint32_t)__shfl((int)upd, src));
+                                } else {
+                                    int cy, cx;
+                                    beam_cell(b0 + k, cy, cx);
+                                    const uint64_t ck = (uint64_t)(uint32_t)__shfl((int)col_lo, src) | ((uint64_t)(uint32_t)__shfl((int)col_hi, src) << 32);
+                                    patch_general(cy, cx, p.zA + 1, (uint32_t)__shfl((int)was, src), beam, ck);
+                                }
                             }
                         }
                     }
@@ -850,9 +930,13 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                     st |= SGW_STATUS_OOB_MOVE;
                     ny = y; nx = x;
                 } else {
+                    col_new = 0ull;
 #pragma unroll
                     for (int zl = 0; zl < SGW_MAX_LAYERS; ++zl)
-                        if (zl < L) reward += s_value[tl[zl] & 31u];                  // every layer of the target, read BEFORE the move
+                        if (zl < L) {
+                            reward += s_value[tl[zl] & 31u];                  // every layer of the target, read BEFORE the move
+                            col_new |= (uint64_t)tl[zl] << (8 * zl);
+                        }
                     total_add = reward * (double)(p.total_factor - 1);       // the extra add inside act() (agents.py:172)
                     uint32_t t = 0xFFu;
 #pragma unroll
@@ -878,7 +962,8 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                 }
             }
         }
-        if (!pass) { ny = y; nx = x; }
+        const uint32_t left = (uint32_t)(col_own >> (8 * p.zA)) & 0xFFu;      // what the agent's own cell holds on the agent layer
+        if (!pass) { ny = y; nx = x; col_new = col_own; }
         // ---- Tag: an agent that is "it" hands the flag to the first NotIt neighbour of the cell it now stands on
         uint32_t mine_now = my_type;
         int vy = -1, vx = -1;
@@ -924,13 +1009,13 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 5 : 8) voi
                     // ... and, if it has yet to observe this turn, the "it" flag behind its window (TagAgent.pov reads self.it)
                     if (jj > a && rp.p[jj] != nullptr && p.tail_kind == SGW_TAIL_AGENT_IS_IT && !p.obs_u8) {
                         reinterpret_cast<float*>(rp.p[jj])[env * rp.stride + (int64_t)C * VV] = 1.f;
-                        if (rp.dual && rp.ts && rp.ts->cap[jj] > 0 && rp.ts->states[jj] && rp.ts->row_elems[jj] > (int64_t)C * VV)
-                            static_cast<float*>(rp.ts->states[jj])[(rp.ts->row[jj] * p.E + env) * rp.ts->row_elems[jj] + (int64_t)C * VV] = 1.f;
+                        if (ring[n] && rp.ts->row_elems[jj] > (int64_t)C * VV) ring[n][(int64_t)C * VV] = 1.f;
                     }
                 }
         }
-        if (pass) patch(y, x, p.zA, left, p.default_type);
-        if (pass || mine_now != my_type) patch(ny, nx, p.zA, pass ? found : left, mine_now);
-        if (vy >= 0) patch(vy, vx, p.zA, p.tag_notit, p.tag_it);
+        // (the own cell's and the target's columns are in registers; the victim's -- Tag worlds with more than one layer -- is read in the repair)
+        if (pass) patch(y, x, p.zA, left, p.default_type, col_own);
+        if (pass || mine_now != my_type) patch(ny, nx, p.zA, pass ? found : left, mine_now, pass && RULE == SGW_AGENT_RULE_CLEANUP ? col_new : (pass ? kNoCol : col_own));
+        if (vy >= 0) patch(vy, vx, p.zA, p.tag_notit, p.tag_it, kNoCol);
     }
 }

@@ -1560,11 +1560,14 @@ static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* a
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = time_begin(e, s)) return rc;
     const int A = e->cfg.num_agents;
-    const int G = A <= 16 ? 8 : (A <= 32 ? 32 : 64);      // lanes per env; 9..16 agents: two per lane
+    const bool wide = A > 8 && A <= 16 && (e->opt.act_lanes == 16 || (e->opt.act_lanes == 0 && p.E <= 32768));   // (two agents per lane pay off once the waves outnumber the SIMDs' slots: profiles/r04_act_probe.txt)
+    const int G = A <= 16 ? (wide ? 16 : 8) : (A <= 32 ? 32 : 64);      // lanes per env; 9..16 agents: two per lane
     const unsigned blocks = (unsigned)ceil_div(p.E, 4 * (64 / G));
-#define ACT_PICK(R) (A <= 8 ? act_patch<8, 1, R> : (A <= 16 ? act_patch<8, 2, R> : (A <= 32 ? act_patch<32, 1, R> : act_patch<64, 1, R>)))
-    RowsFn fn = e->cfg.agent_rule == SGW_AGENT_RULE_TAG ? ACT_PICK(SGW_AGENT_RULE_TAG)
-              : e->cfg.agent_rule == SGW_AGENT_RULE_CLEANUP ? ACT_PICK(SGW_AGENT_RULE_CLEANUP) : ACT_PICK(SGW_AGENT_RULE_MOVE);
+#define ACT_PICK(R, OH) (A <= 8 ? act_patch<8, 1, R, OH> : (A <= 16 ? (wide ? act_patch<16, 1, R, OH> : act_patch<8, 2, R, OH>) : (A <= 32 ? act_patch<32, 1, R, OH> : act_patch<64, 1, R, OH>)))
+#define ACT_RULE(OH) (e->cfg.agent_rule == SGW_AGENT_RULE_TAG ? ACT_PICK(SGW_AGENT_RULE_TAG, OH) \
+                      : e->cfg.agent_rule == SGW_AGENT_RULE_CLEANUP ? ACT_PICK(SGW_AGENT_RULE_CLEANUP, OH) : ACT_PICK(SGW_AGENT_RULE_MOVE, OH))
+    RowsFn fn = e->onehot ? ACT_RULE(true) : ACT_RULE(false);
+#undef ACT_RULE
 #undef ACT_PICK
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, s, p, rp);
     HIP_TRY(hipGetLastError());

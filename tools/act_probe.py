@@ -46,4 +46,14 @@ probe("random actions, no windows (rows = None)", rnd, None)
 probe("every agent moves up, windows repaired", torch.zeros_like(rnd), ROWS)
 probe("every agent fires (zap), windows repaired", torch.full_like(rnd, 5), ROWS)
 probe("every agent fires (zap), no windows", torch.full_like(rnd, 5), None)
+if os.environ.get("ACT_PROBE_MORE"):
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    def rand_from(choices):
+        idx = torch.randint(0, len(choices), tuple(rnd.shape), generator=gen)
+        return torch.tensor(choices, dtype=torch.uint8)[idx].to(rnd.device)
+    probe("random moves only (4 directions)", rand_from([0, 1, 2, 3]), ROWS)
+    probe("random clean / zap", rand_from([4, 5]), ROWS)
+    probe("every agent cleans", torch.full_like(rnd, 4), ROWS)
+    probe("half the envs zap, half move up (by env parity)", torch.where((torch.arange(E, device=rnd.device) % 2 == 0)[:, None], torch.full_like(rnd, 5), torch.zeros_like(rnd)), ROWS)
+    probe("zap in envs 0..7 of every 16, up in the rest (wave-uniform)", torch.where(((torch.arange(E, device=rnd.device) // 8) % 2 == 0)[:, None], torch.full_like(rnd, 5), torch.zeros_like(rnd)), ROWS)
 assert eng.status() == 0

@@ -60,7 +60,54 @@ def run(h, w, a, r, E, policy, spawn_prob=0.005):
     torch.cuda.empty_cache()
 
 
+def run_example(which, E, policy):
+    """The shipped Tag (8x9... as configured below: 11x11 world, 5 agents, 9x9 windows + the "it" flag) and Cleanup (21x31x3, 10 agents, 11x11
+    windows + positional code) examples with a one-layer policy over the finished row."""
+    import numpy as np
+
+    class Linear(BaseModel):
+        def __init__(self, input_size, action_space):
+            n = int(np.prod(input_size))
+            super().__init__((n,), action_space, memory_size=64, num_envs=E, device="cuda:0")
+            self.w = torch.randn(n, action_space, generator=torch.Generator(device="cpu").manual_seed(1)).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.w).argmax(dim=1)
+
+    if which == "tag":
+        from sorrel_amd.entities import EmptyEntity as E0
+        from sorrel_amd.examples.tag.env import TagEnv
+        from sorrel_amd.worlds import Gridworld
+        cfg = {"agent": {"num_agents": 5, "vision_radius": 4, "reward_per_turn": 10}, "experiment": {"epochs": 1, "max_turns": 100}}
+        env = TagEnv(Gridworld(11, 11, 1, E0(), num_envs=E, device="cuda:0", seed=0), cfg, model_factory=Linear)
+    else:
+        sys.path.insert(0, ROOT)
+        from tests.test_api_host import CLEANUP_CFG
+        from sorrel_amd.examples.cleanup.entities import EmptyEntity as CEmpty
+        from sorrel_amd.examples.cleanup.env import CleanupEnv
+        from sorrel_amd.examples.cleanup.world import CleanupWorld
+        env = CleanupEnv(CleanupWorld(CLEANUP_CFG, CEmpty(), num_envs=E, device="cuda:0", seed=0), CLEANUP_CFG, model_factory=Linear)
+    label = "policy (eager)" if policy == 1 else "policy, captured turn"
+    if policy == 2 and env.capture_turn() is None:
+        label = f"NOT capturable: {getattr(env, 'capture_error', None)!r}"[:60]
+    us = time_turns(env, 1000 if E <= 4096 else 200)
+    env.raise_on_status()
+    A = len(env.agents)
+    print(f"{which:8s} A{A} E={E:6d} {label:26s} {us:9.1f} us/turn  {E * A / us * 1e6:.3e} agent-steps/s", flush=True)
+    del env
+    torch.cuda.empty_cache()
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[1] == "examples":         # one case (for a kernel trace): examples <tag|cleanup> <envs> <1|2>
+        run_example(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "examples":
+        for which in ("tag", "cleanup"):
+            for E in (1, 1024, 16384):
+                for policy in (1, 2):
+                    run_example(which, E, policy)
+        return
     for shape in ((21, 21, 2, 2), (32, 32, 8, 3)):
         for E in (1, 64, 1024, 16384, 65536):
             for policy in (0, 1, 2, 3, 4):

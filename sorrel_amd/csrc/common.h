@@ -257,12 +257,6 @@ __device__ __forceinline__ void store_grid(const Params& p, uint8_t* __restrict_
     }
 }
 
-__device__ __forceinline__ uint32_t match_bytes(uint32_t v, uint32_t pat) {
-    // 0x80 in every byte of v that equals the corresponding byte of pat (exact, no carries between bytes)
-    const uint32_t x = v ^ pat;
-    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ~(t | x | 0x7F7F7F7Fu);
-}
 
 // ---------------------------------------------------------------- sweep
 // At most one spawning type (every Treasurehunt-shaped world): byte-parallel match of the spawner id, one Philox block
@@ -274,15 +268,17 @@ __device__ __forceinline__ void sweep_single(const Params& p, uint8_t* lds_grid,
     uint32_t* g32 = reinterpret_cast<uint32_t*>(lds_grid);
     const int ndw = (p.cells + 3) >> 2;
     for (int d = d0 + gtid; d < ndw; d += G) {
-        const uint32_t m = match_bytes(g32[d], p.spawn_pat);
-        if (m == 0) continue;
+        // the spawner test: a byte compare per cell (one v_cmp with a byte select each), combined with the draws as lane masks
+        const uint32_t dv = g32[d], pat = p.spawn_pat & 0xFFu;
+        const bool m0 = (dv & 0xFFu) == pat, m1 = ((dv >> 8) & 0xFFu) == pat, m2 = ((dv >> 16) & 0xFFu) == pat, m3 = (dv >> 24) == pat;
+        if (!(m0 | m1 | m2 | m3)) continue;
         const U4 w = philox4x32_10((uint32_t)d, turn, env_id, ep4 | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
         const bool f = p.spawn_full != 0;
         uint32_t hits = 0;
-        hits |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
-        hits |= ((m & 0x8000u) && (f || w.y < p.spawn_thr)) ? 2u : 0u;
-        hits |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
-        hits |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
+        hits |= (m0 && (f || w.x < p.spawn_thr)) ? 1u : 0u;
+        hits |= (m1 && (f || w.y < p.spawn_thr)) ? 2u : 0u;
+        hits |= (m2 && (f || w.z < p.spawn_thr)) ? 4u : 0u;
+        hits |= (m3 && (f || w.w < p.spawn_thr)) ? 8u : 0u;
         if (hits == 0) continue;
         const U4 k = philox4x32_10((uint32_t)d, turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
 #pragma unroll

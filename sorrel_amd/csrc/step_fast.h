@@ -29,21 +29,25 @@ constexpr size_t kCacheResidentGrid = (size_t)288 << 20;   // on-die capacity: 2
 
 
 // Bernoulli draws of one 16-byte unit: returns a 16-bit mask of the cells that spawn.
+// The spawner test is a byte compare per cell (the compiler emits it as ONE v_cmp with a byte select on the dword) and meets the
+// draw's compare as lane masks in scalar registers; until round 4 a byte-parallel match produced 0x80 flags that every cell then
+// tested again in vector registers (24 + 5.5 vector instructions per dword against 16 now; the kernel is vector-issue bound).
 template <bool OWN_KEYS>
 __device__ __forceinline__ uint32_t sweep_hits(const uint4& u, const uint32_t unit, const Params& p, const uint32_t env_id, const uint32_t turn, const uint32_t ep4) {
     uint32_t hits = 0;
+    const uint32_t pat = p.spawn_pat & 0xFFu;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t dv = k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w;
-        const uint32_t m = match_bytes(dv, p.spawn_pat);
-        if (m) {
+        const bool m0 = (dv & 0xFFu) == pat, m1 = ((dv >> 8) & 0xFFu) == pat, m2 = ((dv >> 16) & 0xFFu) == pat, m3 = (dv >> 24) == pat;
+        if (m0 | m1 | m2 | m3) {
             const U4 w = philox4x32_10<OWN_KEYS>(opaque(unit * 4 + k), turn, env_id, ep4 | SGW_STREAM_SPAWN, p.seed_lo, p.seed_hi);
             const bool f = p.spawn_full != 0;
             uint32_t hb = 0;
-            hb |= ((m & 0x80u) && (f || w.x < p.spawn_thr)) ? 1u : 0u;
-            hb |= ((m & 0x8000u) && (f || w.y < p.spawn_thr)) ? 2u : 0u;
-            hb |= ((m & 0x800000u) && (f || w.z < p.spawn_thr)) ? 4u : 0u;
-            hb |= ((m & 0x80000000u) && (f || w.w < p.spawn_thr)) ? 8u : 0u;
+            hb |= (m0 && (f || w.x < p.spawn_thr)) ? 1u : 0u;
+            hb |= (m1 && (f || w.y < p.spawn_thr)) ? 2u : 0u;
+            hb |= (m2 && (f || w.z < p.spawn_thr)) ? 4u : 0u;
+            hb |= (m3 && (f || w.w < p.spawn_thr)) ? 8u : 0u;
             hits |= hb << (4 * k);
         }
     }

@@ -694,10 +694,11 @@ int plan_engine(sgw_engine* e, bool jit) {
     // specialised instances -- any one-hot plain / Tag world of <= 4 KiB whose windows are a multiple of 4 elements and <= 4 KiB of bytes
     bool fixed_shape = !e->fast_rules && fixed_fast_shape(c.layers, c.num_channels, c.vision_radius, c.height, c.width, tagk);
     if (jit && !fixed_shape && e->fast && !e->fast_rules && onehot && p.cells_pad <= 4096 && (ob_elems & 3) == 0 && ob_elems <= 4096 && o.burst != 2) {
-        // ... while the wave's LDS (tables + grid + the env's window bytes) still lets seven workgroups share a CU; beyond that the
-        // chunked bursts keep the occupancy (option burst = 1: whenever legal)
+        // ... while the wave's LDS (tables + grid + the env's window bytes) still lets SIX workgroups share a CU; beyond that the
+        // chunked bursts keep the occupancy (option burst = 1: whenever legal).  (profiles/r04_jit_probe.txt, whole / chunks: 32x32x2 C8
+        // 143.6 / 148.0 us, 30x30 r4 174.3 / 183.0, 40x40 163.3 / 165.6 -- six per CU; 32x32x3 C10, five per CU: 191.2 / 182.3)
         const size_t per_wave = (size_t)e->fast_tab_bytes + p.cells_pad + ((ob_elems + 15) & ~15);
-        fixed_shape = o.burst == 1 || per_wave * 4 + 1024 <= kLdsPerCu / 7;
+        fixed_shape = o.burst == 1 || per_wave * 4 + 1024 <= kLdsPerCu / 6;
     }
     if (jit && (o.burst == 2 || o.stage_agents >= 0 || o.stage_bytes >= 0)) fixed_shape = false;   // (a forced burst size asks for the chunked emit)
     {   // LDS staging of one-hot observations

@@ -466,7 +466,7 @@ def O_full(spec, grid):
                                    (20, 24, 6, 3, 40000, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>", "step_kernel<32, true, 1, 4, 1, 3, 20, 24>"),     # packed, static 7x7 window
                                    (32, 32, 20, 3, 90, "step_fast<true, 1, 4, 3, 32, 32, true>", None),     # crowded: many tags per turn
                                    (30, 30, 6, 4, 70000, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 4, 30, 30, true>"),   # wave per env: 3-bit packed counters prebuilt, the whole-env burst specialised
-                                   (48, 48, 10, 4, 130, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 4, 48, 48, true, false, true, false, true>"),
+                                   (48, 48, 10, 4, 130, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 4, 48, 48, true>"),    # (six workgroups per CU: still the whole-env burst)
                                    (17, 61, 21, 5, 77, "step_fast<true, 0, 0, 0, 0, 0, true, false, true, false, true>", "step_fast<true, 1, 4, 5, 17, 61, true, false, true, false, true>")],    # ragged, crowded, 11x11 windows
                          ids=["static_32x32", "static_32x32_full_batch", "packed_static_radius", "static_32x32_crowded", "p3_30x30_full_batch",
                               "p3_48x48", "p3_ragged_crowded"])

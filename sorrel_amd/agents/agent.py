@@ -101,8 +101,14 @@ class Agent(Entity):
 
     @property
     def epsilon(self) -> float:
-        """Exploration rate of an agent whose ``get_action`` returns action values: the model's (``iqn.py:305-309``), 0 without one."""
-        return float(getattr(self.model, "epsilon", 0.0) or 0.0)
+        """Exploration rate of an agent whose ``get_action`` returns action values: the model's (``iqn.py:305-309``), 0 without one;
+        assigning to it overrides the model's."""
+        own = self.__dict__.get("_epsilon")
+        return float(own) if own is not None else float(getattr(self.model, "epsilon", 0.0) or 0.0)
+
+    @epsilon.setter
+    def epsilon(self, value) -> None:
+        self.__dict__["_epsilon"] = value
 
 
 class MovingAgent(Agent):

@@ -303,6 +303,63 @@ def policy_turn_bench(eng, iters: int = 40):
     return out
 
 
+def recorded_turn_bench(dev, envs: int = 1024, turns: int = 400):
+    """Wall time per ``Environment.take_turn()`` through the Python API for the headline's world shape (32x32, 8 agents, 7x7) at a
+    batch where the eager agent loop is host-bound: a one-layer torch policy per agent with replay memories, (a) the eager loop (sweep +
+    windows + A x (policy, sgw_act) from Python), (b) the same turn RECORDED once (``Environment.capture_turn``: the turn number and
+    the replay rows are counted on the device, ``sgw_turn_*``) and replayed, (c) recorded, with the policy handing its action VALUES
+    to the act launch (``SGW_ACT_QF32``: argmax + epsilon exploration in-kernel).  Not part of `value`."""
+    import time
+
+    import torch
+    from sorrel_amd.examples.treasurehunt.entities import EmptyEntity
+    from sorrel_amd.examples.treasurehunt.env import TreasurehuntEnv
+    from sorrel_amd.examples.treasurehunt.main import make_config
+    from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
+    from sorrel_amd.models import BaseModel
+
+    def factory(values):
+        class Linear(BaseModel):
+            def __init__(self, input_size, action_space):
+                super().__init__(input_size, action_space, memory_size=64, num_envs=envs, device=dev)
+                self.w = torch.randn(int(input_size[0]), action_space, generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+                self.epsilon = 0.05 if values else 0.0
+
+            def take_action(self, state):
+                q = state.reshape(state.shape[0], -1) @ self.w
+                return q if values else q.argmax(dim=1)
+
+        return Linear
+
+    def run(values, capture):
+        cfg = make_config(32, 32, 8, 3, spawn_prob=0.005)
+        env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=envs, device=dev, seed=0), cfg, model_factory=factory(values))
+        if capture and env.capture_turn() is None:
+            raise RuntimeError(f"not recordable: {getattr(env, 'capture_error', None)!r}")
+        for _ in range(50):
+            env.take_turn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(turns):
+            env.take_turn()
+        torch.cuda.synchronize(dev)
+        us = (time.perf_counter() - t0) / turns * 1e6
+        env.raise_on_status()
+        return us
+
+    out = {"workload": f"32x32 grid x 2 layers, 8 agents, 7x7 window, {envs} envs, one linear policy per agent, 64-row replay memories",
+           "unit": "us per take_turn (wall)", "turns": turns}
+    try:
+        out["eager_loop"] = run(False, False)
+        out["recorded"] = run(False, True)
+        out["recorded_action_values"] = run(True, True)
+        out["what"] = ("eager_loop: Python drives sweep, windows and per agent policy + sgw_act; recorded: the same turn as ONE graph replay "
+                       "(27 dependent launches); recorded_action_values: the act launch takes argmax / explores itself (19 launches)")
+    except Exception as exc:      # (reported, never fatal for the line)
+        out["error"] = repr(exc)[:300]
+    return out
+
+
 def ensure_built() -> None:
     """Both native libraries, checked (and, outside a profiler, rebuilt if stale) BEFORE torch or anything else touches
     the GPU: no compiler is ever started from a GPU-initialised process.  Ranks of one node take turns on a lock."""
@@ -670,6 +727,8 @@ def main() -> int:
                 "c5": side_config("c5", dev, args.side_steps, 700, check_turns=0 if args.no_self_check else 3),
                 "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 60, envs=524288),
             }
+            torch.cuda.empty_cache()
+            out["recorded_turn"] = recorded_turn_bench(dev)      # (the Python API at a host-bound batch: eager loop vs one graph replay per turn)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], played = cpu_baseline(spec, args.config, args.cpu_seconds)
             if valid_line and not args.no_self_check:

@@ -32,6 +32,40 @@ def test_flag_constants_match_the_header():
         assert getattr(N, name) == macros["SGW_" + name], name
     flags = [macros[k] for k in macros if k.startswith("SGW_STEP_") and k != "SGW_STEP_DEFAULT"]
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)      # distinct single bits
+    for name in ("ACT_U8", "ACT_I32", "ACT_I64", "ACT_QF32", "TAIL_NONE", "TAIL_AGENT_IS_IT", "TAIL_POSITION_TABLE"):
+        assert getattr(N, name) == macros["SGW_" + name], name
+    # the counter-RNG streams: the oracle's numbering is the header's (tests compare draws made by either)
+    from oracle import gridstep_oracle as O
+    for name in ("SPAWN", "SPAWN_KIND", "ACTION", "PLACE", "DENSE", "DENSE_KIND", "TAG_INIT", "EXPLORE"):
+        assert getattr(O, "STREAM_" + name) == macros["SGW_STREAM_" + name], name
+
+
+def test_value_action_is_argmax_or_the_engines_uniform_draw():
+    """oracle.value_action -- the checker of SGW_ACT_QF32 -- against its definition: np.argmax (first maximum; NaN counts as one)
+    unless u32(EXPLORE, agent) < floor(epsilon * 2**32), then the action random_actions takes for that (env, turn, agent)
+    (sorrel/models/pytorch/iqn.py:294-309 with the counter RNG in place of `random`)."""
+    import numpy as np
+    from oracle import gridstep_oracle as O
+
+    spec = O.treasurehunt_spec(9, 9, 3, 2, seed=77)
+    nact = len(spec.action_dy)
+    rng = np.random.default_rng(0)
+    assert O.value_action(spec, 0, 0, 1, 0, [1.0, 3.0, 3.0, 2.0]) == 1                 # first maximum
+    assert O.value_action(spec, 0, 0, 1, 0, [1.0, np.nan, 9.0, np.nan]) == 1           # NaN counts as the maximum
+    assert O.value_action(spec, 0, 0, 1, 0, [-np.inf] * nact) == 0
+    explored = 0
+    for env in range(40):
+        for turn in range(1, 6):
+            q = rng.standard_normal(nact).astype(np.float32)
+            rnd = O.random_actions(spec, env, 3, turn)
+            for a in range(spec.num_agents):
+                assert O.value_action(spec, env, 3, turn, a, q, 0.0) == int(np.argmax(q))
+                assert O.value_action(spec, env, 3, turn, a, q, 1.0) == int(rnd[a])
+                u = int(O.rng_u32(spec.seed, env, 3, turn, O.STREAM_EXPLORE, a))
+                want = int(rnd[a]) if u < O.prob_threshold(0.3) else int(np.argmax(q))
+                assert O.value_action(spec, env, 3, turn, a, q, 0.3) == want
+                explored += u < O.prob_threshold(0.3)
+    assert 120 < explored < 240                                                         # ~0.3 of 600 draws
 
 
 def test_library_exports_every_declared_symbol(built):

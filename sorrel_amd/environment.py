@@ -940,6 +940,8 @@ class Environment:
         # one engine call per game -- unless a subclass overrides take_turn: the reference's loop goes through take_turn
         # every turn (sorrel/environment.py:266-282), so an override (per-turn logging, extra world logic) must be called
         one_call = device_random and type(self).take_turn is Environment.take_turn
+        exp = self.config.experiment
+        capture = bool(self.capture_turns or (exp.get("capture_turns", False) if hasattr(exp, "get") else getattr(exp, "capture_turns", False)))
         ring = None
         for game in range(num_games):
             self.reset()
@@ -966,6 +968,8 @@ class Environment:
                     st, ac, rw, dn = ring.agent_view(a)
                     sg.add_turns(st[:n], ac[:n], rw[:n], dn[:n], positions=None if ring.positions is None else ring.positions[:n, :, a])
             else:
+                if capture and self._captured is None and not self.stop_if_done and type(self).take_turn is Environment.take_turn and T - self.turn > 2:
+                    capture = self.capture_turn(warmup=2) is not None      # (capture_turns: as in run_experiment)
                 while self.turn < T:
                     self.take_turn()
                     if self.world.is_done and self.stop_if_done:

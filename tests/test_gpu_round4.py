@@ -759,3 +759,35 @@ def test_captured_turn_of_the_tag_and_cleanup_examples(torch_cuda, which):
                 assert np.array_equal(row[:, -1].cpu().numpy() != 0, co.state_at_pov[:, k] == eng.spec.tag_it_type), (t, k)
     assert cap.turns_replayed == 35
     b.raise_on_status()
+
+
+def test_generate_memories_with_recorded_turns_writes_the_same_files(torch_cuda, tmp_path):
+    """``capture_turns`` in generate_memories (sorrel/environment.py:213-300): the per-agent replay files of three games of nine turns
+    -- states, actions, rewards, dones -- are byte for byte what the eager loop writes."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E = 11
+
+    class Model(BaseModel):
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=40, num_envs=E, device="cuda:0")
+            n = int(np.prod(input_size))
+            self.weight = torch.randn((n, action_space), generator=torch.Generator().manual_seed(11 + n)).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.weight).argmax(dim=1)
+
+    files = []
+    for capture in (False, True):
+        env = make_env(11, 12, 3, 2, E, p=0.06, seed=2, model_factory=Model, max_turns=9)
+        env.capture_turns = capture
+        paths = env.generate_memories(num_games=3, output_dir=tmp_path / ("rec" if capture else "eager"))
+        assert (env._captured is not None) == capture, getattr(env, "capture_error", None)
+        files.append([dict(np.load(p)) for p in paths])
+    for fa, fb in zip(*files):
+        assert set(fa) == set(fb)
+        for k in fa:
+            assert np.array_equal(fa[k], fb[k]), k
+    assert files[0][0]["states"].shape[0] > 0

@@ -13,11 +13,11 @@ G3="GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_BUSY_
 w=0
 for world in "$@"; do
   w=$((w+1))
-  python3 $REPO/tools/world_step.py "$world" 200 > /dev/null 2>&1   # (fills the specialiser's cache: nothing compiles under the profiler)
+  python3 $REPO/tools/${PMC_SCRIPT:-world_step.py} "$world" 200 > /dev/null 2>&1   # (fills the specialiser's cache: nothing compiles under the profiler)
   i=0
   for grp in "$G1" "$G2"; do
     i=$((i+1))
-    timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/w${w}g$i -- python3 $REPO/tools/world_step.py "$world" 40 > $OUT/w${w}g$i.out 2> $OUT/w${w}g$i.err || { echo "pass failed: $world group $i" >&2; tail -3 $OUT/w${w}g$i.err >&2; exit 1; }
+    timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/w${w}g$i -- python3 $REPO/tools/${PMC_SCRIPT:-world_step.py} "$world" 40 > $OUT/w${w}g$i.out 2> $OUT/w${w}g$i.err || { echo "pass failed: $world group $i" >&2; tail -3 $OUT/w${w}g$i.err >&2; exit 1; }
   done
   echo "== $world: $(cat $OUT/w${w}g1.out | tail -1)"
   python3 - $OUT/w${w}g1 $OUT/w${w}g2 <<'PY'
@@ -27,7 +27,7 @@ for d in sys.argv[1:]:
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(list)
         for row in csv.DictReader(open(f)):
-            if "step_" in row.get("Kernel_Name", ""):
+            if os.environ.get("PMC_KERNEL", "step_") in row.get("Kernel_Name", ""):
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             v = v[len(v) // 2:]          # the settled half

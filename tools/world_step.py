@@ -14,11 +14,12 @@ WORLDS = {"c3": treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.005), "32x32x1 C4 A
           "32x32x2 C8 A8 r3": move_world(32, 32, 2, 8, 8, 3),
           "th 21x21 A2 r2": treasurehunt_spec(21, 21, 2, 2, spawn_prob=0.005), "th 10x10 A2 r2": treasurehunt_spec(10, 10, 2, 2, spawn_prob=0.005),
           "th 16x16 A4 r2": treasurehunt_spec(16, 16, 4, 2, spawn_prob=0.005)}
-name, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60
-E = int(os.environ.get("E", 65536))
-eng = GridEngine(WORLDS[name], E, device="cuda:0")
-eng.reset(0)
-for _ in range(steps):
-    eng.step(random_actions=True)
-torch.cuda.synchronize()
-print(name, eng.launch_info().split(" group")[0], "bytes/launch", WORLDS[name].algorithmic_bytes_per_env_step() * E)
+if __name__ == "__main__":
+    name, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    E = int(os.environ.get("E", 65536))
+    eng = GridEngine(WORLDS[name], E, device="cuda:0")
+    eng.reset(0)
+    for _ in range(steps):
+        eng.step(random_actions=True)
+    torch.cuda.synchronize()
+    print(name, eng.launch_info().split(" group")[0], "bytes/launch", WORLDS[name].algorithmic_bytes_per_env_step() * E)

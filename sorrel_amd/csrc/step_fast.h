@@ -346,9 +346,34 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
             }
             gsync<1>();
             if (do_sweep) {
+                // the rare second draws of ALL the lane's units in ONE loop: the wave pays a Philox block per iteration whatever the number
+                // of lanes that still hold a hit, so a loop per unit cost ~1.2 blocks per spawning LAYER (two or three in own-entity
+                // worlds); merged, the iterations are the largest hit count of any lane over all its units (~1.5 blocks)
+                auto kind_draw = [&](const uint32_t b) {
+                    const uint32_t off = ((uint32_t)lane + 64u * (b >> 4)) * 16u + (b & 15u);   // byte offset == RNG index
+                    const U4 kw = philox4x32_10<kOwnKeys>(opaque(off >> 2), turn, env_id, ep4 | SGW_STREAM_SPAWN_KIND, p.seed_lo, p.seed_hi);
+                    const uint32_t pick = __umulhi(word_of(kw, off & 3u), p.spawn_n);
+                    lg[off] = (uint8_t)(((pick < 4 ? p.choice_lo : p.choice_hi) >> (8 * (pick & 3u))) & 0xFFu);
+                };
+                if constexpr (NU <= 2) {
+                    uint32_t hm = hits[0];
+                    if constexpr (NU == 2) hm |= hits[1] << 16;
+                    while (hm) {
+                        const uint32_t b = (uint32_t)__ffs(hm) - 1u;
+                        hm &= hm - 1u;
+                        kind_draw(b);
+                    }
+                } else {
+                    static_assert(NU <= 4, "16 hit bits per unit, four units per lane");
+                    uint64_t hm = 0;
 #pragma unroll
-                for (int k = 0; k < NU; ++k)
-                    if (lane + 64 * k < nunits) sweep_apply<kOwnKeys>(hits[k], (uint32_t)(lane + 64 * k), lg, p, env_id, turn, ep4);
+                    for (int k = 0; k < NU; ++k) hm |= (uint64_t)hits[k] << (16 * k);
+                    while (hm) {
+                        const uint32_t b = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
+                        hm &= hm - 1ull;
+                        kind_draw(b);
+                    }
+                }
                 // the last, partly filled round of units (a 24x24x2 map: 72 units = one full round + 8) as DWORDS on the LDS copy: a
                 // wave pays a round's four Philox blocks whether 8 or 64 of its lanes hold a unit, the dword rounds of the same cells
                 // cost ceil(tail dwords / 64) blocks (24x24x2: 8 -> 5 blocks per turn, 32x33x2: 12 -> 9)

@@ -848,6 +848,7 @@ def main() -> int:
 
     make_round2_fixtures(R)
     make_round3_fixtures(R)
+    make_round5_fixtures(R)
 
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)
@@ -935,6 +936,133 @@ def make_round3_fixtures(R):
     save("full_view_treasurehunt", spec, ids, out)
 
 
+def mixed_views(spec: O.Spec, agent_defs):
+    """Per-agent views of a Treasurehunt-typed world for the restatement (`O.agent_view`): types are
+    [Sand, EmptyEntity, Wall, Gem, Bone, Food, TreasurehuntAgent] with kinds ..."""
+    kinds = ["EmptyEntity", "EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+    moves = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
+    views, full = [], []
+    for d in agent_defs:
+        emap = d["entity_map"]
+        app = np.stack([np.asarray(emap[k], dtype=np.float64) for k in kinds])
+        fill = kinds.index(d["fill"])
+        views.append(O.agent_view(spec, d["radius"], app, fill, [moves.get(n, (0, 0))[0] for n in d["actions"]],
+                                  [moves.get(n, (0, 0))[1] for n in d["actions"]]))
+        full.append(bool(d["full_view"]))
+    return views, full
+
+
+def make_round5_fixtures(R):
+    """Agents that DIFFER (sorrel/agents/agent.py:38-48: every agent holds its own observation_spec / action_spec; Agent.transition,
+    agent.py:155-173, observes through self.observation_spec and acts through self.action_spec): one Treasurehunt world stepped by
+    the reference's own take_turn with five TreasurehuntAgents -- radius 2, radius 4, full_view (the whole map, observation_spec.py:197-203),
+    a reordered seven-channel entity list with another fill kind, and an overridden non-one-hot three-channel map -- and three different
+    action lists.  Each agent's flattened float32 window as its replay Buffer stored it, per turn."""
+    print("mixed_specs_treasurehunt: 12x13x2, five agents with five observation specs / three action lists, 12 turns")
+    OneHot = R["observation_spec"].OneHotObservationSpec
+    ActionSpec = R["action_spec"].ActionSpec
+    Environment = R["environment"].Environment
+    th, tha, thw = R["th_entities"], R["th_agents"], R["th_world"]
+    CounterEmpty, CounterModel, _ = build_plugins(R)
+    std = ["EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]
+    H, W = 12, 13
+    spec = O.treasurehunt_spec(H, W, 5, 2, spawn_prob=0.06, seed=77, dense_prob=0.3)
+    odd_list = ["Wall", "EmptyEntity", "TreasurehuntAgent", "Gem", "Food", "Bone", "Lava"]
+    float_map = {"EmptyEntity": np.array([0.0, 0.25, 0.0]), "Wall": np.array([1.0, 0.0, 0.5]), "Gem": np.array([0.0, 2.0, 0.0]),
+                 "Bone": np.array([0.5, 0.5, 0.5]), "Food": np.array([0.0, 0.0, 3.0]), "TreasurehuntAgent": np.array([7.0, 0.0, 1.5])}
+    defs = [
+        dict(list=std, radius=2, full_view=False, fill="Wall", actions=["up", "down", "left", "right"], override=None),
+        dict(list=std, radius=4, full_view=False, fill="Wall", actions=["up", "down", "left", "right"], override=None),
+        dict(list=std, radius=0, full_view=True, fill="Wall", actions=["left", "right", "up", "down", "noop"], override=None),
+        dict(list=odd_list, radius=3, full_view=False, fill="Gem", actions=["up", "down", "left", "right"], override=None),
+        dict(list=std, radius=2, full_view=False, fill="EmptyEntity", actions=["down", "up", "right"], override=float_map),
+    ]
+    turns, ids = 12, [0, 3, 11]
+
+    def ospec_of(d):
+        if d["full_view"]:
+            o = OneHot(d["list"], full_view=True, env_dims=(H, W), fill_entity_kind=d["fill"])
+        else:
+            o = OneHot(d["list"], full_view=False, vision_radius=d["radius"], fill_entity_kind=d["fill"])
+        if d["override"] is not None:
+            o.override_entity_map(d["override"])
+        return o
+
+    class MixedEnv(Environment):
+        def setup_agents(self):
+            self.agents = []
+            for slot, d in enumerate(defs):
+                ospec = ospec_of(d)
+                n = len(next(iter(ospec.entity_map.values())))
+                size = n * (H * W if d["full_view"] else (2 * d["radius"] + 1) ** 2)
+                ospec.override_input_size((size,))
+                aspec = ActionSpec(list(d["actions"]))
+                model = CounterModel(ospec.input_size, aspec.n_actions, memory_size=turns + 1, slot=slot)
+                self.agents.append(tha.TreasurehuntAgent(observation_spec=ospec, action_spec=aspec, model=model))
+
+        def populate_environment(self):
+            for index in np.ndindex(self.world.map.shape):
+                y, x, z = index
+                if (y in [0, H - 1] or x in [0, W - 1]) and z == 1:
+                    self.world.add(index, th.Wall())
+                elif z == 0:
+                    self.world.add(index, th.Sand())
+            for y in range(1, H - 1):
+                for x in range(1, W - 1):
+                    idx = int(O.cell_index(spec, y, x, 1))
+                    if int(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, O.STREAM_DENSE, idx)) < O.prob_threshold(spec.dense_prob):
+                        k = int(O.categorical(O.rng_u32(Ctx.seed, Ctx.env, Ctx.epoch, 0, O.STREAM_DENSE_KIND, idx), 3))
+                        v = self.world.values
+                        self.world.add((y, x, 1), [th.Gem(v["gem"]), th.Food(v["food"]), th.Bone(v["bone"])][k])
+            for (y, x), agent in zip(O.place_agents(spec, Ctx.env, Ctx.epoch), self.agents):
+                self.world.add((int(y), int(x), 1), agent)
+
+    cfg = {"world": {"height": H, "width": W, "gem_value": spec.type_value[3], "food_value": spec.type_value[5],
+                     "bone_value": spec.type_value[4], "spawn_prob": spec.spawn_prob[1]},
+           "experiment": {"epochs": 1, "max_turns": turns, "record_period": 1}}
+    E, A = len(ids), len(defs)
+    agent_defs = []
+    probe = [ospec_of(d) for d in defs]
+    for d, o in zip(defs, probe):
+        agent_defs.append(dict(radius=d["radius"], full_view=d["full_view"], fill=d["fill"], actions=d["actions"],
+                               entity_map={k: np.asarray(v, dtype=np.float64) for k, v in o.entity_map.items()}))
+    shapes = [((len(next(iter(a["entity_map"].values()))), H, W) if a["full_view"]
+               else (len(next(iter(a["entity_map"].values()))), 2 * a["radius"] + 1, 2 * a["radius"] + 1)) for a in agent_defs]
+    out = dict(grid0=np.zeros((E, 2, H, W), np.uint8), pos0=np.zeros((E, A, 2), np.uint8),
+               actions=np.zeros((turns, E, A), np.uint8), rewards=np.zeros((turns, E, A), np.float32),
+               dones=np.zeros((turns, E, A), np.float32), total_reward=np.zeros((turns, E), np.float64),
+               grid=np.zeros((turns, E, 2, H, W), np.uint8), pos=np.zeros((turns, E, A, 2), np.uint8))
+    for a, s in enumerate(shapes):
+        out[f"obs_a{a}"] = np.zeros((turns, E) + s, np.float32)
+    for n, env_id in enumerate(ids):
+        Ctx.seed, Ctx.env, Ctx.epoch, Ctx.turn, Ctx.spec, Ctx.scripted = spec.seed, int(env_id), 0, 0, spec, None
+        world = thw.TreasurehuntWorld(config=cfg, default_entity=CounterEmpty())
+        env = MixedEnv(world, cfg)
+        out["grid0"][n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
+        out["pos0"][n] = [a.location[:2] for a in env.agents]
+        for t in range(turns):
+            Ctx.turn = env.turn + 1
+            env.take_turn()                                  # <- the reference's own loop over agents that differ
+            for a, agent in enumerate(env.agents):
+                mem = agent.model.memory
+                out[f"obs_a{a}"][t, n] = mem.states[t].reshape(shapes[a])
+                out["actions"][t, n, a], out["rewards"][t, n, a], out["dones"][t, n, a] = mem.actions[t], mem.rewards[t], mem.dones[t]
+                out["pos"][t, n, a] = agent.location[:2]
+            out["total_reward"][t, n] = env.world.total_reward
+            out["grid"][t, n] = type_ids_treasurehunt(R, env.world, CounterEmpty)
+    views, full = mixed_views(spec, agent_defs)
+    mine = O.rollout_mixed(views, full, ids, turns)
+    for k in mine:
+        if not np.array_equal(mine[k], out[k]):
+            raise AssertionError(f"mixed restatement differs from the reference in {k} at {np.argwhere(mine[k] != out[k])[0]}")
+    assert not out["dones"].any()
+    assert out["rewards"].any() and len(np.unique(out["actions"][:, :, 2])) == 5, "the fixture should exercise pickups and all five actions"
+    extra = {"agents_json": np.array(json.dumps([dict(radius=a["radius"], full_view=a["full_view"], fill=a["fill"], actions=a["actions"],
+                                                       entity_list=list(a["entity_map"]),
+                                                       entity_map={k: v.tolist() for k, v in a["entity_map"].items()}) for a in agent_defs]))}
+    save("mixed_specs_treasurehunt", spec, ids, out, extra)
+
+
 def make_buffer_fixture():
     """Replay ring semantics of the reference Buffer (sorrel/buffers.py:11-154): index arithmetic,
     n_frames stacking in current_state(), add_empty(), and sample() for given draws."""
@@ -999,6 +1127,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["round2"]:       # only the fixtures added in round 2
         make_round2_fixtures(_import_reference())
+        sys.exit(0)
+    if sys.argv[1:] == ["round5"]:       # only the fixture added in round 5
+        make_round5_fixtures(_import_reference())
         sys.exit(0)
     if sys.argv[1:] == ["round3"]:       # only the fixtures added in round 3
         make_round3_fixtures(_import_reference())

@@ -38,6 +38,9 @@ struct Options {
     int big_threads = 0;      // step_big workgroup: 0 auto, 256, 512
     int big_stage = -1;       // step_big window staging: -1 by batch size, 0 never, 1 always
     int big_pad = 1;          // step_big padded LDS rows
+    int big_walk_stage = 0;   // ... 1: the walking variant stages its windows too (line-aligned 16-byte stores) (A/B)
+    int big_rot = 0;          // step_big: every env starts its round of windows at another agent
+    int big_wg_per_cu = 0;    // step_big workgroups per CU: 0 = what the code object admits, 1..3 = capped through the LDS request (A/B)
     int big_walk = 1;         // step_big<..., WALK>
     int big_walk_blocks = 0;  // ... this many workgroups whatever the batch (0 auto)
     int big_walk_static = 0;  // ... 1: every env assigned statically (blockIdx + k * gridDim), as in rounds 2-3 (A/B)
@@ -80,6 +83,9 @@ const OptKey kOptKeys[] = {
     {"big_threads", &Options::big_threads, 0, 512, false},
     {"big_stage", &Options::big_stage, -1, 1, false},
     {"big_pad", &Options::big_pad, 0, 1, false},
+    {"big_wg_per_cu", &Options::big_wg_per_cu, 0, 8, false},
+    {"big_rot", &Options::big_rot, 0, 1, false},
+    {"big_walk_stage", &Options::big_walk_stage, 0, 1, false},
     {"big_walk", &Options::big_walk, 0, 1, false},
     {"big_walk_blocks", &Options::big_walk_blocks, 0, 1 << 20, false},
     {"big_walk_static", &Options::big_walk_static, 0, 1, false},

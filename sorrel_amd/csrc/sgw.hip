@@ -905,8 +905,7 @@ int plan_engine(sgw_engine* e, bool jit) {
         // of the CU's LDS -- 1 280 envs of config 5: 55 us there, 71 above)
         const size_t walk_lds = e->step_lds_bytes - (size_t)(e->big_threads / 64) * e->big_stage;   // (the walking variant stores directly: no staging area)
         const int per_cu = resident_per_cu(e->big_threads, walk_lds, SGW_WALK_WAVES);
-        int plain_per_cu = resident_per_cu(e->big_threads, e->step_lds_bytes, 6);
-        if (((e->step_lds_bytes + 1023) & ~(size_t)1023) + 1024 <= kLdsPerCu / 4) plain_per_cu = std::max(plain_per_cu, 4);
+        const int plain_per_cu = resident_per_cu(e->big_threads, e->step_lds_bytes, SGW_BIG_WAVES);
         // Engaged for batches of 1.5x to 3x what the plain kernel holds at once (one env per workgroup, four
         // workgroups per CU at config 5 = 1 024 envs), measured on config 5's shape, same box, us per launch, walking
         // against plain: 1 280 envs 53 / 55, 1 536 74-77 / 70-72, 2 048 88-96 / 109-118, 3 072 161-183 / 174-178,
@@ -1267,6 +1266,13 @@ static size_t step_lds_request(const sgw_engine* e, const Params& p, int* cap_ou
     return lds;
 }
 
+// A/B hook (option big_wg_per_cu): fewer step_big workgroups per CU than the code object admits, through the LDS request
+static size_t big_cap_lds(const sgw_engine* e, size_t lds) {
+    if (!e->big || e->opt.big_wg_per_cu <= 0) return lds;
+    const size_t want = (size_t)(kLdsPerCu / e->opt.big_wg_per_cu - 1024) & ~(size_t)511;
+    return (want > lds && want <= 65536) ? want : lds;
+}
+
 static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     p.agent_state = e->agent_state;
     p.state_at_pov = e->state_at_pov;
@@ -1286,7 +1292,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // step_big: the walking variant keeps the direct stores (measured faster there), and so does a launch whose observation
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
     const bool walk = e->big && p.nturns == 1 && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
-    p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
+    p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && (walk ? e->opt.big_walk_stage != 0 : p.E > e->big_stage_min_envs)) ? e->big_stage : 0;
     if (walk) {     // the walking workgroups: a static share each, the rest off a counter (step_big.h)
         p.walk_ctr = reinterpret_cast<uint32_t*>(e->d_status) + 1;
         p.walk_static = e->opt.big_walk_share > 0 ? e->opt.big_walk_share : (int)std::max<int64_t>(1, p.E / e->walk_blocks);
@@ -1295,9 +1301,13 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     if (e->big && p.nturns > 1 && e->big_threads != kBigThreads) p.big_stage = 0;   // (the rollout instance runs kBigThreads: the staging area is sized for this engine's waves)
     if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
     if (walk) { p.walk_word = (int)lds; lds += 16; }   // (behind the grid image: the walking variant has no staging area there)
+    lds = big_cap_lds(e, lds);
+    p.big_rot = e->big ? e->opt.big_rot : 0;
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
-    const bool one_phase = p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
+    // (the phase kernels take the acting agent's action from the tensor: a phase whose action is drawn on the device -- SGW_STEP_RANDOM_ACTIONS,
+    // an agent with a RandomModel among agents that step one by one -- stays on the step kernel, which draws it)
+    const bool one_phase = p.nturns == 1 && !(p.flags & (SGW_STEP_SWEEP | SGW_STEP_RANDOM_ACTIONS)) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
     if (e->k_rows.usable() && one_phase && !p.obs_u8) {
         // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
         const int64_t N = (int64_t)p.C * p.VV;
@@ -1308,7 +1318,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
         return time_end(e, s);
     }
     // ... otherwise, for worlds above 4 KiB: the byte-gather phase kernel (option phase_kernel)
-    if (e->phase_ok && p.nturns == 1 && !(p.flags & SGW_STEP_SWEEP) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1)) {
+    if (e->phase_ok && one_phase) {
         Params q = p;
         q.env_lds = (e->onehot ? 4 * SGW_MAX_TYPES * 4 : SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8) + SGW_MAX_TYPES * 8;   // + the value table
         hipLaunchKernelGGL(e->onehot ? phase_kernel<true> : phase_kernel<false>, dim3((unsigned)ceil_div(p.E, 4)), dim3(kBlock),
@@ -1891,6 +1901,7 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
     size_t lds = step_lds_request(e, p, &cap);
     const bool big_staged = e->big && !walk && e->base.E > e->big_stage_min_envs;
     if (e->big && !big_staged) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
+    lds = big_cap_lds(e, lds);
     const int threads = e->big ? e->big_threads : kBlock;
     Kernel& k = walk ? e->k_walk : e->k_step;
     if (walk) (void)resolve_kernel(e, k);

@@ -28,6 +28,9 @@ constexpr int kBigThreads = SGW_BIG_THREADS;
 #ifndef SGW_WALK_WAVES
 #define SGW_WALK_WAVES 6   // waves per SIMD the WALK variant is compiled for (8 = 64 VGPRs: spills the prefetched units)
 #endif
+#ifndef SGW_BIG_WAVES
+#define SGW_BIG_WAVES 8    // waves per SIMD the single-turn one-env-per-workgroup variant is compiled for
+#endif
 constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigAgentLds = 64 * 4 * 3 + 64;   // ta, oa, npos | agent types  (round 3: the f64 rewards of a turn and the value table live in wave 0's
                                                 // registers -- with the observation staging, config 5's image then fits a CU four times)
@@ -54,7 +57,7 @@ constexpr int big_agent_lds(bool tag) { return kBigAgentLds + (tag ? kBigTagLds 
 // have one or two windows each and mostly wait at the barriers (round 3, 8 192 envs: 90x90x2 / 16 agents 122 -> 103 us, 100x100x2 / 8
 // agents / 11x11 104 -> 88, Tag 128x128 / 32 agents 145 -> 116; config 5 itself 352 -> 394: it keeps 512).
 template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false, int BT = kBigThreads>
-__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const Params p) {
+__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WAVES)) void step_big(const Params p) {
     constexpr int kBT = BT, kBW = BT / 64;   // threads / waves of this instance
     static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
     // Philox key schedule per block (common.h): config 5's share on the walking variant 94 -> 90 us; the plain variant is indifferent at
@@ -461,7 +464,12 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : 6) void step_big(const 
         const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
         // SGW_STEP_OBS_NEXT: only agent a1, which sees the grid after ALL moves of this call (nothing to undo)
         const int r_lo = p.obs_next ? p.a1 : p.a0, r_hi = p.obs_next ? (p.a1 < p.A ? p.a1 + 1 : p.a1) : p.a1;
-        for (int a = r_lo + wv; a < r_hi; a += kBW) {
+        // (option big_rot: each env starts its round of windows at another agent, so that the workgroups that started together do not
+        // all write window k of their env at the same moment -- addresses a fixed stride apart)
+        const int n_r = r_hi - r_lo;
+        const int rot = (p.big_rot && n_r > 0) ? (int)(((uint32_t)env * 11u) % (uint32_t)n_r) : 0;
+        for (int ia = wv; ia < n_r; ia += kBW) {
+            const int a = r_lo + (ia + rot >= n_r ? ia + rot - n_r : ia + rot);
             const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
             const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
             const int cbase = y * P + x;

@@ -128,10 +128,14 @@ class Environment:
         self._turn_capture = False   # the turn protocol with device-side counters is in charge of this turn (recording or warming up)
         self._value_agents = set()   # slots whose get_action returns action values: the act launch takes the argmax / explores (SGW_ACT_QF32)
         self._eps_pushed = {}        # slot -> (engine id, epsilon) last sent to the device's turn state
-        self._turn_state_at = None   # (engine id, epoch, turn) the device's turn state was last set for by the eager loop
+        self._turn_state_at = {}     # engine id -> (epoch, turn) the device's turn state was last set for by the eager loop
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
+        self._group_engines = {}     # (ospec key, action names) -> the engine handle compiled from them
+        self._agent_engine = []      # per agent slot: its handle
+        self._mixed = False          # agents differ in their specs (or observe the whole map): they step one after another on their own handles
+        self._mixed_obs = []         # per agent slot: the tensor its last window was rendered into (mixed mode)
         self._device_populated = False
         self.world.create_world()
         self.stop_if_done = stop_if_done
@@ -175,24 +179,19 @@ class Environment:
         eng = self._ensure_engine()
         eng.reset(epoch=self.epoch)
 
-    def compile_spec(self, ospec=None) -> WorldSpec:
-        """Entities, agents, observation spec and action spec -> the engine's tables.  ``ospec``
-        compiles another observation spec than the agents' own (on-demand observations)."""
+    def compile_spec(self, ospec=None, aspec=None) -> WorldSpec:
+        """Entities, agents, one observation spec and one action spec -> the engine's tables.  Default: those of agent 0.  Every
+        reference agent carries its OWN specs (``sorrel/agents/agent.py:38-48``); agents that differ are served by one engine handle per
+        distinct (observation spec, action spec) over the same world tensors (``_ensure_engine``), each compiled here.  ``ospec`` alone
+        compiles another observation spec than any agent's (on-demand observations)."""
         w, agents = self.world, self.agents
-        aspec = agents[0].action_spec
-        shared = ospec is None
-        if shared:
+        if aspec is None:
+            aspec = agents[0].action_spec
+        if ospec is None:
             ospec = agents[0].observation_spec
-        for a in agents[1:] if shared else ():
-            o = a.observation_spec
-            if type(o) is not type(ospec) or o.vision_radius != ospec.vision_radius or \
-                    o.fill_entity_kind != ospec.fill_entity_kind or \
-                    list(o.entity_map) != list(ospec.entity_map) or \
-                    any(not np.array_equal(o.entity_map[k], ospec.entity_map[k]) for k in o.entity_map) or \
-                    a.action_spec.names != aspec.names:
-                raise ValueError("all agents of one batched Environment must share observation and action specs")
-        if ospec.full_view and shared:
-            raise ValueError("full_view observation specs are not part of the fused step; use observe() on demand")
+        rules = {type(getattr(a, "interaction_rule", None)) for a in agents}
+        if len(rules) > 1:
+            raise ValueError("the agents of one batched Environment must share their interaction rule (plain movers, Tag or Cleanup)")
         rule = getattr(agents[0], "interaction_rule", None)
         extra = dict(agent_rule=0)
         if rule is None:
@@ -258,7 +257,7 @@ class Environment:
         lay = w.layout or dict(fill=[w.default_type] * w.layers, border=[NO_BORDER] * w.layers, dense_prob=0.0, dense=[])
         return WorldSpec(
             height=w.height, width=w.width, layers=w.layers, num_agents=len(agents),
-            vision_radius=ospec.vision_radius, num_channels=C, agent_layer=w.agent_layer,
+            vision_radius=0 if ospec.full_view else ospec.vision_radius, num_channels=C, agent_layer=w.agent_layer,
             default_type=w.default_type, fill_type=fill_type, action_dy=dy, action_dx=dx,
             agent_type=agent_types,
             type_value=[p.value for p in protos], type_passable=[1 if p.passable else 0 for p in protos],
@@ -273,30 +272,68 @@ class Environment:
             type_names=[type(p).__name__ for p in protos], obs_post=int(getattr(ospec, "obs_post", 0)), **extra,
         )
 
+    def _agent_key(self, agent):
+        """What an agent's engine handle is compiled from: its observation spec (table, radius, fill kind, whole map or window) and
+        its action list."""
+        return (self._ospec_key(agent.observation_spec), tuple(agent.action_spec.names))
+
     def _ensure_engine(self):
+        """The engine handle of agent 0's specs (and of every agent that shares them) -- plus, when agents differ, one more handle per
+        distinct (observation spec, action spec) over the SAME grid / position / action / reward tensors (``_group_engines``)."""
         from sorrel_amd.engine import GridEngine
 
         w = self.world
         if self._engine is not None and self._engine_version == w.registry.version:
             return self._engine
-        spec = self.compile_spec()
-        if self._engine is not None:
-            self._engine.close()
+        keys = [self._agent_key(a) for a in self.agents]
+        distinct = list(dict.fromkeys(keys))
+        owner = {k: self.agents[keys.index(k)] for k in distinct}
+        while True:                       # compiling a spec may register its fill kind as a new type: every table must see all of them
+            n_types = len(w.registry)
+            specs = {k: self.compile_spec(owner[k].observation_spec, owner[k].action_spec) for k in distinct}
+            if len(w.registry) == n_types:
+                break
+        for eng in self._all_engines():
+            eng.close()
         first = getattr(w, "first_env_id", 0)
         tensors = dict(grid=w.grid, agent_pos=w.agent_pos, total_reward=w.total_reward)
         if getattr(w, "agent_state", None) is not None:
             tensors["agent_state"] = w.agent_state          # survives engine rebuilds (and resets)
         if getattr(w, "agent_dir", None) is not None:
             tensors["agent_dir"] = w.agent_dir
-        self._engine = GridEngine(spec, w.num_envs, device=w.device, first_env_id=first, tensors=tensors,
-                                  obs_dtype=self.obs_dtype)
+        # agents that differ, or whose own spec is the whole map, step one after another on their own handles (take_turn); no handle
+        # then needs the [E][A][C][V][V] tensor of a fused turn
+        self._mixed = len(distinct) > 1 or any(a.observation_spec.full_view for a in self.agents)
+        self._engine = GridEngine(specs[distinct[0]], w.num_envs, device=w.device, first_env_id=first, tensors=tensors,
+                                  obs_dtype=self.obs_dtype, allocate_obs=not self._mixed)
         self._fresh_obs = None
         w.agent_state = self._engine.agent_state
         w.agent_dir = self._engine.agent_dir
         self._engine_version = w.registry.version
+        self._group_engines = {distinct[0]: self._engine}
+        shared = dict(tensors, actions=self._engine.actions, rewards=self._engine.rewards)
+        if self._engine.agent_state is not None:
+            shared["agent_state"] = self._engine.agent_state
+        if self._engine.agent_dir is not None:
+            shared["agent_dir"] = self._engine.agent_dir
+        for k in distinct[1:]:
+            self._group_engines[k] = GridEngine(specs[k], w.num_envs, device=w.device, first_env_id=first, tensors=shared,
+                                                obs_dtype=self.obs_dtype, allocate_obs=False)
+        self._agent_engine = [self._group_engines[k] for k in keys]
+        self._mixed_obs = [None] * len(self.agents)
+        self._aux_engines = {}
         self._bind_row_tail()
         self._validate_border()
         return self._engine
+
+    def _all_engines(self):
+        """Every handle this environment has built: the step engine, the handles of agents with other specs, on-demand ones."""
+        seen, out = set(), []
+        for eng in [self._engine] + list(getattr(self, "_group_engines", {}).values()) + list(self._aux_engines.values()):
+            if eng is not None and id(eng) not in seen:
+                seen.add(id(eng))
+                out.append(eng)
+        return out
 
     def _bind_row_tail(self):
         """What the agents' ``pov`` appends behind the flattened window (``Agent.row_tail``: Tag's "it" flag, Cleanup's positional
@@ -312,7 +349,7 @@ class Environment:
         if eng.row_tail:
             eng.bind_row_tail(N.TAIL_NONE)
         tails = [a.row_tail(self.world) for a in self.agents]
-        if any(t is None for t in tails) or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_OBSERVE_ROWS) or not self.row_tails_in_kernel:
+        if self._mixed or any(t is None for t in tails) or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_OBSERVE_ROWS) or not self.row_tails_in_kernel:
             return
         kind, table = tails[0]
         for k, t in tails[1:]:
@@ -379,6 +416,8 @@ class Environment:
                 self._captured.replay()
                 return
             self._captured = None            # the engine was rebuilt (new entity types, another obs dtype): back to the eager loop
+        if self._mixed:
+            return self._take_turn_mixed(eng, actions)
         self.turn += 1
         eng.epoch, eng.turn = self.epoch, self.turn
         self._fresh_obs = None
@@ -397,6 +436,63 @@ class Environment:
             self._fresh_obs = (0, self.world.mutations, slot)
             for agent in self.agents:
                 agent.transition(self.world)
+
+    # ------------------------------------------------------------------ agents that differ (sorrel/agents/agent.py:38-48)
+    def _take_turn_mixed(self, eng, actions) -> None:
+        """``take_turn`` for agents that hold different observation / action specs (or observe the whole map, ``full_view``): the
+        entity sweep once, then agent after agent on the handle compiled from ITS specs -- its window (its radius, table and fill
+        kind; or the whole layer-summed map) from the grid as the agents before it left it, then its act through its own action list
+        (``Agent.transition``, ``agent.py:155-173``).  1 + 2 A launches; the fused one-launch turn needs agents that share their specs.
+        ``actions`` ``[E, A]``: indices into each agent's OWN action list."""
+        self.turn += 1
+        for g in self._all_engines():
+            g.epoch, g.turn = self.epoch, self.turn
+        self._fresh_obs = None
+        self._turn_windows = None
+        if actions is not None:
+            eng.actions.copy_(actions.to(device=eng.device, dtype=torch.uint8).reshape(eng.actions.shape))
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)     # the sweep alone
+        for a, agent in enumerate(self.agents):
+            if actions is not None or getattr(agent.model, "device_random", False):
+                g = self._agent_engine[a]
+                self._mixed_window(a)
+                g.step(g.actions, random_actions=actions is None, sweep=False, write_obs=False, agent_begin=a, agent_end=a + 1,
+                       turn=self.turn)
+            else:
+                agent.transition(self.world)
+
+    def _mixed_window(self, a: int) -> torch.Tensor:
+        """Agent ``a``'s observation through its own spec, from the grid as it stands: ``[E, C, V, V]`` (or ``[E, C, H, W]`` with
+        ``full_view``), rendered by its handle into the replay row its ``add_memory`` is about to fill where that applies, else into a
+        tensor of its own."""
+        g = self._agent_engine[a]
+        ospec = self.agents[a].observation_spec
+        if ospec.full_view:
+            out = self._mixed_obs[a]
+            if out is None or out.dtype != g.obs_dtype:
+                out = None
+            self._mixed_obs[a] = g.observe_full(out)
+            return self._mixed_obs[a]
+        shape = (g.num_envs,) + tuple(g.spec.obs_shape[1:])
+        dest = self._replay_slot(a, None, g)
+        if dest is None:
+            dest = self._mixed_obs[a]
+            if dest is None or dest.dtype != g.obs_dtype or tuple(dest.shape) != shape:
+                dest = torch.zeros(shape, dtype=g.obs_dtype, device=g.device)
+        self._mixed_obs[a] = dest
+        g.step(g.actions, sweep=False, agent_begin=a, agent_end=a, obs_next=True, obs_next_out=dest, turn=self.turn)
+        return dest.view(shape)
+
+    def obs_of(self, agent) -> Optional[torch.Tensor]:
+        """The window agent (or slot) last observed -- ``obs[:, slot]`` when the agents share their specs."""
+        a = agent.slot if isinstance(agent, Agent) else int(agent)
+        if not self._mixed:
+            return self._ensure_engine().obs[:, a]
+        t = self._mixed_obs[a]
+        g = self._agent_engine[a]
+        if t is None or self.agents[a].observation_spec.full_view:
+            return t
+        return t.view((g.num_envs,) + tuple(g.spec.obs_shape[1:]))
 
     #: policy-driven turns render every agent's window once and let each act launch repair the cells its move changed
     #: (``sgw_observe_rows`` / ``sgw_act``); False = the older 1 + A protocol, a window rendered per launch (A/B and test switch)
@@ -510,6 +606,9 @@ class Environment:
 
         self._captured = None
         eng = self._ensure_engine()
+        if self._mixed:
+            self.capture_error = ValueError("agents with different observation / action specs step on separate engine handles: not recorded")
+            return None
         if eng.obs is None or not self.patch_windows:
             return None
         per_env = 1
@@ -570,6 +669,10 @@ class Environment:
         if turns <= 0:
             return
         eng = self._ensure_engine()
+        if self._mixed:                          # agents that differ: turn by turn, agent by agent
+            for _ in range(int(turns)):
+                self.take_turn()
+            return
         eng.epoch, eng.turn = self.epoch, self.turn
         self._fresh_obs = None
         eng.rollout(int(turns))
@@ -579,13 +682,23 @@ class Environment:
         """Synchronising poll of the device status word: raises what the reference would have raised
         (``IndexError`` for a move off an un-walled border, ``KeyError`` for an action index outside the
         ``ActionSpec`` or an unregistered entity type)."""
-        self._ensure_engine().raise_on_status()
+        self._ensure_engine()
+        err = None
+        for g in self._all_engines():            # every handle has a status word of its own
+            try:
+                g.raise_on_status()
+            except (IndexError, KeyError) as exc:
+                err = err or exc
+        if err is not None:
+            raise err
 
     def collect(self, turns: int, buffer, actions=None) -> None:
         """``turns`` fused ``take_turn``s whose observations the step kernel writes straight into ``buffer``
         (a ``sorrel_amd.buffers.TurnBuffer``): no per-step copy of the observation tensor.  ``actions``: optional
         ``[turns, E, A]`` uint8 tensor of policy actions; default = on-device random actions (``RandomModel``)."""
         eng = self._ensure_engine()
+        if self._mixed:
+            raise ValueError("collect() writes one [E, A, C, V, V] tensor per turn: the agents must share their observation and action specs")
         want = (buffer.capacity, eng.num_envs) + tuple(eng.spec.obs_shape)
         if tuple(buffer.obs.shape) != want or buffer.obs.dtype != eng.obs_dtype or buffer.obs.device != eng.device:
             raise ValueError(f"buffer.obs must be {eng.obs_dtype} {want} on {eng.device} (the step kernel writes its "
@@ -628,11 +741,13 @@ class Environment:
         scalar settings) and kept on the spec: every agent's ``pov`` asks for it every turn, and serialising the
         appearance vectors each time cost ~7 us per agent phase.  Replace ``entity_map`` (or change radius / fill kind) to
         have a spec recompiled; after editing an appearance vector IN PLACE call ``ObservationSpec.invalidate()``."""
-        sig = (id(ospec.entity_map), len(ospec.entity_map), ospec.vision_radius, ospec.fill_entity_kind, getattr(ospec, "obs_post", 0))
+        sig = (id(ospec.entity_map), len(ospec.entity_map), ospec.vision_radius, ospec.fill_entity_kind, getattr(ospec, "obs_post", 0),
+               bool(ospec.full_view))
         cached = ospec.__dict__.get("_sgw_key")
         if cached is not None and cached[0] == sig:
             return cached[1]
-        key = (type(ospec).__name__, int(ospec.vision_radius), ospec.fill_entity_kind, int(getattr(ospec, "obs_post", 0)),
+        key = (type(ospec).__name__, 0 if ospec.full_view else int(ospec.vision_radius), ospec.fill_entity_kind,
+               int(getattr(ospec, "obs_post", 0)), bool(ospec.full_view),
                tuple((k, np.asarray(v, dtype=np.float64).tobytes()) for k, v in ospec.entity_map.items()))
         try:
             ospec.__dict__["_sgw_key"] = (sig, key, ospec.entity_map)   # (the map is kept alive so that its id cannot be reused)
@@ -647,6 +762,9 @@ class Environment:
         eng = self._ensure_engine()
         if ospec is None or self._ospec_key(ospec) == self._ospec_key(self.agents[0].observation_spec):
             return eng
+        for (okey, _names), g in self._group_engines.items():      # the handle of an agent that holds this very spec
+            if okey == self._ospec_key(ospec):
+                return g
         from sorrel_amd.engine import GridEngine
 
         key = (self._ospec_key(ospec), self.world.registry.version)
@@ -666,10 +784,13 @@ class Environment:
     def _observe(self, who, ospec=None):
         """[E, C, V, V] float32 of an agent slot (Agent / int), or from a (y, x, z) cell, as seen through
         ``ospec`` (default: the agents' own observation spec)."""
-        eng = self._engine_for(ospec)
-        own = eng is self._engine
         if isinstance(who, Agent):
             who = who.slot
+        if self._ensure_engine() is not None and self._mixed and isinstance(who, int) and \
+                (ospec is None or ospec is self.agents[who].observation_spec):
+            return self._mixed_window(who)          # the agent's own spec on the agent's own handle
+        eng = self._engine_for(ospec)
+        own = eng is self._engine and not self._mixed
         if isinstance(who, int):
             tw = self._turn_windows
             if own and tw is not None and tw[0] == self.world.mutations and who >= tw[2]:
@@ -682,7 +803,7 @@ class Environment:
                 # or straight into the row of this agent's replay buffer that add_memory is about to fill
                 slot = self._fresh_obs[2]
                 return eng.obs[:, who] if slot is None else slot.view((eng.num_envs,) + tuple(eng.spec.obs_shape[1:]))
-            out = eng.obs if own else eng.scratch_obs()
+            out = eng.obs if (own and eng.obs is not None) else eng.scratch_obs()
             eng.observe(who, who + 1, out=out)
             return out[:, who]
         y, x, _z = (int(v) for v in who)          # the window is layer-summed: only (y, x) matters
@@ -691,18 +812,21 @@ class Environment:
         eng.observe(0, 1, pos=pos, out=eng.scratch_obs())
         return eng.scratch_obs()[:, 0]
 
-    def _full_view(self, ospec):
+    def _full_view(self, ospec, who=None):
         """Whole-map appearance summed over layers, ``[E, C, H, W]`` float32 (``visual_field.py:41-55``): the engine's
         ``sgw_observe_full`` on the handle compiled from ``ospec``'s appearance table.  The same for every agent; a
         ``full_view`` spec is still rejected as the agents' OWN spec of a fused step (it would mean A whole maps per env
         and turn), it is an on-demand observation."""
+        if isinstance(who, Agent) and who.slot is not None and self._ensure_engine() is not None and self._mixed \
+                and ospec is self.agents[who.slot].observation_spec:
+            return self._mixed_window(who.slot)       # the agent's own whole-map spec inside a turn: its handle, its tensor
         return self._engine_for(ospec).observe_full()
 
     #: policy-driven turns render each agent's window straight into its replay row where that is possible (see below);
     #: False = always through the observation tensor + a copy in ``Buffer.add`` (A/B and test switch)
     write_obs_into_replay = True
 
-    def _replay_slot(self, a: int, acting: Optional[int]):
+    def _replay_slot(self, a: int, acting: Optional[int], eng=None):
         """The row of agent ``a``'s replay buffer that its next ``add_memory`` will fill, if the step kernel can write
         the agent's window straight into it (``SGW_STEP_OBS_NEXT_PACKED``): a ``sorrel_amd.buffers.Buffer`` of the engine's
         dtype and device whose rows hold exactly one window (a ``pov`` that appends to the window, like Cleanup's
@@ -711,9 +835,9 @@ class Environment:
         65 536 envs of config 3 that copy is 77 MB per agent and turn."""
         from sorrel_amd.buffers import Buffer
 
-        eng = self._engine
+        eng = self._engine if eng is None else eng
         mem = getattr(self.agents[a].model, "memory", None)
-        if not self.write_obs_into_replay or not isinstance(mem, Buffer) or eng is None or eng.obs is None:
+        if not self.write_obs_into_replay or not isinstance(mem, Buffer) or eng is None or (eng.obs is None and not self._mixed):
             return None
         if type(self.agents[a]).transition is not Agent.transition or type(self.agents[a]).add_memory is not Agent.add_memory:
             return None        # (the row is pre-written: only safe if this agent's pov is always followed by its add_memory)
@@ -739,6 +863,8 @@ class Environment:
     def _act(self, agent: Agent, action) -> torch.Tensor:
         eng = self._ensure_engine()
         a = agent.slot
+        if self._mixed:
+            eng = self._agent_engine[a]          # the handle compiled from this agent's own action list
         if not torch.is_tensor(action):
             action = torch.full((self.num_envs,), int(action), dtype=torch.uint8, device=self.world.device)
         values = action.dim() == 2
@@ -752,11 +878,17 @@ class Environment:
                 if self._captured is not None and self._captured.graph is not None:
                     raise RuntimeError("an agent switched to action values after its turn was recorded: capture_turn() again")
                 self._value_agents.add(a)
-            if not self._turn_capture and self._turn_state_at != (id(eng), self.epoch, self.turn):
+            if not self._turn_capture and self._turn_state_at.get(id(eng)) != (self.epoch, self.turn):
                 eng.turn_set(self.epoch, self.turn - 1)               # the exploration draws are keyed by the turn in flight
-                self._turn_state_at = (id(eng), self.epoch, self.turn)
+                self._turn_state_at[id(eng)] = (self.epoch, self.turn)
             if not (self._turn_capture and torch.cuda.is_current_stream_capturing()):
                 self._push_epsilon(eng, (a,))                         # (a recorded turn gets its epsilons before each replay)
+        if self._mixed:                          # windows are rendered per agent at its pov: nothing to keep current
+            direct = values or (action.device == eng.device and action.dtype in eng._ACTION_KINDS and action.dim() == 1
+                                and action.shape[0] == eng.num_envs and action.is_contiguous())
+            if not direct:
+                eng.actions[:, a].copy_(action)
+            return eng.act(a, None, action=action if direct else None)
         tw = self._turn_windows
         if self._turn_capture:                   # the turn protocol with device-side counters (capture_turn): rows by the device's count
             if tw is None or tw[0] != self.world.mutations or a < tw[2]:
@@ -802,7 +934,12 @@ class Environment:
     # ------------------------------------------------------------------ step outputs (batched additions)
     @property
     def obs(self):
-        return self._ensure_engine().obs
+        """``[E, A, C, V, V]`` of the last turn -- or, for agents that differ in their specs, the list of each agent's own window
+        tensor (``obs_of``)."""
+        eng = self._ensure_engine()
+        if self._mixed:
+            return [self.obs_of(a) for a in range(len(self.agents))]
+        return eng.obs
 
     @property
     def rewards(self):

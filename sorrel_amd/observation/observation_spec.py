@@ -76,7 +76,7 @@ class ObservationSpec:
         if env is None:
             raise RuntimeError("the world is not attached to an Environment (the engine is compiled there)")
         if self.full_view:
-            return env._full_view(self)
+            return env._full_view(self, location)
         return env._observe(location, self)
 
 

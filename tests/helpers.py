@@ -21,7 +21,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 NON_WORLD_FIXTURES = {"buffer_ring", "buffer_saved_by_reference", "savedgames_by_reference",
-                      "full_view_treasurehunt"}   # fixtures that are not step-loop traces in the common format
+                      "full_view_treasurehunt", "mixed_specs_treasurehunt"}   # fixtures that are not step-loop traces in the common format
 INJECTED_FIXTURES = {"cleanup_15x16", "cleanup_21x31_default", "cleanup_13x12_r2"}  # worlds populated by host code: runs start from the stored grid0 / pos0
 
 
@@ -73,7 +73,16 @@ def oracle_lib():
     if _olib is None:
         import __graft_entry__ as g
 
-        path = g.build_oracle()
+        # the library is built by the session hook in conftest.py, BEFORE any test touches the GPU (a compiler child process started
+        # from a process that holds the GPU is what this avoids); here it is only loaded -- or built when nothing has initialised HIP yet
+        path = g.ORACLE_LIB
+        if not g._up_to_date(g.ORACLE_LIB, g.ORACLE_SRC, os.path.join(ROOT, "include", "sgw.h")):
+            import torch
+
+            if torch.cuda.is_initialized():
+                raise RuntimeError("oracle/libgridstep_oracle.so is missing or stale and this process already holds the GPU: "
+                                   "run `python -c 'import __graft_entry__ as g; g.build()'` first")
+            path = g.build_oracle()
         lib = C.CDLL(path)
         lib.sgo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         lib.sgo_rng_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -222,3 +231,23 @@ def random_rule_world(rng):
     for y, x in pos:
         g[zA, y, x] = agent_t
     return ws, g, pos
+
+
+# ----------------------------------------------------------------------------- agents that differ (round 5)
+TH_KINDS = ["EmptyEntity", "EmptyEntity", "Wall", "Gem", "Bone", "Food", "TreasurehuntAgent"]   # kind of each Treasurehunt type id
+_MOVES = {"up": (-1, 0), "down": (1, 0), "left": (0, -1), "right": (0, 1)}
+
+
+def load_mixed(name="mixed_specs_treasurehunt"):
+    """(arrays, base oracle Spec, [per-agent view Spec], [full_view flag], [agent definition dict]) of a fixture whose agents
+    each hold their own observation / action specs (oracle/make_golden.py round5)."""
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    base = oracle_spec_from_json(str(d["spec_json"]))
+    defs = json.loads(str(d["agents_json"]))
+    views, full = [], []
+    for a in defs:
+        app = np.stack([np.asarray(a["entity_map"][k], dtype=np.float64) for k in TH_KINDS])
+        views.append(O.agent_view(base, a["radius"], app, TH_KINDS.index(a["fill"]),
+                                  [_MOVES.get(n, (0, 0))[0] for n in a["actions"]], [_MOVES.get(n, (0, 0))[1] for n in a["actions"]]))
+        full.append(bool(a["full_view"]))
+    return d, base, views, full, defs

@@ -590,3 +590,23 @@ def test_alias_imports_leave_the_mirrors_module_specs_alone():
         assert importlib.reload(own) is own
     finally:
         compat.uninstall() if hasattr(compat, "uninstall") else None
+
+
+def test_compile_spec_accepts_agents_that_differ():
+    """``sorrel/agents/agent.py:38-48``: every agent holds its own observation and action spec.  Each distinct pair compiles to its own
+    table set (radius, channels, fill type, action deltas) over the same type registry; nothing is rejected."""
+    from tests.mixed_env import make_mixed_env
+
+    env, (d, base, views, full, defs) = make_mixed_env(2, "cpu", on_device=False)
+    keys = [env._agent_key(a) for a in env.agents]
+    assert len(set(keys)) == 5
+    for agent, view, fv in zip(env.agents, views, full):
+        ws = env.compile_spec(agent.observation_spec, agent.action_spec)
+        assert ws.vision_radius == (0 if fv else view.vision_radius) and ws.num_channels == view.num_channels
+        assert list(ws.action_dy) == list(view.action_dy) and list(ws.action_dx) == list(view.action_dx)
+        kind_of = {"Sand": "EmptyEntity", "_FillEntity": agent.observation_spec.fill_entity_kind}
+        for t, name in enumerate(ws.type_names):              # every registered type shows the appearance of its kind in THIS agent's map
+            want = np.asarray(agent.observation_spec.entity_map[kind_of.get(name, name)], dtype=np.float64)
+            assert np.array_equal(np.asarray(ws.appearance)[t], want), (name, t)
+        assert np.array_equal(np.asarray(ws.appearance)[ws.fill_type], view.appearance[view.fill_type])
+    assert env.compile_spec().vision_radius == 2          # default: agent 0's specs

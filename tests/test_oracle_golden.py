@@ -221,3 +221,46 @@ def test_full_view_restatement_matches_the_reference_fixture():
     for n in range(E):
         for t in range(T):
             assert np.array_equal(O.full_view(rgb, d["grid"][t, n]), d["full_rgb"][t, n]), (n, t)
+
+
+def test_python_oracle_matches_reference_with_agents_that_differ():
+    """oracle/make_golden.py round5: the reference's own take_turn over five agents with five observation specs (radius 2 / 4,
+    full_view, another entity list and fill kind, a float map) and three action lists (sorrel/agents/agent.py:38-48, 155-173)."""
+    d, base, views, full, defs = H.load_mixed()
+    T = d["grid"].shape[0]
+    mine = O.rollout_mixed(views, full, [int(e) for e in d["env_ids"]], T)
+    for k in mine:
+        assert np.array_equal(mine[k], d[k]), k
+    assert [v.num_channels for v in views] == [6, 6, 6, 7, 3] and full == [False, False, True, False, False]
+    assert d["obs_a2"].shape[2:] == (6, base.height, base.width) and d["obs_a1"].shape[2:] == (6, 9, 9)
+
+
+def test_c_oracle_matches_reference_with_agents_that_differ():
+    """The C restatement steps agent ranges: one config per agent (its radius, table, fill kind, action list) over the same state
+    arrays reproduces the mixed fixture -- windows, actions, rewards, totals, grids."""
+    d, base, views, full, defs = H.load_mixed()
+    ids = [int(e) for e in d["env_ids"]]
+    T, A = d["grid"].shape[0], base.num_agents
+    lib = H.oracle_lib()
+    for n, env in enumerate(ids):
+        cos = []
+        for a in range(A):
+            v = views[a]
+            if full[a]:        # (the whole map is not a window: compared through the Python restatement above; the C side only acts)
+                import dataclasses
+                v = dataclasses.replace(v, vision_radius=0)
+            cos.append(H.COracle(H.world_spec(v), 1, first_env_id=env))
+        st = cos[0]
+        st.reset(0)
+        assert np.array_equal(st.grid[0], d["grid0"][n]) and np.array_equal(st.pos[0], d["pos0"][n])
+        for co in cos[1:]:     # one state, many configs
+            co.grid, co.pos, co.total, co.actions, co.rewards = st.grid, st.pos, st.total, st.actions, st.rewards
+        for t in range(T):
+            for a in range(A):
+                co = cos[a]
+                co.step(0, t + 1, random_actions=True, sweep=(a == 0), a0=a, a1=a + 1)
+                if not full[a]:
+                    assert np.array_equal(co.obs[0, a], d[f"obs_a{a}"][t, n]), (env, t, a)
+            assert np.array_equal(st.actions[0], d["actions"][t, n]) and np.array_equal(st.rewards[0], d["rewards"][t, n])
+            assert st.total[0] == d["total_reward"][t, n]
+            assert np.array_equal(st.grid[0], d["grid"][t, n]) and np.array_equal(st.pos[0], d["pos"][t, n])

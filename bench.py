@@ -728,6 +728,12 @@ def main() -> int:
                 "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 60, envs=524288),
             }
             torch.cuda.empty_cache()
+            # the same three, in brief, INSIDE `roofline` (the driver's record keeps `roofline` and `cpu_baseline` of the line): launch time,
+            # fraction of the 8 TB/s peak on the same algorithmic-bytes definition as the headline, and the oracle self-check
+            out["roofline"]["side_configs"] = {
+                k: {"kernel_ms": v["kernel_ms"], "frac": v["roofline"]["frac"], "envs": v["envs"],
+                    "checked_vs_oracle_equal": (v.get("checked_vs_oracle") or {}).get("equal"), "kernel": v["kernel"].split(" group")[0]}
+                for k, v in out["configs"].items()}
             out["recorded_turn"] = recorded_turn_bench(dev)      # (the Python API at a host-bound batch: eager loop vs one graph replay per turn)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], played = cpu_baseline(spec, args.config, args.cpu_seconds)

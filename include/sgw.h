@@ -353,17 +353,24 @@ int sgw_launch_info(sgw_engine* eng, char* buf, int64_t capacity);
 /* ---- Options, the plan, specialised instances (round 4) -----------------------------------------------------------
  * The reference's plugin API takes ANY entity list, channel count and map size (sorrel/observation/observation_spec.py:128-173,
  * sorrel/entities/entity.py:9-68, sorrel/worlds/gridworld.py:36).  The step kernels are templates over exactly those
- * constants; sgw_create instantiates them for the engine's own world in-process (hipRTC; no compiler is spawned), keeps the
- * code object on disk (option "jit_cache_dir", default <directory of libsgw.so>/jit_cache) and falls back to the prebuilt
- * instances of the library when hipRTC is absent, the library was built without its embedded sources, or a compile fails.
+ * constants; sgw_create instantiates them for the engine's own world in-process (hipRTC; no compiler is spawned) -- EVERY
+ * instance its plan counts on (whole turn, direct-store twin, rollout, walking variant, row kernels), so that a refusal of any of
+ * them re-plans the whole engine for the prebuilt instances of the library (hipRTC absent, the library built without its embedded
+ * sources, a compile error, a code object that does not load) instead of surfacing at a later call.  Code objects are kept on disk
+ * (option "jit_cache_dir"; default <directory of libsgw.so>/jit_cache while that is the calling user's own directory, else
+ * $XDG_CACHE_HOME/sgw_jit, $HOME/.cache/sgw_jit, /tmp/sgw_jit_cache_<uid>; mode 0700): a file is read only if it belongs to the
+ * calling user, nobody else may write it, and its size and checksum are the ones its header states; the key names the compiler
+ * (hipRTC version and library file), the architecture, the instance and the embedded source.
  *
  * sgw_set_option: every dispatcher knob is a (key, value) pair of strings; value NULL or "" restores the key's default, key
  * NULL restores all.  eng == NULL addresses the process-wide defaults that the NEXT sgw_create / sgw_plan copies; on a live
- * engine only the keys that do not shape its plan are accepted ("rows_mode", "jit_verbose").  Keys (sorrel_amd/csrc/
- * options.h holds the table): jit, jit_cache, jit_cache_dir, jit_verbose, burst, static_radius, pack3, static_cleanup, rgb16,
- * force_generic, fast_rules, rules_8k, rules_11k, fast_8k, big_tag, group, phase_kernel, phase_rows, stage, stage_bytes,
- * stage_agents, fast_wg_per_cu, big_threads, big_stage, big_pad, big_walk, big_walk_blocks, rows_mode.  The library reads ONE
- * environment variable, SGW_DEBUG=1 (log lines of the specialiser on stderr).
+ * engine only the keys that do not shape its plan are accepted ("rows_mode", "act_lanes", "jit_verbose").  Keys (sorrel_amd/csrc/
+ * options.h holds the table): jit, jit_cache, jit_cache_dir, jit_verbose, jit_own_rtc, jit_refuse (test hook), burst,
+ * static_radius, pack3, static_cleanup, rgb16, force_generic, fast_rules, rules_8k, rules_11k, fast_8k, big_tag, group,
+ * phase_kernel, phase_rows, stage, stage_bytes, stage_agents, fast_wg_per_cu, big_threads, big_stage, big_pad, big_wg_per_cu,
+ * big_rot, big_walk, big_walk_blocks, big_walk_static, big_walk_share, big_walk_stage, rows_mode, act_lanes.  No dispatcher knob is
+ * an environment variable; the library reads SGW_DEBUG=1 (log lines of the specialiser on stderr), ROCM_PATH (which installation's
+ * hipRTC: $ROCM_PATH/lib before /opt/rocm/lib) and, only to place the code-object cache, XDG_CACHE_HOME / HOME.
  *
  * sgw_plan: what sgw_create would decide for `cfg` on a device with `num_cus` compute units and `lds_per_workgroup` bytes of
  * LDS per workgroup -- kernel family, lanes per env, LDS layout, staging, the walk window, the instances to launch -- as pure
@@ -420,7 +427,9 @@ int sgw_bind_row_tail(sgw_engine* eng, int kind, int tail_len, const float* tabl
  * arguments -- Environment.turn, the epoch, and the rows of the agents' replay rings (sorrel/buffers.py:46-63) -- so a turn
  * could not be recorded once and replayed.  They now live in device memory that the engine advances itself:
  *   sgw_turn_bind(rows)        (blocking, rare) the agents' replay rings: base pointers, capacity, the row the NEXT turn
- *                              fills, rows per turn (agents that share one Buffer advance it together); NULL: no replay rows
+ *                              fills, rows per turn (agents that share one Buffer advance it together); NULL: no replay rows.
+ *                              Waits for everything submitted to the device so far (any stream), then writes the ring fields
+ *                              only: epoch, turn and the exploration rates are never touched by it
  *   sgw_turn_set(epoch, turn)  (stream-ordered) the turns of the epoch completed so far: Environment.reset -> (epoch, 0)
  *   sgw_turn_begin(...)        sweep + EVERY agent's window into `obs` [E][A][C][V][V] for turn (completed + 1)
  *                              (= sgw_step(0, A, SGW_STEP_SWEEP | SGW_STEP_NO_MOVE) at the device's turn)

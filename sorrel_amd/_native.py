@@ -241,7 +241,12 @@ def load():
     for item in filter(None, os.environ.get("SGW_OPTIONS", "").replace(";", ",").split(",")):
         key, _, value = item.partition("=")
         set_option(key.strip(), value.strip())
+        _opt_baseline[key.strip()] = value.strip()
     return lib
+
+
+_opt_values = {}      # process-wide options as they stand (key -> text), mirrored here so that a block can put back what it found
+_opt_baseline = {}    # ... as SGW_OPTIONS set them when the library was loaded
 
 
 def set_option(key, value=None, engine=None) -> None:
@@ -251,22 +256,44 @@ def set_option(key, value=None, engine=None) -> None:
     k = None if key is None else str(key).encode()
     v = None if value is None else str(int(value) if isinstance(value, bool) else value).encode()
     check(lib.sgw_set_option(engine, k, v))
+    if engine is None:
+        if key is None:
+            _opt_values.clear()
+        elif value is None:
+            _opt_values.pop(str(key), None)
+        else:
+            _opt_values[str(key)] = v.decode()
+
+
+def get_option(key):
+    """The process-wide value last set for ``key`` through this module (text), or None while it stands at the library's default."""
+    return _opt_values.get(str(key))
+
+
+def reset_options() -> None:
+    """Every process-wide option back to where the process started: the library's defaults plus what ``SGW_OPTIONS`` asked for."""
+    set_option(None)
+    for k, v in _opt_baseline.items():
+        set_option(k, v)
 
 
 class options:
-    """``with options(group=16, jit=0): ...`` -- process-wide options for the engines created inside the block."""
+    """``with options(group=16, jit=0): ...`` -- process-wide options for the engines created inside the block; on exit every key goes
+    back to the value it had on entry (not to the library default: blocks nest, and what ``SGW_OPTIONS`` set survives them)."""
 
     def __init__(self, **kw):
         self.kw = kw
+        self.before = {}
 
     def __enter__(self):
+        self.before = {k: get_option(k) for k in self.kw}
         for k, v in self.kw.items():
             set_option(k, v)
         return self
 
     def __exit__(self, *exc):
-        for k in self.kw:
-            set_option(k, None)
+        for k, v in self.before.items():
+            set_option(k, v)
         return False
 
 
@@ -288,9 +315,9 @@ def jit_code_object(path: str):
     """(lowered kernel name, code object bytes) of a cache file."""
     with open(path, "rb") as fh:
         data = fh.read()
-    assert data[:8] == b"SGWJIT1\n", path
+    assert data[:8] == b"SGWJIT2\n", path
     n = int.from_bytes(data[8:12], "little")
-    return data[12:12 + n].decode(), data[12 + n:]
+    return data[12:12 + n].decode(), data[12 + n + 16:]          # (u64 size + u64 checksum in front of the code object)
 
 
 def jit_stats() -> dict:

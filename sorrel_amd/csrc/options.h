@@ -14,6 +14,7 @@ struct Options {
     int jit_own_rtc = 1;      // load /opt/rocm/lib/libhiprtc.so in a namespace of its own (the ROCm installation's compiler) rather than
                               // the hipRTC the process has already mapped (PyTorch's wheel bundles an older one); read once per process
     std::string jit_cache_dir;   // "" = <directory of libsgw.so>/jit_cache
+    std::string jit_refuse;      // test hook: an instance whose template-id contains this text is refused as if it did not compile ("" = none)
     int burst = 0;            // wave-per-env kernels with a compile-time shape: 0 auto, 1 whole-env burst whenever legal, 2 chunked (STAGE) always
     // ---- which prebuilt instance (A/B and test hooks of rounds 2-3; all default to "the rule decides")
     int static_radius = 0;    // packed kernel: 0 auto, 1 run-time-shape instances, 2 compile-time radius on a run-time map
@@ -107,6 +108,11 @@ int option_set(Options& o, const char* key, const char* value, bool live_only) {
     if (!strcmp(key, "jit_cache_dir")) {
         if (live_only) return 3;
         o.jit_cache_dir = value ? value : "";
+        return 0;
+    }
+    if (!strcmp(key, "jit_refuse")) {
+        if (live_only) return 3;
+        o.jit_refuse = value ? value : "";
         return 0;
     }
     for (const OptKey& k : kOptKeys) {

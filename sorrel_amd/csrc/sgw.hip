@@ -38,6 +38,7 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -1145,18 +1146,22 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     e->dev = dev;
     e->arch = prop.gcnArchName[0] ? prop.gcnArchName : "gfx950";
 
-    // the plan; the whole-turn kernel's specialised instance is compiled / loaded now, and a refusal (no hipRTC, no embedded
-    // sources, a compile error) re-plans for the prebuilt instances -- the other kernels of the plan are resolved at first use
+    // the plan; EVERY specialised instance it counts on is compiled / loaded now, and a refusal of any of them (no hipRTC, no embedded
+    // sources, a compile error, a code object that does not load) re-plans for the prebuilt instances.  (Until round 5 only the whole-turn
+    // kernel was resolved here and the others at first use: a late refusal then left a prebuilt run-time-shape twin running under a plan
+    // laid out for compile-time shapes -- no slack behind the staged chunk for the planes a run-time channel count writes in groups of
+    // four -- and sgw_capabilities promised row kernels that existed only specialised.)
     bool jit = e->opt.jit != 0 && SGW_JIT_SOURCES;
     for (;;) {
         if (int rc = plan_engine(e, jit)) { delete e; return rc; }
         if (!jit) break;
         bool ok = true;
-        if (!e->k_step.want.empty()) {
+        for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk, &e->k_rows, &e->k_obs_rows}) {
+            if (k->want.empty()) continue;
             std::string err;
-            e->k_step.tried = true;
-            e->k_step.jit = jit_get(e->k_step.want, e->opt, e->arch.c_str(), e->dev, &err);
-            ok = e->k_step.jit != nullptr;
+            k->tried = true;
+            k->jit = jit_get(k->want, e->opt, e->arch.c_str(), e->dev, &err);
+            if (!k->jit) { ok = false; break; }
         }
         if (ok) break;
         jit = false;
@@ -1197,8 +1202,9 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk})
             if (err == hipSuccess && k->host)
                 err = hipFuncSetAttribute(k->host, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes + 16);   // (+ the walking variant's hand-over word)
-        if (err == hipSuccess && e->k_step.jit)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(e->k_step.jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes);
+        for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk})
+            if (err == hipSuccess && k->jit)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k->jit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds_bytes + 16);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
         if (err != hipSuccess) {
@@ -1595,8 +1601,14 @@ int sgw_act(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, 
 // ---- a whole policy turn as ONE submission (include/sgw.h: sgw_turn_*)
 int sgw_turn_bind(sgw_engine* e, const sgw_turn_rows* rows) {
     if (!e) return fail(SGW_EINVAL, "sgw_turn_bind: NULL engine");
+    // Only the ring fields (row ... row_elems: one contiguous range of TurnState) are written; epoch, turn and the exploration
+    // thresholds are the stream-ordered kernels' (sgw_turn_set / sgw_turn_epsilon / sgw_turn_end) and are never read back or rewritten
+    // here.  The call blocks: everything submitted before it -- on ANY stream, a recorded turn's side stream included -- has finished
+    // when the rings change (until round 5 a read-modify-write of the whole struct on the null stream could overtake kernels in
+    // flight on a non-blocking stream and write stale counters back).
     TurnState h;
-    HIP_TRY(hipMemcpy(&h, e->d_turn, sizeof(h), hipMemcpyDeviceToHost));   // (epoch and turn stay)
+    memset(&h, 0, sizeof(h));
+    HIP_TRY(hipDeviceSynchronize());
     const int A = e->cfg.num_agents;
     const int64_t N = (int64_t)e->base.C * e->base.VV;
     for (int a = 0; a < SGW_MAX_AGENTS; ++a) {
@@ -1628,7 +1640,8 @@ int sgw_turn_bind(sgw_engine* e, const sgw_turn_rows* rows) {
             if (rows->states[a] && ((reinterpret_cast<uintptr_t>(rows->states[a]) & 7) || (rows->row_elems[a] & 1))) e->turn_rows_even = false;
         }
     }
-    HIP_TRY(hipMemcpy(e->d_turn, &h, sizeof(h), hipMemcpyHostToDevice));
+    constexpr size_t r0 = offsetof(TurnState, row), r1 = offsetof(TurnState, eps_thr);
+    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(e->d_turn) + r0, reinterpret_cast<const char*>(&h) + r0, r1 - r0, hipMemcpyHostToDevice));
     return SGW_OK;
 }
 

@@ -1219,10 +1219,15 @@ class CapturedTurn:
                 raise RuntimeError("an agent's add_memory did not run once per turn")
         before = [(mem.idx, mem.size) for mem in self.buffers]
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            env._turn_protocol_body(eng)                  # recorded, not run: the host-side effects are undone below
-        for mem, (idx, size) in zip(self.buffers, before):
-            mem.idx, mem.size = idx, size
+        try:
+            with torch.cuda.graph(g):
+                env._turn_protocol_body(eng)              # recorded, not run: the host-side effects are undone below
+        finally:
+            # ... also when the capture fails half-way (a later agent's forward pass synchronises): the agents before it have already
+            # counted an add_memory for rows that were never written -- the eager loop must not find them counted as valid
+            for mem, (idx, size) in zip(self.buffers, before):
+                mem.idx, mem.size = idx, size
+                mem._deferred_adds = 0
         self.graph = g
         self._expect, self._at = [mem.idx for mem in self.buffers], (env.epoch, env.turn)
 

@@ -47,4 +47,4 @@ def _sgw_options_back_to_defaults():
     from sorrel_amd import _native as N
 
     if N._lib is not None:
-        N.set_option(None)
+        N.reset_options()          # (the defaults + what SGW_OPTIONS asked for at load)

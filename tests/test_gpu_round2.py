@@ -391,6 +391,11 @@ def test_bench_line_carries_side_configs_cold_start_and_the_oracle_self_check(bu
         assert c["kernel_ms"] > 0 and 0.0 < c["roofline"]["frac"] < 1.5 and c["status"] == 0, name
         assert "step_" in c["kernel"], name
     assert line["configs"]["c3_524288"]["envs"] == 524288 and line["configs"]["c5"]["envs"] == 2048
+    side = line["roofline"]["side_configs"]            # the same, in brief, inside `roofline` (what the driver's record keeps)
+    assert set(side) == {"c2", "c5", "c3_524288"}
+    for name, c in side.items():
+        assert c["kernel_ms"] == line["configs"][name]["kernel_ms"] and c["frac"] == line["configs"][name]["roofline"]["frac"]
+    assert side["c2"]["checked_vs_oracle_equal"] is True and side["c5"]["checked_vs_oracle_equal"] is True
     pw = line["roofline"]["prewarm_series"]
     assert pw["n"] == 120 and pw["launches_0_10_mean_ms"] > 0 and pw["launches_10_100_mean_ms"] > 0
     chk = line["rollout"]["checked_vs_oracle"]

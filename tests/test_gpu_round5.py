@@ -127,3 +127,138 @@ def test_agents_with_different_specs_given_actions_and_a_bad_index(torch_cuda):
     env.take_turn(bad)
     with pytest.raises(KeyError):
         env.raise_on_status()
+
+
+# ------------------------------------------------------------------ the specialiser: every instance of a plan resolved at sgw_create
+def _rollout_vs_oracle(torch, ws, eng, E, d, T=6):
+    """sgw_rollout of T turns from the fixture's start against the C oracle turn by turn (final state + last turn's outputs)."""
+    from tests.test_gpu_parity import assert_same
+
+    co = H.COracle(ws, E, first_env_id=0)
+    g0, p0 = d["grid0"][0], d["pos0"][0]
+    eng.grid.copy_(torch.from_numpy(np.broadcast_to(g0, (E,) + g0.shape).copy()))
+    eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(p0, (E,) + p0.shape).copy()))
+    eng.total_reward.zero_()
+    co.grid[...], co.pos[...], co.total[...] = g0, p0, 0
+    eng.epoch, eng.turn = 0, 0
+    eng.rollout(T)
+    for t in range(1, T + 1):
+        assert co.step(0, t, random_actions=True) == 0
+    assert_same(eng, co, ctx=eng.launch_info().split(" group")[0])
+
+
+def test_a_refused_side_kernel_replans_the_whole_engine_for_the_prebuilt_instances(torch_cuda, tmp_path):
+    """Round-4 advisor: only the whole-turn kernel used to be compiled at sgw_create; when the rollout instance (or any other) was refused
+    later, its prebuilt run-time-shape twin ran under a plan laid out for compile-time shapes -- for a world with C % 4 != 0 (Cleanup:
+    nine channels) the twin's grouped plane writes then ran past the staging area.  Now every instance is resolved at create and ANY
+    refusal re-plans with jit = 0.  The Cleanup fixture's world: rollout instance refused -> prebuilt plan, results = the oracle."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from tests.test_gpu_parity import make_engine
+
+    d, spec = H.load_golden("cleanup_15x16")
+    ws = H.world_spec(spec)
+    E = 24
+    N.set_option("jit_cache_dir", str(tmp_path))
+    plan = N.plan(ws.to_config(E, 0))
+    assert plan["specialised"] == 1 and ws.num_channels % 4 != 0 and plan["kernel_rollout"] != plan["kernel"]
+    good = make_engine(ws, E)
+    assert "specialised=1" in good.launch_info()
+    _rollout_vs_oracle(torch, ws, good, E, d)
+    N.set_option("jit_refuse", plan["kernel_rollout"])
+    eng = make_engine(ws, E)
+    assert "specialised=0" in eng.launch_info(), eng.launch_info()          # the WHOLE engine runs the prebuilt plan
+    with N.options(jit=0):
+        assert eng.launch_info().split(" group")[0] == N.plan(ws.to_config(E, 0))["kernel"]
+    _rollout_vs_oracle(torch, ws, eng, E, d)
+    N.set_option("jit_refuse", None)
+    # a row kernel that exists only specialised: refused -> the capability is not advertised (it used to be, and the first call failed)
+    from sorrel_amd.spec import treasurehunt_spec
+
+    own = treasurehunt_spec(20, 22, 3, 4, spawn_prob=0.05, seed=2)
+    p2 = N.plan(own.to_config(E, 0))
+    assert p2["kernel_observe_rows"].startswith("observe_rows<")
+    N.set_option("jit_refuse", "observe_rows<")
+    e2 = make_engine(own, E)
+    assert "specialised=0" in e2.launch_info() and not (e2.capabilities() & N.CAP_OBSERVE_ROWS)
+    N.set_option("jit_refuse", None)
+    e3 = make_engine(own, E)
+    assert "specialised=1" in e3.launch_info() and (e3.capabilities() & N.CAP_OBSERVE_ROWS)
+
+
+def test_a_damaged_cache_file_is_recompiled_not_remembered_as_a_failure(torch_cuda, tmp_path):
+    """A cached code object that does not load (truncated, bit-flipped, someone else's) is dropped and the instance compiled again on the
+    spot -- the engine still runs its specialised plan -- and a file with a wrong checksum is never handed to hipModuleLoadData."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+    from tests.test_gpu_parity import make_engine, assert_same
+
+    N.set_option("jit_cache_dir", str(tmp_path))
+    ws = treasurehunt_spec(17, 27, 4, 3, spawn_prob=0.05, seed=9)      # a shape no other test uses: nothing of it is loaded yet
+    inst = N.plan(ws.to_config(16, 0))["kernel"]
+    path = N.jit_compile(inst)
+    blob = bytearray(open(path, "rb").read())
+    blob[len(blob) // 2] ^= 0x5A                                       # flip a byte inside the code object: the checksum no longer matches
+    open(path, "wb").write(bytes(blob))
+    s0 = N.jit_stats()
+    eng = make_engine(ws, 16)
+    s1 = N.jit_stats()
+    # (the damaged whole-turn instance is compiled again; the engine's other instances -- rollout, ... -- are new to this cache as well)
+    assert "specialised=1" in eng.launch_info() and s1["compiled"] >= s0["compiled"] + 1 and s1["failed"] == s0["failed"]
+    lowered, code = N.jit_code_object(path)                            # rewritten whole
+    assert code[:4] == b"\x7fELF"
+    co = H.COracle(ws, 16, first_env_id=0)
+    eng.reset(0)
+    co.reset(0)
+    for t in range(1, 4):
+        assert co.step(0, t, random_actions=True) == 0
+        eng.step(random_actions=True)
+        assert_same(eng, co, ctx=f"turn {t}")
+
+
+def test_a_capture_that_fails_half_way_leaves_the_replay_rings_as_the_eager_loop_left_them(torch_cuda):
+    """Round-4 advisor: when the LAST agent's forward pass does something a capture forbids (a host synchronisation), the agents before it
+    have already counted a deferred add_memory inside the failed capture; capture_turn() must hand the rings back exactly as the warm-up
+    turns left them, and the eager loop carries on as if nothing had been tried."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E = 9
+
+    class Policy(BaseModel):
+        made = [0]
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=8, num_envs=E, device="cuda:0")
+            self.slot = Policy.made[0] % 4
+            Policy.made[0] += 1
+            self.capturing_ok = True
+
+        def take_action(self, state):
+            s = state.reshape(state.shape[0], -1).sum(dim=1)
+            if self.slot == 3 and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("this forward pass cannot be recorded")     # (what a host synchronisation under capture ends in)
+            return (s.long() + self.slot) % 4
+
+    def fresh():
+        Policy.made[0] = 0
+        return make_env(12, 14, 4, 2, E, p=0.05, seed=4, model_factory=Policy)
+
+    a, b = fresh(), fresh()
+    assert b.capture_turn(warmup=2) is None and b.capture_error is not None
+    for _ in range(2):
+        a.take_turn()
+    for ag_a, ag_b in zip(a.agents, b.agents):
+        ma, mb = ag_a.model.memory, ag_b.model.memory
+        assert (mb.idx, mb.size) == (ma.idx, ma.size) == (2, 2) and not mb._deferred and mb._deferred_adds == 0
+    for _ in range(5):                          # ... and on: the eager loops agree, every ring row included
+        a.take_turn()
+        b.take_turn()
+    torch.cuda.synchronize()
+    assert torch.equal(a.world.grid, b.world.grid) and torch.equal(a.total_reward, b.total_reward)
+    for ag_a, ag_b in zip(a.agents, b.agents):
+        ma, mb = ag_a.model.memory, ag_b.model.memory
+        assert (mb.idx, mb.size) == (ma.idx, ma.size)
+        assert torch.equal(ma.states, mb.states) and torch.equal(ma.actions, mb.actions) and torch.equal(ma.rewards, mb.rewards)

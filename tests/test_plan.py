@@ -58,7 +58,10 @@ def test_the_shipped_library_reads_one_environment_variable(built):
             with open(os.path.join(ROOT, "sorrel_amd", "csrc", name)) as fh:
                 text += fh.read()
     calls = re.findall(r'getenv\("([A-Z_0-9]+)"\)', text)
-    assert calls == ["SGW_DEBUG"], calls
+    # SGW_DEBUG: the specialiser's log lines.  ROCM_PATH: which installation's hipRTC (jit.h).  No dispatcher knob is an environment variable.
+    assert sorted(calls) == ["ROCM_PATH", "SGW_DEBUG"], calls
+    # ... and one getenv by variable: where code objects are cached when the package directory is not the user's own (jit_default_cache_dir)
+    assert re.findall(r'getenv\((\w+)\)', text) == ["var"] and '{"XDG_CACHE_HOME", "HOME"}' in text
 
 
 def test_a_specialised_instance_compiles_without_a_device(built, tmp_path):

@@ -250,6 +250,7 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
  * a policy-driven epoch loop resets with sgw_reset, as Environment.run_experiment does. */
 #define SGW_CAP_OBSERVE_ROWS 1
 #define SGW_CAP_ACT 2
+#define SGW_CAP_RESOLVE 4      /* sgw_turn_resolve (speculative policy turns): plain movers, impassable agent types, float32 windows */
 #define SGW_ACT_U8 0
 #define SGW_ACT_I32 1
 #define SGW_ACT_I64 2
@@ -469,6 +470,33 @@ int sgw_turn_begin_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint
 int sgw_turn_act_rows(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
                       float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind, void* stream);
 int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* stream);
+/* ---- Speculative policy turns (round 5): many agents without A dependent (forward, act) pairs -----------------------------
+ * Agent.transition runs agent after agent (sorrel/agents/agent.py:155-173): agent j's window shows the moves of the agents before
+ * it.  A move changes two cells and a window is small, so for most (env, agent) pairs the action computed from the PRE-move window is
+ * already the sequential one.  Protocol (needs SGW_CAP_RESOLVE):
+ *   sgw_step(0, 0, SGW_STEP_SWEEP | SGW_STEP_NO_OBS)   the entity sweep alone
+ *   sgw_observe_rows(rows, row_elems, 0, A)           every agent's pre-move window into `rows` [A][E][row_elems] float32
+ *     (or sgw_turn_resolve(pass = 0))                  (rows[a] = rows + a * E * row_elems: agent-major, so agents that share a
+ *                                                      model are ONE contiguous batch for its forward pass; pass 0 renders them for
+ *                                                      ANY appearance table and window size, where there is no row kernel)
+ *   fresh[A * E] <- policy(rows)                       one batched evaluation, int64 action indices in the rows' order
+ *   sgw_turn_resolve(pass = 1, fresh, A * E)          writes the actions into actions[E][A], then resolves every env's moves in agent
+ *             order WITHOUT touching the grid; renders, for each agent whose window an earlier mover touches, the window it really
+ *             has when its turn comes; where that differs from its row the row is rewritten and the row's index (agent * E + env)
+ *             appended to the pass's dirty list.  An env without a dirty agent has reached the fixed point: it is committed (movers'
+ *             cells, agent_pos, rewards, the float64 total in agent order -- exactly what sgw_step with these actions would have
+ *             written -- and, where given, reward / action once more in agent-major rows of a replay ring); later passes skip it.
+ *   n <- counters[pass & 7]                            (the one thing the host reads back per pass)
+ *   fresh[n] <- policy(rows[dirty_list[(pass & 1) * E * A + k]]), k < n;  sgw_turn_resolve(pass + 1, fresh, n);  until n == 0.
+ * At most A passes (the first dirty agent of an env moves to a higher index every pass); measured three to four for 64 agents, with
+ * a fifth of the rows re-evaluated in pass 2 and 0.3 % in pass 3 (profiles/r05_speculation_study.txt, r05_speculative_turn.txt).
+ * With a policy that is a function of its window the result equals the sequential turn bit for bit.  Caller-owned scratch:
+ * `scratch` 4 * E * A bytes (done flags, row states, the dirty bytes of the last pass at + 2 * E * A, previous moves), `dirty_list`
+ * 2 * E * A int64, `counters` 8 uint32; their contents are initialised by pass 0 / 1.  `dirty_list` / `counters` may be NULL
+ * (read the dirty bytes instead), and so may `new_actions` (the caller has written `actions` itself). */
+int sgw_turn_resolve(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rows, int64_t row_elems,
+                     float* rewards, double* total_reward, uint8_t* scratch, int64_t* dirty_list, uint32_t* counters,
+                     const int64_t* new_actions, int64_t n_new, float* reward_rows, int64_t* action_rows, int32_t pass, void* stream);
 /* Buffer.current_state (sorrel/buffers.py:143-154) for a recorded turn -- the frames a frame-stacking policy reads in front of its
  * window: the `count` rows of agent `agent`'s replay states BEFORE the row the turn in flight fills, oldest first, wrapping around
  * the ring, by the device's own row count -> out [count][E][row_elems] (device, element type = sgw_set_obs_format's).  Same

@@ -72,6 +72,11 @@ class Agent(Entity):
     def location(self, value):
         self._location = value
 
+    #: ``pov`` is the flattened window of the agent's observation spec and ``get_action`` is ``model.take_action`` of it (plus nothing
+    #: the host computes per agent): the Environment may then evaluate the policies of many agents in one batch per model and let the
+    #: engine sort out whose window an earlier agent's move changed (``Environment.speculate_turns``).  Off unless a class says so.
+    speculative_ok = False
+
     def row_tail(self, world):
         """What ``pov`` appends behind the flattened window, as the engine can write it itself (``sgw_bind_row_tail``):
         ``(N.TAIL_AGENT_IS_IT, None)``, ``(N.TAIL_POSITION_TABLE, float32 table [H, W, n])``, or None (``pov`` appends nothing, or

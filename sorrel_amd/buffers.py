@@ -73,6 +73,32 @@ class Buffer:
         self.idx = (self.idx + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
 
+    def add_batch(self, obs, actions, rewards, done=False) -> None:
+        """``k`` consecutive ``add`` calls at once -- ``obs [k, E, *obs_shape]``, ``actions`` / ``rewards`` ``[k, E]`` -- as the agents
+        that share this buffer would have made them in list order (``sorrel/buffers.py:46-63``: row ``idx``, ``idx + 1``, ...,
+        wrapping around): three copies instead of ``3 k``."""
+        k = int(obs.shape[0])
+        if k > self.capacity:
+            raise ValueError(f"add_batch of {k} rows into a ring of {self.capacity}")
+        if self._deferred:
+            raise RuntimeError("add_batch inside a recorded turn")
+        first = min(k, self.capacity - self.idx)
+        for lo, hi, at in ((0, first, self.idx), (first, k, 0)):
+            if hi <= lo:
+                continue
+            n = hi - lo
+            if obs[lo].data_ptr() != self.states[at].data_ptr():          # (the windows may have been rendered straight into these rows)
+                self.states[at:at + n].copy_(obs[lo:hi].reshape((n,) + tuple(self.states.shape[1:])))
+            self.actions[at:at + n].copy_(actions[lo:hi])
+            self.rewards[at:at + n].copy_(rewards[lo:hi])
+            if torch.is_tensor(done) or done:
+                self.dones[at:at + n] = done
+                self._dones_dirty = True
+            elif self._dones_dirty:
+                self.dones[at:at + n] = 0
+        self.idx = (self.idx + k) % self.capacity
+        self.size = min(self.size + k, self.capacity)
+
     def add_from_buffer(self, buffer: "Buffer") -> None:
         """Append the first ``min(capacity - idx, buffer.size)`` rows of another buffer, the reference's
         ``add_from_buffer`` exactly (``sorrel/buffers.py:71-99``): no wrap-around, ``idx`` only advances, ``size``

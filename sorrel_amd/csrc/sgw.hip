@@ -65,6 +65,7 @@ namespace {
 #include "step_big.h"
 #include "phase.h"
 #include "small_kernels.h"
+#include "resolve.h"
 
 // ---------------------------------------------------------------- host side
 #include "options.h"
@@ -1472,6 +1473,11 @@ int sgw_capabilities(sgw_engine* e) {
     int caps = 0;
     if (e->k_obs_rows.usable() && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_OBSERVE_ROWS;
     caps |= SGW_CAP_ACT;      // MovingAgent.act, TagAgent.act and CleanupAgent.act all have an sgw_act instance
+    {   // sgw_turn_resolve: plain movers with impassable agent types, float32 windows
+        bool ok = e->cfg.agent_rule == SGW_AGENT_RULE_MOVE && e->obs_format == SGW_OBS_F32;
+        for (int a = 0; a < e->cfg.num_agents; ++a) ok = ok && !e->cfg.type_passable[e->cfg.agent_type[a]];
+        if (ok) caps |= SGW_CAP_RESOLVE;
+    }
     return caps;
 }
 
@@ -1709,6 +1715,59 @@ int sgw_turn_act_rows(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t*
     if (!e || !rows) return fail(SGW_EINVAL, "sgw_turn_act_rows: NULL argument");
     return act_impl(e, grid, agent_pos, actions, rows, env_stride, rewards, total_reward, agent, agent_action, action_kind, nullptr, nullptr,
                     e->d_turn, stream, 1);
+}
+
+int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rows, int64_t row_elems, float* rewards,
+                     double* total_reward, uint8_t* scratch, int64_t* dirty_list, uint32_t* counters, const int64_t* new_actions,
+                     int64_t n_new, float* reward_rows, int64_t* action_rows, int32_t pass, void* stream) {
+    if (!e || !grid || !agent_pos || !actions || !rows || !rewards || !total_reward || !scratch)
+        return fail(SGW_EINVAL, "sgw_turn_resolve: NULL argument");
+    const sgw_config& c = e->cfg;
+    if (c.agent_rule != SGW_AGENT_RULE_MOVE) return fail(SGW_EINVAL, "sgw_turn_resolve: plain movers only (SGW_AGENT_RULE_MOVE)");
+    if (e->obs_format != SGW_OBS_F32) return fail(SGW_EINVAL, "sgw_turn_resolve: float32 windows only");
+    for (int a = 0; a < c.num_agents; ++a)
+        if (c.type_passable[c.agent_type[a]]) return fail(SGW_EINVAL, "sgw_turn_resolve: agent types must be impassable");
+    if (row_elems < (int64_t)e->base.C * e->base.VV) return fail(SGW_EINVAL, "sgw_turn_resolve: row_elems is smaller than one window");
+    if (reinterpret_cast<uintptr_t>(rows) & 3u) return fail(SGW_EINVAL, "sgw_turn_resolve: rows is not 4-byte aligned");
+    if (pass < 0) return fail(SGW_EINVAL, "sgw_turn_resolve: pass must be 0 (render the pre-move windows) or the number of the pass, 1 ...");
+    const int64_t EA = (int64_t)c.num_envs * c.num_agents;
+    if ((dirty_list == nullptr) != (counters == nullptr)) return fail(SGW_EINVAL, "sgw_turn_resolve: dirty_list and counters come together");
+    if (new_actions && (n_new < 0 || n_new > EA || (pass == 1 && n_new != EA) || pass == 0))
+        return fail(SGW_EINVAL, "sgw_turn_resolve: new_actions holds every row's action in pass 1 (n_new = E * A), the previous pass's dirty rows' afterwards");
+    if (new_actions && pass > 1 && !dirty_list) return fail(SGW_EINVAL, "sgw_turn_resolve: new_actions of a later pass follow the dirty list");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = time_begin(e, s)) return rc;
+    if (pass == 1 && counters) HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), s));
+    if (new_actions && n_new > 0) {      // the policy's output -> actions[env][agent]
+        const int64_t* lst = pass == 1 ? nullptr : dirty_list + ((pass - 1) & 1) * EA;
+        const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n_new, kBlock), (int64_t)e->num_cus * 8);
+        hipLaunchKernelGGL(resolve_apply_actions, dim3(blocks), dim3(kBlock), 0, s, actions, lst, new_actions, n_new, (int64_t)c.num_envs, c.num_agents);
+    }
+    Params p = e->base;
+    p.grid = grid; p.pos = agent_pos; p.actions = actions; p.rewards = rewards; p.total = total_reward;
+    p.a0 = 0; p.a1 = c.num_agents; p.do_move = 1; p.flags = 0;
+    ResolveArgs ra;
+    ra.rows = rows; ra.row_elems = row_elems;
+    ra.env_done = scratch; ra.pristine = scratch + EA; ra.dirty = scratch + 2 * EA; ra.prev = scratch + 3 * EA;
+    ra.list = dirty_list ? dirty_list + (pass & 1) * EA : nullptr;
+    ra.count = counters ? counters + (pass & 7) : nullptr;
+    ra.count_next = counters ? counters + ((pass + 1) & 7) : nullptr;
+    ra.reward_rows = reward_rows; ra.action_rows = action_rows;
+    ra.first = pass == 0 ? 2 : (pass == 1 ? 1 : 0);
+    // a workgroup per env (four waves share the windows to verify) from 16 agents on, a wave per env below
+    const bool wide = c.num_agents >= 16;
+    const unsigned blocks = (unsigned)(wide ? p.E : ceil_div(p.E, 4));
+    const size_t tab = e->onehot ? (size_t)4 * SGW_MAX_TYPES * 4 : (size_t)SGW_MAX_TYPES * SGW_MAX_CHANNELS * 8;
+    const size_t lds = 4 * tab + 64;
+    if (e->onehot) {
+        if (wide) hipLaunchKernelGGL((turn_resolve<true, 4>), dim3(blocks), dim3(kBlock), lds, s, p, ra);
+        else hipLaunchKernelGGL((turn_resolve<true, 1>), dim3(blocks), dim3(kBlock), lds, s, p, ra);
+    } else {
+        if (wide) hipLaunchKernelGGL((turn_resolve<false, 4>), dim3(blocks), dim3(kBlock), lds, s, p, ra);
+        else hipLaunchKernelGGL((turn_resolve<false, 1>), dim3(blocks), dim3(kBlock), lds, s, p, ra);
+    }
+    HIP_TRY(hipGetLastError());
+    return time_end(e, s);
 }
 
 int sgw_turn_prev_rows(sgw_engine* e, int32_t agent, int32_t count, void* out, void* stream) {

@@ -427,6 +427,79 @@ class GridEngine:
         if rc:
             N.check(rc)
 
+    # ------------------------------------------------------------------ speculative policy turns
+    def speculation_rows(self, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``[A, E, C*V*V]`` float32, agent-major: the windows the policies read in a speculative turn (``turn_resolve``).  Agents that
+        share a model are one contiguous ``[A_g * E, C*V*V]`` batch of it.  ``rows``: the caller's own tensor of that shape -- e.g. the
+        ``A`` rows of a shared replay ring this turn fills -- instead of the engine's scratch."""
+        A, E = self.spec.num_agents, self.num_envs
+        per_env = 1
+        for d in self.spec.obs_shape[1:]:
+            per_env *= int(d)
+        if getattr(self, "_spec_state", None) is None:
+            self._spec_state = torch.zeros((4, E, A), dtype=torch.uint8, device=self.device)      # env_done (the first E bytes of [0]), pristine, dirty, previous moves
+            self._spec_list = torch.zeros((2, E * A), dtype=torch.int64, device=self.device)      # the dirty rows of the odd / even passes
+            self._spec_ctr = torch.zeros((8,), dtype=torch.int32, device=self.device)             # ... and how many (pass & 7)
+            self._spec_rows = None
+            self._spec_cache = {}
+        if rows is None:
+            if self._spec_rows is None:
+                self._spec_rows = torch.zeros((A, E, per_env), dtype=torch.float32, device=self.device)
+            rows = self._spec_rows
+        elif tuple(rows.shape) != (A, E, per_env) or rows.dtype != torch.float32 or rows.device != self.device or not rows.is_contiguous():
+            raise ValueError(f"rows must be a contiguous float32 [{A}, {E}, {per_env}] tensor on {self.device}")
+        return rows
+
+    def speculation_windows(self, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Every agent's PRE-move window into ``speculation_rows(rows)``: ``sgw_observe_rows`` where the engine has a row kernel for the
+        world (one-hot tables), else ``sgw_turn_resolve``'s render mode (any table)."""
+        rows = self.speculation_rows(rows)
+        if self.capabilities() & N.CAP_OBSERVE_ROWS and not self.row_tail:
+            key = rows.data_ptr()
+            wr = self._spec_cache.get(key)
+            if wr is None:
+                if len(self._spec_cache) > 64:
+                    self._spec_cache.clear()
+                wr = self._spec_cache[key] = self.window_rows([rows[a] for a in range(self.spec.num_agents)])
+            self.observe_rows(wr)
+        else:
+            self.turn_resolve(0, rows)
+        return rows
+
+    def turn_resolve(self, pass_no: int, rows: Optional[torch.Tensor] = None, new_actions: Optional[torch.Tensor] = None,
+                     reward_rows: Optional[torch.Tensor] = None, action_rows: Optional[torch.Tensor] = None) -> None:
+        """``sgw_turn_resolve``: pass ``pass_no`` (1, 2, ...; 0 = render the pre-move windows) of a speculative policy turn over
+        ``speculation_rows(rows)``.  ``new_actions``: the policy's int64 output -- for every row (``[A * E]``, agent-major) in pass 1, for
+        the previous pass's dirty rows (``spec_dirty(pass_no - 1)`` order) afterwards; it is written into ``self.actions`` first.  Envs
+        without a dirty agent are committed (grid, positions, ``self.rewards``, ``total_reward``; and ``reward_rows`` float32 /
+        ``action_rows`` int64 ``[A, E]``, e.g. the rows of a replay ring).  ``spec_dirty(pass_no)`` then says which rows to think about again."""
+        rows = self.speculation_rows(rows)
+        st = self._spec_state
+        A, E = self.spec.num_agents, self.num_envs
+        pn, n_new = 0, 0
+        if new_actions is not None:
+            if new_actions.dtype != torch.int64 or new_actions.device != self.device or not new_actions.is_contiguous() or new_actions.dim() != 1 \
+                    or (pass_no == 1 and new_actions.numel() != A * E) or new_actions.numel() > A * E:
+                raise ValueError(f"new_actions must be a contiguous int64 vector on {self.device} ({A * E} elements in pass 1)")
+            pn, n_new = new_actions.data_ptr(), int(new_actions.numel())
+        for name, t, dt in (("reward_rows", reward_rows, torch.float32), ("action_rows", action_rows, torch.int64)):
+            if t is not None and (t.dtype != dt or t.device != self.device or not t.is_contiguous() or t.numel() != A * E):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of [{A}, {E}] on {self.device}")
+        with self._on_device():
+            rc = self._lib.sgw_turn_resolve(self._h, self.grid.data_ptr(), self.agent_pos.data_ptr(), self.actions.data_ptr(), rows.data_ptr(),
+                                            int(rows.shape[2]), self.rewards.data_ptr(), self.total_reward.data_ptr(), st.data_ptr(),
+                                            self._spec_list.data_ptr(), self._spec_ctr.data_ptr(), pn or None, n_new,
+                                            None if reward_rows is None else reward_rows.data_ptr(),
+                                            None if action_rows is None else action_rows.data_ptr(), int(pass_no), self._stream())
+        if rc:
+            N.check(rc)
+
+    def spec_dirty(self, pass_no: int) -> torch.Tensor:
+        """The rows pass ``pass_no`` rewrote, as int64 indices ``agent * E + env`` into the flattened ``[A * E, N]`` rows (synchronises: the
+        host reads the count)."""
+        n = int(self._spec_ctr[pass_no & 7].item())
+        return self._spec_list[pass_no & 1, :n]
+
     def turn_prev_rows(self, agent: int, count: int, out: torch.Tensor) -> torch.Tensor:
         """``sgw_turn_prev_rows``: ``Buffer.current_state`` by the device's row count -- the ``count`` rows of the agent's bound replay
         states before the row the turn in flight fills, oldest first, into ``out`` ``[count, E, row_elems]`` (contiguous, the engine's

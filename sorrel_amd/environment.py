@@ -425,6 +425,8 @@ class Environment:
             eng.step(actions, turn=self.turn)
         elif all(getattr(a.model, "device_random", False) for a in self.agents):
             eng.step(random_actions=True, turn=self.turn)
+        elif self._speculation_groups(eng) is not None:
+            self._take_turn_speculative(eng, self._speculation_groups(eng))
         elif self._begin_policy_turn(eng):
             for agent in self.agents:
                 agent.transition(self.world)
@@ -436,6 +438,115 @@ class Environment:
             self._fresh_obs = (0, self.world.mutations, slot)
             for agent in self.agents:
                 agent.transition(self.world)
+
+    # ------------------------------------------------------------------ many policy-driven agents: speculative turns
+    #: Evaluate the policies of ALL agents on their pre-move windows in one batch per model, let the engine find the (env, agent) pairs
+    #: whose window an earlier agent's move changed (``sgw_turn_resolve``) and re-evaluate only those, until nothing changes: the
+    #: fixed point is the reference's agent-after-agent turn (``sorrel/agents/agent.py:155-173``) -- bit for bit when a policy is a
+    #: function of its window -- in two or three batched passes instead of A dependent (forward, act) pairs.  Pays with many agents
+    #: whose models are shared (one forward pass per model and pass); needs plain movers, ``Agent.speculative_ok`` agents, one-frame
+    #: memories.  Off by default: the agents' ``pov`` / ``get_action`` / ``act`` hooks are not called one by one in such a turn.
+    speculate_turns = False
+
+    def _speculation_groups(self, eng):
+        """``[(a0, a1, model)]``: runs of consecutive agents that share a model object -- or None when this turn must run agent after
+        agent (the switch is off, an agent does not qualify, the engine cannot resolve this world)."""
+        from sorrel_amd import _native as N
+        from sorrel_amd.buffers import Buffer
+
+        if not self.speculate_turns or self._mixed or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_RESOLVE) or eng.row_tail:
+            return None
+        per_env = int(np.prod(eng.spec.obs_shape[1:]))
+        groups = []
+        for a, agent in enumerate(self.agents):
+            model = agent.model
+            if not getattr(agent, "speculative_ok", False) or type(agent).transition is not Agent.transition \
+                    or type(agent).add_memory is not Agent.add_memory or getattr(model, "device_random", False):
+                return None
+            mem = getattr(model, "memory", None)
+            if mem is not None and (not isinstance(mem, Buffer) or mem.n_frames != 1 or mem.extra_data or mem.num_envs != eng.num_envs
+                                    or mem.device != eng.device or mem.states[0, 0].numel() != per_env or mem._deferred):
+                return None
+            if groups and groups[-1][2] is model:
+                groups[-1][1] = a + 1
+            else:
+                groups.append([a, a + 1, model])
+        for a0, a1, model in groups:
+            mem = getattr(model, "memory", None)
+            if mem is not None and a1 - a0 > mem.capacity:
+                return None
+        if 3 * len(groups) > len(self.agents):         # (nearly) a model per agent: a pass is then as many forward passes as the sequential turn has
+            return None                                # -- measured 17 ms against 3.3 ms for 64 agents with 64 models (profiles/r05_speculative_turn.txt)
+        return groups
+
+    def _take_turn_speculative(self, eng, groups) -> None:
+        E, A = eng.num_envs, len(self.agents)
+        self._turn_windows = None
+        # what the policies read, [A, E, N]: where ONE model (and so one replay ring) serves every agent and the ring's rows of this turn
+        # are contiguous, those rows themselves -- add_memory then has nothing to copy (config 5: 381 MB of windows per turn)
+        own = rrows = arows = None
+        mem = getattr(groups[0][2], "memory", None) if len(groups) == 1 else None
+        if mem is not None and mem.capacity % A == 0 and mem.idx % A == 0 and self.write_obs_into_replay:
+            own = mem.states[mem.idx:mem.idx + A].view(A, E, -1)
+            rrows, arows = mem.rewards[mem.idx:mem.idx + A], mem.actions[mem.idx:mem.idx + A]
+        rows = eng.speculation_rows(own)
+        flat = rows.view(A * E, -1)
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)    # the sweep alone
+        eng.speculation_windows(own)                                     # every agent's PRE-move window, once
+
+        def choose(model, x):
+            out = model.take_action(x)
+            if out.dim() == 2:                                           # action values: greedy (an exploring policy draws inside take_action)
+                out = out.argmax(dim=1)
+            return out.to(torch.int64)
+
+        if len(groups) == 1:                                             # pass 1: one batch per model
+            fresh = choose(groups[0][2], flat)
+        else:
+            fresh = torch.cat([choose(model, flat[a0 * E:a1 * E]) for a0, a1, model in groups])
+        k = 1
+        while True:
+            eng.turn_resolve(k, own, fresh.contiguous(), rrows, arows)   # writes the actions, commits the envs that have reached their fixed point
+            lst = eng.spec_dirty(k)                                      # (synchronises: the host learns how many rows must be thought about again)
+            n = int(lst.numel())
+            if n == 0:
+                break
+            k += 1
+            if len(groups) == 1:
+                # a batch of a few sizes only (the BLAS picks its kernel per shape: a new shape every turn costs more than the padding)
+                m = 64 if n <= 64 else (1 << (n - 1).bit_length() if n <= 4096 else -(-n // 4096) * 4096)
+                pad = eng._spec_list[(k - 1) & 1, :m] if m <= A * E else lst
+                if m > n and m <= A * E:
+                    pad[n:m] = 0                                         # (row 0: evaluated again, the result thrown away)
+                fresh = choose(groups[0][2], flat.index_select(0, pad))[:n]
+            else:
+                fresh = torch.empty_like(lst)
+                a_i = torch.div(lst, E, rounding_mode="floor")
+                for a0, a1, model in groups:
+                    sel = torch.nonzero((a_i >= a0) & (a_i < a1)).squeeze(1)
+                    if sel.numel():
+                        fresh[sel] = choose(model, flat.index_select(0, lst[sel]))
+        self.speculation_passes = k
+        if own is not None:                                              # windows, rewards and actions already lie in the ring's rows
+            done = [self.agents[a].is_done(self.world) for a in range(A)]
+            if any(torch.is_tensor(d) or d for d in done):
+                mem.dones[mem.idx:mem.idx + A] = torch.stack([torch.as_tensor(d, dtype=torch.float32, device=eng.device).expand(E) for d in done])
+                mem._dones_dirty = True
+            elif mem._dones_dirty:
+                mem.dones[mem.idx:mem.idx + A] = 0
+            mem.idx = (mem.idx + A) % mem.capacity
+            mem.size = min(mem.size + A, mem.capacity)
+            return
+        taken = eng.actions.t().to(torch.int64)                          # [A, E]
+        rew = eng.rewards.t().contiguous()
+        for a0, a1, model in groups:                                     # add_memory of every agent, in list order
+            mem = getattr(model, "memory", None)
+            if mem is None:
+                continue
+            dones = [self.agents[a].is_done(self.world) for a in range(a0, a1)]
+            done = False if not any(torch.is_tensor(d) or d for d in dones) else \
+                torch.stack([torch.as_tensor(d, dtype=torch.float32, device=eng.device).expand(E) for d in dones])
+            mem.add_batch(rows[a0:a1], taken[a0:a1].contiguous(), rew[a0:a1], done)
 
     # ------------------------------------------------------------------ agents that differ (sorrel/agents/agent.py:38-48)
     def _take_turn_mixed(self, eng, actions) -> None:

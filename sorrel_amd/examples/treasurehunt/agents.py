@@ -5,6 +5,8 @@ from sorrel_amd.agents import MovingAgent
 
 
 class TreasurehuntAgent(MovingAgent):
+    speculative_ok = True        # pov = the flattened window, get_action = model.take_action (frame stacks excepted: checked per turn)
+
     def __init__(self, observation_spec, action_spec, model):
         super().__init__(observation_spec, action_spec, model)
 

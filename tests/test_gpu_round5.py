@@ -262,3 +262,150 @@ def test_a_capture_that_fails_half_way_leaves_the_replay_rings_as_the_eager_loop
         ma, mb = ag_a.model.memory, ag_b.model.memory
         assert (mb.idx, mb.size) == (ma.idx, ma.size)
         assert torch.equal(ma.states, mb.states) and torch.equal(ma.actions, mb.actions) and torch.equal(ma.rewards, mb.rewards)
+
+
+# ------------------------------------------------------------------ speculative policy turns (sgw_turn_resolve)
+def _float_world():
+    d, spec = H.load_golden("float_appearance_3layer")
+    return H.world_spec(spec)
+
+
+SPEC_CASES = [
+    ("c3_shape", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.02, seed=3, dense_prob=0.2), 96, 6),
+    ("c5_shape", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=4, dense_prob=0.25), 10, 4),
+    ("crowded_6x6", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(6, 6, 6, 2, spawn_prob=0.2, seed=5), 64, 8),
+    ("ragged_9x13_rmax", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(9, 13, 5, 4, spawn_prob=0.1, seed=6, dense_prob=0.3), 33, 6),
+    ("float_tables_3layer", _float_world, 21, 6),
+]
+
+
+@pytest.mark.parametrize("case", SPEC_CASES, ids=[c[0] for c in SPEC_CASES])
+def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
+    """sgw_turn_resolve through the C ABI: sweep, every pre-move window, one batched policy evaluation, then resolve / re-evaluate the
+    dirty rows until nobody is dirty.  Against the C oracle's agent-after-agent turn: (1) stepping the actions the speculation ended
+    on gives the engine's grid, positions, rewards and totals; (2) the window each agent had when ITS turn came (the oracle's
+    observation) is the row its action was computed on, and the policy of that window is that action -- i.e. the fixed point IS the
+    sequential policy-driven turn.  Also: committed envs are skipped, passes stay far below A, every env ends done."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from tests.test_gpu_parity import make_engine
+
+    name, mk, E, T = case
+    ws = mk()
+    A, nact = ws.num_agents, len(ws.action_dy)
+    eng = make_engine(ws, E)
+    assert eng.capabilities() & N.CAP_RESOLVE
+    co = H.COracle(ws, E, first_env_id=0)
+    if name == "float_tables_3layer":           # (a world populated by the fixture: every env starts from its grid)
+        d, _ = H.load_golden("float_appearance_3layer")
+        g0, p0 = d["grid0"][0], d["pos0"][0]
+        eng.grid.copy_(torch.from_numpy(np.broadcast_to(g0, (E,) + g0.shape).copy()))
+        eng.agent_pos.copy_(torch.from_numpy(np.broadcast_to(p0, (E,) + p0.shape).copy()))
+        eng.total_reward.zero_()
+        co.grid[...], co.pos[...], co.total[...] = g0, p0, 0
+    else:
+        eng.reset(0)
+        co.reset(0)
+    rows = eng.speculation_rows()
+    Nw = rows.shape[2]
+    gen = torch.Generator().manual_seed(11)
+    Wt = torch.randn((A, Nw, nact), generator=gen).cuda()
+
+    def policy(x, agents):                      # a linear layer per agent + argmax: a pure function of the window
+        return torch.einsum("bn,bnk->bk", x, Wt[agents]).argmax(dim=1)
+
+    agent_of_row = torch.arange(A, device="cuda:0").repeat_interleave(E)
+    most = 0
+    for t in range(1, T + 1):
+        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)
+        eng.speculation_windows()                   # (sgw_observe_rows, or -- float tables -- the resolve kernel's render mode)
+        flat = rows.view(A * E, Nw)
+        taken = policy(flat, agent_of_row).view(A, E).clone()
+        fresh, passes = taken.view(-1).contiguous(), 1
+        while True:
+            eng.turn_resolve(passes, None, fresh)
+            lst = eng.spec_dirty(passes)
+            dirty = eng._spec_state[2]                       # the same set as bytes [E][A]
+            want = torch.nonzero(dirty.t().reshape(-1)).squeeze(1)
+            assert torch.equal(torch.sort(lst).values, want), f"{name} turn {t} pass {passes}: the dirty list and the dirty bytes agree"
+            if lst.numel() == 0:
+                break
+            passes += 1
+            assert passes <= A + 1
+            fresh = policy(flat[lst], lst // E)
+            taken.view(-1)[lst] = fresh
+        most = max(most, passes)
+        torch.cuda.synchronize()
+        assert bool(eng._spec_state[0].view(-1)[:E].all()), "every env committed"
+        assert torch.equal(eng.actions, taken.t().to(torch.uint8)), "the actions tensor holds what the policies ended on"
+        acts = taken.t().contiguous().cpu().numpy().astype(np.uint8)
+        assert co.step(0, t, actions=acts) == 0
+        for key, mine, ref in (("grid", eng.grid, co.grid), ("pos", eng.agent_pos, co.pos), ("rewards", eng.rewards, co.rewards),
+                               ("total", eng.total_reward, co.total)):
+            assert np.array_equal(mine.cpu().numpy(), ref), f"{name} turn {t}: {key}"
+        seen = torch.from_numpy(co.obs.reshape(E, A, Nw)).cuda().permute(1, 0, 2).contiguous()       # what each agent saw when its turn came
+        assert torch.equal(seen, rows), f"{name} turn {t}: the rows are the windows at pov time"
+        assert torch.equal(policy(seen.view(A * E, Nw), agent_of_row).view(A, E), taken), f"{name} turn {t}: every action is the policy of that window"
+    assert eng.status() == 0
+    assert most <= (4 if name != "crowded_6x6" else 7), most
+
+
+def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):
+    """Environment.speculate_turns: agents that share one model (one batched forward pass per pass, one shared replay ring filled in
+    agent order) and agents with a model each -- grids, totals, step outputs and every replay row equal the eager agent-after-agent
+    loop's after 12 turns and a reset."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E, A = 40, 6
+
+    class Linear(BaseModel):
+        def __init__(self, input_size, action_space, memory=0):
+            super().__init__(input_size, action_space, memory_size=memory, num_envs=E, device="cuda:0")
+            g = torch.Generator().manual_seed(99)
+            self.weight = torch.randn((int(np.prod(input_size)), action_space), generator=g).cuda()
+            self.calls = 0
+
+        def take_action(self, state):
+            self.calls += 1
+            return (state.reshape(state.shape[0], -1) @ self.weight).argmax(dim=1)
+
+    for shared, cap in ((1, 4 * A), (1, 4 * A + 1), (2, 3 * A)):             # (4 A: the turn's rows of the shared ring are contiguous -- the windows are
+        envs = []                                                             # rendered straight into them; 4 A + 1: they are not, add_batch copies;
+        for speculate in (False, True):                                       # 2: two models of three agents each -- two batches per pass)
+            made = []
+
+            def factory(input_size, action_space):
+                k = len(made) * shared // A
+                made.append(k)
+                if k >= len(models):
+                    models.append(Linear(input_size, action_space, memory=cap))
+                return models[k]
+
+            models = []
+
+            env = make_env(14, 17, A, 3, E, p=0.06, seed=7, model_factory=factory)
+            env.speculate_turns = speculate
+            envs.append(env)
+        eager, spec = envs
+        for t in range(12):
+            if t == 7:
+                eager.reset()
+                spec.reset()
+            eager.take_turn()
+            spec.take_turn()
+        torch.cuda.synchronize()
+        assert spec.speculation_passes >= 1 and spec._speculation_groups(spec._engine) is not None
+        assert len(spec._speculation_groups(spec._engine)) == shared
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(eager.world, name), getattr(spec.world, name)), (shared, name)
+        assert torch.equal(eager.rewards, spec.rewards) and torch.equal(eager.actions, spec.actions)
+        for a in range(A):
+            ma, mb = eager.agents[a].model.memory, spec.agents[a].model.memory
+            assert (ma.idx, ma.size) == (mb.idx, mb.size)
+            assert torch.equal(ma.states, mb.states) and torch.equal(ma.actions, mb.actions) and torch.equal(ma.rewards, mb.rewards)
+            assert torch.equal(ma.dones, mb.dones)
+        assert spec.agents[0].model.calls < eager.agents[0].model.calls          # one forward pass per PASS, not per agent
+        eager.raise_on_status()
+        spec.raise_on_status()

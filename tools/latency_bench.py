@@ -47,15 +47,32 @@ def time_turns(env, turns):
 def run(h, w, a, r, E, policy, spawn_prob=0.005):
     cfg = make_config(h, w, a, r, spawn_prob=spawn_prob)
     world = TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0)
-    env = TreasurehuntEnv(world, cfg, model_factory=policy_factory(E, values=policy >= 3) if policy else None)
+    factory = policy_factory(E, values=policy in (3, 4)) if policy else None
+    if policy in (5, 6):                  # ONE model object (and one replay ring of A rows per turn) shared by every agent
+        cls, one = factory, [None]
+
+        class Shared(cls):
+            def __init__(self, input_size, action_space):
+                super().__init__(input_size, action_space)
+                from sorrel_amd.buffers import Buffer
+                self.memory = Buffer(capacity=4 * a, obs_shape=tuple(input_size), num_envs=E, device="cuda:0")
+
+        def factory(input_size, action_space):
+            if one[0] is None:
+                one[0] = Shared(input_size, action_space)
+            return one[0]
+    env = TreasurehuntEnv(world, cfg, model_factory=factory)
+    env.speculate_turns = policy in (6, 7)    # round 5: batched policy evaluation + sgw_turn_resolve (Environment.speculate_turns)
     env.write_obs_into_replay = os.environ.get("LAT_NO_DIRECT") != "1"      # A/B: windows through the observation tensor + a copy
-    label = {0: "device-random (1 launch)", 1: "policy (1+A launches)", 2: "policy, captured turn", 3: "values -> act, eager", 4: "values -> act, captured"}[policy]
+    label = {0: "device-random (1 launch)", 1: "policy (1+A launches)", 2: "policy, captured turn", 3: "values -> act, eager", 4: "values -> act, captured",
+             5: "shared policy, eager", 6: "shared policy, speculative", 7: "own policies, speculative"}[policy]
     if policy in (2, 4) and env.capture_turn() is None:                          # round 4: the whole turn recorded once, replayed
         label = f"policy, NOT capturable: {getattr(env, 'capture_error', None)!r}"[:60]
     turns = 2000 if E <= 4096 else 300
     us = time_turns(env, turns)
     env.raise_on_status()
-    print(f"{h}x{w} A{a} r{r} E={E:6d} {label:26s} {us:9.1f} us/turn  {E * a / us * 1e6:.3e} agent-steps/s", flush=True)
+    extra = f"  passes of the last turn: {env.speculation_passes}" if policy in (6, 7) else ""
+    print(f"{h}x{w} A{a} r{r} E={E:6d} {label:26s} {us:9.1f} us/turn  {E * a / us * 1e6:.3e} agent-steps/s{extra}", flush=True)
     del env, world
     torch.cuda.empty_cache()
 
@@ -107,6 +124,17 @@ def main():
             for E in (1, 1024, 16384):
                 for policy in (1, 2):
                     run_example(which, E, policy)
+        return
+    if len(sys.argv) > 7 and sys.argv[1] == "one":              # one case (for a kernel trace): one <h> <w> <agents> <radius> <envs> <policy>
+        h, w, a, r, E, policy = (int(v) for v in sys.argv[2:8])
+        run(h, w, a, r, E, policy, spawn_prob=0.05 if h > 64 else 0.005)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "spec":             # the speculative policy turn beside the eager / recorded ones
+        for policy in (1, 2, 5, 6, 7):
+            run(128, 128, 64, 5, 2048, policy, spawn_prob=0.05)
+        for E in (1024, 16384, 65536):
+            for policy in (1, 5, 6, 7):
+                run(32, 32, 8, 3, E, policy)
         return
     for shape in ((21, 21, 2, 2), (32, 32, 8, 3)):
         for E in (1, 64, 1024, 16384, 65536):

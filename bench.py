@@ -336,7 +336,7 @@ def recorded_turn_bench(dev, envs: int = 1024, turns: int = 400):
         env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=envs, device=dev, seed=0), cfg, model_factory=factory(values))
         if capture and env.capture_turn() is None:
             raise RuntimeError(f"not recordable: {getattr(env, 'capture_error', None)!r}")
-        for _ in range(50):
+        for _ in range(50 - (2 if capture else 0)):      # (capture_turn played two real turns before it recorded: the same count either way)
             env.take_turn()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -345,14 +345,23 @@ def recorded_turn_bench(dev, envs: int = 1024, turns: int = 400):
         torch.cuda.synchronize(dev)
         us = (time.perf_counter() - t0) / turns * 1e6
         env.raise_on_status()
-        return us
+        import hashlib
+
+        # what the run ended in: world state, the step's outputs and every agent's replay ring -- a recorded turn must leave exactly
+        # what the eager loop leaves (same policies, same seeds, same number of turns)
+        h = hashlib.sha256()
+        for t in [env.world.grid, env.world.agent_pos, env.world.total_reward, env.rewards, env.actions] + \
+                [x for a in env.agents for x in (a.model.memory.states, a.model.memory.actions, a.model.memory.rewards)]:
+            h.update(t.cpu().numpy().tobytes())
+        return us, h.hexdigest()[:16]
 
     out = {"workload": f"32x32 grid x 2 layers, 8 agents, 7x7 window, {envs} envs, one linear policy per agent, 64-row replay memories",
            "unit": "us per take_turn (wall)", "turns": turns}
     try:
-        out["eager_loop"] = run(False, False)
-        out["recorded"] = run(False, True)
-        out["recorded_action_values"] = run(True, True)
+        out["eager_loop"], eager_state = run(False, False)
+        out["recorded"], recorded_state = run(False, True)
+        out["recorded_action_values"], _ = run(True, True)
+        out["recorded_equals_eager"] = recorded_state == eager_state      # (digest of grid, positions, totals, step outputs and all replay rings)
         out["what"] = ("eager_loop: Python drives sweep, windows and per agent policy + sgw_act; recorded: the same turn as ONE graph replay "
                        "(27 dependent launches); recorded_action_values: the act launch takes argmax / explores itself (19 launches)")
     except Exception as exc:      # (reported, never fatal for the line)

@@ -695,7 +695,13 @@ class Environment:
             self._turn_windows = None
         eng.turn_end(commit_windows=self._capture_rows is None)
 
-    def capture_turn(self, warmup: int = 2):
+    #: a recorded turn writes every window twice (a fixed address for the policy + the replay row); above this many bytes of windows per
+    #: turn that costs more than the host time a replay saves while there are few agents (measured: 32x32 / 8 agents, 65 536 envs = 617 MB:
+    #: 610 us recorded against 500 eager; 16 384 envs = 154 MB: 249 against 385; config 5's 64 agents gain at any size) -- capture_turn()
+    #: then declines unless forced
+    capture_max_window_bytes = 384 << 20
+
+    def capture_turn(self, warmup: int = 2, force: bool = False):
         """Record ONE whole policy-driven ``take_turn`` -- sweep + every agent's window, then per agent the policy's forward pass
         and its act, then the copy of the turn's windows into the agents' replay rows -- as a graph (``torch.cuda.graph``), so that
         every later ``take_turn()`` is one replay without Python in the agent loop (``sorrel/agents/agent.py:155-173`` costs
@@ -725,6 +731,11 @@ class Environment:
         per_env = 1
         for d in eng.spec.obs_shape[1:]:
             per_env *= int(d)
+        window_bytes = eng.num_envs * len(self.agents) * per_env * (4 if eng.obs_dtype == torch.float32 else 1)
+        if not force and len(self.agents) <= 16 and window_bytes > self.capture_max_window_bytes:
+            self.capture_error = ValueError(f"{window_bytes >> 20} MiB of windows per turn: a recorded turn writes them twice, which costs more than the "
+                                            "replay saves at this batch (capture_turn(force=True) records anyway)")
+            return None
         # what pov appends behind the window (Tag's "it" flag, Cleanup's positional code) is the engine's to write (_bind_row_tail): the
         # rows the policies read and the replay rows then hold window + tail
         use_rows = self.capture_layout != "tensor" and bool(eng.capabilities() & N.CAP_OBSERVE_ROWS)

@@ -409,3 +409,54 @@ def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):
         assert spec.agents[0].model.calls < eager.agents[0].model.calls          # one forward pass per PASS, not per agent
         eager.raise_on_status()
         spec.raise_on_status()
+
+
+# ------------------------------------------------------------------ recorded turns at a batch where the kernels change form
+@pytest.mark.parametrize("layout", ["rows", "tensor"])
+@pytest.mark.parametrize("agents", [8, 12])
+def test_recorded_turn_at_16384_envs_vs_the_oracle(torch_cuda, layout, agents):
+    """Round-4 review: every recorded-turn test ran at <= 45 envs, although the "rows" layout's double write and sgw_act's 16-lane form (9-16
+    agents) switch on the batch size.  16 384 envs of the headline's world, 8 and 12 agents, both layouts: ten replayed turns against the C
+    oracle stepping the actions the policies chose -- state, rewards, totals, and the replay row each agent's window went to."""
+    torch = torch_cuda
+    from tests.test_gpu_round4 import _policy_env
+
+    E = 16384
+    b = _policy_env(E, shape=(32, 32, agents, 3), memory=4, seed=9)
+    b.capture_layout = layout
+    cap = b.capture_turn(warmup=2)
+    assert cap is not None, getattr(b, "capture_error", None)
+    ws = b._engine.spec
+    co = H.COracle(ws, E, first_env_id=0, threads=16)
+    torch.cuda.synchronize()
+    co.grid[...] = b.world.grid.cpu().numpy()
+    co.pos[...] = b.world.agent_pos.cpu().numpy()
+    co.total[...] = b.world.total_reward.cpu().numpy()
+    for t in range(10):
+        b.take_turn()
+        torch.cuda.synchronize()
+        assert co.step(b.epoch, b.turn, actions=b.actions.cpu().numpy()) == 0
+        assert np.array_equal(b.world.grid.cpu().numpy(), co.grid) and np.array_equal(b.world.agent_pos.cpu().numpy(), co.pos), t
+        assert np.array_equal(b.rewards.cpu().numpy(), co.rewards) and np.array_equal(b.world.total_reward.cpu().numpy(), co.total), t
+        for k, agent in enumerate(b.agents):
+            mem = agent.model.memory
+            last = (mem.idx - 1) % mem.capacity
+            assert np.array_equal(mem.states[last].cpu().numpy().reshape(E, -1), co.obs[:, k].reshape(E, -1)), (t, k)
+            assert np.array_equal(mem.actions[last].cpu().numpy(), b.actions[:, k].cpu().numpy().astype(np.int64)), (t, k)
+            assert np.array_equal(mem.rewards[last].cpu().numpy(), co.rewards[:, k]), (t, k)
+    assert cap.turns_replayed == 10
+    b.raise_on_status()
+
+
+def test_capture_turn_declines_where_a_replay_would_be_slower(torch_cuda):
+    """Few agents, hundreds of MB of windows per turn: the second copy of every window costs more than the host time a replay saves (32x32 /
+    8 agents at 65 536 envs: 610 us recorded, 500 eager) -- capture_turn() keeps the eager loop and says why; force=True records."""
+    from tests.test_gpu_round4 import _policy_env
+
+    env = _policy_env(4096, shape=(32, 32, 8, 3), memory=2)
+    env.capture_max_window_bytes = 16 << 20            # (the same rule at a size a test can afford: 4 096 x 8 x 294 x 4 = 38.5 MB)
+    assert env.capture_turn() is None and "twice" in str(env.capture_error)
+    env.take_turn()
+    assert env.capture_turn(force=True) is not None
+    env.take_turn()
+    env.raise_on_status()

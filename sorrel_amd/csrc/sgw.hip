@@ -288,30 +288,46 @@ using RowsFn = void (*)(const Params, const RowPtrs);
         return multi ? reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, true>)) \
                      : reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
     } while (0)
+// (round 5) The library holds the turn-loop (sgw_rollout) instance of the packed / wave-per-env kernels for plain movers only, plus the Tag
+// example as shipped: every run-time-shape turn-loop instance of the Tag / Cleanup rules and every one of the workgroup-per-env form
+// (G = 256) spilled registers to scratch (12-100 bytes per lane; tools/regs.py), and with hipRTC the normal path they were fallbacks of
+// fallbacks.  Without one, sgw_rollout is a loop of single-turn launches (the specialised instance, where hipRTC is there, has none of that).
+#define PICK_SK1(G_, OH, L_, C_, RULE_, R_, H_, W_, NAME)                         \
+    do {                                                                          \
+        *name = multi ? "-" : NAME;                                               \
+        return multi ? nullptr : reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
+    } while (0)
 template <int G>
 const void* pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
     constexpr int kMove = SGW_AGENT_RULE_MOVE, kTag = SGW_AGENT_RULE_TAG, kCleanup = SGW_AGENT_RULE_CLEANUP;
     if (rule == SGW_AGENT_RULE_CLEANUP) {
-        if (onehot) PICK_SK(G, true, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>");
-        PICK_SK(G, false, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, false, 0, 0, SGW_AGENT_RULE_CLEANUP>");
+        if (onehot) PICK_SK1(G, true, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_CLEANUP>");
+        PICK_SK1(G, false, 0, 0, kCleanup, 0, 0, 0, "step_kernel<G, false, 0, 0, SGW_AGENT_RULE_CLEANUP>");
     }
     if (rule == SGW_AGENT_RULE_TAG) {
         if constexpr (G == 32) {
             if (onehot && L == 1 && C == 4 && r == 4 && H == 11 && W == 11) PICK_SK(32, true, 1, 4, kTag, 4, 11, 11, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4, 11, 11>");   // the Tag example as shipped
-            if (onehot && L == 1 && C == 4 && r == 4) PICK_SK(32, true, 1, 4, kTag, 4, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>");
-            if (onehot && L == 1 && C == 4 && r == 3) PICK_SK(32, true, 1, 4, kTag, 3, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>");
+            if (onehot && L == 1 && C == 4 && r == 4) PICK_SK1(32, true, 1, 4, kTag, 4, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 4>");
+            if (onehot && L == 1 && C == 4 && r == 3) PICK_SK1(32, true, 1, 4, kTag, 3, 0, 0, "step_kernel<32, true, 1, 4, SGW_AGENT_RULE_TAG, 3>");
         }
-        if (onehot && L == 1 && C == 4) PICK_SK(G, true, 1, 4, kTag, 0, 0, 0, "step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>");   // the Tag example's tables
-        if (onehot) PICK_SK(G, true, 0, 0, kTag, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>");
-        PICK_SK(G, false, 0, 0, kTag, 0, 0, 0, "step_kernel<G, false, 0, 0, SGW_AGENT_RULE_TAG>");
+        if (onehot && L == 1 && C == 4) PICK_SK1(G, true, 1, 4, kTag, 0, 0, 0, "step_kernel<G, true, 1, 4, SGW_AGENT_RULE_TAG>");   // the Tag example's tables
+        if (onehot) PICK_SK1(G, true, 0, 0, kTag, 0, 0, 0, "step_kernel<G, true, 0, 0, SGW_AGENT_RULE_TAG>");
+        PICK_SK1(G, false, 0, 0, kTag, 0, 0, 0, "step_kernel<G, false, 0, 0, SGW_AGENT_RULE_TAG>");
     }
-    if constexpr (G == 16)
-        if (onehot && L == 2 && C == 6 && r == 2) PICK_SK(16, true, 2, 6, kMove, 2, 0, 0, "step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>");   // the Treasurehunt example's 5x5 windows
-    if (onehot && L == 2 && C == 6) PICK_SK(G, true, 2, 6, kMove, 0, 0, 0, "step_kernel<G, true, 2, 6>");                             // Treasurehunt-shaped tables
-    if (onehot) PICK_SK(G, true, 0, 0, kMove, 0, 0, 0, "step_kernel<G, true>");
-    PICK_SK(G, false, 0, 0, kMove, 0, 0, 0, "step_kernel<G, false>");
+    if constexpr (G == 256) {      // a workgroup per env: single-turn instances only
+        if (onehot && L == 2 && C == 6) PICK_SK1(G, true, 2, 6, kMove, 0, 0, 0, "step_kernel<G, true, 2, 6>");
+        if (onehot) PICK_SK1(G, true, 0, 0, kMove, 0, 0, 0, "step_kernel<G, true>");
+        PICK_SK1(G, false, 0, 0, kMove, 0, 0, 0, "step_kernel<G, false>");
+    } else {
+        if constexpr (G == 16)
+            if (onehot && L == 2 && C == 6 && r == 2) PICK_SK(16, true, 2, 6, kMove, 2, 0, 0, "step_kernel<16, true, 2, 6, SGW_AGENT_RULE_MOVE, 2>");   // the Treasurehunt example's 5x5 windows
+        if (onehot && L == 2 && C == 6) PICK_SK(G, true, 2, 6, kMove, 0, 0, 0, "step_kernel<G, true, 2, 6>");                             // Treasurehunt-shaped tables
+        if (onehot) PICK_SK(G, true, 0, 0, kMove, 0, 0, 0, "step_kernel<G, true>");
+        PICK_SK(G, false, 0, 0, kMove, 0, 0, 0, "step_kernel<G, false>");
+    }
 }
 #undef PICK_SK
+#undef PICK_SK1
 
 const void* pick_step(const Options& o, int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
     if (o.static_radius == 1) r = -1;          // A/B hook: the run-time-shape instances
@@ -373,7 +389,8 @@ bool fixed_fast_shape(int L, int C, int r, int H, int W, bool tag) {   // = the 
 const void* pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
     if (!onehot) PICK(step_big<false, 0, 0, 0, true>);
     if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, true>);
-    PICK(step_big<true, 0, 0, 0, true>);
+    *name = "-";      // (round 5: the run-time-table turn-loop instance used 28 bytes of scratch per lane; without hipRTC such a world's rollout
+    return nullptr;   // is a loop of single-turn launches)
 }
 
 const void* pick_big_walk(bool onehot, int L, int C, int r, int threads, const char** name) {
@@ -857,7 +874,7 @@ int plan_engine(sgw_engine* e, bool jit) {
             e->k_walk.host = pick_big_walk(e->onehot, L, C, r, e->big_threads, &e->k_walk.host_name);
         if (jit) {
             e->k_step.want = big_id(e->onehot, L, C, r, false, false, tag_move, e->big_threads);
-            if (e->k_multi.host) e->k_multi.want = big_id(e->onehot, L, C, r, true, false, false, kBigThreads);
+            if (!tag_move) e->k_multi.want = big_id(e->onehot, L, C, r, true, false, false, kBigThreads);   // (whether or not the library holds a twin)
             if (e->k_walk.host) e->k_walk.want = big_id(e->onehot, L, C, r, false, true, false, e->big_threads);
         }
     } else {

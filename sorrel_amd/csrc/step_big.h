@@ -19,8 +19,11 @@
 // registers + barrier 118-122.  The last is kept: it has no cross-wave race to reason about.
 // Requires impassable agent types (a passable agent could be "entered" twice in one turn, which the
 // two-batch patch cannot order); the host dispatch checks it.
-// Eight waves per workgroup, four workgroups per CU = the CU's 32 wave slots: measured 115 us per config-5 launch
-// against 123 us with four waves per workgroup and 143 us with two (round 2, same box, interleaved A/B).
+// Eight waves per workgroup (measured 115 us per config-5 launch against 123 us with four waves per workgroup and 143 us with two: round 2,
+// same box, interleaved A/B).  Workgroups per CU: the single-turn one-env-per-workgroup instances are compiled for SGW_BIG_WAVES = 8 waves per
+// SIMD (50 VGPRs, no scratch) = FOUR per CU (round 5; rounds 2-4 said four here but compiled for 6-7 waves per SIMD: three); the walking
+// and rollout variants (80 VGPRs) hold three.  What the fourth buys (profiles/r05_c5_occupancy_ab.txt): 1 024 envs 47.8 -> 43.1 us; nothing
+// from two rounds of workgroups on (2 048 envs 114 against the walking variant's 91; 4 096 / 8 192 staged 187 / 358 at either occupancy).
 #ifndef SGW_BIG_THREADS
 #define SGW_BIG_THREADS 512
 #endif

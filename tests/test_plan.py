@@ -95,3 +95,56 @@ def test_a_specialised_instance_compiles_without_a_device(built, tmp_path):
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta)[1]) == 0, "the specialised instance spills to scratch"
     with pytest.raises(N.SgwError):
         N.jit_compile("step_fast<true, 2, 6, 3, 32>")          # not an instance of the template: hipRTC's error comes back
+
+
+def _canonical(name: str, lanes: int):
+    """A plan's kernel name -> (template, full argument tuple) as `nm -C` spells the instance: trailing defaults filled in, the
+    SGW_AGENT_RULE_* macros and the packed kernels' `G` resolved, `(turn loop)` = the MULTI argument."""
+    import re
+
+    multi = name.endswith(" (turn loop)")
+    name = name.replace(" (turn loop)", "")
+    m = re.fullmatch(r"(\w+)<(.*)>", name)
+    assert m, name
+    tmpl, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    rules = {"SGW_AGENT_RULE_MOVE": "0", "SGW_AGENT_RULE_TAG": "1", "SGW_AGENT_RULE_CLEANUP": "2"}
+    args = [rules.get(a, str(lanes) if a == "G" else a) for a in args]
+    defaults = {"step_fast": ["?"] * 6 + ["false"] * 6, "step_big": ["?"] * 4 + ["false", "false", "false", "512"],
+                "step_kernel": ["?", "?", "0", "0", "0", "0", "0", "0", "false"]}.get(tmpl)
+    if defaults:
+        args += defaults[len(args):]
+        if multi:
+            args[-1] = "true"
+    return tmpl, tuple(args)
+
+
+def test_every_plan_without_specialised_instances_names_kernels_the_library_holds(built):
+    """hipRTC absent (option jit = 0): whatever a plan of tools/plan_cases.py says will run -- whole turn, direct-store twin, rollout,
+    walking variant, phase and row kernels -- is an instance compiled into libsgw.so (round 5 removed 26 turn-loop instances that
+    spilled to scratch: nothing may still point at one)."""
+    import re
+    import subprocess
+
+    import plan_cases
+    from sorrel_amd import _native as N
+
+    out = subprocess.run(["nm", "-C", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    have = set()
+    for line in out.splitlines():
+        m = re.search(r"__device_stub__(\w+)<(.*)>\(", line.replace("(anonymous namespace)::", ""))
+        if m:
+            have.add((m.group(1), tuple(a.strip() for a in m.group(2).split(","))))
+    assert len(have) > 100
+    checked = 0
+    for case, plan in plan_cases.plans().items():
+        if plan["specialised"]:
+            continue
+        for key in ("kernel", "kernel_plain", "kernel_rollout", "kernel_walk", "kernel_phase", "kernel_observe_rows"):
+            name = plan[key]
+            if "<" not in name:                   # "-", "the step kernel"
+                continue
+            assert _canonical(name, plan["lanes_per_env"]) in have, (case, key, name)
+            checked += 1
+    assert checked > 100
+    # ... and the count the round ended on (tools/regs.py lists them with registers / scratch): 177 before, 151 now
+    assert len([h for h in have if h[0].startswith("step_")]) == 92

@@ -687,6 +687,7 @@ int plan_engine(sgw_engine* e, bool jit) {
     if (o.fast_8k == 1) fast_8k = fast_8k_ok;
     if (o.force_generic) fast_8k = false;
     e->wpe = (p.cells_pad <= 4096 || rules_8k || fast_8k) ? 1 : 4;
+    if (o.force_big && simple_rules && !o.force_generic) e->wpe = 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsPlain : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act

@@ -131,6 +131,10 @@ extern "C" {
                                      * from the grid after it -- step 1 + 2 of a policy-driven turn in one launch when the windows
                                      * live in the [E][A][C][V][V] tensor (see sgw_act).  No rewards, no totals, no auto-reset;
                                      * SGW_STEP_RANDOM_ACTIONS / SGW_STEP_OBS_NEXT do not combine with it */
+#define SGW_STEP_OBS_AGENT_MAJOR 64u /* `obs` is [A][E][C][V][V] (agent-major: agent a's windows of all envs are one contiguous [E][C*V*V] row, the shape a
+                                     * replay ring row and a batched policy want) instead of [E][A][C][V][V].  Whole-turn calls (agent range 0 .. A, no
+                                     * SGW_STEP_OBS_NEXT) of engines with SGW_CAP_OBS_AGENT_MAJOR -- the workgroup-per-env kernels (worlds above
+                                     * 4 KiB): with SGW_STEP_NO_MOVE that is the sweep AND every agent's pre-move window into such rows in one launch */
 #define SGW_STEP_DEFAULT (SGW_STEP_SWEEP)
 
 /* error codes */
@@ -251,6 +255,7 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
 #define SGW_CAP_OBSERVE_ROWS 1
 #define SGW_CAP_ACT 2
 #define SGW_CAP_RESOLVE 4      /* sgw_turn_resolve (speculative policy turns): plain movers, impassable agent types, float32 windows */
+#define SGW_CAP_OBS_AGENT_MAJOR 8   /* sgw_step accepts SGW_STEP_OBS_AGENT_MAJOR */
 #define SGW_ACT_U8 0
 #define SGW_ACT_I32 1
 #define SGW_ACT_I64 2
@@ -497,6 +502,9 @@ int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* s
 int sgw_turn_resolve(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rows, int64_t row_elems,
                      float* rewards, double* total_reward, uint8_t* scratch, int64_t* dirty_list, uint32_t* counters,
                      const int64_t* new_actions, int64_t n_new, float* reward_rows, int64_t* action_rows, int32_t pass, void* stream);
+/* dst[k][:] = src[idx[k]][:] for k < n: rows of `row_elems` float32 (the dirty rows of a speculative pass as ONE contiguous batch for the
+ * policy); src / dst 4-byte aligned device pointers, idx int64 on the device.  Asynchronous on `stream`; needs no engine. */
+int sgw_gather_rows(const float* src, int64_t row_elems, const int64_t* idx, int64_t n, float* dst, void* stream);
 /* Buffer.current_state (sorrel/buffers.py:143-154) for a recorded turn -- the frames a frame-stacking policy reads in front of its
  * window: the `count` rows of agent `agent`'s replay states BEFORE the row the turn in flight fills, oldest first, wrapping around
  * the ring, by the device's own row count -> out [count][E][row_elems] (device, element type = sgw_set_obs_format's).  Same

@@ -11,13 +11,13 @@ import os
 MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
 RULE_NONE, RULE_SPAWN, RULE_BECOME_IF = 0, 1, 2
 NO_BORDER = 255
-STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT, STEP_OBS_NEXT_PACKED, STEP_NO_MOVE = 1, 2, 4, 8, 16, 32
+STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT, STEP_OBS_NEXT_PACKED, STEP_NO_MOVE, STEP_OBS_AGENT_MAJOR = 1, 2, 4, 8, 16, 32, 64
 OBS_POST_NONE, OBS_POST_CLIP255_DIV255 = 0, 1
 AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
 ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2
 OBS_F32, OBS_U8 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE, STATUS_BAD_POS = 1, 2, 4, 8
-CAP_OBSERVE_ROWS, CAP_ACT, CAP_RESOLVE = 1, 2, 4
+CAP_OBSERVE_ROWS, CAP_ACT, CAP_RESOLVE, CAP_OBS_AGENT_MAJOR = 1, 2, 4, 8
 ACT_U8, ACT_I32, ACT_I64, ACT_QF32 = 0, 1, 2, 3
 TAIL_NONE, TAIL_AGENT_IS_IT, TAIL_POSITION_TABLE = 0, 1, 2
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
@@ -109,7 +109,7 @@ EXPORTS = (
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
     "sgw_set_option", "sgw_plan", "sgw_jit_stats", "sgw_jit_compile", "sgw_bind_row_tail",
-    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state", "sgw_turn_begin_rows", "sgw_turn_act_rows", "sgw_turn_epsilon", "sgw_turn_prev_rows", "sgw_turn_resolve",
+    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state", "sgw_turn_begin_rows", "sgw_turn_act_rows", "sgw_turn_epsilon", "sgw_turn_prev_rows", "sgw_turn_resolve", "sgw_gather_rows",
     "sgw_last_error", "sgw_version",
 )
 
@@ -229,6 +229,8 @@ def load():
     lib.sgw_turn_state.restype = C.c_int
     lib.sgw_turn_resolve.argtypes = [vp, u8p, u8p, u8p, vp, C.c_int64, f32p, f64p, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_int32, vp]
     lib.sgw_turn_resolve.restype = C.c_int
+    lib.sgw_gather_rows.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp]
+    lib.sgw_gather_rows.restype = C.c_int
     lib.sgw_turn_prev_rows.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     lib.sgw_turn_prev_rows.restype = C.c_int
     lib.sgw_turn_epsilon.argtypes = [vp, C.c_int32, C.c_double, vp]

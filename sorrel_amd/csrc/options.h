@@ -27,6 +27,7 @@ struct Options {
     int rules_8k = 1;         // ... up to 8 KiB per env
     int rules_11k = 0;        // ... up to 11 KiB whatever the batch (default: from 16 384 envs on)
     int fast_8k = -1;         // plain / Tag worlds of 4-11 KiB per env on the wave-per-env kernel: -1 by batch size, 0 never, 1 always
+    int resolve_diag = 0;     // sgw_turn_resolve timing aid (resolve.h: ResolveArgs::diag)
     int force_big = 0;        // 1: the workgroup-per-env kernel (step_big) whatever the world's size (A/B: small batches of small worlds)
     int big_tag = 1;          // Tag worlds above 4 KiB on step_big<..., TAG>
     int group = 0;            // lanes per env of the packed kernel: 0 auto, 16 / 32 force a packing, 64 forbids it
@@ -75,6 +76,7 @@ const OptKey kOptKeys[] = {
     {"rules_11k", &Options::rules_11k, 0, 1, false},
     {"fast_8k", &Options::fast_8k, -1, 1, false},
     {"force_big", &Options::force_big, 0, 1, false},
+    {"resolve_diag", &Options::resolve_diag, 0, 7, true},
     {"big_tag", &Options::big_tag, 0, 1, false},
     {"group", &Options::group, 0, 64, false},
     {"phase_kernel", &Options::phase_kernel, -1, 1, false},

@@ -32,6 +32,8 @@ struct ResolveArgs {
     uint32_t* count_next;  // the counter the NEXT pass will use: zeroed by this launch
     float* reward_rows;    // optional [A][E] float32 / int64: at the commit of an env, reward and action of every agent once more in
     int64_t* action_rows;  // agent-major rows (the rows of a replay ring: add_memory then copies nothing)
+    int diag;              // timing aid (option resolve_diag): bit 0 = verify no window, bit 1 = commit nothing and append nothing (the pass can be
+                           // repeated on the same state), bit 2 = skip the move resolution and the touch tests
     int first;             // 1: first pass of the turn -- env_done / pristine are taken as 0 / 1 whatever the arrays hold;
                            // 2: no pass at all -- render every agent's PRE-move window into its row (what sgw_observe_rows does for
                            //    one-hot worlds, here for any appearance table and window size) and initialise the arrays
@@ -48,11 +50,35 @@ __global__ __launch_bounds__(kBlock) void resolve_apply_actions(uint8_t* actions
     }
 }
 
+// dst[k][:] = src[idx[k]][:]: a wave per row, 8-byte pieces where rows and pointers allow (sgw_gather_rows).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ src, const int64_t row_elems, const int64_t* __restrict__ idx,
+                                                             const int64_t n, float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < n; k += waves) {
+        const int64_t r = idx[k];
+        if constexpr (VEC == 2) {
+            typedef float vfloat2 __attribute__((ext_vector_type(2)));
+            const vfloat2* s2 = reinterpret_cast<const vfloat2*>(src + r * row_elems);
+            vfloat2* d2 = reinterpret_cast<vfloat2*>(dst + k * row_elems);
+            for (int64_t i = lane; i < (row_elems >> 1); i += 64) __builtin_nontemporal_store(s2[i], d2 + i);
+        } else {
+            const float* s1 = src + r * row_elems;
+            float* d1 = dst + k * row_elems;
+            for (int64_t i = lane; i < row_elems; i += 64) d1[i] = s1[i];
+        }
+    }
+}
+
 // WPE: waves per env.  1: four envs per 256-thread workgroup (few agents: the turn of an env is little work).  4: a workgroup per env --
 // wave 0 resolves the env's moves (a loop over the agents: sequential by nature) and publishes who moved and which windows must be
 // verified through LDS; the windows (each a dependent chain of loads) are dealt out among the four waves.
+#ifndef SGW_RESOLVE_SLOTS
+#define SGW_RESOLVE_SLOTS 1
+#endif
 template <bool ONEHOT, int WPE>
-__global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const ResolveArgs ra) {
+__global__ __launch_bounds__(kBlock, 8) void turn_resolve(const Params p, const ResolveArgs ra) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const Res
         yx = reinterpret_cast<const uint16_t*>(p.pos)[env * A + lane];
         act = p.actions[env * A + lane];
         atype = gtab->agent_type[lane];
-        if (!ra.first && lead) prev = ra.prev[env * A + lane];
+        if (!ra.first) prev = ra.prev[env * A + lane];           // (every wave: each takes its share of the agents whose move changed)
         if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
     }
     const int py = (int)(yx & 0xFFu), px = (int)(yx >> 8);
@@ -112,14 +138,32 @@ __global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const Res
     gsync<1>();                                               // the table words are visible to every lane of this wave
 
     uint32_t passed = 0, found = 0xFFu;                       // lane a: did agent a move; the type it found on its target
-    bool tok_v = false, touched = false, checked = false;
-    uint32_t cur = 0;
-    unsigned long long check = 0ull;
-    if (lead) {
-        // ---- the moves, strictly in agent order (sorrel/agents/agent.py:213-225, worlds/gridworld.py:95-122), in registers: what agent a
-        // finds on its target differs from the pre-move grid only if an earlier mover entered or left that very cell -- the latest decides
+    bool tok_v = false;
+    if (lead && !render_only && !(ra.diag & 4)) {
+        // ---- the moves, strictly in agent order (sorrel/agents/agent.py:213-225, worlds/gridworld.py:95-122), in registers.  What agent a
+        // finds on its target differs from the pre-move grid only if an earlier mover entered or left that very cell: an agent INTERFERES
+        // if another agent has the same target or stands on it.  Everyone else resolves at once from the pre-move grid; only the
+        // interfering agents (typically none, or a pair) are walked in agent order -- the latest earlier mover that entered or left the
+        // cell decides.  (Until the walk was restricted to them the loop over all 64 agents of config 5 was a third of the pass.)
         const uint32_t t0 = ta != 0xFFFFFFFFu ? (uint32_t)ga[ta] : 0xFFu;
-        for (int a = 0; a < (render_only ? 0 : A); ++a) {
+        const bool valid = ta != 0xFFFFFFFFu;
+        bool cf = false;
+        for (int b = 0; b < A; ++b) {
+            const uint32_t Xb = (uint32_t)__builtin_amdgcn_readlane((int)ta, b), Ob = (uint32_t)__builtin_amdgcn_readlane((int)oaddr, b);
+            cf = cf || (lane != b && (ta == Xb || ta == Ob));
+        }
+        cf = cf && valid && live;
+        {
+            const bool tok = valid && t0 < (uint32_t)p.T;
+            found = t0;
+            tok_v = tok;
+            passed = (tok && ((p.pass_mask >> (t0 & 31u)) & 1u)) ? 1u : 0u;
+            if (valid && !tok) st |= SGW_STATUS_BAD_TYPE;
+        }
+        unsigned long long walk = __ballot(cf);
+        while (walk) {
+            const int a = __builtin_ctzll(walk);
+            walk &= walk - 1ull;
             const uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)ta, a);
             uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t0, a);
             const unsigned long long m_dst = __ballot(passed && lane < a && ta == X);
@@ -129,37 +173,55 @@ __global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const Res
                 const int last = 63 - __builtin_clzll(m_any);
                 t = ((m_dst >> last) & 1ull) ? (uint32_t)__builtin_amdgcn_readlane((int)atype, last) : p.default_type;
             }
-            const bool valid = X != 0xFFFFFFFFu;
-            const bool tok = valid && t < (uint32_t)p.T;
+            const bool tok = t < (uint32_t)p.T;
             const bool pass = tok && ((p.pass_mask >> (t & 31u)) & 1u);
             if (lane == a) {
                 found = t;
                 tok_v = tok;
                 passed = pass ? 1u : 0u;
-                if (valid && !tok) st |= SGW_STATUS_BAD_TYPE;
+                if (!tok) st |= SGW_STATUS_BAD_TYPE;
             }
         }
-        cur = (act & 0x7Fu) | (passed << 7);
+    }
+    if constexpr (WPE > 1) {
+        const unsigned long long moved = __ballot(passed != 0);   // (taken with every lane active; lane 0 then writes it)
+        if (wave == 0 && lane == 0) sh[0] = moved;
+        __syncthreads();
+        if (wave != 0) passed = (uint32_t)((sh[0] >> lane) & 1ull);
+    }
+    const uint32_t cur = (act & 0x7Fu) | (passed << 7);
+
+    // ---- which windows must be verified.  First pass: those an earlier mover touches (agent j still stands where the turn began when
+    // its turn comes).  Later passes: only an agent whose move CHANGED since the previous pass (another action, or the same action with
+    // another outcome) can have changed a window -- one it touched before (its source cell, its old destination) or touches now.
+    // The loop over the movers is dealt out among the env's waves (every WPE-th mover each); the partial findings meet in LDS.
+    bool touched = false, recheck = false;
+    auto touch_of = [&](unsigned long long movers) {          // does a mover of `movers` touch lane j's window?
+        bool t = false;
+        int nth = 0;
+        while (movers) {
+            const int i = __builtin_ctzll(movers);
+            movers &= movers - 1ull;
+            if (WPE > 1 && (nth++ % WPE) != wave) continue;
+            const int sy = __builtin_amdgcn_readlane(py, i), sx = __builtin_amdgcn_readlane(px, i);
+            const int ey = __builtin_amdgcn_readlane(ny, i), ex = __builtin_amdgcn_readlane(nx, i);
+            const bool near_s = (unsigned)(sy - py + r) <= (unsigned)(2 * r) && (unsigned)(sx - px + r) <= (unsigned)(2 * r);
+            const bool near_e = (unsigned)(ey - py + r) <= (unsigned)(2 * r) && (unsigned)(ex - px + r) <= (unsigned)(2 * r);
+            t = t || (lane > i && (near_s || near_e));
+        }
+        return t;
+    };
+    if (!render_only && !(ra.diag & 4)) {
+        const unsigned long long movers = __ballot(passed != 0);
         if (ra.first == 1) {
-            // ---- first pass: whose window does an earlier mover touch?  (agent j still stands where the turn began when its turn comes)
-            unsigned long long movers = __ballot(passed != 0);
-            while (movers) {
-                const int i = __builtin_ctzll(movers);
-                movers &= movers - 1ull;
-                const int sy = __builtin_amdgcn_readlane(py, i), sx = __builtin_amdgcn_readlane(px, i);
-                const int ey = __builtin_amdgcn_readlane(ny, i), ex = __builtin_amdgcn_readlane(nx, i);
-                const bool near_s = (unsigned)(sy - py + r) <= (unsigned)(2 * r) && (unsigned)(sx - px + r) <= (unsigned)(2 * r);
-                const bool near_e = (unsigned)(ey - py + r) <= (unsigned)(2 * r) && (unsigned)(ex - px + r) <= (unsigned)(2 * r);
-                touched = touched || (lane > i && (near_s || near_e));
-            }
-            checked = live && touched;
-        } else if (ra.first == 0) {
-            // ---- later passes: only an agent whose move CHANGED since the previous pass (another action, or the same action with
-            // another outcome) can have changed a window -- one it touched before (its source cell, its old destination) or touches now
+            touched = touch_of(movers);
+        } else {
             unsigned long long changed = __ballot(live && prev != cur);
+            int nth = 0;
             while (changed) {
                 const int i = __builtin_ctzll(changed);
                 changed &= changed - 1ull;
+                if (WPE > 1 && (nth++ % WPE) != wave) continue;
                 const int sy = __builtin_amdgcn_readlane(py, i), sx = __builtin_amdgcn_readlane(px, i);
                 const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)prev, i), cv = (uint32_t)__builtin_amdgcn_readlane((int)cur, i);
                 const int ody = (int)((p.dy_pack >> (2 * (pv & 15u))) & 3u) - 1, odx = (int)((p.dx_pack >> (2 * (pv & 15u))) & 3u) - 1;
@@ -169,40 +231,44 @@ __global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const Res
                 const bool near_o = (unsigned)(oy - py + r) <= (unsigned)(2 * r) && (unsigned)(ox - px + r) <= (unsigned)(2 * r);
                 const bool near_e = (unsigned)(ey - py + r) <= (unsigned)(2 * r) && (unsigned)(ex - px + r) <= (unsigned)(2 * r);
                 const bool was_moving = (pv >> 7) != 0, is_moving = (cv >> 7) != 0;
-                checked = checked || (lane > i && (((was_moving || is_moving) && near_s) || (was_moving && near_o) || (is_moving && near_e)));
+                recheck = recheck || (lane > i && (((was_moving || is_moving) && near_s) || (was_moving && near_o) || (is_moving && near_e)));
             }
-            checked = checked && live;
-            if (__ballot(checked)) {                          // (rare in later passes) is a checked window touched NOW?  -> its `pristine` flag
-                unsigned long long movers = __ballot(passed != 0);
-                while (movers) {
-                    const int i = __builtin_ctzll(movers);
-                    movers &= movers - 1ull;
-                    const int sy = __builtin_amdgcn_readlane(py, i), sx = __builtin_amdgcn_readlane(px, i);
-                    const int ey = __builtin_amdgcn_readlane(ny, i), ex = __builtin_amdgcn_readlane(nx, i);
-                    const bool near_s = (unsigned)(sy - py + r) <= (unsigned)(2 * r) && (unsigned)(sx - px + r) <= (unsigned)(2 * r);
-                    const bool near_e = (unsigned)(ey - py + r) <= (unsigned)(2 * r) && (unsigned)(ex - px + r) <= (unsigned)(2 * r);
-                    touched = touched || (lane > i && (near_s || near_e));
-                }
-            }
-        } else {
-            checked = live;                                   // render mode: every window
         }
-        check = __ballot(checked);
     }
+    unsigned long long check;
     if constexpr (WPE > 1) {
-        const unsigned long long moved = __ballot(passed != 0);   // (taken with every lane active; lane 0 then writes the two masks)
-        if (wave == 0 && lane == 0) {
-            sh[0] = moved;
-            sh[1] = check;
-        }
+        const unsigned long long part = __ballot(ra.first == 1 ? touched : recheck);
+        if (lane == 0) sh[2 + wave] = part;
         __syncthreads();
-        if (wave != 0) {
-            passed = (uint32_t)((sh[0] >> lane) & 1ull);
-            check = sh[1];
+        unsigned long long all = 0ull;
+#pragma unroll
+        for (int k = 0; k < WPE; ++k) all |= sh[2 + k];
+        if (ra.first == 1) touched = (all >> lane) & 1ull;
+        else recheck = (all >> lane) & 1ull;
+        __syncthreads();                                      // (sh[2 ..] is used again below)
+    }
+    bool checked = live && (render_only || (ra.first == 1 ? touched : recheck));
+    if (ra.first == 0 && __ballot(checked)) {                 // (rare in later passes) is a checked window touched NOW?  -> its `pristine` flag
+        const bool part = touch_of(__ballot(passed != 0));
+        if constexpr (WPE > 1) {
+            const unsigned long long pm = __ballot(part);
+            if (lane == 0) sh[2 + wave] = pm;
+            __syncthreads();
+            unsigned long long all = 0ull;
+#pragma unroll
+            for (int k = 0; k < WPE; ++k) all |= sh[2 + k];
+            touched = (all >> lane) & 1ull;
+            __syncthreads();
+        } else {
+            touched = part;
         }
     }
+    check = (ra.diag & 1) ? 0ull : __ballot(checked);
 
-    // ---- the windows that may differ from their rows: rendered as the agent really has them, compared, rewritten where they differ
+    // ---- the windows that may differ from their rows: rendered as the agent really has them, compared, rewritten where they differ.
+    // kSlots rounds of 64 cells at a time; every load of a round -- the row's old values first, then the grid bytes -- is issued before
+    // the first is used: one round trip to memory per round where the straightforward loop had half a dozen.
+    constexpr int kSlots = SGW_RESOLVE_SLOTS;
     unsigned long long dmask = 0ull;
     int nth = 0;
     while (check) {
@@ -216,60 +282,77 @@ __global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const Res
         const unsigned long long tmask = __ballot(passed && lane < j && (near_s || near_e));
         float* rowp = ra.rows + ((int64_t)j * p.E + env) * ra.row_elems;
         bool diff = false;
-        for (int w = lane; w < VV; w += 64) {
-            const int wi = w / V, wj = w - wi * V;
-            const int gy = y - r + wi, gx = x - r + wj;
-            const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const uint32_t cell = (uint32_t)(gy * W + gx);
-            uint32_t lo = 0, hi = 0;
-            if (inb) {
-                for (int z = 0; z < L; ++z) {
-                    uint32_t tz = g[z * HW + cell];
-                    if (z == p.zA) {                          // the agent layer as the agents before j have left it
-                        unsigned long long m = tmask;
-                        while (m) {
-                            const int b = __builtin_ctzll(m);
-                            m &= m - 1ull;
-                            const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)oaddr, b);
-                            const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)ta, b);
-                            const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)atype, b);
-                            if (cell == src) tz = p.default_type;
-                            if (cell == dst) tz = bt;
-                        }
-                    }
-                    if (z < 4) lo |= (tz & 31u) << (8 * z);
-                    else hi |= (tz & 31u) << (8 * (z - 4));
-                }
+        for (int w0 = 0; w0 < VV; w0 += 64 * kSlots) {
+            bool inw[kSlots], inb[kSlots];
+            uint32_t cell[kSlots];
+            float oldv[kSlots][SGW_MAX_CHANNELS];
+            uint32_t raw[kSlots][SGW_MAX_LAYERS];
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) {
+                const int w = w0 + 64 * k + lane;
+                inw[k] = w < VV;
+                const int wi = w / V, wj = w - wi * V;
+                const int gy = y - r + wi, gx = x - r + wj;
+                inb[k] = inw[k] && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                cell[k] = inb[k] ? (uint32_t)(gy * W + gx) : 0u;
+#pragma unroll
+                for (int c = 0; c < SGW_MAX_CHANNELS; ++c)
+                    if (c < C && inw[k]) oldv[k][c] = __builtin_nontemporal_load(rowp + c * VV + w);
             }
-            if constexpr (ONEHOT) {
-                uint32_t cnt[4] = {0u, 0u, 0u, 0u};
-                for (int z = 0; z < L; ++z) {
-                    const uint32_t t = z < 4 ? (lo >> (8 * z)) & 31u : (hi >> (8 * (z - 4))) & 31u;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cnt[q] += wdelta[q * 32 + t];
-                }
+            for (int k = 0; k < kSlots; ++k) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cnt[q] = inb ? cnt[q] : p.fill_delta[q];
-                // (every load of the row first, then the compares and the rare stores: a load behind a store to the same array must wait
-                // for it -- six dependent round trips to memory per cell where one will do)
-                float oldv[SGW_MAX_CHANNELS];
+                for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+                    if (z < L) raw[k][z] = inb[k] ? (uint32_t)g[z * HW + cell[k]] : 0u;
+            }
 #pragma unroll
-                for (int c = 0; c < SGW_MAX_CHANNELS; ++c)
-                    if (c < C) oldv[c] = __builtin_nontemporal_load(rowp + c * VV + w);
+            for (int k = 0; k < kSlots; ++k) {
+                if (!inw[k]) continue;
+                const int w = w0 + 64 * k + lane;
+                if (inb[k]) {                                 // the agent layer as the agents before j have left it
+                    unsigned long long m = tmask;
+                    while (m) {
+                        const int b = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)oaddr, b);
+                        const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)ta, b);
+                        const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)atype, b);
 #pragma unroll
-                for (int c = 0; c < SGW_MAX_CHANNELS; ++c)
-                    if (c < C) {
-                        const float v = (float)((cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu);
-                        if (oldv[c] != v) { rowp[c * VV + w] = v; diff = true; }
+                        for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+                            if (z == p.zA) {
+                                if (cell[k] == src) raw[k][z] = p.default_type;
+                                if (cell[k] == dst) raw[k][z] = bt;
+                            }
                     }
-            } else {
-                for (int c = 0; c < C; ++c) {
-                    double acc = wapp[lo & 31u][c];           // left-to-right float64 layer sum (np.sum over <= 7 layers)
-                    for (int z = 1; z < L; ++z) acc += wapp[z < 4 ? (lo >> (8 * z)) & 31u : (hi >> (8 * (z - 4))) & 31u][c];
-                    const float v = obs_finish(inb ? acc : wapp[p.fill_type][c], p.obs_post);
-                    float* o = rowp + c * VV + w;
-                    const float old = *o;
-                    if (!(old == v) && !(old != old && v != v)) { *o = v; diff = true; }   // (a NaN appearance equals itself here)
+                }
+                if constexpr (ONEHOT) {
+                    uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int z = 0; z < SGW_MAX_LAYERS; ++z)
+                        if (z < L) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cnt[q] += wdelta[q * 32 + (raw[k][z] & 31u)];
+                        }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cnt[q] = inb[k] ? cnt[q] : p.fill_delta[q];
+#pragma unroll
+                    for (int c = 0; c < SGW_MAX_CHANNELS; ++c)
+                        if (c < C) {
+                            const float v = (float)((cnt[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+                            if (oldv[k][c] != v) { rowp[c * VV + w] = v; diff = true; }
+                        }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < SGW_MAX_CHANNELS; ++c)
+                        if (c < C) {
+                            double acc = wapp[raw[k][0] & 31u][c];   // left-to-right float64 layer sum (np.sum over <= 7 layers)
+#pragma unroll
+                            for (int z = 1; z < SGW_MAX_LAYERS; ++z)
+                                if (z < L) acc += wapp[raw[k][z] & 31u][c];
+                            const float v = obs_finish(inb[k] ? acc : wapp[p.fill_type][c], p.obs_post);
+                            const float old = oldv[k][c];
+                            if (!(old == v) && !(old != old && v != v)) { rowp[c * VV + w] = v; diff = true; }   // (a NaN appearance equals itself here)
+                        }
                 }
             }
         }
@@ -300,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void turn_resolve(const Params p, const Res
         ra.dirty[env * A + lane] = (uint8_t)((dmask >> lane) & 1ull);
         ra.prev[env * A + lane] = (uint8_t)cur;
     }
+    if (ra.diag & 2) return;
     if (dmask) {                                              // somebody must think again: nothing of this env is committed
         if (lane == 0 && ra.first) ra.env_done[env] = 0;
         if (ra.list) {                                        // the dirty rows of the env behind the others': ONE atomic per env

@@ -1411,6 +1411,12 @@ int sgw_step(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions,
     Params p = e->base;
     p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = obs; p.rewards = rewards; p.total = total_reward;
     p.epoch = epoch; p.turn = turn; p.a0 = agent_begin; p.a1 = agent_end; p.flags = flags; p.do_move = 1;
+    if (flags & SGW_STEP_OBS_AGENT_MAJOR) {
+        if (!e->big || agent_begin != 0 || agent_end != e->cfg.num_agents || (flags & (SGW_STEP_OBS_NEXT | SGW_STEP_NO_OBS)) || !obs)
+            return fail(SGW_EINVAL, "sgw_step: SGW_STEP_OBS_AGENT_MAJOR is for whole-turn calls with observations on engines with SGW_CAP_OBS_AGENT_MAJOR");
+        p.obs_ag = (int64_t)e->cfg.num_envs * e->base.C * e->base.VV;
+        p.flags &= ~SGW_STEP_OBS_AGENT_MAJOR;
+    }
     if (flags & SGW_STEP_NO_MOVE) {    // sweep + windows, nobody acts
         if (flags & (SGW_STEP_RANDOM_ACTIONS | SGW_STEP_OBS_NEXT | SGW_STEP_OBS_NEXT_PACKED))
             return fail(SGW_EINVAL, "sgw_step: SGW_STEP_NO_MOVE does not combine with RANDOM_ACTIONS / OBS_NEXT");
@@ -1496,6 +1502,7 @@ int sgw_capabilities(sgw_engine* e) {
         for (int a = 0; a < e->cfg.num_agents; ++a) ok = ok && !e->cfg.type_passable[e->cfg.agent_type[a]];
         if (ok) caps |= SGW_CAP_RESOLVE;
     }
+    if (e->big) caps |= SGW_CAP_OBS_AGENT_MAJOR;
     return caps;
 }
 
@@ -1772,6 +1779,7 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
     ra.count_next = counters ? counters + ((pass + 1) & 7) : nullptr;
     ra.reward_rows = reward_rows; ra.action_rows = action_rows;
     ra.first = pass == 0 ? 2 : (pass == 1 ? 1 : 0);
+    ra.diag = e->opt.resolve_diag;
     // a workgroup per env (four waves share the windows to verify) from 16 agents on, a wave per env below
     const bool wide = c.num_agents >= 16;
     const unsigned blocks = (unsigned)(wide ? p.E : ceil_div(p.E, 4));
@@ -1786,6 +1794,18 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
     }
     HIP_TRY(hipGetLastError());
     return time_end(e, s);
+}
+
+int sgw_gather_rows(const float* src, int64_t row_elems, const int64_t* idx, int64_t n, float* dst, void* stream) {
+    if (!src || !idx || !dst || row_elems < 1 || n < 0) return fail(SGW_EINVAL, "sgw_gather_rows: bad argument");
+    if (n == 0) return SGW_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, kBlock / 64), 256 * 32);
+    const bool v2 = (row_elems & 1) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7) == 0;
+    if (v2) hipLaunchKernelGGL(gather_rows_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, src, row_elems, idx, n, dst);
+    else hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, src, row_elems, idx, n, dst);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
 }
 
 int sgw_turn_prev_rows(sgw_engine* e, int32_t agent, int32_t count, void* out, void* stream) {

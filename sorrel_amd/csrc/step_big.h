@@ -552,7 +552,8 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     }
                 }
             }
-            float* obase = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
+            float* obase = p.obs_ag ? p.obs + tix * p.ts_obs + (int64_t)a * p.obs_ag + env * (int64_t)(C * VV)       // [A][E][C][V][V]
+                                    : p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
             if constexpr (ONEHOT) {
                 // the packed byte counts of window cell lane + 64 k: one table word per layer and group of four channels
                 auto counts = [&](const int k, uint32_t (&cq)[NW]) {

@@ -450,6 +450,19 @@ class GridEngine:
             raise ValueError(f"rows must be a contiguous float32 [{A}, {E}, {per_env}] tensor on {self.device}")
         return rows
 
+    def gather_rows(self, flat: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """``flat[idx]`` for float32 rows (``sgw_gather_rows``: the dirty rows of a speculative pass as one contiguous batch) into a buffer
+        the engine keeps; valid until the next call."""
+        n, ne = int(idx.numel()), int(flat.shape[1])
+        buf = getattr(self, "_gather_buf", None)
+        if buf is None or buf.shape[1] != ne or buf.shape[0] < n:
+            buf = self._gather_buf = torch.empty((max(n, 4096), ne), dtype=torch.float32, device=self.device)
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or idx.dtype != torch.int64 or not idx.is_contiguous() or idx.device != self.device:
+            raise ValueError("gather_rows: float32 contiguous rows and a contiguous int64 index vector on the engine's device")
+        with self._on_device():
+            N.check(self._lib.sgw_gather_rows(flat.data_ptr(), ne, idx.data_ptr(), n, buf.data_ptr(), self._stream()))
+        return buf[:n]
+
     def speculation_windows(self, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Every agent's PRE-move window into ``speculation_rows(rows)``: ``sgw_observe_rows`` where the engine has a row kernel for the
         world (one-hot tables), else ``sgw_turn_resolve``'s render mode (any table)."""
@@ -493,6 +506,10 @@ class GridEngine:
                                             None if action_rows is None else action_rows.data_ptr(), int(pass_no), self._stream())
         if rc:
             N.check(rc)
+
+    def spec_count(self, pass_no: int) -> int:
+        """How many rows pass ``pass_no`` rewrote (synchronises: the one read-back per pass)."""
+        return int(self._spec_ctr[pass_no & 7].item())
 
     def spec_dirty(self, pass_no: int) -> torch.Tensor:
         """The rows pass ``pass_no`` rewrote, as int64 indices ``agent * E + env`` into the flattened ``[A * E, N]`` rows (synchronises: the
@@ -546,7 +563,7 @@ class GridEngine:
     def step(self, actions: Optional[torch.Tensor] = None, *, random_actions: bool = False, sweep: bool = True,
              write_obs: bool = True, agent_begin: int = 0, agent_end: Optional[int] = None,
              turn: Optional[int] = None, advance_turn: bool = True, obs_out: Optional[torch.Tensor] = None,
-             obs_next: bool = False, obs_next_out: Optional[torch.Tensor] = None, no_move: bool = False):
+             obs_next: bool = False, obs_next_out: Optional[torch.Tensor] = None, no_move: bool = False, agent_major: bool = False):
         """One ``Environment.take_turn`` for every env (K2).
 
         ``actions``: uint8 ``[E, A]`` chosen by a policy; or ``random_actions=True``
@@ -569,7 +586,11 @@ class GridEngine:
             self.actions.copy_(actions.to(device=self.device, dtype=torch.uint8).reshape(self.actions.shape))
         actions = self.actions
         flags = (N.STEP_SWEEP if sweep else 0) | (N.STEP_RANDOM_ACTIONS if random_actions else 0) | (N.STEP_NO_MOVE if no_move else 0)
-        obs = self.obs if obs_out is None else self._check_obs(obs_out, "obs_out")
+        if agent_major:      # obs_out is [A, E, C*V*V] (SGW_STEP_OBS_AGENT_MAJOR: engines with CAP_OBS_AGENT_MAJOR, whole-turn calls)
+            obs = self.speculation_rows(obs_out)
+            flags |= N.STEP_OBS_AGENT_MAJOR
+        else:
+            obs = self.obs if obs_out is None else self._check_obs(obs_out, "obs_out")
         if obs_next_out is not None:
             if not obs_next:
                 raise ValueError("obs_next_out is the destination of obs_next=True")

@@ -425,7 +425,7 @@ class Environment:
             eng.step(actions, turn=self.turn)
         elif all(getattr(a.model, "device_random", False) for a in self.agents):
             eng.step(random_actions=True, turn=self.turn)
-        elif self._speculation_groups(eng) is not None:
+        elif self.speculate_turns and self._speculation_groups(eng) is not None:
             self._take_turn_speculative(eng, self._speculation_groups(eng))
         elif self._begin_policy_turn(eng):
             for agent in self.agents:
@@ -454,7 +454,23 @@ class Environment:
         from sorrel_amd import _native as N
         from sorrel_amd.buffers import Buffer
 
-        if not self.speculate_turns or self._mixed or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_RESOLVE) or eng.row_tail:
+        if not self.speculate_turns:
+            return None
+        # (the answer only changes with the engine, the agents' models and their memories: asked every turn, computed once -- with 64 agents
+        # the checks below are ~100 us of Python)
+        key = (id(eng), eng.row_tail, tuple((id(a.model), id(getattr(a.model, "memory", None)), type(a)) for a in self.agents))
+        cached = self.__dict__.get("_spec_groups")
+        if cached is not None and cached[0] == key:
+            groups = cached[1]
+            if groups is not None and any(getattr(m, "memory", None) is not None and m.memory._deferred for _a0, _a1, m in groups):
+                return None
+            return groups
+        groups = self._speculation_groups_uncached(eng, N, Buffer)
+        self.__dict__["_spec_groups"] = (key, groups)
+        return groups
+
+    def _speculation_groups_uncached(self, eng, N, Buffer):
+        if self._mixed or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_RESOLVE) or eng.row_tail:
             return None
         per_env = int(np.prod(eng.spec.obs_shape[1:]))
         groups = []
@@ -491,8 +507,13 @@ class Environment:
             rrows, arows = mem.rewards[mem.idx:mem.idx + A], mem.actions[mem.idx:mem.idx + A]
         rows = eng.speculation_rows(own)
         flat = rows.view(A * E, -1)
-        eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)    # the sweep alone
-        eng.speculation_windows(own)                                     # every agent's PRE-move window, once
+        from sorrel_amd import _native as N
+
+        if eng.capabilities() & N.CAP_OBS_AGENT_MAJOR:                   # (worlds above 4 KiB) the sweep AND every agent's PRE-move window in ONE launch
+            eng.step(eng.actions, sweep=True, no_move=True, turn=self.turn, obs_out=rows, agent_major=True)
+        else:
+            eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)    # the sweep alone
+            eng.speculation_windows(own)                                 # every agent's PRE-move window, once
 
         def choose(model, x):
             out = model.take_action(x)
@@ -504,29 +525,45 @@ class Environment:
             fresh = choose(groups[0][2], flat)
         else:
             fresh = torch.cat([choose(model, flat[a0 * E:a1 * E]) for a0, a1, model in groups])
+        def bucket(n):
+            # a batch of a few sizes only (the BLAS picks its kernel per shape: a new shape every turn costs more than the padding)
+            return 64 if n <= 64 else (1 << (n - 1).bit_length() if n <= 4096 else -(-n // 4096) * 4096)
+
+        guess = self.__dict__.setdefault("_spec_guess", {})              # pass -> rows it left dirty the last time: how many to evaluate ahead
         k = 1
+        eng.turn_resolve(1, own, fresh.contiguous(), rrows, arows)       # writes the actions, commits the envs that are at their fixed point already
         while True:
-            eng.turn_resolve(k, own, fresh.contiguous(), rrows, arows)   # writes the actions, commits the envs that have reached their fixed point
-            lst = eng.spec_dirty(k)                                      # (synchronises: the host learns how many rows must be thought about again)
-            n = int(lst.numel())
+            # The host learns the dirty count with a synchronisation.  While it waits the GPU would idle, and after it the next batch's
+            # launches would only start to arrive: so the rows this pass will PROBABLY leave dirty (as many as last turn, rounded up) are
+            # gathered and evaluated before the count is read -- the list's entries beyond the count are older valid indices, harmless.
+            ahead, m = None, 0
+            if len(groups) == 1 and guess.get(k, 0) > 0:
+                m = min(bucket(int(guess[k] * 1.2) + 1), A * E)
+                ahead = choose(groups[0][2], eng.gather_rows(flat, eng._spec_list[k & 1, :m]))
+            n = eng.spec_count(k)                                        # (synchronises)
+            guess[k] = n
             if n == 0:
                 break
-            k += 1
-            if len(groups) == 1:
-                # a batch of a few sizes only (the BLAS picks its kernel per shape: a new shape every turn costs more than the padding)
-                m = 64 if n <= 64 else (1 << (n - 1).bit_length() if n <= 4096 else -(-n // 4096) * 4096)
-                pad = eng._spec_list[(k - 1) & 1, :m] if m <= A * E else lst
-                if m > n and m <= A * E:
+            if ahead is not None and n <= m:
+                fresh = ahead[:n]
+            elif len(groups) == 1:
+                m = min(bucket(n), A * E)
+                pad = eng._spec_list[k & 1, :m]
+                if m > n:
                     pad[n:m] = 0                                         # (row 0: evaluated again, the result thrown away)
-                fresh = choose(groups[0][2], flat.index_select(0, pad))[:n]
+                fresh = choose(groups[0][2], eng.gather_rows(flat, pad))[:n]
             else:
+                lst = eng._spec_list[k & 1, :n]
                 fresh = torch.empty_like(lst)
                 a_i = torch.div(lst, E, rounding_mode="floor")
                 for a0, a1, model in groups:
                     sel = torch.nonzero((a_i >= a0) & (a_i < a1)).squeeze(1)
                     if sel.numel():
                         fresh[sel] = choose(model, flat.index_select(0, lst[sel]))
+            k += 1
+            eng.turn_resolve(k, own, fresh.contiguous(), rrows, arows)
         self.speculation_passes = k
+        self._spec_seen = (self.epoch, self.turn, rows)                  # (obs_of: the windows of this turn live here, not in the [E, A, ...] tensor)
         if own is not None:                                              # windows, rewards and actions already lie in the ring's rows
             done = [self.agents[a].is_done(self.world) for a in range(A)]
             if any(torch.is_tensor(d) or d for d in done):
@@ -598,7 +635,11 @@ class Environment:
         """The window agent (or slot) last observed -- ``obs[:, slot]`` when the agents share their specs."""
         a = agent.slot if isinstance(agent, Agent) else int(agent)
         if not self._mixed:
-            return self._ensure_engine().obs[:, a]
+            eng = self._ensure_engine()
+            seen = getattr(self, "_spec_seen", None)
+            if seen is not None and seen[:2] == (self.epoch, self.turn):      # the last turn was a speculative one
+                return seen[2][a].view((eng.num_envs,) + tuple(eng.spec.obs_shape[1:]))
+            return eng.obs[:, a]
         t = self._mixed_obs[a]
         g = self._agent_engine[a]
         if t is None or self.agents[a].observation_spec.full_view:

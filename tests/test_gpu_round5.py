@@ -407,6 +407,11 @@ def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):
             assert torch.equal(ma.states, mb.states) and torch.equal(ma.actions, mb.actions) and torch.equal(ma.rewards, mb.rewards)
             assert torch.equal(ma.dones, mb.dones)
         assert spec.agents[0].model.calls < eager.agents[0].model.calls          # one forward pass per PASS, not per agent
+        for a in range(A):          # obs_of: the window each agent acted on (the eager loop's lives in its replay row; the last add is the last turn's)
+            mem = eager.agents[a].model.memory
+            k = sum(1 for b in range(a + 1, A) if eager.agents[b].model.memory is mem)
+            last = (mem.idx - 1 - k) % mem.capacity
+            assert torch.equal(spec.obs_of(a).reshape(E, -1), mem.states[last].reshape(E, -1)), (shared, a)
         eager.raise_on_status()
         spec.raise_on_status()
 
@@ -460,3 +465,42 @@ def test_capture_turn_declines_where_a_replay_would_be_slower(torch_cuda):
     assert env.capture_turn(force=True) is not None
     env.take_turn()
     env.raise_on_status()
+
+
+def test_agent_major_windows_in_one_launch_and_gather_rows(torch_cuda):
+    """SGW_STEP_OBS_AGENT_MAJOR (workgroup-per-env kernels): the sweep and every agent's pre-move window into [A][E][C*V*V] rows in ONE
+    launch = the sweep alone + sgw_observe_rows; a whole turn with moves into such rows = the [E][A][...] tensor transposed -- on the
+    walking, the staged and the direct-store variant.  sgw_gather_rows = index_select."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+    from tests.test_gpu_parity import make_engine
+
+    ws = treasurehunt_spec(72, 80, 20, 4, spawn_prob=0.05, seed=12, dense_prob=0.2)
+    for opts in ({}, {"big_walk_blocks": 3}, {"big_walk": 0, "big_stage": 1}, {"big_walk": 0, "big_stage": 0}):
+        for k, v in opts.items():
+            N.set_option(k, v)
+        E = 23
+        a, b = make_engine(ws, E), make_engine(ws, E)
+        assert a.capabilities() & N.CAP_OBS_AGENT_MAJOR
+        for e in (a, b):
+            e.reset(0)
+        rows_a = torch.full((ws.num_agents, E, int(np.prod(ws.obs_shape[1:]))), -5.0, device="cuda:0")
+        a.step(a.actions, sweep=True, no_move=True, turn=1, obs_out=rows_a, agent_major=True)
+        b.step(b.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=1)
+        rows_b = b.speculation_windows()
+        torch.cuda.synchronize()
+        assert torch.equal(a.grid, b.grid) and torch.equal(rows_a, rows_b), opts
+        a.step(random_actions=True, turn=2, obs_out=rows_a, agent_major=True)           # a whole turn, windows agent-major
+        b.step(random_actions=True, turn=2)
+        torch.cuda.synchronize()
+        assert torch.equal(a.grid, b.grid) and torch.equal(a.rewards, b.rewards) and torch.equal(a.total_reward, b.total_reward)
+        assert torch.equal(rows_a, b.obs.reshape(E, ws.num_agents, -1).permute(1, 0, 2).contiguous()), opts
+        N.reset_options()
+    flat = rows_a.view(-1, rows_a.shape[2])
+    idx = torch.randint(0, flat.shape[0], (1000,), device="cuda:0")
+    assert torch.equal(a.gather_rows(flat, idx), flat.index_select(0, idx))
+    small = make_engine(treasurehunt_spec(16, 16, 4, 2), 8)                              # a wave-per-env world: not offered, and refused
+    assert not (small.capabilities() & N.CAP_OBS_AGENT_MAJOR)
+    with pytest.raises(ValueError):
+        small.step(random_actions=True, obs_out=small.speculation_rows(), agent_major=True)

@@ -68,7 +68,7 @@ def run(h, w, a, r, E, policy, spawn_prob=0.005):
              5: "shared policy, eager", 6: "shared policy, speculative", 7: "own policies, speculative"}[policy]
     if policy in (2, 4) and env.capture_turn() is None:                          # round 4: the whole turn recorded once, replayed
         label = f"policy, NOT capturable: {getattr(env, 'capture_error', None)!r}"[:60]
-    turns = 2000 if E <= 4096 else 300
+    turns = int(os.environ.get("LAT_TURNS", 2000 if E <= 4096 else 300))
     us = time_turns(env, turns)
     env.raise_on_status()
     extra = f"  passes of the last turn: {env.speculation_passes}" if policy in (6, 7) else ""

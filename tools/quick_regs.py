@@ -11,9 +11,12 @@ flags = [a for a in sys.argv[1:] if a.startswith("-")]
 ids = [a for a in sys.argv[1:] if not a.startswith("-")]
 csrc = os.path.join(ROOT, "sorrel_amd", "csrc")
 src = "#include <hip/hip_runtime.h>\n#include <stdint.h>\n#include <stddef.h>\n#include \"" + os.path.join(ROOT, "include", "sgw.h") + "\"\n"
-src += "".join(f'#include "{os.path.join(csrc, n)}"\n' for n in G.JIT_PARTS)
+src += "".join(f'#include "{os.path.join(csrc, n)}"\n' for n in G.JIT_PARTS + ("small_kernels.h", "resolve.h"))
 for i, inst in enumerate(ids):
     rows = inst.startswith(("phase_rows", "observe_rows", "act_patch"))
+    if inst.startswith("turn_resolve"):
+        src += f"template __global__ void {inst}(const Params, const ResolveArgs);\n"
+        continue
     src += f"template __global__ void {inst}(const Params{', const RowPtrs' if rows else ''});\n"
 with tempfile.TemporaryDirectory() as d:
     path = os.path.join(d, "tu.hip")

@@ -71,7 +71,9 @@ def run(h, w, a, r, E, policy, spawn_prob=0.005):
     turns = int(os.environ.get("LAT_TURNS", 2000 if E <= 4096 else 300))
     us = time_turns(env, turns)
     env.raise_on_status()
-    extra = f"  passes of the last turn: {env.speculation_passes}" if policy in (6, 7) else ""
+    extra = ""
+    if policy in (6, 7):
+        extra = f"  passes of the last turn: {env.speculation_passes}" if hasattr(env, "speculation_passes") else "  (a model per agent: Environment keeps the sequential turn)"
     print(f"{h}x{w} A{a} r{r} E={E:6d} {label:26s} {us:9.1f} us/turn  {E * a / us * 1e6:.3e} agent-steps/s{extra}", flush=True)
     del env, world
     torch.cuda.empty_cache()

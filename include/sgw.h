@@ -484,6 +484,7 @@ int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* s
  *     (or sgw_turn_resolve(pass = 0))                  (rows[a] = rows + a * E * row_elems: agent-major, so agents that share a
  *                                                      model are ONE contiguous batch for its forward pass; pass 0 renders them for
  *                                                      ANY appearance table and window size, where there is no row kernel)
+ *     (or, with SGW_CAP_OBS_AGENT_MAJOR, both in ONE launch: sgw_step(0, A, SGW_STEP_SWEEP | SGW_STEP_NO_MOVE | SGW_STEP_OBS_AGENT_MAJOR))
  *   fresh[A * E] <- policy(rows)                       one batched evaluation, int64 action indices in the rows' order
  *   sgw_turn_resolve(pass = 1, fresh, A * E)          writes the actions into actions[E][A], then resolves every env's moves in agent
  *             order WITHOUT touching the grid; renders, for each agent whose window an earlier mover touches, the window it really
@@ -497,7 +498,9 @@ int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* s
  * a fifth of the rows re-evaluated in pass 2 and 0.3 % in pass 3 (profiles/r05_speculation_study.txt, r05_speculative_turn.txt).
  * With a policy that is a function of its window the result equals the sequential turn bit for bit.  Caller-owned scratch:
  * `scratch` 4 * E * A bytes (done flags, row states, the dirty bytes of the last pass at + 2 * E * A, previous moves), `dirty_list`
- * 2 * E * A int64, `counters` 8 uint32; their contents are initialised by pass 0 / 1.  `dirty_list` / `counters` may be NULL
+ * 2 * E * A int64, `counters` 8 uint32; their contents are initialised by pass 0 / 1.  (The list is appended with one atomic per env that has
+ * dirty rows; from 8 192 envs on -- where that many atomics on one counter would serialise -- it is laid out by a scan over per-env counts,
+ * two more small launches inside the call.)  `dirty_list` / `counters` may be NULL
  * (read the dirty bytes instead), and so may `new_actions` (the caller has written `actions` itself). */
 int sgw_turn_resolve(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rows, int64_t row_elems,
                      float* rewards, double* total_reward, uint8_t* scratch, int64_t* dirty_list, uint32_t* counters,

@@ -29,6 +29,9 @@ struct ResolveArgs {
                            // move CHANGED since then touches (before or after the change); every other row is still what it was verified to be
     int64_t* list;         // out: the dirty rows of this pass as indices a * E + env, in no particular order (NULL: only the `dirty` bytes)
     uint32_t* count;       // ... and how many (zero when the launch starts; one wave-aggregated atomic per env that has any)
+    uint8_t* dcount;       // [E], instead of list / count for large batches: how many rows of the env this pass left dirty -- the list is then laid
+    uint32_t* bsum;        // out by a scan over these and over their sums per block of 256 envs (resolve_scan_blocks / resolve_fill_list): tens of
+                           // thousands of atomics on ONE counter serialise (config 3's 65 536 envs: 575 us for the first pass)
     uint32_t* count_next;  // the counter the NEXT pass will use: zeroed by this launch
     float* reward_rows;    // optional [A][E] float32 / int64: at the commit of an env, reward and action of every agent once more in
     int64_t* action_rows;  // agent-major rows (the rows of a replay ring: add_memory then copies nothing)
@@ -48,6 +51,54 @@ __global__ __launch_bounds__(kBlock) void resolve_apply_actions(uint8_t* actions
         const int64_t v = fresh[k];
         actions[e * A + a] = (v >= 0 && v < 255) ? (uint8_t)v : (uint8_t)255;      // (an index no ActionSpec has: SGW_STATUS_BAD_ACTION at the resolve)
     }
+}
+
+// Large batches: the dirty list without tens of thousands of atomics on one counter.  The resolve kernel leaves the number of dirty rows of each
+// env in dcount[env] and adds it to the sum of its block of 256 envs (256 envs share a counter: the atomics spread over E / 256 addresses);
+// one workgroup turns the block sums into block offsets (and the total); a workgroup per block then scans its 256 counts and writes the
+// dirty rows' indices (agent * E + env) behind the block's offset.
+__global__ __launch_bounds__(256) void resolve_scan_blocks(uint32_t* __restrict__ bsum, const int nb, uint32_t* __restrict__ boff, uint32_t* __restrict__ count) {
+    __shared__ uint32_t part[256];
+    const int t = threadIdx.x;
+    const int per = (nb + 255) / 256, lo = t * per, hi = lo + per < nb ? lo + per : nb;
+    uint32_t sum = 0;
+    for (int b = lo; b < hi; ++b) sum += bsum[b];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 partial sums
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int b = lo; b < hi; ++b) {
+        const uint32_t v = bsum[b];
+        boff[b] = run;
+        bsum[b] = 0u;                                         // (for the next pass)
+        run += v;
+    }
+    if (t == 255) *count = part[255];
+}
+
+__global__ __launch_bounds__(256) void resolve_fill_list(const uint8_t* __restrict__ dirty, const uint8_t* __restrict__ dcount, const uint8_t* __restrict__ env_done,
+                                                         const uint32_t* __restrict__ boff, const int64_t E, const int A, int64_t* __restrict__ list) {
+    __shared__ uint32_t part[256];
+    const int t = threadIdx.x;
+    const int64_t env = (int64_t)blockIdx.x * 256 + t;
+    const uint32_t mine = (env < E && !env_done[env]) ? (uint32_t)dcount[env] : 0u;
+    part[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (mine == 0) return;
+    uint32_t at = boff[blockIdx.x] + part[t] - mine;
+    for (int a = 0; a < A; ++a)
+        if (dirty[env * A + a]) list[at++] = (int64_t)a * E + env;
 }
 
 // dst[k][:] = src[idx[k]][:]: a wave per row, 8-byte pieces where rows and pointers allow (sgw_gather_rows).
@@ -384,6 +435,11 @@ __global__ __launch_bounds__(kBlock, 8) void turn_resolve(const Params p, const 
         ra.prev[env * A + lane] = (uint8_t)cur;
     }
     if (ra.diag & 2) return;
+    if (ra.dcount && lane == 0) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(dmask);
+        ra.dcount[env] = (uint8_t)n;
+        if (n) atomicAdd(ra.bsum + (env >> 8), n);
+    }
     if (dmask) {                                              // somebody must think again: nothing of this env is committed
         if (lane == 0 && ra.first) ra.env_done[env] = 0;
         if (ra.list) {                                        // the dirty rows of the env behind the others': ONE atomic per env

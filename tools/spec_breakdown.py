@@ -84,7 +84,7 @@ for turn in range(T):
         m = 64 if n <= 64 else (1 << (n - 1).bit_length() if n <= 4096 else -(-n // 4096) * 4096)
         pad = eng._spec_list[(k - 1) & 1, :m]
         pad[n:m] = 0
-        x = flat.index_select(0, pad)
+        x = eng.gather_rows(flat, pad)
         seg(f"8.{k - 1} gather of the dirty rows (padded)")
         fresh = model.take_action(x)[:n]
         seg(f"9.{k - 1} forward pass, dirty rows")

@@ -4,17 +4,19 @@ set -e
 cd "$(dirname "$0")/.."
 if [ -d gpurun_out/prof_r05_c3 ]; then
   cp gpurun_out/prof_r05_c3/summary.txt profiles/r05_c3_rocprofv3_summary.txt
-  cp gpurun_out/prof_r05_c3/trace/*/*_kernel_stats.csv profiles/r05_c3_kernel_stats.csv
+  newest() { ls -t $1 | head -1; }      # (gpurun merges into gpurun_out/: an earlier run's files of the same kind may still be there)
+  cp $(newest "gpurun_out/prof_r05_c3/trace/*/*_kernel_stats.csv") profiles/r05_c3_kernel_stats.csv
   cp gpurun_out/prof_r05_c3/trace_bench.json profiles/r05_c3_bench_under_rocprof.json
-  cp gpurun_out/prof_r05_c3/trace_full/*/*_kernel_stats.csv profiles/r05_c3_full_line_kernel_stats.csv
+  cp $(newest "gpurun_out/prof_r05_c3/trace_full/*/*_kernel_stats.csv") profiles/r05_c3_full_line_kernel_stats.csv
   cp gpurun_out/prof_r05_c3/trace_full_bench.json profiles/r05_c3_full_line_bench_under_rocprof.json
   cp gpurun_out/r05_bench_driver_flags.json profiles/r05_c3_bench_driver_flags.json
   python tools/make_traffic_json.py c3 65536 gpurun_out/prof_r05_c3/summary.txt profiles/r05_c3_rocprofv3_summary.txt
 fi
 if [ -d gpurun_out/prof_r05_c5 ]; then
-  cp gpurun_out/prof_r05_c5/*/*_kernel_stats.csv profiles/r05_c5_kernel_stats.csv
+  newest() { ls -t $1 | head -1; }
+  cp $(newest "gpurun_out/prof_r05_c5/*/*_kernel_stats.csv") profiles/r05_c5_kernel_stats.csv
   cp gpurun_out/prof_r05_c5.json profiles/r05_c5_bench_under_rocprof.json
-  cp gpurun_out/prof_r05_c2/*/*_kernel_stats.csv profiles/r05_c2_kernel_stats.csv
+  cp $(newest "gpurun_out/prof_r05_c2/*/*_kernel_stats.csv") profiles/r05_c2_kernel_stats.csv
   cp gpurun_out/prof_r05_c2.json profiles/r05_c2_bench_under_rocprof.json
   cp gpurun_out/r05_c5_traffic.txt profiles/r05_c5_traffic.txt
   python tools/make_traffic_json.py c5 2048 profiles/r05_c5_traffic.txt profiles/r05_c5_traffic.txt

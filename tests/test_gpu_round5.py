@@ -417,6 +417,90 @@ def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):
         spec.raise_on_status()
 
 
+@pytest.mark.parametrize("case", ["own_rings", "shared_ring", "values_and_ints", "model_edits_the_world", "subclass_with_own_pov"])
+def test_fast_policy_loop_equals_the_generic_transition_loop(torch_cuda, case):
+    """Environment.fast_policy_loop (agents with the standard hooks stepped without the generic hooks in between) against the
+    Agent.transition loop it replaces: grids, positions, totals, step outputs and every replay row after 11 turns and a reset --
+    for a ring per agent, one shared ring whose rows wrap mid-turn, agents that return action values (in-kernel argmax / exploration)
+    or a plain int, a model that edits the world between two agents (windows rendered on demand from there on), and a subclass that
+    overrides pov (the fast loop must not take it)."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.examples.treasurehunt.agents import TreasurehuntAgent
+    from sorrel_amd.examples.treasurehunt.entities import Wall
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E, A = 37, 5
+
+    class Linear(BaseModel):
+        def __init__(self, input_size, action_space, k=0, memory=9):
+            super().__init__(input_size, action_space, memory_size=memory, num_envs=E, device="cuda:0")
+            g = torch.Generator().manual_seed(50 + k)
+            self.weight = torch.randn((int(np.prod(input_size)), action_space), generator=g).cuda()
+            self.k, self.env, self.turns = k, None, 0
+            self.epsilon = 0.25 if (case == "values_and_ints" and k == 1) else 0.0
+
+        def take_action(self, state):
+            q = state.reshape(state.shape[0], -1) @ self.weight
+            if case == "values_and_ints" and self.k in (1, 3):
+                return q                                   # action values: the act launch chooses
+            if case == "values_and_ints" and self.k == 2:
+                return 1                                   # a plain int for every env
+            if case == "values_and_ints" and self.k == 4:
+                return q.argmax(dim=1).to(torch.int32)
+            if case == "model_edits_the_world" and self.k == 2:
+                self.turns += 1
+                if self.turns % 3 == 0:
+                    self.env.world.add((1 + self.turns % 5, 2, 0), Wall(), env=None)
+            return q.argmax(dim=1)
+
+    envs = []
+    for fast in (False, True):
+        made = []
+
+        def factory(input_size, action_space):
+            if case == "shared_ring":
+                if not made:
+                    made.append(Linear(input_size, action_space, 0, memory=0))
+                    made[0].memory = Buffer(capacity=2 * A + 3, obs_shape=tuple(input_size), num_envs=E, device="cuda:0")
+                return made[0]
+            made.append(Linear(input_size, action_space, len(made)))
+            return made[-1]
+
+        env = make_env(13, 16, A, 2, E, p=0.07, seed=11, model_factory=factory)
+        for m in made:
+            m.env = env
+        if case == "subclass_with_own_pov":
+            class Dimmed(TreasurehuntAgent):
+                def pov(self, world):
+                    return super().pov(world) * 0.5
+            env.agents[3].__class__ = Dimmed
+        env.fast_policy_loop = fast
+        envs.append(env)
+    generic, quick = envs
+    for t in range(11):
+        if t == 6:
+            generic.reset()
+            quick.reset()
+        generic.take_turn()
+        quick.take_turn()
+    torch.cuda.synchronize()
+    plan = quick._fast_plan(quick._engine)
+    assert (plan is None) == (case == "subclass_with_own_pov") and generic.__dict__.get("_fast_plan_cache") is None
+    for name in ("grid", "agent_pos", "total_reward"):
+        assert torch.equal(getattr(generic.world, name), getattr(quick.world, name)), name
+    assert torch.equal(generic.rewards, quick.rewards) and torch.equal(generic.actions, quick.actions)
+    assert float(quick.world.total_reward.abs().sum()) > 0
+    for a in range(A):
+        ma, mb = generic.agents[a].model.memory, quick.agents[a].model.memory
+        assert (ma.idx, ma.size, ma._dones_dirty) == (mb.idx, mb.size, mb._dones_dirty)
+        for name in ("states", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(ma, name), getattr(mb, name)), (a, name)
+    generic.raise_on_status()
+    quick.raise_on_status()
+
+
 # ------------------------------------------------------------------ recorded turns at a batch where the kernels change form
 @pytest.mark.parametrize("layout", ["rows", "tensor"])
 @pytest.mark.parametrize("agents", [8, 12])

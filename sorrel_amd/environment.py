@@ -786,7 +786,7 @@ class Environment:
         capture).  Returns the ``CapturedTurn``, or ``None`` -- and the eager loop stays in charge -- when the turn cannot be
         recorded: an agent class overrides ``transition`` / ``add_memory``, a model's memory is not a ``sorrel_amd.buffers.Buffer``
         of plain windows (appended features index the ring from the host; frame stacks -- ``n_frames > 1`` -- are recorded: ``current_state()``
-        becomes a gather by the device's row count, ``sgw_turn_prev_rows``, unless agents share the ring), the engine has
+        becomes a gather by the device's row count, ``sgw_turn_prev_rows``; agents that share such a ring need the "rows" layout), the engine has
         no observation tensor, or a model's forward pass does something a capture forbids (a host synchronisation)."""
         from sorrel_amd import _native as N
         from sorrel_amd.buffers import Buffer
@@ -823,8 +823,12 @@ class Environment:
                     or mem.states.dtype != eng.obs_dtype or mem.states[0, 0].numel() != per_row or mem.n_frames - 1 > mem.capacity:
                 return None
             sharers.setdefault(id(mem), [mem, []])[1].append(agent.slot)
-        if any(v[0].n_frames > 1 and len(v[1]) > 1 for v in sharers.values()):
-            return None        # (frame stacks of agents that share one ring interleave their rows: left to the eager loop)
+        if not use_rows and any(v[0].n_frames > 1 and len(v[1]) > 1 for v in sharers.values()):
+            # frame stacks of agents that share one ring interleave their rows: agent k's stack holds the windows of agents k-1, k-2 of THIS turn
+            # (sorrel/buffers.py:143-154 with idx advanced by their adds).  The "rows" layout has them in the ring by then (every window is
+            # rendered into its replay row at the start of the turn and repaired there); the "tensor" layout copies them at the end of the turn
+            self.capture_error = ValueError("agents that share a frame-stacking ring need capture_layout = 'rows' (windows written into the ring as the turn goes)")
+            return None
         buffers = [v[0] for v in sharers.values()]
 
         def rings():
@@ -1501,8 +1505,10 @@ class CapturedTurn:
             mem._deferred, mem._deferred_adds = True, 0
         for mem, slots in self._stacked:
             # Buffer.current_state (frame stacks, n_frames > 1): gathered by the device's row count into a fixed tensor
-            out = torch.zeros((mem.n_frames - 1,) + tuple(mem.states.shape[1:]), dtype=mem.states.dtype, device=mem.device)
-            mem._prev_rows = (lambda a=slots[0], k=mem.n_frames - 1, out=out: eng.turn_prev_rows(a, k, out))
+            # (agents that share the ring: the j-th of them to ask in a turn stands at row idx + j -- its own slot's row count on the device)
+            outs = [torch.zeros((mem.n_frames - 1,) + tuple(mem.states.shape[1:]), dtype=mem.states.dtype, device=mem.device) for _ in slots]
+            mem._prev_rows = (lambda mem=mem, slots=slots, k=mem.n_frames - 1, outs=outs:
+                              eng.turn_prev_rows(slots[mem._deferred_adds % len(slots)], k, outs[mem._deferred_adds % len(slots)]))
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(torch.cuda.current_stream(eng.device))
         with torch.cuda.stream(side):

@@ -673,11 +673,12 @@ def test_captured_turn_with_frame_stacks(torch_cuda):
     eng = b._engine
     with pytest.raises(ValueError):
         eng.turn_prev_rows(0, 6, torch.empty((6, E, my.states.shape[2]), device="cuda:0"))      # more rows than the ring has
-    # agents that SHARE a frame-stacking ring: not recorded
+    # agents that SHARE a frame-stacking ring: recorded only where the windows reach the ring as the turn goes (test_gpu_round5.py)
     c = make_env(12, 13, 3, 2, E, p=0.05, seed=4, model_factory=Stacked)
     for ag in c.agents[1:]:
         ag.model.memory = c.agents[0].model.memory
-    assert c.capture_turn() is None
+    c.capture_layout = "tensor"
+    assert c.capture_turn() is None and "rows" in str(c.capture_error)
     c.take_turn()
 
 

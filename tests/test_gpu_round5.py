@@ -538,6 +538,62 @@ def test_recorded_turn_at_16384_envs_vs_the_oracle(torch_cuda, layout, agents):
     b.raise_on_status()
 
 
+def test_recorded_turn_of_agents_that_share_a_frame_stacking_ring(torch_cuda):
+    """Round-4 review, "missing" 5: agents that share ONE ring with ``n_frames = 3`` (sorrel/buffers.py:143-154: agent k's stack is the last
+    two rows of the shared ring, i.e. the windows agents k-1 and k-2 acted on this very turn) were refused by capture_turn().  In the "rows"
+    layout every window sits in its replay row from the start of the turn, so the gather by the device's row count (sgw_turn_prev_rows of
+    the asking agent's own slot) finds them: 26 replayed turns over a 7-row ring (the turn's three rows wrap in most turns), a reset with
+    add_empty, equal the eager loop in every replay row."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E, A = 21, 3
+    rings = []
+
+    class Stacked(BaseModel):
+        n_frames = 3
+
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=0, num_envs=E, device="cuda:0")
+            n = int(np.prod(input_size))
+            if len(rings) % A == 0:
+                rings.append(Buffer(capacity=7, obs_shape=(n,), n_frames=3, num_envs=E, device="cuda:0"))
+            else:
+                rings.append(rings[-1])
+            self.memory = rings[-1]
+            self.weight = torch.randn((3 * n, action_space), generator=torch.Generator().manual_seed(len(rings) % A)).cuda()
+
+        def take_action(self, state):
+            assert state.shape[1] == self.weight.shape[0]
+            return (state @ self.weight).argmax(dim=1)
+
+    a, b = (make_env(12, 13, A, 2, E, p=0.05, seed=4, model_factory=Stacked) for _ in range(2))
+    assert a.agents[0].model.memory is a.agents[2].model.memory is not b.agents[0].model.memory
+    cap = b.capture_turn(warmup=2)
+    assert cap is not None, getattr(b, "capture_error", None)
+    for _ in range(2):
+        a.take_turn()
+    for t in range(26):
+        if t == 15:
+            for env in (a, b):
+                env.reset()
+                env.agents[0].model.memory.add_empty()
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.rewards, b.rewards), t
+        mx, my = a.agents[0].model.memory, b.agents[0].model.memory
+        assert (mx.idx, mx.size) == (my.idx, my.size), t
+        for name in ("states", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(mx, name), getattr(my, name)), (t, name)
+    assert cap.turns_replayed == 26 and float(a.world.total_reward.abs().sum()) > 0
+    b.raise_on_status()
+
+
 def test_capture_turn_declines_where_a_replay_would_be_slower(torch_cuda):
     """Few agents, hundreds of MB of windows per turn: the second copy of every window costs more than the host time a replay saves (32x32 /
     8 agents at 65 536 envs: 610 us recorded, 500 eager) -- capture_turn() keeps the eager loop and says why; force=True records."""

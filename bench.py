@@ -337,9 +337,10 @@ def recorded_turn_bench(dev, envs: int = 1024, turns: int = 400):
 
         return Linear
 
-    def run(values, capture):
+    def run(values, capture, generic=False):
         cfg = make_config(32, 32, 8, 3, spawn_prob=0.005)
         env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=envs, device=dev, seed=0), cfg, model_factory=factory(values))
+        env.fast_policy_loop = not generic
         if capture and env.capture_turn() is None:
             raise RuntimeError(f"not recordable: {getattr(env, 'capture_error', None)!r}")
         for _ in range(50 - (2 if capture else 0)):      # (capture_turn played two real turns before it recorded: the same count either way)
@@ -365,12 +366,82 @@ def recorded_turn_bench(dev, envs: int = 1024, turns: int = 400):
            "unit": "us per take_turn (wall)", "turns": turns}
     try:
         out["eager_loop"], eager_state = run(False, False)
+        out["eager_generic_loop"], generic_state = run(False, False, generic=True)
         out["recorded"], recorded_state = run(False, True)
         out["recorded_action_values"], _ = run(True, True)
         out["recorded_equals_eager"] = recorded_state == eager_state      # (digest of grid, positions, totals, step outputs and all replay rings)
-        out["what"] = ("eager_loop: Python drives sweep, windows and per agent policy + sgw_act; recorded: the same turn as ONE graph replay "
-                       "(27 dependent launches); recorded_action_values: the act launch takes argmax / explores itself (19 launches)")
+        out["generic_equals_eager"] = generic_state == eager_state
+        out["what"] = ("eager_loop: Python drives sweep, windows and per agent policy + sgw_act (Environment.fast_policy_loop: agents with the "
+                       "standard hooks); eager_generic_loop: the same through Agent.transition's hooks (round 4's loop); recorded: the same turn as "
+                       "ONE graph replay (27 dependent launches); recorded_action_values: the act launch takes argmax / explores itself (19 launches)")
     except Exception as exc:      # (reported, never fatal for the line)
+        out["error"] = repr(exc)[:300]
+    return out
+
+
+def many_agents_turn_bench(dev, envs: int = 2048, turns: int = 60):
+    """Config 5's shape (128x128 grid x 2 layers, 64 agents, 11x11 windows: BASELINE.json's configs[4]) through the Python API with
+    ONE linear policy and ONE replay ring shared by every agent: the eager agent-after-agent loop against ``Environment.speculate_turns``
+    (every policy evaluated in one batch on the pre-move windows, ``sgw_turn_resolve`` finds whose window an earlier mover changed, those
+    are evaluated again until nothing changes: the sequential turn, bit for bit).  Wall us per take_turn; not part of `value`."""
+    import hashlib
+    import time
+
+    import torch
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.examples.treasurehunt.entities import EmptyEntity
+    from sorrel_amd.examples.treasurehunt.env import TreasurehuntEnv
+    from sorrel_amd.examples.treasurehunt.main import make_config
+    from sorrel_amd.examples.treasurehunt.world import TreasurehuntWorld
+    from sorrel_amd.models import BaseModel
+
+    h, w, a, r, _envs, p_spawn, _dense = CONFIGS["c5"]
+
+    def run(speculate):
+        one = []
+
+        class Shared(BaseModel):
+            def __init__(self, input_size, action_space):
+                super().__init__(input_size, action_space, memory_size=0, num_envs=envs, device=dev)
+                self.memory = Buffer(capacity=4 * a, obs_shape=tuple(input_size), num_envs=envs, device=dev)
+                self.w = torch.randn(int(input_size[0]), action_space, generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+
+            def take_action(self, state):
+                return (state.reshape(state.shape[0], -1) @ self.w).argmax(dim=1)
+
+        def factory(input_size, action_space):
+            if not one:
+                one.append(Shared(input_size, action_space))
+            return one[0]
+
+        cfg = make_config(h, w, a, r, spawn_prob=p_spawn)
+        env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=envs, device=dev, seed=0), cfg, model_factory=factory)
+        env.speculate_turns = speculate
+        for _ in range(12):
+            env.take_turn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(turns):
+            env.take_turn()
+        torch.cuda.synchronize(dev)
+        us = (time.perf_counter() - t0) / turns * 1e6
+        env.raise_on_status()
+        d = hashlib.sha256()
+        mem = one[0].memory
+        for t in (env.world.grid, env.world.agent_pos, env.world.total_reward, env.rewards, env.actions, mem.actions, mem.rewards):
+            d.update(t.cpu().numpy().tobytes())
+        passes = getattr(env, "speculation_passes", None)
+        del env, one
+        torch.cuda.empty_cache()
+        return us, d.hexdigest()[:16], passes
+
+    out = {"workload": f"{h}x{w} grid, {a} agents, {2 * r + 1}x{2 * r + 1} window, {envs} envs, ONE linear policy + one replay ring shared by all agents",
+           "unit": "us per take_turn (wall)", "turns": turns}
+    try:
+        out["eager_loop"], eager_state, _ = run(False)
+        out["speculative"], spec_state, out["passes_of_the_last_turn"] = run(True)
+        out["speculative_equals_eager"] = spec_state == eager_state       # (grid, positions, totals, step outputs, the ring's actions and rewards)
+    except Exception as exc:
         out["error"] = repr(exc)[:300]
     return out
 
@@ -750,6 +821,13 @@ def main() -> int:
                     "checked_vs_oracle_equal": (v.get("checked_vs_oracle") or {}).get("equal"), "kernel": v["kernel"].split(" group")[0]}
                 for k, v in out["configs"].items()}
             out["recorded_turn"] = recorded_turn_bench(dev)      # (the Python API at a host-bound batch: eager loop vs one graph replay per turn)
+            out["many_agents_turn"] = many_agents_turn_bench(dev)   # (config 5's shape: the eager loop vs the speculative turn)
+            # ... and, in brief, inside `roofline` like the side configs (wall us per Environment.take_turn through the Python API)
+            rt, ma = out["recorded_turn"], out["many_agents_turn"]
+            out["roofline"]["side_configs"]["policy_turns_us"] = {
+                "c3_shape_1024_envs": {k: rt.get(k) for k in ("eager_loop", "eager_generic_loop", "recorded", "recorded_action_values",
+                                                               "recorded_equals_eager", "generic_equals_eager", "error") if k in rt},
+                "c5_shape_2048_envs": {k: ma.get(k) for k in ("eager_loop", "speculative", "passes_of_the_last_turn", "speculative_equals_eager", "error") if k in ma}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], played = cpu_baseline(spec, args.config, args.cpu_seconds)
             if valid_line and not args.no_self_check:

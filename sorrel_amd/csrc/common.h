@@ -115,7 +115,6 @@ struct Params {
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int big_stage;    // step_big: bytes of LDS observation staging per wave (0: windows go straight to HBM, a dword store per lane and channel)
     int big_stage_off; // ... and where the first wave's area starts (behind the grid image)
-    int big_rot;      // step_big: 1 = every env starts its round of windows at another agent (A/B option big_rot)
     // step_big<..., WALK>: the envs behind every workgroup's static share are handed out through a counter in device memory
     // (whichever workgroup is free takes the next one: the XCDs of a chip do not run at the same speed)
     uint32_t* walk_ctr;   // the counter (0 between launches: the workgroup that takes the last number resets it)

@@ -16,37 +16,27 @@ struct Options {
     std::string jit_cache_dir;   // "" = <directory of libsgw.so>/jit_cache
     std::string jit_refuse;      // test hook: an instance whose template-id contains this text is refused as if it did not compile ("" = none)
     int burst = 0;            // wave-per-env kernels with a compile-time shape: 0 auto, 1 whole-env burst whenever legal, 2 chunked (STAGE) always
-    // ---- which prebuilt instance (A/B and test hooks of rounds 2-3; all default to "the rule decides")
-    int static_radius = 0;    // packed kernel: 0 auto, 1 run-time-shape instances, 2 compile-time radius on a run-time map
+    // ---- which prebuilt instance
     int pack3 = 1;            // 3-bit packed counters for one-hot tables of <= 10 channels
-    int static_cleanup = 1;   // the Cleanup-as-shipped compile-time instance
-    int rgb16 = 1;            // integer RGB tables on the byte-staging pipeline
     // ---- which kernel family
     int force_generic = 0;    // the LDS-resident generic kernel for everything
     int fast_rules = 1;       // layered rule sets on the wave-per-env RULES kernel
-    int rules_8k = 1;         // ... up to 8 KiB per env
     int rules_11k = 0;        // ... up to 11 KiB whatever the batch (default: from 16 384 envs on)
     int fast_8k = -1;         // plain / Tag worlds of 4-11 KiB per env on the wave-per-env kernel: -1 by batch size, 0 never, 1 always
     int resolve_diag = 0;     // sgw_turn_resolve timing aid (resolve.h: ResolveArgs::diag)
     int force_big = 0;        // 1: the workgroup-per-env kernel (step_big) whatever the world's size (A/B: small batches of small worlds)
-    int big_tag = 1;          // Tag worlds above 4 KiB on step_big<..., TAG>
     int group = 0;            // lanes per env of the packed kernel: 0 auto, 16 / 32 force a packing, 64 forbids it
     int phase_kernel = -1;    // the byte-gather phase kernel: -1 worlds above 4 KiB, 0 never, 1 every plain-move world
     int phase_rows = 1;       // the row-load phase kernels (phase_rows / observe_rows)
     // ---- staging and occupancy
     int stage = 1;            // LDS staging of one-hot observations on the wave-per-env kernels
-    int stage_bytes = -1;     // staging budget per wave (-1 auto)
     int stage_agents = -1;    // agents per staged burst (-1 auto)
     int fast_wg_per_cu = 0;   // workgroup-per-CU cap of the wave-per-env kernels' large float32 writes (0 auto)
     int big_threads = 0;      // step_big workgroup: 0 auto, 256, 512
     int big_stage = -1;       // step_big window staging: -1 by batch size, 0 never, 1 always
-    int big_pad = 1;          // step_big padded LDS rows
-    int big_walk_stage = 0;   // ... 1: the walking variant stages its windows too (line-aligned 16-byte stores) (A/B)
-    int big_rot = 0;          // step_big: every env starts its round of windows at another agent
     int big_wg_per_cu = 0;    // step_big workgroups per CU: 0 = what the code object admits, 1..3 = capped through the LDS request (A/B)
     int big_walk = 1;         // step_big<..., WALK>
     int big_walk_blocks = 0;  // ... this many workgroups whatever the batch (0 auto)
-    int big_walk_static = 0;  // ... 1: every env assigned statically (blockIdx + k * gridDim), as in rounds 2-3 (A/B)
     int big_walk_share = 0;   // ... envs per workgroup assigned statically before the shared counter takes over (0 auto)
     // ---- live (also settable on an engine after sgw_create)
     int rows_mode = 0;        // sgw_observe_rows emit: 0 auto, 1 single floats, 2 float2 runs where legal, 3 aligned float4 runs
@@ -66,34 +56,24 @@ const OptKey kOptKeys[] = {
     {"jit_verbose", &Options::jit_verbose, 0, 1, true},
     {"jit_own_rtc", &Options::jit_own_rtc, 0, 1, false},
     {"burst", &Options::burst, 0, 2, false},
-    {"static_radius", &Options::static_radius, 0, 2, false},
     {"pack3", &Options::pack3, 0, 1, false},
-    {"static_cleanup", &Options::static_cleanup, 0, 1, false},
-    {"rgb16", &Options::rgb16, 0, 1, false},
     {"force_generic", &Options::force_generic, 0, 1, false},
     {"fast_rules", &Options::fast_rules, 0, 1, false},
-    {"rules_8k", &Options::rules_8k, 0, 1, false},
     {"rules_11k", &Options::rules_11k, 0, 1, false},
     {"fast_8k", &Options::fast_8k, -1, 1, false},
     {"force_big", &Options::force_big, 0, 1, false},
     {"resolve_diag", &Options::resolve_diag, 0, 7, true},
-    {"big_tag", &Options::big_tag, 0, 1, false},
     {"group", &Options::group, 0, 64, false},
     {"phase_kernel", &Options::phase_kernel, -1, 1, false},
     {"phase_rows", &Options::phase_rows, 0, 1, false},
     {"stage", &Options::stage, 0, 1, false},
-    {"stage_bytes", &Options::stage_bytes, -1, 1 << 20, false},
     {"stage_agents", &Options::stage_agents, -1, SGW_MAX_AGENTS, false},
     {"fast_wg_per_cu", &Options::fast_wg_per_cu, 0, 8, false},
     {"big_threads", &Options::big_threads, 0, 512, false},
     {"big_stage", &Options::big_stage, -1, 1, false},
-    {"big_pad", &Options::big_pad, 0, 1, false},
     {"big_wg_per_cu", &Options::big_wg_per_cu, 0, 8, false},
-    {"big_rot", &Options::big_rot, 0, 1, false},
-    {"big_walk_stage", &Options::big_walk_stage, 0, 1, false},
     {"big_walk", &Options::big_walk, 0, 1, false},
     {"big_walk_blocks", &Options::big_walk_blocks, 0, 1 << 20, false},
-    {"big_walk_static", &Options::big_walk_static, 0, 1, false},
     {"big_walk_share", &Options::big_walk_share, 0, 1 << 20, false},
     {"rows_mode", &Options::rows_mode, 0, 3, true},
     {"act_lanes", &Options::act_lanes, 0, 16, true},

@@ -332,8 +332,6 @@ const void* pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W
 #undef PICK_SK1
 
 const void* pick_step(const Options& o, int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
-    if (o.static_radius == 1) r = -1;          // A/B hook: the run-time-shape instances
-    if (o.static_radius == 2) H = W = -1;      // ... static radius but run-time world size
     if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, multi, name);
     if (group == 32) return pick_step_g<32>(onehot, L, C, rule, r, H, W, multi, name);
     if (group == 64) return pick_step_g<64>(onehot, L, C, rule, r, H, W, multi, name);
@@ -429,7 +427,7 @@ const void* pick_fast(const Options& o, bool onehot, bool rgb16, int L, int C, i
     if (rules) {
         // one-hot tables of <= 10 channels: 3-bit packed counters (ONE table word per cell and layer instead of ceil(C / 4))
         const bool p3 = onehot && C <= 10 && L <= 7 && o.pack3;
-        if (p3 && L == 3 && C == 9 && stage && r == 5 && H == 21 && W == 31 && o.static_cleanup)
+        if (p3 && L == 3 && C == 9 && stage && r == 5 && H == 21 && W == 31)
             PICK(step_fast<true, 3, 9, 5, 21, 31, false, true, true, false, true>);   // Cleanup as shipped (21x31x3 map, 11x11 windows)
         if (p3 && stage) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, true, false, true>);
         if (p3) PICK(step_fast<true, 0, 0, 0, 0, 0, false, true, false, false, true>);
@@ -569,7 +567,6 @@ int plan_engine(sgw_engine* e, bool jit) {
             const double v = c.appearance[t][k];
             if (!(v >= 0.0 && v <= 9362.0 && v == std::floor(v))) rgb16 = false;
         }
-    if (!o.rgb16) rgb16 = false;   // A/B and test hook: the float64 path
     if (rgb16) {
         for (int t = 0; t < c.num_types; ++t)
             for (int k = 0; k < c.num_channels; ++k) h.delta16[k >> 1][t] |= (uint32_t)c.appearance[t][k] << (16 * (k & 1));
@@ -674,7 +671,7 @@ int plan_engine(sgw_engine* e, bool jit) {
     // (Cleanup 56x64x3 at 4 096 / 16 384 / 65 536 envs 97 / 394 / 1 499 us on the generic kernel, 107 / 308 / 1 229 here)
     const int rules_units = (c.num_envs >= 16384 || o.rules_11k) ? kMaxUnitsPlain : kMaxUnitsRules;
     bool rules_8k = !simple_rules && !tagk && vec16 && p.cells_pad > 4096 && (p.cells_pad >> 4) <= 64 * rules_units && p.VV <= 128;
-    if (!o.rules_8k || !o.fast_rules || o.force_generic) rules_8k = false;
+    if (!o.fast_rules || o.force_generic) rules_8k = false;
     // Plain and Tag worlds between 4 and 8 KiB per env: a LARGE batch of them also runs a wave per env (step_big spends a 512-thread
     // workgroup and three barriers on an env; per env that is about twice the time of the wave-per-env kernel, which pays only when the
     // batch is too small to fill the chip with waves).  tools/mid_world_probe.py, us per turn at 2 048 / 4 096 / 8 192 / 65 536 envs,
@@ -707,7 +704,6 @@ int plan_engine(sgw_engine* e, bool jit) {
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
     const bool tag_move = tagk;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
     e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && (plain_move || tag_move) && simple_rules;
-    if (!o.big_tag && tag_move) e->big = false;   // A/B and test hook: the ticket-ordered generic kernel
     e->big_threads = kBigThreads;
     if (e->big) e->big_threads = big_threads_for(o, onehot, c.num_agents, p.VV);
     bool stage_kernel = false;   // a STAGE kernel (bursts of agents) applies
@@ -722,7 +718,7 @@ int plan_engine(sgw_engine* e, bool jit) {
         const size_t per_wave = (size_t)e->fast_tab_bytes + p.cells_pad + ((ob_elems + 15) & ~15);
         fixed_shape = o.burst == 1 || per_wave * 4 + 1024 <= kLdsPerCu / 6;
     }
-    if (jit && (o.burst == 2 || o.stage_agents >= 0 || o.stage_bytes >= 0)) fixed_shape = false;   // (a forced burst size asks for the chunked emit)
+    if (jit && (o.burst == 2 || o.stage_agents >= 0)) fixed_shape = false;   // (a forced burst size asks for the chunked emit)
     {   // LDS staging of one-hot observations
         const int per_agent = c.num_channels * p.VV;
         e->obs_stage = 0;
@@ -738,14 +734,13 @@ int plan_engine(sgw_engine* e, bool jit) {
             // kernels -- Cleanup 21x31x3 at 65 536 envs, agents per burst 1 / 2 / 3 / 4 / 5 / 10: 666 / 695 / 643-680 / 640 / 643 / 850 us
             // (16 384 envs: 201 / 193 / 185-190 / 188 / 181 / 240).
             // instances with a run-time channel count write their planes in groups of four: up to three planes of slack behind a chunk
-            const bool static_channels = jit || (e->fast_rules ? (c.layers == 3 && c.num_channels == 9 && c.vision_radius == 5 && c.height == 21 && c.width == 31 && o.static_cleanup && o.pack3)
+            const bool static_channels = jit || (e->fast_rules ? (c.layers == 3 && c.num_channels == 9 && c.vision_radius == 5 && c.height == 21 && c.width == 31 && o.pack3)
                                                                  : (!tagk && c.layers == 2 && c.num_channels == 6));
             const int slack = 48 + (static_channels ? 0 : 3 * p.VV);
             int budget = e->fast_rules ? (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack : (int)(kLdsPerCu / 8 / 4) - base - slack;
             for (int wg = 4; (e->fast_rules || fast_8k) && budget < per_agent && wg >= 2; --wg)      // big envs: fewer workgroups per CU until a window fits
                 budget = (int)((kLdsPerCu / wg - 1024) / 4) - base - slack;
             if (budget < per_agent) budget = (int)((kLdsPerCu / 5 - 1024) / 4) - base - slack;
-            if (o.stage_bytes >= 0) budget = o.stage_bytes;                 // A/B hook
             int apc = budget >= per_agent ? std::min(c.num_agents, budget / per_agent) : 0;
             if (o.stage_agents >= 0) apc = std::min(c.num_agents, o.stage_agents);   // A/B hook
             if (apc > 0) {
@@ -835,7 +830,6 @@ int plan_engine(sgw_engine* e, bool jit) {
         const size_t plain_img = (size_t)p.cells_pad, padded_img = (size_t)c.layers * c.height * (c.width + 16);
         const bool can_pad = (c.width & 15) == 0 && (p.cells & 15) == 0;
         if (can_pad && per_cu(fixed + padded_img + stage_all) >= per_cu(fixed + plain_img + stage_all)) p.big_pitch = c.width + 16;
-        if (!o.big_pad) p.big_pitch = c.width;   // A/B hook
         e->step_lds_bytes = fixed + (p.big_pitch == c.width ? plain_img : padded_img);
         p.big_stage = p.big_stage_off = 0;
         if (e->big_stage) {
@@ -1321,17 +1315,15 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // step_big: the walking variant keeps the direct stores (measured faster there), and so does a launch whose observation
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
     const bool walk = e->big && p.nturns == 1 && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
-    p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && (walk ? e->opt.big_walk_stage != 0 : p.E > e->big_stage_min_envs)) ? e->big_stage : 0;
+    p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
     if (walk) {     // the walking workgroups: a static share each, the rest off a counter (step_big.h)
         p.walk_ctr = reinterpret_cast<uint32_t*>(e->d_status) + 1;
         p.walk_static = e->opt.big_walk_share > 0 ? e->opt.big_walk_share : (int)std::max<int64_t>(1, p.E / e->walk_blocks);
-        if (e->opt.big_walk_static) p.walk_static = 1 << 30;           // A/B hook: the purely static split of rounds 2-3
     }
     if (e->big && p.nturns > 1 && e->big_threads != kBigThreads) p.big_stage = 0;   // (the rollout instance runs kBigThreads: the staging area is sized for this engine's waves)
     if (e->big && e->big_stage && !p.big_stage) lds -= (size_t)(e->big_threads / 64) * e->big_stage;
     if (walk) { p.walk_word = (int)lds; lds += 16; }   // (behind the grid image: the walking variant has no staging area there)
     lds = big_cap_lds(e, lds);
-    p.big_rot = e->big ? e->opt.big_rot : 0;
     // A policy-driven phase (at most one agent moves, at most one window is rendered, no sweep, plain moves) of a one-hot
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     // (the phase kernels take the acting agent's action from the tensor: a phase whose action is drawn on the device -- SGW_STEP_RANDOM_ACTIONS,

@@ -467,12 +467,9 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
         const int zsh = 8 * (p.zA & 3), zw = p.zA >> 2;
         // SGW_STEP_OBS_NEXT: only agent a1, which sees the grid after ALL moves of this call (nothing to undo)
         const int r_lo = p.obs_next ? p.a1 : p.a0, r_hi = p.obs_next ? (p.a1 < p.A ? p.a1 + 1 : p.a1) : p.a1;
-        // (option big_rot: each env starts its round of windows at another agent, so that the workgroups that started together do not
-        // all write window k of their env at the same moment -- addresses a fixed stride apart)
-        const int n_r = r_hi - r_lo;
-        const int rot = (p.big_rot && n_r > 0) ? (int)(((uint32_t)env * 11u) % (uint32_t)n_r) : 0;
-        for (int ia = wv; ia < n_r; ia += kBW) {
-            const int a = r_lo + (ia + rot >= n_r ? ia + rot - n_r : ia + rot);
+        // (Starting each env's round of windows at another agent -- so that workgroups that started together do not all write window k of
+        // their env at the same moment, addresses a fixed stride apart -- was measured in round 5: no change)
+        for (int a = r_lo + wv; a < r_hi; a += kBW) {
             const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oa[a]);
             const int y = (int)(pk & 0xFFu), x = (int)((pk >> 8) & 0xFFu);
             const int cbase = y * P + x;

@@ -392,7 +392,12 @@ def test_bench_line_carries_side_configs_cold_start_and_the_oracle_self_check(bu
         assert "step_" in c["kernel"], name
     assert line["configs"]["c3_524288"]["envs"] == 524288 and line["configs"]["c5"]["envs"] == 2048
     side = line["roofline"]["side_configs"]            # the same, in brief, inside `roofline` (what the driver's record keeps)
-    assert set(side) == {"c2", "c5", "c3_524288"}
+    assert set(side) == {"c2", "c5", "c3_524288", "policy_turns_us"}
+    turns = side.pop("policy_turns_us")              # wall time of Environment.take_turn through the Python API, and that every variant ends in the same state
+    small, many = turns["c3_shape_1024_envs"], turns["c5_shape_2048_envs"]
+    assert "error" not in small and "error" not in many, (small, many)
+    assert small["recorded_equals_eager"] is True and small["generic_equals_eager"] is True and many["speculative_equals_eager"] is True
+    assert 0 < small["recorded"] < small["eager_loop"] < 1.1 * small["eager_generic_loop"] and 0 < many["speculative"] < many["eager_loop"]
     for name, c in side.items():
         assert c["kernel_ms"] == line["configs"][name]["kernel_ms"] and c["frac"] == line["configs"][name]["roofline"]["frac"]
     assert side["c2"]["checked_vs_oracle_equal"] is True and side["c5"]["checked_vs_oracle_equal"] is True

@@ -20,7 +20,7 @@ us = timed_us(lambda: eng.step(random_actions=True), 100)
 print("RESULT %%7.1f us  %%s  %%s" %% (us, dig, eng.launch_info().split(" threads")[0] + " " + " ".join(x for x in eng.launch_info().split() if x.startswith(("lds=", "big_stage=")))))
 ''' % (ROOT, ROOT)
 shapes = [(128, 128, 64, 5, 2048), (128, 128, 64, 5, 4096), (128, 128, 64, 5, 8192), (48, 48, 8, 5, 16384), (72, 72, 16, 5, 8192)]
-variants = [{}, {"SGW_OPTIONS": "big_stage=0"}, {"SGW_OPTIONS": "big_pad=0"}]
+variants = [{}, {"SGW_OPTIONS": "big_stage=0"}]       # (the unpadded-rows variant, option big_pad, was retired in round 5)
 if os.environ.get("PROBE_WALK"):   # where does the walking variant pay?
     shapes = [(128, 128, 64, 5, e) for e in (1024, 1280, 1536, 2048, 2560, 3072, 4096)]
     variants = [{}, {"SGW_OPTIONS": "big_walk=0"}, {"SGW_OPTIONS": "big_walk=0,big_stage=0"}]

@@ -85,7 +85,7 @@ print("box:", rd("/proc/sys/kernel/hostname"), "| card:", (subprocess.run("rocm-
 opts = {"jit": 0} if STAMPS else {}
 measure("walking workgroups, dynamic tail (default)", dict(opts))
 measure("walking workgroups, first env static, rest dynamic", dict(opts, big_walk_share=1))
-measure("walking workgroups, static split", dict(opts, big_walk_static=1))
+measure("walking workgroups, static split", dict(opts, big_walk_share=1 << 20))
 measure("1 024 walking workgroups, all dynamic", dict(opts, big_walk_share=1, big_walk_blocks=1024))
 eng = measure("one env per workgroup", dict(opts, big_walk=0))
 if STAMPS:

@@ -24,7 +24,6 @@ from sorrel_amd.spec import treasurehunt_spec
 VARIANTS = [
     ("default dispatch", {}),
     ("walking", dict(big_walk_blocks=-1)),                       # (filled in below: whatever the batch)
-    ("walking, staged", dict(big_walk_blocks=-1, big_walk_stage=1)),
     ("plain direct, 4/CU", dict(big_walk=0, big_stage=0)),
     ("plain direct, 3/CU", dict(big_walk=0, big_stage=0, big_wg_per_cu=3)),
     ("plain staged, 4/CU", dict(big_walk=0, big_stage=1)),

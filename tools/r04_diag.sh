@@ -18,7 +18,7 @@ if [ "$PART" = "c2" ]; then
   timeout -k 10 700 bash tools/pmc_pass.sh r04_c2 "--config c2" "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" > $OUT/r04_c2_pmc.txt 2>&1 || exit 1
 elif [ "$PART" = "c5" ]; then
   (hostname; rocm-smi --showserial --showuniqueid 2>/dev/null | grep -i -E "serial|unique" | head -4) > $OUT/r04_c5_modes.txt 2>&1
-  for v in "" "big_walk_static=1" "big_walk=0" "big_walk=0;big_stage=1"; do
+  for v in "" "big_walk_share=1048576" "big_walk=0" "big_walk=0;big_stage=1"; do
     echo "== options: ${v:-default (walking workgroups at 2 048 envs)}" >> $OUT/r04_c5_modes.txt
     SGW_OPTIONS="$v" timeout -k 10 200 python3 -c "
 import sys; sys.path.insert(0, '$REPO'); sys.path.insert(0, '$REPO/tools')

@@ -1,5 +1,7 @@
 """Round 5, GPU: agents that differ in their observation / action specs (one engine handle per distinct pair over the same world
 tensors) against the reference-generated fixture and the oracle; step_big at eight waves per SIMD."""
+import os
+
 import numpy as np
 import pytest
 
@@ -280,23 +282,15 @@ SPEC_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", SPEC_CASES, ids=[c[0] for c in SPEC_CASES])
-def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
-    """sgw_turn_resolve through the C ABI: sweep, every pre-move window, one batched policy evaluation, then resolve / re-evaluate the
-    dirty rows until nobody is dirty.  Against the C oracle's agent-after-agent turn: (1) stepping the actions the speculation ended
-    on gives the engine's grid, positions, rewards and totals; (2) the window each agent had when ITS turn came (the oracle's
-    observation) is the row its action was computed on, and the policy of that window is that action -- i.e. the fixed point IS the
-    sequential policy-driven turn.  Also: committed envs are skipped, passes stay far below A, every env ends done."""
-    torch = torch_cuda
+def _speculative_vs_oracle(torch, name, ws, E, T, first=0, epoch=0, seed=11):
+    """The body of the two tests below; returns the largest number of passes a turn needed."""
     from sorrel_amd import _native as N
     from tests.test_gpu_parity import make_engine
 
-    name, mk, E, T = case
-    ws = mk()
     A, nact = ws.num_agents, len(ws.action_dy)
-    eng = make_engine(ws, E)
+    eng = make_engine(ws, E, first=first)
     assert eng.capabilities() & N.CAP_RESOLVE
-    co = H.COracle(ws, E, first_env_id=0)
+    co = H.COracle(ws, E, first_env_id=first)
     if name == "float_tables_3layer":           # (a world populated by the fixture: every env starts from its grid)
         d, _ = H.load_golden("float_appearance_3layer")
         g0, p0 = d["grid0"][0], d["pos0"][0]
@@ -305,11 +299,12 @@ def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
         eng.total_reward.zero_()
         co.grid[...], co.pos[...], co.total[...] = g0, p0, 0
     else:
-        eng.reset(0)
-        co.reset(0)
+        eng.reset(epoch)
+        co.reset(epoch)
+    eng.epoch = epoch
     rows = eng.speculation_rows()
     Nw = rows.shape[2]
-    gen = torch.Generator().manual_seed(11)
+    gen = torch.Generator().manual_seed(seed)
     Wt = torch.randn((A, Nw, nact), generator=gen).cuda()
 
     def policy(x, agents):                      # a linear layer per agent + argmax: a pure function of the window
@@ -340,7 +335,7 @@ def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
         assert bool(eng._spec_state[0].view(-1)[:E].all()), "every env committed"
         assert torch.equal(eng.actions, taken.t().to(torch.uint8)), "the actions tensor holds what the policies ended on"
         acts = taken.t().contiguous().cpu().numpy().astype(np.uint8)
-        assert co.step(0, t, actions=acts) == 0
+        assert co.step(epoch, t, actions=acts) == 0
         for key, mine, ref in (("grid", eng.grid, co.grid), ("pos", eng.agent_pos, co.pos), ("rewards", eng.rewards, co.rewards),
                                ("total", eng.total_reward, co.total)):
             assert np.array_equal(mine.cpu().numpy(), ref), f"{name} turn {t}: {key}"
@@ -348,7 +343,41 @@ def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
         assert torch.equal(seen, rows), f"{name} turn {t}: the rows are the windows at pov time"
         assert torch.equal(policy(seen.view(A * E, Nw), agent_of_row).view(A, E), taken), f"{name} turn {t}: every action is the policy of that window"
     assert eng.status() == 0
+    return most
+
+
+@pytest.mark.parametrize("case", SPEC_CASES, ids=[c[0] for c in SPEC_CASES])
+def test_speculative_turn_reaches_the_sequential_turn(torch_cuda, case):
+    """sgw_turn_resolve through the C ABI: sweep, every pre-move window, one batched policy evaluation, then resolve / re-evaluate the
+    dirty rows until nobody is dirty.  Against the C oracle's agent-after-agent turn: (1) stepping the actions the speculation ended
+    on gives the engine's grid, positions, rewards and totals; (2) the window each agent had when ITS turn came (the oracle's
+    observation) is the row its action was computed on, and the policy of that window is that action -- i.e. the fixed point IS the
+    sequential policy-driven turn.  Also: committed envs are skipped, passes stay far below A, every env ends done."""
+    name, mk, E, T = case
+    most = _speculative_vs_oracle(torch_cuda, name, mk(), E, T)
     assert most <= (5 if name != "crowded_6x6" else 7), most
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "24"))))
+def test_speculative_turn_soak_random_worlds(torch_cuda, case):
+    """The same check on random Treasurehunt-like worlds: maps from 5x5 to 90x90 (wave-per-env and workgroup-per-env step kernels; the
+    resolve kernel with one wave and with four per env from 16 agents on), 1 ... 64 agents, radii 1 ... 6, sparse to crowded, random
+    batch sizes, global env ids and epochs; every eighth case has more than 8 192 envs (dirty list by scan)."""
+    from sorrel_amd.spec import treasurehunt_spec
+
+    rng = np.random.default_rng(77000 + case)
+    h, w = int(rng.integers(5, 91)), int(rng.integers(5, 91))
+    if case % 8 == 7:
+        h, w = int(rng.integers(5, 20)), int(rng.integers(5, 20))
+    free = (h - 2) * (w - 2)
+    a = int(min(rng.integers(1, 65), max(1, free // 3)))
+    r = min(int(rng.integers(1, 5 if case % 8 == 7 else 7)), (min(h, w) - 1) // 2)      # (visual_field's own limit)
+    ws = treasurehunt_spec(h, w, a, r, spawn_prob=float(rng.choice([0.0, 0.01, 0.1, 0.5])), seed=int(rng.integers(0, 2**31)),
+                           dense_prob=float(rng.choice([0.0, 0.2, 0.6])), gem_value=int(rng.integers(1, 20)), bone_value=-int(rng.integers(1, 20)))
+    E = int(rng.integers(8193, 9000)) if case % 8 == 7 else int(rng.integers(1, 70))
+    T = 2 if case % 8 == 7 else int(rng.integers(2, 7))
+    _speculative_vs_oracle(torch_cuda, f"soak {case} ({h}x{w}, {a} agents, r {r}, {E} envs)", ws, E, T, first=int(rng.integers(0, 2**31)),
+                           epoch=int(rng.integers(0, 9)), seed=case)
 
 
 def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):
@@ -499,6 +528,96 @@ def test_fast_policy_loop_equals_the_generic_transition_loop(torch_cuda, case):
             assert torch.equal(getattr(ma, name), getattr(mb, name)), (a, name)
     generic.raise_on_status()
     quick.raise_on_status()
+
+
+_LOOPS_SEEN = {"cases": 0, "speculative": 0, "recorded": 0, "fast": 0}
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("SGW_SOAK", "16")) // 2))
+def test_environment_turn_loops_soak(torch_cuda, case):
+    """Random Treasurehunt environments through the Python API, policy-driven, four ways: the generic Agent.transition loop, the fast
+    loop, the speculative turn (where the agents share few enough models) and a recorded turn -- same seeds, same policies: every world
+    tensor, step output and replay row equal after a few turns, a reset and a few more."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    rng = np.random.default_rng(52000 + case)
+    h, w = int(rng.integers(7, 70)), int(rng.integers(7, 70))
+    A = int(min(rng.integers(1, 25), max(1, (h - 2) * (w - 2) // 4)))
+    r = min(int(rng.integers(1, 6)), (min(h, w) - 1) // 2)
+    E = int(rng.integers(1, 50))
+    n_models = int(rng.choice([1, 1, 2, A]))                      # agents per model: all share one, two groups, or a model each
+    n_models = max(1, min(n_models, A))
+    cap = int(rng.integers(A, 4 * A + 3))                          # (a shared ring takes A rows per turn: wraps mid-turn unless a multiple)
+    p, seed, T = float(rng.choice([0.0, 0.02, 0.2])), int(rng.integers(0, 2**31)), int(rng.integers(3, 8))
+
+    class Linear(BaseModel):
+        def __init__(self, input_size, action_space, k):
+            super().__init__(input_size, action_space, memory_size=0, num_envs=E, device="cuda:0")
+            self.memory = Buffer(capacity=cap, obs_shape=tuple(input_size), num_envs=E, device="cuda:0")
+            g = torch.Generator().manual_seed(1000 * case + k)
+            self.weight = torch.randn((int(np.prod(input_size)), action_space), generator=g).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.weight).argmax(dim=1)
+
+    def build(mode):
+        models, made = [], []
+
+        def factory(input_size, action_space):
+            k = len(made) * n_models // A
+            made.append(k)
+            if k >= len(models):
+                models.append(Linear(input_size, action_space, k))
+            return models[k]
+
+        env = make_env(h, w, A, r, E, p=p, seed=seed % 1000, model_factory=factory)
+        env.fast_policy_loop = mode != "generic"
+        env.speculate_turns = mode == "speculative"
+        if mode == "recorded":
+            env.capture_turn(warmup=1)                             # (may decline: the eager loop then plays, which is as good a check)
+        return env
+
+    envs = {mode: build(mode) for mode in ("generic", "fast", "speculative", "recorded")}
+    envs["generic"].take_turn()
+    envs["fast"].take_turn()
+    envs["speculative"].take_turn()
+    if envs["recorded"]._captured is None:
+        envs["recorded"].take_turn()
+    for t in range(2 * T):
+        for env in envs.values():
+            if t == T:
+                env.reset()
+            env.take_turn()
+    torch.cuda.synchronize()
+    ref = envs["generic"]
+    ctx = f"case {case}: {h}x{w}, {A} agents on {n_models} models, r {r}, {E} envs, ring of {cap}"
+    _LOOPS_SEEN["cases"] += 1
+    _LOOPS_SEEN["speculative"] += int(getattr(envs["speculative"], "speculation_passes", 0) > 0)
+    _LOOPS_SEEN["recorded"] += int(envs["recorded"]._captured is not None and envs["recorded"]._captured.turns_replayed > 0)
+    _LOOPS_SEEN["fast"] += int(envs["fast"]._fast_plan(envs["fast"]._engine) is not None)
+    for mode, env in envs.items():
+        if mode == "generic":
+            continue
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(ref.world, name), getattr(env.world, name)), (ctx, mode, name)
+        assert torch.equal(ref.rewards, env.rewards) and torch.equal(ref.actions, env.actions), (ctx, mode)
+        for a in range(A):
+            ma, mb = ref.agents[a].model.memory, env.agents[a].model.memory
+            assert (ma.idx, ma.size) == (mb.idx, mb.size), (ctx, mode, a)
+            for name in ("states", "actions", "rewards", "dones"):
+                assert torch.equal(getattr(ma, name), getattr(mb, name)), (ctx, mode, a, name)
+        env.raise_on_status()
+
+
+def test_environment_turn_loops_soak_reached_every_loop():
+    """... and the soak above did run what it names (a case whose agents have a model each keeps the sequential turn; a capture may decline)."""
+    seen = _LOOPS_SEEN
+    if seen["cases"] < 8:
+        pytest.skip("the soak did not run in this session")
+    assert seen["fast"] == seen["cases"] and seen["speculative"] >= seen["cases"] // 4 and seen["recorded"] >= seen["cases"] // 2, seen
 
 
 # ------------------------------------------------------------------ recorded turns at a batch where the kernels change form

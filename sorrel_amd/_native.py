@@ -17,7 +17,7 @@ AGENT_RULE_MOVE, AGENT_RULE_TAG, AGENT_RULE_CLEANUP = 0, 1, 2
 ACTION_MOVE, ACTION_CLEAN, ACTION_ZAP = 0, 1, 2
 OBS_F32, OBS_U8 = 0, 1
 STATUS_OOB_MOVE, STATUS_BAD_ACTION, STATUS_BAD_TYPE, STATUS_BAD_POS = 1, 2, 4, 8
-CAP_OBSERVE_ROWS, CAP_ACT, CAP_RESOLVE, CAP_OBS_AGENT_MAJOR = 1, 2, 4, 8
+CAP_OBSERVE_ROWS, CAP_ACT, CAP_RESOLVE, CAP_OBS_AGENT_MAJOR, CAP_SWEEP_ROWS = 1, 2, 4, 8, 16
 ACT_U8, ACT_I32, ACT_I64, ACT_QF32 = 0, 1, 2, 3
 TAIL_NONE, TAIL_AGENT_IS_IT, TAIL_POSITION_TABLE = 0, 1, 2
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
@@ -109,7 +109,7 @@ EXPORTS = (
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
     "sgw_set_option", "sgw_plan", "sgw_jit_stats", "sgw_jit_compile", "sgw_bind_row_tail",
-    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state", "sgw_turn_begin_rows", "sgw_turn_act_rows", "sgw_turn_epsilon", "sgw_turn_prev_rows", "sgw_turn_resolve", "sgw_gather_rows",
+    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state", "sgw_turn_begin_rows", "sgw_turn_act_rows", "sgw_turn_epsilon", "sgw_turn_prev_rows", "sgw_turn_resolve", "sgw_gather_rows", "sgw_sweep_observe_rows",
     "sgw_last_error", "sgw_version",
 )
 
@@ -199,6 +199,8 @@ def load():
     lib.sgw_capabilities.restype = C.c_int
     lib.sgw_observe_rows.argtypes = [vp, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, vp]
     lib.sgw_observe_rows.restype = C.c_int
+    lib.sgw_sweep_observe_rows.argtypes = [vp, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    lib.sgw_sweep_observe_rows.restype = C.c_int
     lib.sgw_act.argtypes = [vp, u8p, u8p, u8p, C.POINTER(C.c_void_p), C.c_int64, f32p, f64p, C.c_int32, vp, C.c_int32, vp, vp, vp]
     lib.sgw_act.restype = C.c_int
     lib.sgw_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]

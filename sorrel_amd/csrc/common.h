@@ -54,6 +54,21 @@ struct TurnState {
     uint64_t eps_thr[SGW_MAX_AGENTS];     // SGW_ACT_QF32: explore when u32 < eps_thr (floor(epsilon * 2^32): 2^32 = always)
 };
 
+// per-agent window destinations (sgw_observe_rows / sgw_act): agent a's window of env e starts at p[a] + e * stride elements
+struct RowPtrs {
+    void* p[SGW_MAX_AGENTS];
+    int64_t stride;
+    // sgw_act only: where the acting agent's action comes from and where else its outputs go (all optional)
+    const void* agent_action;   // [E] of the agent's own actions (the policy's output tensor as it is); NULL: actions[E][A]
+    int action_kind;            // SGW_ACT_U8 / _I32 / _I64 / _QF32 (agent_action: [E][nact] action values)
+    float* reward_row;          // [E]: a second copy of the rewards (the row of the agent's replay buffer)
+    int64_t* action_row;        // [E]: the actions as int64 (the row of the agent's replay buffer)
+    const TurnState* ts;        // sgw_turn_act: reward_row / action_row are the acting agent's ring rows of the turn the engine has counted up to
+    const TurnState* ets;       // SGW_ACT_QF32: where the exploration reads epsilon, epoch and turn (= ts under the turn protocol)
+    int dual;                   // sgw_turn_*_rows: every window (and every repair) is ALSO written to the agent's ring row of the turn in flight
+    int rows_mode2;             // ... how those second copies leave (kRowsFlat where the rings allow it, else kRowsRun)
+};
+
 struct Params {
     int H, W, L, A, r, V, VV, C, T, nact, zA;
     int cells;      // L*H*W bytes of one env's grid

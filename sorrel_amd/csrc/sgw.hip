@@ -141,6 +141,7 @@ struct sgw_engine {
     Kernel k_walk;        // step_big<..., WALK>: resident workgroups walking the batch
     Kernel k_rows;        // phase_rows<L, NW, R>: a policy-driven phase with a lane per window row (one-hot, plain moves)
     Kernel k_obs_rows;    // observe_rows<L, NW, R>: a range of agents, per-agent destinations
+    Kernel k_sweep_rows;  // step_fast_rows<L, C, R, H, W>: the sweep + every agent's window into per-agent destinations, one launch
     int walk_blocks = 0;                            // how many workgroups of the walking kernel the chip holds at once
     int64_t walk_min_envs = 0, walk_max_envs = 0;  // batches above min and up to max take it (multiples of what the plain kernel holds at once)
     int64_t big_stage_min_envs = 0;                // step_big stages its windows for batches above this
@@ -467,6 +468,9 @@ std::string join_args(const char* tmpl, std::vector<std::string> a, size_t keep,
     return s + ">";
 }
 const char* tf(bool b) { return b ? "true" : "false"; }
+std::string fast_rows_id(int L, int C, int r, int H, int W) {
+    return "step_fast_rows<" + std::to_string(L) + ", " + std::to_string(C) + ", " + std::to_string(r) + ", " + std::to_string(H) + ", " + std::to_string(W) + ">";
+}
 std::string fast_id(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, bool multi, bool p3, bool i16) {
     return join_args("step_fast", {tf(onehot), std::to_string(L), std::to_string(C), std::to_string(r), std::to_string(H), std::to_string(W),
                                    tf(tag), tf(rules), tf(stage), tf(multi), tf(p3), tf(i16)}, 6, "false");
@@ -519,7 +523,7 @@ int plan_engine(sgw_engine* e, bool jit) {
     const sgw_config& c = e->cfg;
     const Options& o = e->opt;
     e->jit = jit;
-    e->k_step = e->k_plain = e->k_multi = e->k_walk = e->k_rows = e->k_obs_rows = Kernel();
+    e->k_step = e->k_plain = e->k_multi = e->k_walk = e->k_rows = e->k_obs_rows = e->k_sweep_rows = Kernel();
     e->stage_agents = 0;
     e->walk_blocks = 0;
     e->walk_min_envs = e->walk_max_envs = e->big_stage_min_envs = 0;
@@ -864,6 +868,14 @@ int plan_engine(sgw_engine* e, bool jit) {
         } else if (e->whole_env_burst) {
             e->k_plain = Kernel();
         }
+        // the policy turn's first launch into per-agent rows (sgw_sweep_observe_rows): plain movers whose env leaves as one burst
+        if (e->whole_env_burst && static_map && !tagk && !e->fast_rules && ((C * (2 * r + 1) * (2 * r + 1)) & 1) == 0) {
+            if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) {
+                e->k_sweep_rows.host = reinterpret_cast<const void*>(&step_fast_rows<2, 6, 3, 32, 32>);
+                e->k_sweep_rows.host_name = "step_fast_rows<2, 6, 3, 32, 32>";
+            }
+            if (jit) e->k_sweep_rows.want = fast_rows_id(L, C, r, H, W);
+        }
     } else if (e->big) {
         e->k_step.host = pick_big(e->onehot, L, C, r, tag_move, e->big_threads, &e->k_step.host_name);
         if (!tag_move) e->k_multi.host = pick_big_multi(e->onehot, L, C, r, &e->k_multi.host_name);
@@ -883,7 +895,7 @@ int plan_engine(sgw_engine* e, bool jit) {
         }
     }
     if (!o.big_walk) e->k_walk = Kernel();   // A/B hook
-    for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk})
+    for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk, &e->k_sweep_rows})
         if (k->host && k->want == k->host_name) k->want.clear();   // the library already holds exactly this instance
     e->multi_turn = e->k_multi.usable();   // kernels with sgw_rollout's turn loop
     e->reset_fn = pick_reset(e->wpe);
@@ -1171,7 +1183,7 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         if (int rc = plan_engine(e, jit)) { delete e; return rc; }
         if (!jit) break;
         bool ok = true;
-        for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk, &e->k_rows, &e->k_obs_rows}) {
+        for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk, &e->k_rows, &e->k_obs_rows, &e->k_sweep_rows}) {
             if (k->want.empty()) continue;
             std::string err;
             k->tried = true;
@@ -1296,7 +1308,7 @@ static size_t big_cap_lds(const sgw_engine* e, size_t lds) {
     return (want > lds && want <= 65536) ? want : lds;
 }
 
-static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
+static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_rows = nullptr) {
     p.agent_state = e->agent_state;
     p.state_at_pov = e->state_at_pov;
     p.agent_dir = e->agent_dir;
@@ -1309,6 +1321,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     p.env_lds = e->step_env_lds;
     if (e->fast || e->big) p.tab_bytes = e->big ? e->big_tab_bytes : e->fast_tab_bytes;
     p.obs_stage = (e->fast && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) ? e->obs_stage : 0;
+    if (sweep_rows) p.obs_stage = e->obs_stage;   // (step_fast_rows: the staged windows leave per agent, whatever `obs` is)
     if (p.spawn_mask == 0 && !p.has_become) p.flags &= ~SGW_STEP_SWEEP;   // nothing transitions
     int cap = 0;
     size_t lds = step_lds_request(e, p, &cap);
@@ -1328,6 +1341,10 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s) {
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     // (the phase kernels take the acting agent's action from the tensor: a phase whose action is drawn on the device -- SGW_STEP_RANDOM_ACTIONS,
     // an agent with a RandomModel among agents that step one by one -- stays on the step kernel, which draws it)
+    if (sweep_rows) {
+        if (int rc = launch_kernel(e, e->k_sweep_rows, (unsigned)e->grid_blocks, kBlock, lds, s, p, sweep_rows)) return rc;
+        return time_end(e, s);
+    }
     const bool one_phase = p.nturns == 1 && !(p.flags & (SGW_STEP_SWEEP | SGW_STEP_RANDOM_ACTIONS)) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
     if (e->k_rows.usable() && one_phase && !p.obs_u8) {
         // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
@@ -1499,6 +1516,7 @@ int sgw_capabilities(sgw_engine* e) {
         if (ok) caps |= SGW_CAP_RESOLVE;
     }
     if (e->big) caps |= SGW_CAP_OBS_AGENT_MAJOR;
+    if (e->k_sweep_rows.usable() && e->obs_format == SGW_OBS_F32 && e->tail_kind == SGW_TAIL_NONE) caps |= SGW_CAP_SWEEP_ROWS;
     return caps;
 }
 
@@ -1571,6 +1589,25 @@ static int observe_rows_impl(sgw_engine* e, const uint8_t* grid, const uint8_t* 
 int sgw_observe_rows(sgw_engine* e, const uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,
                      int32_t agent_begin, int32_t agent_end, void* stream) {
     return observe_rows_impl(e, grid, agent_pos, rows, env_stride, agent_begin, agent_end, nullptr, stream);
+}
+
+int sgw_sweep_observe_rows(sgw_engine* e, uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride, uint32_t epoch,
+                           uint32_t turn, uint32_t flags, void* stream) {
+    if (!e || !grid || !agent_pos) return fail(SGW_EINVAL, "sgw_sweep_observe_rows: NULL argument");
+    if (!(sgw_capabilities(e) & SGW_CAP_SWEEP_ROWS))
+        return fail(SGW_EINVAL, "sgw_sweep_observe_rows: no fused instance for this world (see sgw_capabilities: SGW_CAP_SWEEP_ROWS) -- "
+                                "sgw_step(sweep only) + sgw_observe_rows do the same in two launches");
+    if (flags & ~(uint32_t)SGW_STEP_SWEEP) return fail(SGW_EINVAL, "sgw_sweep_observe_rows: flags may hold SGW_STEP_SWEEP only");
+    if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
+    const int A = e->cfg.num_agents;
+    if (env_stride != (int64_t)e->base.C * e->base.VV) return fail(SGW_EINVAL, "sgw_sweep_observe_rows: env_stride must be exactly one window (C * V * V elements)");
+    RowPtrs rp;
+    if (int rc = fill_rows(e, rows, env_stride, 0, A, true, &rp, "sgw_sweep_observe_rows")) return rc;
+    Params p = e->base;
+    p.grid = grid; p.pos = const_cast<uint8_t*>(agent_pos);
+    p.actions = nullptr; p.obs = nullptr; p.rewards = nullptr; p.total = nullptr;
+    p.epoch = epoch; p.turn = turn; p.a0 = 0; p.a1 = A; p.flags = flags & SGW_STEP_SWEEP; p.do_move = 0;
+    return launch_step(e, p, static_cast<hipStream_t>(stream), &rp);
 }
 
 static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,

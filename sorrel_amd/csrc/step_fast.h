@@ -1,4 +1,3 @@
-// step_fast.h -- part of the single translation unit sgw.hip (included inside its anonymous namespace).
 // step_fast<...>: a wave per env, worlds <= 4 KiB (the headline kernel and its STAGE / TAG / RULES / MULTI variants).
 #pragma once
 
@@ -116,8 +115,12 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // its uint8 colours): the window pipeline of the one-hot path with 16-bit counters -- the layer sum of a cell is an integer, the clip
 // makes it a byte, the byte is staged, and the burst turns it into (float)(k / 255.0) through a 256-entry table of exactly those
 // floats (DevTables::post_lut, one copy per workgroup in LDS) instead of a float64 sum, clip and DIVISION per cell and channel.
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false, bool P3 = false, bool I16 = false>
-__global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (STAGE ? 7 : SGW_FAST_RULES_PLAIN_WAVES) : 8)) void step_fast(const Params p) {
+// ROWS (round 5): the instance behind sgw_sweep_observe_rows -- the sweep and EVERY agent's window in one launch, each window going to
+// its agent's own destination (rp->p[a] + env * rp->stride: the row of that agent's replay buffer) instead of the [E][A][C][V][V] tensor.
+// Only the emit differs (see there); compiled for compile-time shapes with the whole-env burst.
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS>
+__device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]] const RowPtrs* rp) {
+    static_assert(!ROWS || (ONEHOT && TL && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
     // wave-private LDS (grid slice + the table words this wave reads), no s_barrier.
@@ -713,7 +716,32 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
             gsync<1>();
             const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
-            if (!p.obs_u8) {
+            if constexpr (ROWS) {
+                // Agent a's C * V * V staged bytes -> floats at rp->p[a] + env * rp->stride.  Streaming stores as below, 8 bytes per lane (a
+                // window of an odd env of config 3 starts 8 bytes off a 16-byte boundary; 16-byte stores with two single floats in front
+                // or behind were measured: 123.2 us against 121.2 for these at 65 536 envs), lane 0 of every store on a 128-byte line
+                // (mis = float2s between the line and the window's first element).
+                typedef float vfloat2 __attribute__((ext_vector_type(2)));
+                const int N = C * VV;
+                for (int a = 0; a < p.A; ++a) {
+                    float* dst = static_cast<float*>(rp->p[a]) + env * rp->stride;
+                    const uint8_t* src = ob + a * N;
+                    const uintptr_t ad = reinterpret_cast<uintptr_t>(dst);
+                    if ((N & 1) == 0 && (ad & 7u) == 0) {
+                        const int mis = (int)((ad >> 3) & 15u);
+                        for (int i = lane - mis; i < (N >> 1); i += 64) {
+                            if (i < 0) continue;
+                            const uint32_t b = *reinterpret_cast<const uint16_t*>(src + 2 * i);   // (a * N is even)
+                            vfloat2 v;
+                            v.x = (float)(b & 0xFFu);
+                            v.y = (float)(b >> 8);
+                            __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(dst) + i);
+                        }
+                    } else {
+                        for (int i = lane; i < N; i += 64) __builtin_nontemporal_store((float)src[i], dst + i);
+                    }
+                }
+            } else if (!p.obs_u8) {
                 // Non-temporal (streaming) stores: every wave instruction here writes eight whole 128-byte lines that
                 // nothing reads again in this launch; keeping them out of the caches leaves those to the grids (134 MB,
                 // re-read next turn) and takes config 3 from 167 to 125-132 us.  (The same hint on the per-agent dword
@@ -792,3 +820,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     }
 }
 
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool RULES = false, bool STAGE = false, bool MULTI = false, bool P3 = false, bool I16 = false>
+__global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (STAGE ? 7 : SGW_FAST_RULES_PLAIN_WAVES) : 8)) void step_fast(const Params p) {
+    step_fast_body<ONEHOT, TL, TC, TR, TH, TW, TAG, RULES, STAGE, MULTI, P3, I16, false>(p, nullptr);
+}
+
+// sweep + every agent's window into per-agent rows (sgw_sweep_observe_rows): nobody acts in this launch
+template <int TL, int TC, int TR, int TH, int TW>
+__global__ __launch_bounds__(kBlock, 8) void step_fast_rows(const Params p, const RowPtrs rp) {
+    step_fast_body<true, TL, TC, TR, TH, TW, false, false, false, false, false, false, true>(p, &rp);
+}

@@ -238,6 +238,15 @@ class GridEngine:
             arr[a] = self._check_window(t, f"dests[{a}]", self.row_tail).data_ptr()
         return arr, per_env + self.row_tail, list(dests)
 
+    def sweep_observe_rows(self, rows, sweep: bool = True, turn: Optional[int] = None):
+        """Steps 1 and 2 of a policy-driven turn in ONE launch (``sgw_sweep_observe_rows``, ``CAP_SWEEP_ROWS``): the entity sweep, then every
+        agent's window of the swept grid into its own destination (``rows`` from ``window_rows``, exactly one window per env and row)."""
+        arr, stride, _ = rows
+        turn = self.turn if turn is None else turn
+        with self._on_device():
+            N.check(self._lib.sgw_sweep_observe_rows(self._h, self._ptr(self.grid), self._ptr(self.agent_pos), arr, stride, self.epoch, turn,
+                                                     N.STEP_SWEEP if sweep else 0, self._stream()))
+
     def observe_rows(self, rows, agent_begin: int = 0, agent_end: Optional[int] = None):
         """Every agent's window, once, into its own destination (``rows`` from ``window_rows``): step 2 of a policy-driven
         turn.  Needs ``CAP_OBSERVE_ROWS``; otherwise ``observe()`` into the observation tensor does the same job."""
@@ -463,19 +472,28 @@ class GridEngine:
             N.check(self._lib.sgw_gather_rows(flat.data_ptr(), ne, idx.data_ptr(), n, buf.data_ptr(), self._stream()))
         return buf[:n]
 
-    def speculation_windows(self, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def speculation_windows(self, rows: Optional[torch.Tensor] = None, sweep_turn: Optional[int] = None) -> torch.Tensor:
         """Every agent's PRE-move window into ``speculation_rows(rows)``: ``sgw_observe_rows`` where the engine has a row kernel for the
-        world (one-hot tables), else ``sgw_turn_resolve``'s render mode (any table)."""
+        world (one-hot tables), else ``sgw_turn_resolve``'s render mode (any table).  ``sweep_turn``: the entity sweep of that turn runs
+        first -- in the same launch where the engine has ``CAP_SWEEP_ROWS``."""
         rows = self.speculation_rows(rows)
-        if self.capabilities() & N.CAP_OBSERVE_ROWS and not self.row_tail:
+        caps = self.capabilities()
+        if caps & N.CAP_OBSERVE_ROWS and not self.row_tail:
             key = rows.data_ptr()
             wr = self._spec_cache.get(key)
             if wr is None:
                 if len(self._spec_cache) > 64:
                     self._spec_cache.clear()
                 wr = self._spec_cache[key] = self.window_rows([rows[a] for a in range(self.spec.num_agents)])
+            if sweep_turn is not None and caps & N.CAP_SWEEP_ROWS:
+                self.sweep_observe_rows(wr, sweep=True, turn=sweep_turn)
+                return rows
+            if sweep_turn is not None:
+                self.step(self.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=sweep_turn)
             self.observe_rows(wr)
         else:
+            if sweep_turn is not None:
+                self.step(self.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=sweep_turn)
             self.turn_resolve(0, rows)
         return rows
 

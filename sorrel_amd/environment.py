@@ -525,8 +525,7 @@ class Environment:
         if eng.capabilities() & N.CAP_OBS_AGENT_MAJOR:                   # (worlds above 4 KiB) the sweep AND every agent's PRE-move window in ONE launch
             eng.step(eng.actions, sweep=True, no_move=True, turn=self.turn, obs_out=rows, agent_major=True)
         else:
-            eng.step(eng.actions, sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)    # the sweep alone
-            eng.speculation_windows(own)                                 # every agent's PRE-move window, once
+            eng.speculation_windows(own, sweep_turn=self.turn)           # the sweep, then every agent's PRE-move window, once (one launch with CAP_SWEEP_ROWS)
 
         def choose(model, x):
             out = model.take_action(x)
@@ -659,6 +658,10 @@ class Environment:
             return t
         return t.view((g.num_envs,) + tuple(g.spec.obs_shape[1:]))
 
+    #: where the engine has the instance (``CAP_SWEEP_ROWS``), the sweep and every agent's window into its replay row are ONE launch
+    #: (``sgw_sweep_observe_rows``); False = the sweep alone + ``sgw_observe_rows`` (A/B and tests)
+    fuse_sweep_and_rows = True
+
     #: agents with the standard hooks (``Agent.speculative_ok``: pov = the flattened window, get_action = ``model.take_action``) and replay
     #: memories whose rows hold exactly one window are stepped by a loop that does per agent what ``Agent.transition`` does -- the model's
     #: forward pass, one ``sgw_act`` with pointers worked out once per turn, the ring's bookkeeping -- without the generic hooks' checks in
@@ -699,7 +702,9 @@ class Environment:
                 self._tail_rows = [torch.zeros((eng.num_envs, per_env), dtype=torch.float32, device=eng.device) for _ in self.agents]
             dests = self._tail_rows
         rows = eng.window_rows(dests)
-        if dests is not None:                   # the sweep alone, then every window into its agent's replay row
+        if dests is not None and self.fuse_sweep_and_rows and not eng.row_tail and caps & N.CAP_SWEEP_ROWS:
+            eng.sweep_observe_rows(rows, sweep=True, turn=self.turn)      # both in one launch (the grid read once, a burst per env)
+        elif dests is not None:                 # the sweep alone, then every window into its agent's replay row
             eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
             eng.observe_rows(rows)
         else:                                   # the windows live in the observation tensor: sweep + all of them in ONE launch
@@ -1408,6 +1413,8 @@ class _FastPolicyTurn:
         self.views = {}                               # (id(states), row) -> the [E, N] view the policy reads
         self.lib = eng._lib
         self.kinds = eng._ACTION_KINDS
+        from sorrel_amd import _native as N
+        self.fused = bool(eng.capabilities() & N.CAP_SWEEP_ROWS)
 
     def still_valid(self) -> bool:
         return not any(mem._deferred for _a, _m, mem, _k in self.agents)
@@ -1421,8 +1428,11 @@ class _FastPolicyTurn:
             i = (mem.idx + k) % mem.capacity
             rows_i.append(i)
             self.arr[a] = mem.states.data_ptr() + i * row_bytes
-        eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=env.turn)      # the sweep alone
-        eng.observe_rows(self.rows)                                                         # every agent's window into its replay row
+        if self.fused and env.fuse_sweep_and_rows:
+            eng.sweep_observe_rows(self.rows, sweep=True, turn=env.turn)                        # the sweep + every agent's window into its replay row
+        else:
+            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=env.turn)  # the sweep alone
+            eng.observe_rows(self.rows)                                                     # every agent's window into its replay row
         h, stream = eng._h, eng._stream()
         grid, pos, acts, rew, tot = eng.grid.data_ptr(), eng.agent_pos.data_ptr(), eng.actions.data_ptr(), eng.rewards.data_ptr(), eng.total_reward.data_ptr()
         dev = eng.device

@@ -28,7 +28,7 @@ def test_flag_constants_match_the_header():
     """The ctypes binding's flag / rule constants are the header's macros (the header is the interface)."""
     text = open(HEADER).read()
     macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(SGW_[A-Z_0-9]+)\s+(\d+)u?\b", text)}
-    for name in ("STEP_SWEEP", "STEP_RANDOM_ACTIONS", "STEP_NO_OBS", "STEP_OBS_NEXT", "STEP_OBS_NEXT_PACKED", "STEP_NO_MOVE", "STEP_OBS_AGENT_MAJOR", "CAP_OBSERVE_ROWS", "CAP_ACT", "CAP_RESOLVE", "CAP_OBS_AGENT_MAJOR"):
+    for name in ("STEP_SWEEP", "STEP_RANDOM_ACTIONS", "STEP_NO_OBS", "STEP_OBS_NEXT", "STEP_OBS_NEXT_PACKED", "STEP_NO_MOVE", "STEP_OBS_AGENT_MAJOR", "CAP_OBSERVE_ROWS", "CAP_ACT", "CAP_RESOLVE", "CAP_OBS_AGENT_MAJOR", "CAP_SWEEP_ROWS"):
         assert getattr(N, name) == macros["SGW_" + name], name
     flags = [macros[k] for k in macros if k.startswith("SGW_STEP_") and k != "SGW_STEP_DEFAULT"]
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)      # distinct single bits

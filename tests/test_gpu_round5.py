@@ -764,3 +764,89 @@ def test_agent_major_windows_in_one_launch_and_gather_rows(torch_cuda):
     assert not (small.capabilities() & N.CAP_OBS_AGENT_MAJOR)
     with pytest.raises(ValueError):
         small.step(random_actions=True, obs_out=small.speculation_rows(), agent_major=True)
+
+
+SWEEP_ROWS_CASES = [
+    ("c3_prebuilt_instance", (32, 32, 8, 3), 67, {"jit": 0}),
+    ("c3_specialised", (32, 32, 8, 3), 67, {}),
+    ("c2_shape", (16, 16, 4, 2), 33, {}),
+    ("ragged_26x23_r2", (26, 23, 6, 2), 41, {}),
+    ("30x30_r4_two_agents", (30, 30, 2, 4), 29, {}),
+    ("24x40_r3_twelve_agents", (24, 40, 12, 3), 130, {}),
+]
+
+
+@pytest.mark.parametrize("case", SWEEP_ROWS_CASES, ids=[c[0] for c in SWEEP_ROWS_CASES])
+def test_sweep_and_every_window_into_rows_in_one_launch(torch_cuda, case):
+    """sgw_sweep_observe_rows (SGW_CAP_SWEEP_ROWS) = sgw_step(sweep only) + sgw_observe_rows = the C oracle's sweep followed by every agent's
+    window: the grid after the sweep and every row, bit for bit, over several turns with acts in between (destinations in separate
+    allocations, 8 bytes off a 16-byte boundary for odd envs, guard elements around them untouched)."""
+    torch = torch_cuda
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+    from tests.test_gpu_parity import make_engine
+
+    name, (h, w, A, r), E, opts = case
+    for k, v in opts.items():
+        N.set_option(k, v)
+    ws = treasurehunt_spec(h, w, A, r, spawn_prob=0.04, seed=21, dense_prob=0.15)
+    a, b = make_engine(ws, E), make_engine(ws, E)
+    N.reset_options()
+    co = H.COracle(ws, E, first_env_id=0)
+    assert a.capabilities() & N.CAP_SWEEP_ROWS, a.plan() if hasattr(a, "plan") else name
+    for e in (a, b):
+        e.reset(0)
+    co.reset(0)
+    Nw = int(np.prod(ws.obs_shape[1:]))
+    guard = 7
+    bufs_a = [torch.full((guard + E * Nw + guard,), -9.0, device="cuda:0") for _ in range(A)]
+    dest_a = [buf[guard:guard + E * Nw].view(E, Nw) for buf in bufs_a]
+    dest_b = [torch.full((E, Nw), -9.0, device="cuda:0") for _ in range(A)]
+    rows_a = (N_ptr_array(dest_a), Nw, dest_a)
+    rows_b = b.window_rows(dest_b)
+    gen = np.random.default_rng(5)
+    for t in range(1, 6):
+        a.sweep_observe_rows(rows_a, sweep=t != 3, turn=t)
+        b.step(sweep=t != 3, agent_begin=0, agent_end=0, write_obs=False, turn=t)
+        b.observe_rows(rows_b)
+        assert co.step(0, t, sweep=t != 3, write_obs=False, a0=0, a1=0) == 0
+        co.observe()
+        torch.cuda.synchronize()
+        assert np.array_equal(a.grid.cpu().numpy(), co.grid) and torch.equal(a.grid, b.grid), (name, t, "grid after the sweep")
+        for k in range(A):
+            assert torch.equal(dest_a[k], dest_b[k]), (name, t, k)
+            assert np.array_equal(dest_a[k].cpu().numpy(), co.obs[:, k].reshape(E, Nw)), (name, t, k, "oracle")
+            assert bool((bufs_a[k][:guard] == -9.0).all()) and bool((bufs_a[k][-guard:] == -9.0).all()), (name, t, k, "guards")
+        acts = gen.integers(0, 4, (E, A)).astype(np.uint8)          # the agents act (one whole-turn step without a sweep), then the next turn
+        ta = torch.from_numpy(acts).cuda()
+        for e in (a, b):
+            e.step(ta, sweep=False, write_obs=False, turn=t)
+        assert co.step(0, t, actions=acts, sweep=False, write_obs=False) == 0
+    assert a.status() == 0 and b.status() == 0
+    with pytest.raises(ValueError):                                   # rows of another size are refused, not written
+        a.sweep_observe_rows((rows_a[0], Nw + 2, None))
+
+
+def N_ptr_array(tensors):
+    import ctypes
+
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def test_engines_without_the_fused_instance_say_so(torch_cuda):
+    from sorrel_amd import _native as N
+    from sorrel_amd.spec import treasurehunt_spec
+    from tests.test_gpu_parity import make_engine
+
+    big = make_engine(treasurehunt_spec(72, 80, 6, 3), 5)                       # workgroup per env
+    odd = make_engine(treasurehunt_spec(20, 20, 3, 1), 5)                       # 6 * 9 = 54 elements per window: even, offered; 3 agents * 54 % 4 != 0: no whole-env burst
+    for eng in (big, odd):
+        if eng.capabilities() & N.CAP_SWEEP_ROWS:
+            continue
+        rows = eng.window_rows([torch_cuda.zeros((5, int(np.prod(eng.spec.obs_shape[1:]))), device="cuda:0") for _ in range(eng.spec.num_agents)])
+        with pytest.raises(ValueError):
+            eng.sweep_observe_rows(rows)
+    assert not (big.capabilities() & N.CAP_SWEEP_ROWS)

@@ -17,8 +17,8 @@ cfg = make_config(h, w, a, r, spawn_prob=0.005)
 env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0), cfg, model_factory=LB.policy_factory(E))
 turns = 2000 if E <= 4096 else 300
 for k in range(rounds):
-    for fast in (False, True):
-        env.fast_policy_loop = fast
+    for fast, fuse in ((False, False), (True, False), (True, True)):
+        env.fast_policy_loop, env.fuse_sweep_and_rows = fast, fuse
         us = LB.time_turns(env, turns)
         # host time alone: the same loop without waiting for the device at the end is what the host needs to issue a turn
         torch.cuda.synchronize()
@@ -27,5 +27,5 @@ for k in range(rounds):
             env.take_turn()
         issue = (time.perf_counter() - t0) / turns * 1e6
         torch.cuda.synchronize()
-        print(f"{h}x{w} A{a} r{r} E={E:6d} {'fast loop   ' if fast else 'generic loop'} {us:8.1f} us/turn   issued in {issue:8.1f} us/turn", flush=True)
+        print(f"{h}x{w} A{a} r{r} E={E:6d} {('fast loop, sweep + rows in one launch' if fuse else 'fast loop, two launches            ') if fast else 'generic loop, two launches         '} {us:8.1f} us/turn   issued in {issue:8.1f} us/turn", flush=True)
 env.raise_on_status()

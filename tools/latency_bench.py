@@ -65,6 +65,7 @@ def run(h, w, a, r, E, policy, spawn_prob=0.005):
     env.speculate_turns = policy in (6, 7)    # round 5: batched policy evaluation + sgw_turn_resolve (Environment.speculate_turns)
     env.write_obs_into_replay = os.environ.get("LAT_NO_DIRECT") != "1"      # A/B: windows through the observation tensor + a copy
     env.fast_policy_loop = os.environ.get("LAT_GENERIC_LOOP") != "1"        # A/B: the generic Agent.transition loop (round 4's)
+    env.fuse_sweep_and_rows = os.environ.get("LAT_NO_FUSE") != "1"           # A/B: the sweep alone + sgw_observe_rows (two launches)
     label = {0: "device-random (1 launch)", 1: "policy (1+A launches)", 2: "policy, captured turn", 3: "values -> act, eager", 4: "values -> act, captured",
              5: "shared policy, eager", 6: "shared policy, speculative", 7: "own policies, speculative"}[policy]
     if policy in (2, 4) and env.capture_turn() is None:                          # round 4: the whole turn recorded once, replayed

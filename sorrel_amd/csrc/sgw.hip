@@ -1758,6 +1758,17 @@ int sgw_turn_begin_rows(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_
     if (flags & ~(SGW_STEP_SWEEP)) return fail(SGW_EINVAL, "sgw_turn_begin_rows: only SGW_STEP_SWEEP may be set");
     if (!(sgw_capabilities(e) & SGW_CAP_OBSERVE_ROWS)) return fail(SGW_EINVAL, "sgw_turn_begin_rows needs SGW_CAP_OBSERVE_ROWS (one-hot float32 windows); use sgw_turn_begin");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((sgw_capabilities(e) & SGW_CAP_SWEEP_ROWS) && env_stride == (int64_t)e->base.C * e->base.VV) {   // both steps in one launch
+        RowPtrs rp;
+        if (int rc = fill_rows(e, rows, env_stride, 0, e->cfg.num_agents, true, &rp, "sgw_turn_begin_rows")) return rc;
+        rp.ts = e->d_turn;
+        rp.dual = e->turn_rows ? 1 : 0;
+        Params p = e->base;
+        p.grid = grid; p.pos = agent_pos; p.actions = nullptr; p.obs = nullptr; p.rewards = nullptr; p.total = nullptr;
+        p.ts = e->d_turn;
+        p.a0 = 0; p.a1 = e->cfg.num_agents; p.flags = flags & SGW_STEP_SWEEP; p.do_move = 0;
+        return launch_step(e, p, s, &rp);
+    }
     if (flags & SGW_STEP_SWEEP) {     // the entity sweep alone, at the device's turn
         Params p = e->base;
         p.grid = grid; p.pos = agent_pos; p.actions = actions; p.obs = nullptr; p.rewards = rewards; p.total = total_reward;

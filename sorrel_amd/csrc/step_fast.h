@@ -724,22 +724,28 @@ __device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]]
                 typedef float vfloat2 __attribute__((ext_vector_type(2)));
                 const int N = C * VV;
                 for (int a = 0; a < p.A; ++a) {
-                    float* dst = static_cast<float*>(rp->p[a]) + env * rp->stride;
                     const uint8_t* src = ob + a * N;
-                    const uintptr_t ad = reinterpret_cast<uintptr_t>(dst);
-                    if ((N & 1) == 0 && (ad & 7u) == 0) {
-                        const int mis = (int)((ad >> 3) & 15u);
-                        for (int i = lane - mis; i < (N >> 1); i += 64) {
-                            if (i < 0) continue;
-                            const uint32_t b = *reinterpret_cast<const uint16_t*>(src + 2 * i);   // (a * N is even)
-                            vfloat2 v;
-                            v.x = (float)(b & 0xFFu);
-                            v.y = (float)(b >> 8);
-                            __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(dst) + i);
+                    auto emit_to = [&](float* dst) {
+                        const uintptr_t ad = reinterpret_cast<uintptr_t>(dst);
+                        if ((N & 1) == 0 && (ad & 7u) == 0) {
+                            const int mis = (int)((ad >> 3) & 15u);
+                            for (int i = lane - mis; i < (N >> 1); i += 64) {
+                                if (i < 0) continue;
+                                const uint32_t b = *reinterpret_cast<const uint16_t*>(src + 2 * i);   // (a * N is even)
+                                vfloat2 v;
+                                v.x = (float)(b & 0xFFu);
+                                v.y = (float)(b >> 8);
+                                __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(dst) + i);
+                            }
+                        } else {
+                            for (int i = lane; i < N; i += 64) __builtin_nontemporal_store((float)src[i], dst + i);
                         }
-                    } else {
-                        for (int i = lane; i < N; i += 64) __builtin_nontemporal_store((float)src[i], dst + i);
-                    }
+                    };
+                    emit_to(static_cast<float*>(rp->p[a]) + env * rp->stride);
+                    // a recorded turn (sgw_turn_begin_rows): the window ALSO goes to the agent's replay row of the turn in flight, by the
+                    // engine's own row count
+                    if (rp->dual && rp->ts->cap[a] > 0 && rp->ts->states[a])
+                        emit_to(static_cast<float*>(rp->ts->states[a]) + (rp->ts->row[a] * p.E + env) * rp->ts->row_elems[a]);
                 }
             } else if (!p.obs_u8) {
                 // Non-temporal (streaming) stores: every wave instruction here writes eight whole 128-byte lines that

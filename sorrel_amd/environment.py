@@ -1415,6 +1415,7 @@ class _FastPolicyTurn:
         self.kinds = eng._ACTION_KINDS
         from sorrel_amd import _native as N
         self.fused = bool(eng.capabilities() & N.CAP_SWEEP_ROWS)
+        self.qf32, self.nact = N.ACT_QF32, eng.spec.num_actions
 
     def still_valid(self) -> bool:
         return not any(mem._deferred for _a, _m, mem, _k in self.agents)
@@ -1455,18 +1456,28 @@ class _FastPolicyTurn:
                     for later, _m, _mem, _k in self.agents[a + 1:]:
                         later.transition(world)
                     return
-                if not torch.is_tensor(action) or action.dim() == 2:      # a plain int, or action values (the act launch takes the argmax / explores):
-                    env._turn_windows = [edits, self.rows, a, slots]      # the generic act knows how
+                values = torch.is_tensor(action) and action.dim() == 2
+                if values and a in env._value_agents and action.dtype == torch.float32 and action.device == dev and action.is_contiguous() \
+                        and tuple(action.shape) == (E, self.nact):
+                    # action VALUES: the act launch takes the argmax / explores (SGW_ACT_QF32); the draws are keyed by the turn in flight
+                    if env._turn_state_at.get(id(eng)) != (env.epoch, env.turn):
+                        eng.turn_set(env.epoch, env.turn - 1)
+                        env._turn_state_at[id(eng)] = (env.epoch, env.turn)
+                    env._push_epsilon(eng, (a,))
+                    pa, kind = action.data_ptr(), self.qf32
+                elif not torch.is_tensor(action) or values:               # a plain int, or an agent's FIRST action values (or odd ones): the generic act
+                    env._turn_windows = [edits, self.rows, a, slots]      # knows how
                     reward = env._act(agent, action)
                     env._turn_windows = None
                     mem.add(state, eng.actions[:, a], reward, agent.is_done(world))
                     continue
-                kind = self.kinds.get(action.dtype)
-                if kind is None or action.device != dev or action.dim() != 1 or action.shape[0] != E or not action.is_contiguous():
-                    eng.actions[:, a].copy_(action)
-                    pa, kind = None, 0
                 else:
-                    pa = action.data_ptr()
+                    kind = self.kinds.get(action.dtype)
+                    if kind is None or action.device != dev or action.dim() != 1 or action.shape[0] != E or not action.is_contiguous():
+                        eng.actions[:, a].copy_(action)
+                        pa, kind = None, 0
+                    else:
+                        pa = action.data_ptr()
                 rc = self.lib.sgw_act(h, grid, pos, acts, self.arr, N_, rew, tot, a, pa, kind, mem.rewards.data_ptr() + i * E * 4,
                                       mem.actions.data_ptr() + i * E * 8, stream)
                 if rc:

@@ -297,6 +297,12 @@ def policy_turn_bench(eng, iters: int = 40):
         for a in range(A):
             eng.act(a, rows_own)
 
+    def replay_rows_fused():
+        eng.turn += 1
+        eng.sweep_observe_rows(rows_own, sweep=True, turn=eng.turn)
+        for a in range(A):
+            eng.act(a, rows_own)
+
     out = {"fused_turn_ms": timed(fused, 500), "policy_turn_ms": timed(tensor_windows, 400), "launches": 1 + A,
            "what": "policy_turn_ms: sgw_step(SGW_STEP_NO_MOVE) = sweep + every agent's window (into the observation tensor), then "
                    "sgw_act per agent; fused_turn_ms: the same engine's one-launch turn with given actions; the policy's own forward "
@@ -305,6 +311,9 @@ def policy_turn_bench(eng, iters: int = 40):
     if eng.capabilities() & N.CAP_OBSERVE_ROWS:
         out["policy_turn_replay_rows_ms"] = timed(replay_rows, 300)
         out["replay_rows_what"] = "windows rendered straight into per-agent [E][C*V*V] rows (what Environment.take_turn does when every agent has a replay Buffer): sweep, sgw_observe_rows, sgw_act per agent"
+    if eng.capabilities() & N.CAP_SWEEP_ROWS:
+        out["policy_turn_replay_rows_one_launch_ms"] = timed(replay_rows_fused, 300)
+        out["replay_rows_one_launch_what"] = "the same with sweep + every window in ONE launch (sgw_sweep_observe_rows, round 5): what Environment.take_turn does now"
     out["status"] = eng.status()
     return out
 

@@ -410,6 +410,7 @@ def test_bench_line_carries_side_configs_cold_start_and_the_oracle_self_check(bu
     pt = line["policy_turn"]                       # the policy-driven turn on the headline's engine
     assert pt["status"] == 0 and pt["launches"] == 9
     assert 0.0 < pt["fused_turn_ms"] < pt["policy_turn_ms"] < 3 * pt["fused_turn_ms"] and pt["policy_turn_replay_rows_ms"] > 0
+    assert 0.0 < pt["policy_turn_replay_rows_one_launch_ms"] < 1.05 * pt["policy_turn_replay_rows_ms"]
 
 
 ROLLOUT_CASES = [

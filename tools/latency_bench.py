@@ -34,8 +34,15 @@ def policy_factory(E, values=False):
 
 
 def time_turns(env, turns):
-    for _ in range(20):
+    # warm up by TIME: a chip that idled between two processes runs ~25 % slower for its first ~150 ms of work (32x32 / 8 agents at 65 536 envs:
+    # 560-600 us per turn over the first 300 turns of a process, 435-450 once warm) -- the same ramp bench.py's prewarm launches are for
+    t0 = time.perf_counter()
+    n = 0
+    while n < 20 or time.perf_counter() - t0 < float(os.environ.get("LAT_WARM_S", "0.5")):
         env.take_turn()
+        n += 1
+        if n % 50 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(turns):

@@ -31,4 +31,12 @@ if [ -f gpurun_out/r05_resolve_probe.txt ]; then
     echo; echo "== tools/spec_trace.sh: the kernels of the last turns (rocprofv3 --kernel-trace; 'gap' = idle time of the GPU before the kernel; the tracer slows the host)"
     tail -80 gpurun_out/r05_spec_trace.txt; } > profiles/r05_speculative_turn.txt
 fi
+if [ -f gpurun_out/r05_eager_turn.txt ]; then
+  { echo "== tools/fast_loop_ab.py: the eager policy turn through the Python API, ONE process per shape (same tensors), alternating: the generic"
+    echo "== Agent.transition loop, Environment.fast_policy_loop, and the latter with sweep + every window in one launch (sgw_sweep_observe_rows);"
+    echo "== then tools/sweep_rows_bench.py: that launch against the two it replaces, engine kernels only"
+    grep -v amdgpu.ids gpurun_out/r05_eager_turn.txt
+    echo; echo "== tools/eager_trace.sh 65536: device time of one eager turn by kernel (rocprofv3 --kernel-trace)"
+    grep -v amdgpu.ids gpurun_out/r05_eager_trace.txt; } > profiles/r05_eager_turn.txt
+fi
 ls -la profiles/r05_* profiles/traffic_*.json | awk '{print $5, $9}'

@@ -2,7 +2,8 @@
 # Run ON THE GPU BOX (through gpurun): the artefacts of round 5 kept under profiles/.  usage: tools/r05_final.sh <part: 1 | 2 | 3>
 #   1  headline: kernel trace + stats, the whole line under the tracer, HBM counter passes (tools/profile_gpu.sh), the line with the driver's flags
 #   2  config 5 and config 2: kernel stats under the tracer, config 5's traffic counters for both store variants
-#   3  the speculative / recorded / eager policy turns (tools/latency_bench.py spec), breakdown and kernel timeline of a speculative turn
+#   3  the speculative / recorded / eager policy turns (tools/latency_bench.py spec), breakdown and kernel timeline of a speculative turn,
+#      the eager turn's loops A/B (tools/fast_loop_ab.py), sweep + rows in one launch (tools/sweep_rows_bench.py), kernel time of an eager turn
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
@@ -30,5 +31,8 @@ else
   timeout -k 10 300 python3 tools/spec_breakdown.py > $OUT/r05_spec_breakdown.txt 2>&1 || exit 1
   timeout -k 10 300 python3 tools/resolve_probe.py > $OUT/r05_resolve_probe.txt 2>&1 || exit 1
   bash tools/spec_trace.sh > $OUT/r05_spec_trace.txt 2>&1 || exit 1
+  { timeout -k 10 300 python3 tools/fast_loop_ab.py 32 32 8 3 65536 3 && timeout -k 10 300 python3 tools/fast_loop_ab.py 32 32 8 3 16384 2 && timeout -k 10 300 python3 tools/fast_loop_ab.py 32 32 8 3 1024 2 \
+    && timeout -k 10 300 python3 tools/fast_loop_ab.py 128 128 64 5 2048 2 && timeout -k 10 300 python3 tools/sweep_rows_bench.py 16384 65536; } > $OUT/r05_eager_turn.txt 2>&1 || exit 1
+  bash tools/eager_trace.sh 65536 > $OUT/r05_eager_trace.txt 2>&1 || exit 1
   echo policy-turn measurements done
 fi

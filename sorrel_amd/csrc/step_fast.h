@@ -115,12 +115,88 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // its uint8 colours): the window pipeline of the one-hot path with 16-bit counters -- the layer sum of a cell is an integer, the clip
 // makes it a byte, the byte is staged, and the burst turns it into (float)(k / 255.0) through a 256-entry table of exactly those
 // floats (DevTables::post_lut, one copy per workgroup in LDS) instead of a float64 sum, clip and DIVISION per cell and channel.
+// step_fast_rows' emit (called once by EVERY wave of the workgroup, also one whose env lies beyond the batch):
+template <int TL, int TC, int TR, int TH, int TW>
+__device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* rp, uint8_t* smem, const int sub, const int lane) {
+    // Agent a's C * V * V staged bytes of env e -> floats at rp->p[a] + e * rp->stride.  The workgroup's four envs are consecutive,
+    // so with stride = C * V * V their windows of ONE agent are one run of 4 C V V floats: the waves meet (the only barrier of
+    // this kernel), then wave w writes the runs of agents w, w + 4, ... out of all four staging areas -- 16-byte streaming
+    // stores with lane 0 on a 128-byte line, as below.  (A wave writing its own env's eight windows, 1 176 bytes each: 121 us
+    // at 65 536 envs on a good day, 148-185 on others -- eight short runs per wave, each between two other waves' runs,
+    // made the kernel depend on where the rows lie.)
+    typedef float vfloat4 __attribute__((ext_vector_type(4)));
+    typedef float vfloat2 __attribute__((ext_vector_type(2)));
+    constexpr int kN = TC * (2 * TR + 1) * (2 * TR + 1);
+    const int ob_off = p.tab_bytes + ((TL * TH * TW + 15) & ~15);   // (= ob - wl in step_fast_body: [table words][grid][staged windows])
+    const int64_t env_first = (int64_t)blockIdx.x * 4;
+    const int live = (int)(p.E - env_first < 4 ? p.E - env_first : 4);     // envs of this workgroup
+    __syncthreads();
+    // floats [0, n * kN) of agent a's windows of envs k0 .. k0 + n - 1, contiguous from dst on
+    auto emit_run = [&](float* dst, const int a, const int k0, const int n) {
+        const uintptr_t ad = reinterpret_cast<uintptr_t>(dst);
+        const int T = n * kN;
+        auto src16 = [&](const int t) -> uint32_t {       // staged bytes 2t, 2t + 1 of the run (kN even)
+            const int k = t / (kN / 2), j2 = t - k * (kN / 2);
+            return *reinterpret_cast<const uint16_t*>(smem + (k0 + k) * p.env_lds + ob_off + a * kN + 2 * j2);
+        };
+        if ((kN & 1) == 0 && (ad & 15u) == 0) {
+            const int q = T >> 2;
+            const int mis = (int)((ad >> 4) & 7u);
+            for (int i = lane - mis; i < q; i += 64) {
+                if (i < 0) continue;
+                const uint32_t lo = src16(2 * i), hi = src16(2 * i + 1);
+                vfloat4 v;
+                v.x = (float)(lo & 0xFFu);
+                v.y = (float)(lo >> 8);
+                v.z = (float)(hi & 0xFFu);
+                v.w = (float)(hi >> 8);
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst) + i);
+            }
+            if ((T & 3) && lane == 0) {                   // (an odd number of envs of an odd kN / 2: two floats behind the last float4)
+                const uint32_t b = src16(2 * q);
+                vfloat2 v;
+                v.x = (float)(b & 0xFFu);
+                v.y = (float)(b >> 8);
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(dst) + 2 * q);
+            }
+        } else if ((kN & 1) == 0 && (ad & 7u) == 0) {
+            const int mis = (int)((ad >> 3) & 15u);
+            for (int i = lane - mis; i < (T >> 1); i += 64) {
+                if (i < 0) continue;
+                const uint32_t b = src16(i);
+                vfloat2 v;
+                v.x = (float)(b & 0xFFu);
+                v.y = (float)(b >> 8);
+                __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(dst) + i);
+            }
+        } else {
+            for (int i = lane; i < T; i += 64) {
+                const int k = i / kN, j = i - k * kN;
+                __builtin_nontemporal_store((float)smem[(k0 + k) * p.env_lds + ob_off + a * kN + j], dst + i);
+            }
+        }
+    };
+    for (int a = sub; a < p.A; a += 4) {
+        float* base = static_cast<float*>(rp->p[a]) + env_first * rp->stride;
+        if (rp->stride == kN) emit_run(base, a, 0, live);
+        else for (int k = 0; k < live; ++k) emit_run(base + k * rp->stride, a, k, 1);
+        // a recorded turn (sgw_turn_begin_rows): the windows ALSO go to the agent's replay row of the turn in flight, by the
+        // engine's own row count
+        if (rp->dual && rp->ts->cap[a] > 0 && rp->ts->states[a]) {
+            const int64_t re = rp->ts->row_elems[a];
+            float* ring = static_cast<float*>(rp->ts->states[a]) + (rp->ts->row[a] * p.E + env_first) * re;
+            if (re == kN) emit_run(ring, a, 0, live);
+            else for (int k = 0; k < live; ++k) emit_run(ring + k * re, a, k, 1);
+        }
+    }
+}
+
 // ROWS (round 5): the instance behind sgw_sweep_observe_rows -- the sweep and EVERY agent's window in one launch, each window going to
 // its agent's own destination (rp->p[a] + env * rp->stride: the row of that agent's replay buffer) instead of the [E][A][C][V][V] tensor.
 // Only the emit differs (see there); compiled for compile-time shapes with the whole-env burst.
 template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS>
 __device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]] const RowPtrs* rp) {
-    static_assert(!ROWS || (ONEHOT && TL && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
+    static_assert(!ROWS || (ONEHOT && TL && TC && TR && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
     // wave-private LDS (grid slice + the table words this wave reads), no s_barrier.
@@ -129,7 +205,11 @@ __device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]]
     const int lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps all env-indexed address math scalar
     const int64_t env = (int64_t)blockIdx.x * 4 + sub;
-    if (env >= p.E) return;   // whole wave exits together
+    if (env >= p.E) {         // whole wave exits together
+        if constexpr (ROWS)      // (the workgroup's waves meet once, in the emit, and every wave writes its share of the agents)
+            if (p.obs_stage > 0 && !(p.flags & SGW_STEP_NO_OBS)) fast_rows_emit<TL, TC, TR, TH, TW>(p, rp, smem, sub, lane);
+        return;
+    }
 #ifdef SGW_STAMPS
     unsigned long long tprev_ = 0;
     STAMP(0);
@@ -717,36 +797,7 @@ __device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]]
             const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
             if constexpr (ROWS) {
-                // Agent a's C * V * V staged bytes -> floats at rp->p[a] + env * rp->stride.  Streaming stores as below, 8 bytes per lane (a
-                // window of an odd env of config 3 starts 8 bytes off a 16-byte boundary; 16-byte stores with two single floats in front
-                // or behind were measured: 123.2 us against 121.2 for these at 65 536 envs), lane 0 of every store on a 128-byte line
-                // (mis = float2s between the line and the window's first element).
-                typedef float vfloat2 __attribute__((ext_vector_type(2)));
-                const int N = C * VV;
-                for (int a = 0; a < p.A; ++a) {
-                    const uint8_t* src = ob + a * N;
-                    auto emit_to = [&](float* dst) {
-                        const uintptr_t ad = reinterpret_cast<uintptr_t>(dst);
-                        if ((N & 1) == 0 && (ad & 7u) == 0) {
-                            const int mis = (int)((ad >> 3) & 15u);
-                            for (int i = lane - mis; i < (N >> 1); i += 64) {
-                                if (i < 0) continue;
-                                const uint32_t b = *reinterpret_cast<const uint16_t*>(src + 2 * i);   // (a * N is even)
-                                vfloat2 v;
-                                v.x = (float)(b & 0xFFu);
-                                v.y = (float)(b >> 8);
-                                __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(dst) + i);
-                            }
-                        } else {
-                            for (int i = lane; i < N; i += 64) __builtin_nontemporal_store((float)src[i], dst + i);
-                        }
-                    };
-                    emit_to(static_cast<float*>(rp->p[a]) + env * rp->stride);
-                    // a recorded turn (sgw_turn_begin_rows): the window ALSO goes to the agent's replay row of the turn in flight, by the
-                    // engine's own row count
-                    if (rp->dual && rp->ts->cap[a] > 0 && rp->ts->states[a])
-                        emit_to(static_cast<float*>(rp->ts->states[a]) + (rp->ts->row[a] * p.E + env) * rp->ts->row_elems[a]);
-                }
+                fast_rows_emit<TL, TC, TR, TH, TW>(p, rp, smem, sub, lane);
             } else if (!p.obs_u8) {
                 // Non-temporal (streaming) stores: every wave instruction here writes eight whole 128-byte lines that
                 // nothing reads again in this launch; keeping them out of the caches leaves those to the grids (134 MB,

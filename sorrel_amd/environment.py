@@ -1543,10 +1543,25 @@ class CapturedTurn:
                 raise RuntimeError("an agent's add_memory did not run once per turn")
         before = [(mem.idx, mem.size) for mem in self.buffers]
         g = torch.cuda.CUDAGraph()
+        # No garbage collection inside the capture: an unreachable engine or graph of an EARLIER environment that the collector happens to
+        # free now would call hipFree / hipGraphDestroy while a stream is capturing, which HIP forbids -- the capture fails, and torch aborts
+        # the process while it unwinds (seen under rocprofv3, where the timing differs; torch.cuda.graph no longer collects on entry itself)
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(g):
                 env._turn_protocol_body(eng)              # recorded, not run: the host-side effects are undone below
+        except BaseException:
+            import os, sys, traceback
+            env.capture_error_trace = traceback.format_exc()      # (what failed INSIDE the capture; torch may abort while it unwinds the graph)
+            if os.environ.get("SGW_DEBUG"):
+                print(env.capture_error_trace, file=sys.stderr, flush=True)
+            raise
         finally:
+            if gc_was_on:
+                gc.enable()
             # ... also when the capture fails half-way (a later agent's forward pass synchronises): the agents before it have already
             # counted an add_memory for rows that were never written -- the eager loop must not find them counted as valid
             for mem, (idx, size) in zip(self.buffers, before):

@@ -126,7 +126,7 @@ __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* r
     // made the kernel depend on where the rows lie.)
     typedef float vfloat4 __attribute__((ext_vector_type(4)));
     typedef float vfloat2 __attribute__((ext_vector_type(2)));
-    constexpr int kN = TC * (2 * TR + 1) * (2 * TR + 1);
+    constexpr int kN = TC * (2 * TR + 1) * (2 * TR + 1);   // (TR = 0 is the radius 0 itself here: the host instantiates the engine's own radius)
     const int ob_off = p.tab_bytes + ((TL * TH * TW + 15) & ~15);   // (= ob - wl in step_fast_body: [table words][grid][staged windows])
     const int64_t env_first = (int64_t)blockIdx.x * 4;
     const int live = (int)(p.E - env_first < 4 ? p.E - env_first : 4);     // envs of this workgroup
@@ -196,7 +196,7 @@ __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* r
 // Only the emit differs (see there); compiled for compile-time shapes with the whole-env burst.
 template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS>
 __device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]] const RowPtrs* rp) {
-    static_assert(!ROWS || (ONEHOT && TL && TC && TR && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
+    static_assert(!ROWS || (ONEHOT && TL && TC && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
     // wave-private LDS (grid slice + the table words this wave reads), no s_barrier.

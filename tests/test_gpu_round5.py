@@ -773,6 +773,7 @@ SWEEP_ROWS_CASES = [
     ("ragged_26x23_r2", (26, 23, 6, 2), 41, {}),
     ("30x30_r4_two_agents", (30, 30, 2, 4), 29, {}),
     ("24x40_r3_twelve_agents", (24, 40, 12, 3), 130, {}),
+    ("radius_0_20x34", (20, 34, 6, 0), 27, {}),
 ]
 
 
@@ -804,17 +805,19 @@ def test_sweep_and_every_window_into_rows_in_one_launch(torch_cuda, case):
     dest_b = [torch.full((E, Nw), -9.0, device="cuda:0") for _ in range(A)]
     rows_a = (N_ptr_array(dest_a), Nw, dest_a)
     rows_b = b.window_rows(dest_b)
+    two = bool(b.capabilities() & N.CAP_OBSERVE_ROWS)               # (radius 0 has no row-load instance: the oracle alone checks that case)
     gen = np.random.default_rng(5)
     for t in range(1, 6):
         a.sweep_observe_rows(rows_a, sweep=t != 3, turn=t)
         b.step(sweep=t != 3, agent_begin=0, agent_end=0, write_obs=False, turn=t)
-        b.observe_rows(rows_b)
+        if two:
+            b.observe_rows(rows_b)
         assert co.step(0, t, sweep=t != 3, write_obs=False, a0=0, a1=0) == 0
         co.observe()
         torch.cuda.synchronize()
         assert np.array_equal(a.grid.cpu().numpy(), co.grid) and torch.equal(a.grid, b.grid), (name, t, "grid after the sweep")
         for k in range(A):
-            assert torch.equal(dest_a[k], dest_b[k]), (name, t, k)
+            assert not two or torch.equal(dest_a[k], dest_b[k]), (name, t, k)
             assert np.array_equal(dest_a[k].cpu().numpy(), co.obs[:, k].reshape(E, Nw)), (name, t, k, "oracle")
             assert bool((bufs_a[k][:guard] == -9.0).all()) and bool((bufs_a[k][-guard:] == -9.0).all()), (name, t, k, "guards")
         acts = gen.integers(0, 4, (E, A)).astype(np.uint8)          # the agents act (one whole-turn step without a sweep), then the next turn

@@ -195,7 +195,7 @@ __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* r
 // its agent's own destination (rp->p[a] + env * rp->stride: the row of that agent's replay buffer) instead of the [E][A][C][V][V] tensor.
 // Only the emit differs (see there); compiled for compile-time shapes with the whole-env burst.
 template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS>
-__device__ __forceinline__ void step_fast_body(const Params& p, [[maybe_unused]] const RowPtrs* rp) {
+__device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] const RowPtrs* rp) {
     static_assert(!ROWS || (ONEHOT && TL && TC && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),

@@ -1,0 +1,101 @@
+// Micro-benchmark (diagnostic only, not part of the product): write-only streams shaped like config 5's observations -- f32 [E][64][6][11][11],
+// 185 856 B per env, a 512-thread workgroup per env -- to see what the emit pattern alone is worth:
+//   mode 0  step_big's direct stores: wave w renders windows w, w + 8, ...; per window 6 planes x (64 + 57) lanes, one dword each
+//   mode 1  the whole env as ONE burst by all 8 waves (16-byte streaming stores from staged bytes), after all the "work"
+//   mode 2  two half-env bursts (32 agents each)
+//   mode 3  per window a contiguous run of 8-byte streaming stores by its wave (the staged variant's shape)
+//   mode 4  eight windows at a time (one per wave) staged, then the 23 232-byte run of the eight written by all 8 waves together
+// `spin` = dependent VALU ops per window before its stores (stands in for the gather); lds = dynamic LDS bytes (sets workgroups per CU).
+// usage: c5_emit <mode> <envs> <spin> <lds bytes> [nontemporal 0/1]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+constexpr int A = 64, C = 6, VV = 121, N = C * VV, ENV = A * N;   // floats
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(512) void emit(float* __restrict__ out, int E, int spin) {
+    extern __shared__ uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long env = blockIdx.x;
+    if (env >= E) return;
+    float* o = out + env * (long)ENV;
+    int x = tid;
+    auto work = [&](int n) { for (int i = 0; i < n; ++i) x = x * 1664525 + 1013904223; };
+    auto st1 = [&](float* p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+    if (MODE == 0) {
+        for (int a = wv; a < A; a += 8) {
+            work(spin);
+            float* ob = o + a * N;
+            const float v = (float)(x & 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                *(ob + c * VV + lane) = v;
+                if (lane + 64 < VV) *(ob + c * VV + 64 + lane) = v;
+            }
+        }
+    } else if (MODE == 3) {
+        for (int a = wv; a < A; a += 8) {
+            work(spin);
+            lds[wv * 768 + lane] = (uint8_t)x;
+            __builtin_amdgcn_wave_barrier();
+            float* ob = o + a * N;   // 8-byte aligned (N even)
+            const uint16_t* s2 = reinterpret_cast<const uint16_t*>(lds + wv * 768);
+            for (int i = lane; i < N / 2; i += 64) {
+                const uint32_t b = s2[i & 255];
+                vfloat2 v = {(float)(b & 0xFF), (float)(b >> 8)};
+                if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vfloat2*>(ob) + i); else reinterpret_cast<vfloat2*>(ob)[i] = v;
+            }
+        }
+    } else {
+        const int groups = MODE == 1 ? 1 : (MODE == 2 ? 2 : 8);
+        const int per = A / groups;                      // agents per burst
+        for (int g = 0; g < groups; ++g) {
+            for (int k = 0; k < per / 8; ++k) {          // every wave "renders" its windows of this group into LDS
+                work(spin);
+                lds[(wv * 2048 + lane + 64 * k) & 0x3FFF] = (uint8_t)x;
+            }
+            __syncthreads();
+            const int n4 = per * N / 4;                  // float4 of the burst (per * 726 / 4: per even -> integer)
+            vfloat4* o4 = reinterpret_cast<vfloat4*>(o + g * per * N);
+            const uint32_t* l4 = reinterpret_cast<const uint32_t*>(lds);
+            for (int i = tid; i < n4; i += 512) {
+                const uint32_t b = l4[i & 0xFFF];
+                vfloat4 v = {(float)(b & 0xFF), (float)((b >> 8) & 0xFF), (float)((b >> 16) & 0xFF), (float)(b >> 24)};
+                if (NT) __builtin_nontemporal_store(v, o4 + i); else o4[i] = v;
+            }
+            __syncthreads();
+        }
+    }
+    if (x == 0x7ffffff1) out[0] = 1.f;
+}
+
+template <int MODE, bool NT>
+float run(float* out, int E, int spin, int ldsb, int iters) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&emit<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL((emit<MODE, NT>), dim3(E), dim3(512), ldsb, 0, out, E, spin);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((emit<MODE, NT>), dim3(E), dim3(512), ldsb, 0, out, E, spin);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1000.f;
+}
+
+int main(int argc, char** argv) {
+    const int mode = argc > 1 ? atoi(argv[1]) : 0, E = argc > 2 ? atoi(argv[2]) : 2048, spin = argc > 3 ? atoi(argv[3]) : 0;
+    const int ldsb = argc > 4 ? atoi(argv[4]) : 39936, nt = argc > 5 ? atoi(argv[5]) : 1;
+    float* out;
+    CK(hipMalloc(&out, (size_t)E * ENV * 4 + 4096));
+    float us = 0;
+#define RUN(M) us = nt ? run<M, true>(out, E, spin, ldsb, 200) : run<M, false>(out, E, spin, ldsb, 200)
+    if (mode == 0) RUN(0); else if (mode == 1) RUN(1); else if (mode == 2) RUN(2); else if (mode == 3) RUN(3); else RUN(4);
+    printf("mode %d  envs %5d  spin %4d  lds %6d  nt %d : %8.1f us  %.2f TB/s\n", mode, E, spin, ldsb, nt, us, (double)E * ENV * 4 / us / 1e6);
+    return 0;
+}

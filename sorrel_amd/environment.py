@@ -775,6 +775,10 @@ class Environment:
     #: 610 us recorded against 500 eager; 16 384 envs = 154 MB: 249 against 385; config 5's 64 agents gain at any size) -- capture_turn()
     #: then declines unless forced
     capture_max_window_bytes = 384 << 20
+    #: ... and where the eager loop is the fast one (``fast_policy_loop``: agents with the standard hooks) the crossover is lower (round 5, same
+    #: shape: 16 384 envs = 154 MB: 245 us recorded against 283 eager; 24 576 envs = 231 MB: 331 against 297; 32 768: 367 against 312) --
+    #: counted per agent, since the host time a replay saves grows with the agents as the windows do: 24 MB of windows per agent and turn
+    capture_max_window_bytes_per_agent_fast = 24 << 20
 
     def capture_turn(self, warmup: int = 2, force: bool = False):
         """Record ONE whole policy-driven ``take_turn`` -- sweep + every agent's window, then per agent the policy's forward pass
@@ -807,7 +811,10 @@ class Environment:
         for d in eng.spec.obs_shape[1:]:
             per_env *= int(d)
         window_bytes = eng.num_envs * len(self.agents) * per_env * (4 if eng.obs_dtype == torch.float32 else 1)
-        if not force and len(self.agents) <= 16 and window_bytes > self.capture_max_window_bytes:
+        limit = self.capture_max_window_bytes
+        if self.fast_policy_loop and self._fast_plan(eng) is not None:
+            limit = min(limit, self.capture_max_window_bytes_per_agent_fast * len(self.agents))
+        if not force and len(self.agents) <= 16 and window_bytes > limit:
             self.capture_error = ValueError(f"{window_bytes >> 20} MiB of windows per turn: a recorded turn writes them twice, which costs more than the "
                                             "replay saves at this batch (capture_turn(force=True) records anyway)")
             return None

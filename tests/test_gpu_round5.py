@@ -725,6 +725,15 @@ def test_capture_turn_declines_where_a_replay_would_be_slower(torch_cuda):
     assert env.capture_turn(force=True) is not None
     env.take_turn()
     env.raise_on_status()
+    # where the eager loop is the fast one the crossover is lower: its own limit applies (and only there)
+    env = _policy_env(4096, shape=(32, 32, 8, 3), memory=2)
+    env.capture_max_window_bytes_per_agent_fast = 2 << 20          # (4 096 envs x 294 x 4 = 4.8 MB per agent)
+    fast = env._fast_plan(env._ensure_engine()) is not None
+    assert (env.capture_turn() is None) == fast
+    env.fast_policy_loop = False
+    assert env.capture_turn() is not None
+    env.take_turn()
+    env.raise_on_status()
 
 
 def test_agent_major_windows_in_one_launch_and_gather_rows(torch_cuda):

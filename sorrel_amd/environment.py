@@ -455,6 +455,8 @@ class Environment:
         """The agent's class declares (``speculative_ok``) that its ``pov`` is the flattened window of its own spec and its ``get_action`` is
         ``model.take_action`` of it -- and no class derived from the one that says so overrides a hook of the turn."""
         hooks = ("pov", "get_action", "act", "transition", "add_memory")
+        if any(h in agent.__dict__ for h in hooks):       # (a hook patched onto the instance)
+            return False
         for cls in type(agent).__mro__:
             if cls.__dict__.get("speculative_ok") is True:
                 return True

@@ -610,3 +610,45 @@ def test_compile_spec_accepts_agents_that_differ():
             assert np.array_equal(np.asarray(ws.appearance)[t], want), (name, t)
         assert np.array_equal(np.asarray(ws.appearance)[ws.fill_type], view.appearance[view.fill_type])
     assert env.compile_spec().vision_radius == 2          # default: agent 0's specs
+
+
+def test_standard_hooks_rule_of_the_fast_and_the_speculative_loops():
+    """Which agents the Environment may step without calling their hooks one by one (``Environment._standard_hooks``): the class that declares
+    ``speculative_ok`` and subclasses that override no hook of the turn -- not a subclass with its own pov / get_action / act / transition /
+    add_memory, not an instance with a hook patched on, not a class that never said so."""
+    import types
+
+    from sorrel_amd.agents import MovingAgent
+    from sorrel_amd.environment import Environment
+    from sorrel_amd.examples.treasurehunt.agents import TreasurehuntAgent
+
+    def make(cls):
+        return cls.__new__(cls)              # (the rule looks at classes and the instance dict only)
+
+    class Renamed(TreasurehuntAgent):
+        def is_done(self, world):
+            return False
+
+    class OwnPov(TreasurehuntAgent):
+        def pov(self, world):
+            return super().pov(world)
+
+    class OwnMemory(Renamed):
+        def add_memory(self, state, action, reward, done):
+            pass
+
+    class SaysNo(TreasurehuntAgent):
+        speculative_ok = False
+
+    class Plain(MovingAgent):
+        def reset(self): ...
+        def pov(self, world): ...
+        def get_action(self, state): ...
+        def is_done(self, world): ...
+
+    ok = Environment._standard_hooks
+    assert ok(make(TreasurehuntAgent)) and ok(make(Renamed))
+    assert not ok(make(OwnPov)) and not ok(make(OwnMemory)) and not ok(make(SaysNo)) and not ok(make(Plain))
+    patched = make(TreasurehuntAgent)
+    patched.get_action = types.MethodType(lambda self, state: 0, patched)
+    assert not ok(patched)

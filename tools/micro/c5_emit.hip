@@ -73,6 +73,48 @@ __global__ __launch_bounds__(512) void emit(float* __restrict__ out, int E, int 
     if (x == 0x7ffffff1) out[0] = 1.f;
 }
 
+// mode 5..8: no LDS, no work -- only WHO writes WHAT, to find what separates the patterns above from torch's fill_ (6.9 TB/s):
+//   5  fill_'s shape: 256-thread blocks, each 16 KB contiguous (4 float4 per thread, 4 KB apart); `spin` = 1: 512-thread blocks, 32 KB each
+//   6  a 512-thread block per env writes the env's 185 856 B front to back (mode 1 without staging and barriers)
+//   7  like 6, but block b writes the b-th 185 856-byte slice in 8 pieces of 23 232 B with all OTHER blocks' pieces in between
+//      (piece p of block b at ((p * gridDim + b) * 23 232 B): the chip's blocks advance through memory together, as with agent-major rows)
+template <int MODE, bool NT>
+__global__ __launch_bounds__(512) void plain(float* __restrict__ out, long total4, int spin) {
+    vfloat4* o4 = reinterpret_cast<vfloat4*>(out);
+    const vfloat4 v = {1.f, 2.f, 3.f, (float)spin};
+    auto st = [&](long i) { if (i < total4) { if (NT) __builtin_nontemporal_store(v, o4 + i); else o4[i] = v; } };
+    if (MODE == 5) {
+        const long base = (long)blockIdx.x * blockDim.x * 4;
+        for (int k = 0; k < 4; ++k) st(base + k * blockDim.x + threadIdx.x);
+    } else if (MODE == 6) {
+        const long base = (long)blockIdx.x * (ENV / 4);
+        for (int i = threadIdx.x; i < ENV / 4; i += 512) st(base + i);
+    } else {
+        constexpr int P4 = ENV / 4 / 8;      // float4 per piece (5 808)
+        for (int p = 0; p < 8; ++p) {
+            const long base = ((long)p * gridDim.x + blockIdx.x) * P4;
+            for (int i = threadIdx.x; i < P4; i += 512) st(base + i);
+        }
+    }
+}
+
+template <int MODE, bool NT>
+float run_plain(float* out, int E, int spin, int iters) {
+    const long total4 = (long)E * ENV / 4;
+    const int threads = MODE == 5 ? (spin ? 512 : 256) : 512;
+    const long blocks = MODE == 5 ? (total4 + threads * 4 - 1) / (threads * 4) : E;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL((plain<MODE, NT>), dim3(blocks), dim3(threads), 0, 0, out, total4, spin);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((plain<MODE, NT>), dim3(blocks), dim3(threads), 0, 0, out, total4, spin);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1000.f;
+}
+
 template <int MODE, bool NT>
 float run(float* out, int E, int spin, int ldsb, int iters) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&emit<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
@@ -95,7 +137,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out, (size_t)E * ENV * 4 + 4096));
     float us = 0;
 #define RUN(M) us = nt ? run<M, true>(out, E, spin, ldsb, 200) : run<M, false>(out, E, spin, ldsb, 200)
-    if (mode == 0) RUN(0); else if (mode == 1) RUN(1); else if (mode == 2) RUN(2); else if (mode == 3) RUN(3); else RUN(4);
+#define RUNP(M) us = nt ? run_plain<M, true>(out, E, spin, 200) : run_plain<M, false>(out, E, spin, 200)
+    if (mode == 0) RUN(0); else if (mode == 1) RUN(1); else if (mode == 2) RUN(2); else if (mode == 3) RUN(3); else if (mode == 4) RUN(4);
+    else if (mode == 5) RUNP(5); else if (mode == 6) RUNP(6); else RUNP(7);
     printf("mode %d  envs %5d  spin %4d  lds %6d  nt %d : %8.1f us  %.2f TB/s\n", mode, E, spin, ldsb, nt, us, (double)E * ENV * 4 / us / 1e6);
     return 0;
 }

@@ -425,7 +425,7 @@ def many_agents_turn_bench(dev, envs: int = 2048, turns: int = 60):
 
         cfg = make_config(h, w, a, r, spawn_prob=p_spawn)
         env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=envs, device=dev, seed=0), cfg, model_factory=factory)
-        env.speculate_turns = speculate
+        env.speculate_turns = speculate                # (True: the cost model agrees for 64 agents on one model)
         for _ in range(12):
             env.take_turn()
         torch.cuda.synchronize(dev)

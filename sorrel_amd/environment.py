@@ -448,6 +448,7 @@ class Environment:
     #: function of its window -- in two or three batched passes instead of A dependent (forward, act) pairs.  Pays with many agents
     #: whose models are shared (one forward pass per model and pass); needs plain movers, ``Agent.speculative_ok`` agents, one-frame
     #: memories.  Off by default: the agents' ``pov`` / ``get_action`` / ``act`` hooks are not called one by one in such a turn.
+    #: True: where it is possible AND the cost model below says it pays; "always": wherever it is possible.
     speculate_turns = False
 
     @staticmethod
@@ -474,7 +475,8 @@ class Environment:
             return None
         # (the answer only changes with the engine, the agents' models and their memories: asked every turn, computed once -- with 64 agents
         # the checks below are ~100 us of Python)
-        key = (id(eng), eng.row_tail, tuple((id(a.model), id(getattr(a.model, "memory", None)), type(a)) for a in self.agents))
+        key = (id(eng), eng.row_tail, self.speculate_turns, self.speculation_cost_model,
+               tuple((id(a.model), id(getattr(a.model, "memory", None)), type(a)) for a in self.agents))
         cached = self.__dict__.get("_spec_groups")
         if cached is not None and cached[0] == key:
             groups = cached[1]
@@ -482,8 +484,25 @@ class Environment:
                 return None
             return groups
         groups = self._speculation_groups_uncached(eng, N, Buffer)
+        if groups is not None and self.speculate_turns != "always" and not self._speculation_pays(eng):
+            groups = None
         self.__dict__["_spec_groups"] = (key, groups)
         return groups
+
+    #: (fixed us of a speculative turn, us per MB of windows, us of host time per agent of the sequential loop, its fixed us): the sequential
+    #: loop costs ~33 us of host time per agent (two torch ops + ``sgw_act``), a speculative turn ~200 us of passes and read-backs plus device
+    #: time that grows with the windows it renders, compares and re-evaluates.  Measured (one linear policy shared by all agents, wall us per
+    #: turn, speculative / sequential): 8 agents 235 / 281 at 2 048 envs, 244 / 277 at 4 096, 306 / 304 at 8 192, 406 / 292 at 16 384;
+    #: 16 agents 237 / 479 at 1 024, 459 / 552 at 8 192; config 5's 64 agents 546 / 2 190 at 2 048.
+    speculation_cost_model = (200.0, 1.6, 33.0, 20.0)
+
+    def _speculation_pays(self, eng) -> bool:
+        """``speculate_turns = True`` speculates where the model above says it is the faster turn (``"always"``: wherever it is possible)."""
+        fixed, per_mb, per_agent, seq_fixed = self.speculation_cost_model
+        A = len(self.agents)
+        per_env = int(np.prod(eng.spec.obs_shape[1:]))
+        mb = eng.num_envs * A * per_env * 4 / 1e6
+        return per_agent * A + seq_fixed > fixed + per_mb * mb
 
     def _speculation_groups_uncached(self, eng, N, Buffer):
         if self._mixed or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_RESOLVE) or eng.row_tail:

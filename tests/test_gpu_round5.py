@@ -416,7 +416,7 @@ def test_environment_speculative_turns_equal_the_eager_loop(torch_cuda):
             models = []
 
             env = make_env(14, 17, A, 3, E, p=0.06, seed=7, model_factory=factory)
-            env.speculate_turns = speculate
+            env.speculate_turns = "always" if speculate else False      # ("always": also where the cost model would keep the sequential loop)
             envs.append(env)
         eager, spec = envs
         for t in range(12):
@@ -575,7 +575,7 @@ def test_environment_turn_loops_soak(torch_cuda, case):
 
         env = make_env(h, w, A, r, E, p=p, seed=seed % 1000, model_factory=factory)
         env.fast_policy_loop = mode != "generic"
-        env.speculate_turns = mode == "speculative"
+        env.speculate_turns = "always" if mode == "speculative" else False
         if mode == "recorded":
             env.capture_turn(warmup=1)                             # (may decline: the eager loop then plays, which is as good a check)
         return env
@@ -862,3 +862,41 @@ def test_engines_without_the_fused_instance_say_so(torch_cuda):
         with pytest.raises(ValueError):
             eng.sweep_observe_rows(rows)
     assert not (big.capabilities() & N.CAP_SWEEP_ROWS)
+
+
+def test_speculate_turns_true_follows_the_cost_model(torch_cuda):
+    """``speculate_turns = True`` speculates only where the measured cost model says it is the faster turn: many agents on one model yes, few
+    agents over a large batch no (the sequential loop is device-bound there); "always" speculates wherever it is possible."""
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    def env_of(h, w, A, r, E):
+        one = []
+
+        class Shared(BaseModel):
+            def __init__(self, input_size, action_space):
+                super().__init__(input_size, action_space, memory_size=2 * A, num_envs=E, device="cuda:0")
+
+            def take_action(self, state):
+                return state.reshape(state.shape[0], -1).sum(dim=1).long() % 4
+
+        def factory(input_size, action_space):
+            if not one:
+                one.append(Shared(input_size, action_space))
+            return one[0]
+
+        return make_env(h, w, A, r, E, p=0.02, seed=3, model_factory=factory)
+
+    many = env_of(24, 24, 20, 2, 64)
+    many.speculate_turns = True
+    many.take_turn()
+    assert many._speculation_groups(many._engine) is not None and many.speculation_passes >= 1
+    few = env_of(32, 32, 8, 3, 16384)                      # 154 MB of windows, eight agents: 406 us speculative against 292 sequential
+    few.speculate_turns = True
+    few.take_turn()
+    assert few._speculation_groups(few._engine) is None and not hasattr(few, "speculation_passes")
+    few.speculate_turns = "always"
+    few.take_turn()
+    assert few.speculation_passes >= 1
+    many.raise_on_status()
+    few.raise_on_status()

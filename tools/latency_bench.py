@@ -69,7 +69,8 @@ def run(h, w, a, r, E, policy, spawn_prob=0.005):
                 one[0] = Shared(input_size, action_space)
             return one[0]
     env = TreasurehuntEnv(world, cfg, model_factory=factory)
-    env.speculate_turns = policy in (6, 7)    # round 5: batched policy evaluation + sgw_turn_resolve (Environment.speculate_turns)
+    env.speculate_turns = "always" if policy in (6, 7) else False    # (whatever the cost model says: this tool measures it)
+    # round 5: batched policy evaluation + sgw_turn_resolve (Environment.speculate_turns)
     env.write_obs_into_replay = os.environ.get("LAT_NO_DIRECT") != "1"      # A/B: windows through the observation tensor + a copy
     env.fast_policy_loop = os.environ.get("LAT_GENERIC_LOOP") != "1"        # A/B: the generic Agent.transition loop (round 4's)
     env.fuse_sweep_and_rows = os.environ.get("LAT_NO_FUSE") != "1"           # A/B: the sweep alone + sgw_observe_rows (two launches)

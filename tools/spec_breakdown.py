@@ -35,7 +35,7 @@ def factory(i, a):
 
 cfg = make_config(h, w, A, r, spawn_prob=0.05 if h > 64 else 0.005)
 env = TreasurehuntEnv(TreasurehuntWorld(cfg, EmptyEntity(), num_envs=E, device="cuda:0", seed=0), cfg, model_factory=factory)
-env.speculate_turns = True
+env.speculate_turns = "always"
 for _ in range(10):
     env.take_turn()
 eng = env._engine

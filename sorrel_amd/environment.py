@@ -1413,10 +1413,10 @@ class _FastPolicyTurn:
         from sorrel_amd.buffers import Buffer
 
         caps = eng.capabilities()
-        if env._mixed or not env.patch_windows or not env.write_obs_into_replay or eng.obs is None or eng.row_tail \
+        if env._mixed or not env.patch_windows or not env.write_obs_into_replay or eng.obs is None \
                 or eng.obs_dtype != torch.float32 or not (caps & N.CAP_ACT) or not (caps & N.CAP_OBSERVE_ROWS):
             return None
-        per_env = int(np.prod(eng.spec.obs_shape[1:]))
+        per_env = int(np.prod(eng.spec.obs_shape[1:])) + eng.row_tail       # (the engine writes what pov appends behind the window: Tag, Cleanup)
         taken, agents = {}, []
         for agent in env.agents:
             mem = getattr(agent.model, "memory", None)
@@ -1442,7 +1442,7 @@ class _FastPolicyTurn:
         self.lib = eng._lib
         self.kinds = eng._ACTION_KINDS
         from sorrel_amd import _native as N
-        self.fused = bool(eng.capabilities() & N.CAP_SWEEP_ROWS)
+        self.fused = bool(eng.capabilities() & N.CAP_SWEEP_ROWS) and not eng.row_tail
         self.qf32, self.nact = N.ACT_QF32, eng.spec.num_actions
 
     def still_valid(self) -> bool:

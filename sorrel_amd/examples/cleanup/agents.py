@@ -49,6 +49,8 @@ class CleanupAgent(MovingAgent):
     """One agent slot of every env.  ``directions`` (uint8 ``[E]``: 0 up, 1 right, 2 down, 3 left)
     is per-env state kept by the engine; it starts at 2 and survives resets (agents.py:74)."""
 
+    speculative_ok = True        # pov = the engine's row (window + positional code, row_tail), get_action = model.take_action: the fast eager loop applies
+
     def __init__(self, observation_spec, action_spec, model, beam_radius: int = 3):
         super().__init__(observation_spec, action_spec, model)
         self.interaction_rule = CleanupRule(beam_radius, CleanBeam, ZapBeam)

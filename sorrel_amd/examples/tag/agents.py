@@ -12,6 +12,8 @@ class TagAgent(MovingAgent):
     by the engine as the agent's current entity type; it survives ``Environment.reset`` as in
     the reference (agents are not re-created)."""
 
+    speculative_ok = True        # pov = the engine's row (window + the "it" flag, row_tail), get_action = model.take_action: the fast eager loop applies
+
     def __init__(self, observation_spec, action_spec, model, reward_per_turn=10):
         super().__init__(observation_spec, action_spec, model)
         self.reward_per_turn = reward_per_turn

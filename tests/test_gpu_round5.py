@@ -900,3 +900,60 @@ def test_speculate_turns_true_follows_the_cost_model(torch_cuda):
     assert few.speculation_passes >= 1
     many.raise_on_status()
     few.raise_on_status()
+
+
+@pytest.mark.parametrize("which", ["tag", "cleanup"])
+def test_fast_policy_loop_on_the_tag_and_cleanup_examples(torch_cuda, which):
+    """The shipped Tag and Cleanup agents -- pov = the engine's row (window + the "it" flag / the positional code), get_action =
+    model.take_action -- go through the fast eager loop too: 30 turns across ring wrap-arounds and a reset leave exactly what the generic
+    Agent.transition loop leaves (world, agent state, step outputs, every replay row incl. its tail)."""
+    torch = torch_cuda
+    from sorrel_amd.models import BaseModel
+
+    E = 23
+
+    class Policy(BaseModel):
+        def __init__(self, input_size, n_actions):
+            n = int(np.prod(input_size))
+            super().__init__((n,), n_actions, memory_size=6, num_envs=E, device="cuda:0")
+            self.weight = torch.randn((n, n_actions), generator=torch.Generator().manual_seed(3 + n)).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.weight).argmax(dim=1)
+
+    def make(fast):
+        if which == "tag":
+            from sorrel_amd.entities import EmptyEntity
+            from sorrel_amd.examples.tag.env import TagEnv
+            from sorrel_amd.worlds import Gridworld
+
+            cfg = {"agent": {"num_agents": 6, "vision_radius": 2, "reward_per_turn": 10}, "experiment": {"epochs": 1, "max_turns": 50}}
+            env = TagEnv(Gridworld(8, 9, 1, EmptyEntity(), num_envs=E, device="cuda:0", seed=31), cfg, model_factory=Policy)
+        else:
+            from tests.test_api_host import make_cleanup_env
+
+            env = make_cleanup_env(E=E, seed=7, device="cuda:0", model_factory=Policy)
+        env.fast_policy_loop = fast
+        return env
+
+    a, b = make(False), make(True)
+    for t in range(30):
+        if t == 17:
+            a.reset(); b.reset()
+        a.take_turn()
+        b.take_turn()
+    torch.cuda.synchronize()
+    eng = b._engine
+    assert eng.row_tail == (1 if which == "tag" else 12)
+    assert b._fast_plan(eng) is not None and a.__dict__.get("_fast_plan_cache") is None
+    for name in ("grid", "agent_pos", "total_reward") + (("agent_state",) if which == "tag" else ("agent_dir",)):
+        assert torch.equal(getattr(a.world, name), getattr(b.world, name)), name
+    assert torch.equal(a.rewards, b.rewards) and torch.equal(a.actions, b.actions)
+    assert float(b.world.total_reward.abs().sum()) > 0
+    for x, y in zip(a.agents, b.agents):
+        mx, my = x.model.memory, y.model.memory
+        assert (mx.idx, mx.size) == (my.idx, my.size)
+        for name in ("states", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(mx, name), getattr(my, name)), name
+    a.raise_on_status()
+    b.raise_on_status()

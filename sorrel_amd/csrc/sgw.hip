@@ -1342,6 +1342,8 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
     // (the phase kernels take the acting agent's action from the tensor: a phase whose action is drawn on the device -- SGW_STEP_RANDOM_ACTIONS,
     // an agent with a RandomModel among agents that step one by one -- stays on the step kernel, which draws it)
     if (sweep_rows) {
+        if (p.obs_stage <= 0 || p.a0 != 0 || p.a1 != p.A || (p.flags & SGW_STEP_NO_OBS))      // (step_fast_rows has no other way to emit than its staged burst)
+            return fail(SGW_EINVAL, "sgw_sweep_observe_rows: this engine does not stage a whole env's windows");
         if (int rc = launch_kernel(e, e->k_sweep_rows, (unsigned)e->grid_blocks, kBlock, lds, s, p, sweep_rows)) return rc;
         return time_end(e, s);
     }

@@ -207,7 +207,8 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
     const int64_t env = (int64_t)blockIdx.x * 4 + sub;
     if (env >= p.E) {         // whole wave exits together
         if constexpr (ROWS)      // (the workgroup's waves meet once, in the emit, and every wave writes its share of the agents)
-            if (p.obs_stage > 0 && !(p.flags & SGW_STEP_NO_OBS)) fast_rows_emit<TL, TC, TR, TH, TW>(p, rp, smem, sub, lane);
+            if (p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A && !(p.flags & SGW_STEP_NO_OBS))   // (= `stage && write_obs` of the waves that have an env)
+                fast_rows_emit<TL, TC, TR, TH, TW>(p, rp, smem, sub, lane);
         return;
     }
 #ifdef SGW_STAMPS

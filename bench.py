@@ -318,6 +318,28 @@ def policy_turn_bench(eng, iters: int = 40):
     return out
 
 
+def write_only_probe(dev, nbytes: int, iters: int = 60):
+    """What a linear write-only kernel reaches on THIS card right now: torch's ``fill_`` over a buffer of the observation tensor's size.
+    Context for ``roofline.frac`` (priced against the 8 TB/s peak): the step kernels are write-dominated."""
+    import torch
+
+    x = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    for _ in range(20):
+        x.fill_(1.0)
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        x.fill_(2.0)
+    b.record()
+    torch.cuda.synchronize(dev)
+    us = a.elapsed_time(b) * 1e3 / iters
+    del x
+    torch.cuda.empty_cache()
+    return {"what": "torch fill_ over a buffer of the observation tensor's size: a linear write-only stream, nothing else",
+            "bytes": nbytes, "us": us, "tb_per_s": nbytes / us / 1e6, "of_peak": nbytes / us / 1e6 / 8.0}
+
+
 def recorded_turn_bench(dev, envs: int = 1024, turns: int = 400):
     """Wall time per ``Environment.take_turn()`` through the Python API for the headline's world shape (32x32, 8 agents, 7x7) at a
     batch where the eager agent loop is host-bound: a one-layer torch policy per agent with replay memories, (a) the eager loop (sweep +
@@ -811,6 +833,7 @@ def main() -> int:
         valid_line = write_obs and sweep and args.diag_agents < 0 and args.obs_dtype == "f32"
         if world == 1 and valid_line and not args.no_side_configs and args.max_turns == 0:
             out["policy_turn"] = policy_turn_bench(eng)          # (after every timed region of the headline; same engine)
+            out["roofline"]["write_only_probe"] = write_only_probe(dev, eng.obs.numel() * eng.obs.element_size())
         if world == 1 and args.config == "c3" and valid_line and not args.no_side_configs:
             # the other 1-GPU BASELINE shapes, briefly, AFTER the headline run (its numbers are not touched by them)
             eng_obs, eng.obs = eng.obs, None                       # give the headline's 617 MB observation tensor back first

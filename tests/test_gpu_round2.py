@@ -407,6 +407,8 @@ def test_bench_line_carries_side_configs_cold_start_and_the_oracle_self_check(bu
     assert chk["equal"] is True and chk["tensors_that_differ"] == [] and chk["envs"] == 32768 and chk["turns"] >= 5
     assert chk["sum_total_reward"] == chk["oracle_sum_total_reward"]
     assert "wg_per_cu=8" in line["roofline"]["kernel"] and "cap=auto:0" in line["roofline"]["kernel"]     # what config 3 really launches
+    wp = line["roofline"]["write_only_probe"]      # what fill_ reaches on this card: context for frac
+    assert wp["bytes"] == 65536 * 8 * 6 * 49 * 4 and 3.0 < wp["tb_per_s"] < 8.0
     pt = line["policy_turn"]                       # the policy-driven turn on the headline's engine
     assert pt["status"] == 0 and pt["launches"] == 9
     assert 0.0 < pt["fused_turn_ms"] < pt["policy_turn_ms"] < 3 * pt["fused_turn_ms"] and pt["policy_turn_replay_rows_ms"] > 0

@@ -1183,6 +1183,12 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
         if (int rc = plan_engine(e, jit)) { delete e; return rc; }
         if (!jit) break;
         bool ok = true;
+        {   // (the ones that have to be compiled: in one program, jit.h)
+            std::vector<std::string> names;
+            for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk, &e->k_rows, &e->k_obs_rows, &e->k_sweep_rows})
+                if (!k->want.empty()) names.push_back(k->want);
+            jit_prefetch(names, e->opt, e->arch.c_str(), e->dev);
+        }
         for (Kernel* k : {&e->k_step, &e->k_plain, &e->k_multi, &e->k_walk, &e->k_rows, &e->k_obs_rows, &e->k_sweep_rows}) {
             if (k->want.empty()) continue;
             std::string err;

@@ -441,6 +441,34 @@ class Environment:
             for agent in self.agents:
                 agent.transition(self.world)
 
+    def turn_plan(self) -> dict:
+        """Which of the loops above will play the next ``take_turn()`` (without actions), and why the faster ones do not apply: a diagnostic --
+        ``{"loop": "recorded" | "per-agent handles" | "fused" | "speculative" | "fast" | "generic", ...}``."""
+        from sorrel_amd import _native as N
+
+        eng = self._ensure_engine()
+        if self._captured is not None and self._captured.valid(eng):
+            return {"loop": "recorded", "turns_replayed": self._captured.turns_replayed}
+        if self._mixed:
+            return {"loop": "per-agent handles", "why": "the agents hold different observation / action specs", "handles": len(self._all_engines())}
+        if all(getattr(a.model, "device_random", False) for a in self.agents):
+            return {"loop": "fused", "why": "every agent's actions are drawn on the device: one launch per turn"}
+        out = {}
+        if self.speculate_turns:
+            if self._speculation_groups(eng) is not None:
+                return {"loop": "speculative", "models": len(self._speculation_groups(eng))}
+            out["speculative"] = "not possible for these agents, or the cost model keeps the sequential loop (speculate_turns = 'always' overrides it)"
+        plan = self._fast_plan(eng) if self.fast_policy_loop else None
+        caps = eng.capabilities()
+        if plan is not None:
+            out.update(loop="fast", one_launch_windows=bool(plan.fused and self.fuse_sweep_and_rows), launches=(1 if plan.fused and self.fuse_sweep_and_rows else 2) + len(self.agents))
+            return out
+        out["fast"] = ("switched off" if not self.fast_policy_loop else
+                       "needs agents whose class sets speculative_ok (no hook overridden), one-frame Buffer memories of exactly one window (+ tail) per row, float32 windows")
+        patched = self.patch_windows and bool(caps & N.CAP_ACT) and eng.obs is not None
+        out.update(loop="generic", protocol="windows once + sgw_act per agent" if patched else "a window per agent launch (1 + A)")
+        return out
+
     # ------------------------------------------------------------------ many policy-driven agents: speculative turns
     #: Evaluate the policies of ALL agents on their pre-move windows in one batch per model, let the engine find the (env, agent) pairs
     #: whose window an earlier agent's move changed (``sgw_turn_resolve``) and re-evaluate only those, until nothing changes: the

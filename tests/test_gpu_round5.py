@@ -957,3 +957,37 @@ def test_fast_policy_loop_on_the_tag_and_cleanup_examples(torch_cuda, which):
             assert torch.equal(getattr(mx, name), getattr(my, name)), name
     a.raise_on_status()
     b.raise_on_status()
+
+
+def test_turn_plan_names_the_loop_that_plays(torch_cuda):
+    """Environment.turn_plan(): the diagnostic agrees with what take_turn() then does."""
+    from sorrel_amd.examples.treasurehunt.agents import TreasurehuntAgent
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+    from tests.test_gpu_round4 import _policy_env
+
+    rnd = make_env(14, 14, 3, 2, 16)                                   # RandomModel agents
+    assert rnd.turn_plan()["loop"] == "fused"
+    env = _policy_env(64, shape=(32, 32, 8, 3), memory=4)
+    plan = env.turn_plan()
+    assert plan["loop"] == "fast" and plan["one_launch_windows"] is True and plan["launches"] == 9, plan
+    env.fuse_sweep_and_rows = False
+    assert env.turn_plan()["launches"] == 10
+    env.fast_policy_loop = False
+    assert env.turn_plan()["loop"] == "generic" and "switched off" in env.turn_plan()["fast"]
+    env.fast_policy_loop = True
+
+    class Own(TreasurehuntAgent):
+        def get_action(self, state):
+            return super().get_action(state)
+
+    env.agents[2].__class__ = Own
+    env.__dict__.pop("_fast_plan_cache", None)
+    assert env.turn_plan()["loop"] == "generic"
+    env.agents[2].__class__ = TreasurehuntAgent
+    env.__dict__.pop("_fast_plan_cache", None)
+    assert env.capture_turn() is not None
+    assert env.turn_plan()["loop"] == "recorded"
+    env.take_turn()
+    mixed = make_mixed_env(9, "cuda:0")[0]
+    assert mixed.turn_plan()["loop"] == "per-agent handles" and mixed.turn_plan()["handles"] >= 2

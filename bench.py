@@ -182,7 +182,53 @@ def check_against_oracle(spec, played, dev, obs_dtype):
                     "compared with np.array_equal"}
 
 
-def side_config(name, dev, steps, prewarm, envs=0, check_turns=0, tune_placement=False):
+def rollout_bytes_per_turn(spec, E, T, obs_bytes):
+    """HBM-side bytes one turn of ``sgw_rollout(T)`` moves: every turn's windows, actions and rewards; grid, positions and totals once per launch."""
+    A = spec.num_agents
+    return E * (A * (spec.num_channels * spec.window ** 2 * obs_bytes + 1 + 4)) + (E * (2 * spec.grid_bytes_per_env() + A * 4 + 16)) / T
+
+
+def continue_against_oracle(eng, spec, turns, rollout=False):
+    """From the state THIS engine is in (the launches that were just timed ended there): copy it to the host, step the engine `turns` more
+    turns with the very call that was timed (``sgw_step`` with device-drawn actions; `rollout`: one ``sgw_rollout`` of that many turns) and
+    oracle/gridstep_oracle.c from the copy, compare every tensor with np.array_equal (each turn; the rollout: after its last).  The checker
+    only: nothing here is timed."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    lib = C.CDLL(g.ORACLE_LIB)
+    E, A = eng.num_envs, spec.num_agents
+    cfg = spec.to_config(E, eng.first_env_id)
+    torch.cuda.synchronize(eng.device)
+    arr = dict(grid=np.ascontiguousarray(eng.grid.cpu().numpy()), pos=eng.agent_pos.cpu().numpy().copy(), act=np.zeros((E, A), np.uint8),
+               obs=np.zeros((E,) + spec.obs_shape, np.float32), rew=np.zeros((E, A), np.float32), tot=eng.total_reward.cpu().numpy().copy())
+    t_at = eng.turn
+    differ = []
+    if rollout:
+        eng.rollout(turns)
+    for k in range(1, turns + 1):
+        if not rollout:
+            eng.step(random_actions=True)
+        lib.sgo_step(C.byref(cfg), *(a.ctypes.data_as(C.c_void_p) for a in (arr["grid"], arr["pos"], arr["act"], arr["obs"], arr["rew"], arr["tot"])),
+                     C.c_uint32(eng.epoch), C.c_uint32(t_at + k), C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(host_cores()),
+                     C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+        if rollout and k < turns:
+            continue
+        torch.cuda.synchronize(eng.device)
+        for key, mine in (("grid", eng.grid), ("pos", eng.agent_pos), ("act", eng.actions), ("obs", eng.obs), ("rew", eng.rewards), ("tot", eng.total_reward)):
+            if key not in differ and not np.array_equal(mine.cpu().numpy(), arr[key]):
+                differ.append(key)
+    return {"envs": E, "from_turn": t_at, "turns": turns, "equal": not differ and eng.status() == 0, "tensors_that_differ": differ,
+            "kernel": eng.launch_info().split(" group")[0],
+            "what": "from the state the timed launches ended in: the TIMED engine and oracle/gridstep_oracle.c (started from a copy of that state) "
+                    "step on, every tensor compared with np.array_equal" + (" after the rollout's last turn" if rollout else " each turn")}
+
+
+def side_config(name, dev, steps, prewarm, envs=0, check_turns=0, tune_placement=False, rollout_turns=0):
     """One more BASELINE shape in the same line: a short pre-warm, then `steps` launches between two
     HIP events on the launch stream.  Random actions, sweep on, float32 observations written, no reset in the region."""
     import torch
@@ -212,33 +258,29 @@ def side_config(name, dev, steps, prewarm, envs=0, check_turns=0, tune_placement
     kernel_ms = e0.elapsed_time(e1) / steps
     alg = spec.algorithmic_bytes_per_env_step() * E
     achieved = alg / (kernel_ms * 1e-3) / 1e9
-    checked = None
-    if check_turns > 0:     # the self-check of a side config: from the state the timed launches ended in, a few more turns on the
-        # engine and on the C oracle (oracle/gridstep_oracle.c, started from a copy of that state), every tensor compared
-        import ctypes as C
-
-        import numpy as np
-
-        import __graft_entry__ as g
-
-        lib = C.CDLL(g.ORACLE_LIB)
-        cfg = spec.to_config(E, 0)
-        arr = dict(grid=np.ascontiguousarray(eng.grid.cpu().numpy()), pos=eng.agent_pos.cpu().numpy().copy(), act=np.zeros((E, A), np.uint8),
-                   obs=np.zeros((E,) + spec.obs_shape, np.float32), rew=np.zeros((E, A), np.float32), tot=eng.total_reward.cpu().numpy().copy())
-        t_at = eng.turn
-        differ = []
-        for k in range(1, check_turns + 1):
-            eng.step(random_actions=True)
-            lib.sgo_step(C.byref(cfg), *(a.ctypes.data_as(C.c_void_p) for a in (arr["grid"], arr["pos"], arr["act"], arr["obs"], arr["rew"], arr["tot"])),
-                         C.c_uint32(0), C.c_uint32(t_at + k), C.c_int32(0), C.c_int32(A), C.c_uint32(1 | 2), C.c_int(host_cores()),
-                         C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
-            torch.cuda.synchronize(dev)
-            for key, mine in (("grid", eng.grid), ("pos", eng.agent_pos), ("act", eng.actions), ("obs", eng.obs), ("rew", eng.rewards), ("tot", eng.total_reward)):
-                if not np.array_equal(mine.cpu().numpy(), arr[key]) and key not in differ:
-                    differ.append(key)
-        checked = {"envs": E, "from_turn": t_at, "turns": check_turns, "equal": not differ and eng.status() == 0, "tensors_that_differ": differ,
-                   "what": "from the state the timed launches ended in: the engine and oracle/gridstep_oracle.c (started from a copy of that state) "
-                           "step on, every tensor compared with np.array_equal each turn"}
+    checked = continue_against_oracle(eng, spec, check_turns) if check_turns > 0 else None
+    rollout_leg = None
+    if rollout_turns > 0:   # the same shape through sgw_rollout: T whole turns per launch (how a user with a launch-bound batch runs it)
+        calls = max(2, steps // 4)
+        eng.rollout(rollout_turns)
+        for _ in range(calls):
+            eng.rollout(rollout_turns)
+        torch.cuda.synchronize(dev)
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for _ in range(calls):
+            eng.rollout(rollout_turns)
+        r1.record()
+        torch.cuda.synchronize(dev)
+        rms = r0.elapsed_time(r1) / (calls * rollout_turns)
+        moved = rollout_bytes_per_turn(spec, E, rollout_turns, 4)
+        rollout_leg = {"turns_per_launch": rollout_turns, "calls": calls, "ms_per_turn": rms, "bytes_moved_per_turn": moved,
+                       "algorithmic_frac": alg / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, "hbm_side_frac": moved / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "value": E * A / (rms * 1e-3),
+                       "what": "sgw_rollout, T turns per launch: algorithmic_frac prices a turn at SURVEY 8d's per-turn bytes (same numerator as `frac`), "
+                               "hbm_side_frac at what a turn of the rollout moves (windows / actions / rewards of every turn + grid, positions, totals once per launch)"}
+        if check_turns > 0:
+            rollout_leg["checked_vs_oracle_equal"] = continue_against_oracle(eng, spec, 2, rollout=True)["equal"]
     out = {"workload": f"{H}x{W} grid x {spec.layers} layers, {A} agents, {spec.window}x{spec.window} window, {E} envs on one GPU",
            "envs": E, "steps": steps, "prewarm_steps": prewarm, "kernel_ms": kernel_ms, "wall_ms_per_step": wall / steps * 1e3,
            "value": E * A / (kernel_ms * 1e-3), "unit": "agent-steps/s",
@@ -247,6 +289,8 @@ def side_config(name, dev, steps, prewarm, envs=0, check_turns=0, tune_placement
            "kernel": eng.launch_info(), "status": eng.status()}
     if checked is not None:
         out["checked_vs_oracle"] = checked
+    if rollout_leg is not None:
+        out["rollout"] = rollout_leg
     if placement is not None:
         out["obs_placement"] = dict(placement, what="GridEngine.pick_obs_placement: us per launch with the observation tensor in each of four allocations; the fastest kept "
                                                      "(the walking workgroups' dword stores are sensitive to where the tensor lies, stable per allocation)")
@@ -505,6 +549,27 @@ def ensure_built() -> None:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as a FRESH child (``python -m torch.distributed.run``, one
+    process per GPU) with this very command line, relay its output and exit code.  This process has made no GPU call (nothing here
+    imports torch; the libraries were checked just above, so the ranks find them built) and never replaces itself: no exec."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
 def series_stats(ms):
     if not ms:
         return None
@@ -556,6 +621,9 @@ def main() -> int:
 
     ensure_built()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
+
     import torch
     import torch.distributed as dist
 
@@ -567,9 +635,8 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no HIP device; the hot path has no CPU fallback", file=sys.stderr)
         return 2
@@ -579,8 +646,13 @@ def main() -> int:
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # under a launcher (torch.distributed.run exports RANK / WORLD_SIZE / MASTER_*) the process group exists even for ONE rank: a 1-GPU box then
+    # runs the very RCCL calls of the N > 1 line (tests/test_gpu_distributed.py); a plain `python bench.py` (the driver's N = 1 command) has none
+    grouped = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    backend = None
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -596,7 +668,7 @@ def main() -> int:
         eng.set_auto_reset(args.max_turns)
 
     def barrier():
-        if world > 1:
+        if grouped:
             if rehearsal:
                 dist.barrier()
             else:
@@ -722,8 +794,7 @@ def main() -> int:
         barrier()
         fwall = time.perf_counter() - tw
         fms = e0.elapsed_time(e1) / (calls * T)
-        per_turn_moved = E * (A * (spec.num_channels * spec.window ** 2 * (4 if args.obs_dtype == "f32" else 1) + 1 + 4)) \
-            + (E * (2 * spec.grid_bytes_per_env() + A * 4 + 16)) / T
+        per_turn_moved = rollout_bytes_per_turn(spec, E, T, 4 if args.obs_dtype == "f32" else 1)
         fused = {"turns_per_launch": T, "calls": calls, "ms_per_step": fms, "wall_ms_per_step": fwall / (calls * T) * 1e3,
                  "value_one_rank": E * A / (fms * 1e-3), "unit": "agent-steps/s",
                  "bytes_moved_per_step": per_turn_moved, "hbm_side_achieved": per_turn_moved / (fms * 1e-3) / 1e9,
@@ -742,13 +813,15 @@ def main() -> int:
     kernel_ms_rank = kernel_ms
     tmax = torch.tensor([dt, kernel_ms, barrier_ms], dtype=torch.float64, device=dev)
     per_rank_kernel_ms, group_size = [kernel_ms], 1
-    if world > 1:
+    if grouped:
         group_size = dist.get_world_size()       # what the process group itself says (the line's n_gpus is checked against it)
         mine = torch.zeros((world,), dtype=torch.float64, device=dev)
         mine[rank] = kernel_ms
+        from sorrel_amd.distributed import all_reduce_metrics
+
+        metrics = all_reduce_metrics(metrics)                # the product's ONE collective: SUM of the float64[4] metric vector (RCCL; gloo in a rehearsal)
         if rehearsal:     # gloo reduces host tensors
-            metrics, tmax, mine = metrics.cpu(), tmax.cpu(), mine.cpu()
-        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+            tmax, mine = tmax.cpu(), mine.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)      # (every rank wrote its own slot: the sum is the list)
         per_rank_kernel_ms = [float(x) for x in mine.tolist()]
@@ -790,7 +863,7 @@ def main() -> int:
             pass
         out = {
             "metric": "agent-steps/sec" if args.obs_dtype == "f32" else "agent-steps/sec (compact uint8 observations; NOT the contract metric)",
-            "value": value, "unit": "agent-steps/s", "n_gpus": group_size if world > 1 else 1,
+            "value": value, "unit": "agent-steps/s", "n_gpus": group_size if grouped else 1,
             "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm_steps),
             "rewarm_steps": max(0, args.rewarm_steps) if args.prewarm_steps > 0 else 0,
             "timed_region_submission": "one hipGraph replay of the K sgw_step launches (captured before the pre-warm pass, each node with the turn number it carries)" if timed_graph is not None else "K sgw_step calls",
@@ -803,8 +876,10 @@ def main() -> int:
                             f"{E} envs/GPU x {world} GPU = {total_envs} envs, treasurehunt rules, random actions, {args.obs_dtype} one-hot obs",
                 "envs_per_gpu": E, "global_envs": total_envs, "agents": A, "grid": [H, W, spec.layers],
                 "window": spec.window, "channels": spec.num_channels, "spawn_prob": p_spawn, "dense_prob": p_dense,
-                "sharding": f"env-batch x{world}, no data-path collective; one 32-byte all-reduce at end of rollout",
-                "process_group_world_size": group_size,
+                "sharding": f"env-batch x{world} by global env id, no data-path collective; after the rollout ONE 32-byte SUM all-reduce of the metric "
+                            f"vector (the product's only collective), plus this script's own timing reductions (one MAX over [wall, kernel_ms, barrier_ms], "
+                            f"one SUM that gathers kernel_ms per rank) and the barriers that bracket the timed region",
+                "process_group_world_size": group_size, "collectives_backend": backend,
                 "obs_written": write_obs, "sweep": sweep, "max_turns": args.max_turns,
             },
             "roofline": {
@@ -831,9 +906,27 @@ def main() -> int:
                         "first_env_id_rank0": 0, "first_env_id_last_rank": (world - 1) * E},
         }
         valid_line = write_obs and sweep and args.diag_agents < 0 and args.obs_dtype == "f32"
+        rf = out["roofline"]
+        if prewarm_series is not None:
+            rf["prewarm_10_100_ms"] = prewarm_series["launches_10_100_mean_ms"]    # what a short-lived process gets (the driver's record keeps scalars of `roofline`)
+            rf["prewarm_last_100_ms"] = prewarm_series["last_100_mean_ms"]
+        if fused is not None:
+            rf["c3_rollout_ms_per_turn"] = fused["ms_per_step"]
+            rf["c3_rollout_algorithmic_frac"] = alg_bytes / (fused["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if world == 1 and valid_line and not args.no_self_check and args.max_turns == 0:
+            # the self-check of the headline on the engine (and code object) that was just timed: from the state its launches ended in
+            chk = continue_against_oracle(eng, spec, 3)
+            out["rollout"]["timed_engine_checked_vs_oracle"] = chk
+            rf["timed_engine_checked_equal"] = chk["equal"]
+            rf["timed_engine_checked_what"] = f"{chk['envs']} envs x {chk['turns']} turns from turn {chk['from_turn']} on {chk['kernel']} vs the C oracle, all tensors"
         if world == 1 and valid_line and not args.no_side_configs and args.max_turns == 0:
             out["policy_turn"] = policy_turn_bench(eng)          # (after every timed region of the headline; same engine)
+            pt = out["policy_turn"]
+            for key in ("fused_turn_ms", "policy_turn_ms", "policy_turn_replay_rows_ms", "policy_turn_replay_rows_one_launch_ms"):
+                if key in pt:
+                    rf[key] = pt[key]
             out["roofline"]["write_only_probe"] = write_only_probe(dev, eng.obs.numel() * eng.obs.element_size())
+            rf["write_only_tb_per_s"] = rf["write_only_probe"]["tb_per_s"]
         if world == 1 and args.config == "c3" and valid_line and not args.no_side_configs:
             # the other 1-GPU BASELINE shapes, briefly, AFTER the headline run (its numbers are not touched by them)
             eng_obs, eng.obs = eng.obs, None                       # give the headline's 617 MB observation tensor back first
@@ -841,7 +934,7 @@ def main() -> int:
             torch.cuda.empty_cache()
             out["configs"] = {
                 # (pre-warm counts: ~60 ms of uninterrupted launches each -- the engine's creation leaves the chip idle)
-                "c2": side_config("c2", dev, args.side_steps, 5000, check_turns=0 if args.no_self_check else 3),
+                "c2": side_config("c2", dev, args.side_steps, 5000, check_turns=0 if args.no_self_check else 3, rollout_turns=args.turns_per_launch),
                 "c5": side_config("c5", dev, args.side_steps, 700, check_turns=0 if args.no_self_check else 3, tune_placement=True),
                 "c3_524288": side_config("c3", dev, max(10, args.side_steps // 2), 60, envs=524288),
             }
@@ -852,6 +945,22 @@ def main() -> int:
                 k: {"kernel_ms": v["kernel_ms"], "frac": v["roofline"]["frac"], "envs": v["envs"], "obs_placement_us": (v.get("obs_placement") or {}).get("candidates_us"),
                     "checked_vs_oracle_equal": (v.get("checked_vs_oracle") or {}).get("equal"), "kernel": v["kernel"].split(" group")[0]}
                 for k, v in out["configs"].items()}
+            # ... and FLAT, as scalars of `roofline` itself: the driver's record keeps only those
+            for k, v in out["configs"].items():
+                rf[f"{k}_kernel_ms"], rf[f"{k}_frac"] = v["kernel_ms"], v["roofline"]["frac"]
+                if v.get("checked_vs_oracle") is not None:
+                    rf[f"{k}_checked_vs_oracle_equal"] = v["checked_vs_oracle"]["equal"]
+                if v.get("rollout") is not None:
+                    rf[f"{k}_rollout_ms_per_turn"], rf[f"{k}_rollout_frac"] = v["rollout"]["ms_per_turn"], v["rollout"]["algorithmic_frac"]
+                    rf[f"{k}_rollout_hbm_side_frac"] = v["rollout"]["hbm_side_frac"]
+                    if "checked_vs_oracle_equal" in v["rollout"]:
+                        rf[f"{k}_rollout_checked_vs_oracle_equal"] = v["rollout"]["checked_vs_oracle_equal"]
+                pl = v.get("obs_placement")
+                if pl and pl.get("candidates_us"):     # the picked placement is the best of four: the first and the median beside it
+                    c = sorted(pl["candidates_us"])
+                    to_frac = v["roofline"]["algorithmic_bytes_per_launch"] / 1e3 / HBM_PEAK_GBS
+                    rf[f"{k}_first_placement_frac"] = to_frac / pl["candidates_us"][0]
+                    rf[f"{k}_median_placement_frac"] = to_frac / (0.5 * (c[(len(c) - 1) // 2] + c[len(c) // 2]))
             out["recorded_turn"] = recorded_turn_bench(dev)      # (the Python API at a host-bound batch: eager loop vs one graph replay per turn)
             out["many_agents_turn"] = many_agents_turn_bench(dev)   # (config 5's shape: the eager loop vs the speculative turn)
             # ... and, in brief, inside `roofline` like the side configs (wall us per Environment.take_turn through the Python API)
@@ -860,12 +969,18 @@ def main() -> int:
                 "c3_shape_1024_envs": {k: rt.get(k) for k in ("eager_loop", "eager_generic_loop", "recorded", "recorded_action_values",
                                                                "recorded_equals_eager", "generic_equals_eager", "error") if k in rt},
                 "c5_shape_2048_envs": {k: ma.get(k) for k in ("eager_loop", "speculative", "passes_of_the_last_turn", "speculative_equals_eager", "error") if k in ma}}
+            for key in ("eager_loop", "recorded", "recorded_equals_eager"):
+                if key in rt:
+                    rf[f"take_turn_1024_envs_{key}" + ("" if key.endswith("eager") else "_us")] = rt[key]
+            for key in ("eager_loop", "speculative", "speculative_equals_eager"):
+                if key in ma:
+                    rf[f"take_turn_c5_{key}" + ("" if key.endswith("eager") else "_us")] = ma[key]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], played = cpu_baseline(spec, args.config, args.cpu_seconds)
             if valid_line and not args.no_self_check:
                 out["rollout"]["checked_vs_oracle"] = check_against_oracle(spec, played, dev, obs_dtype)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         barrier()
         dist.destroy_process_group()
     return 0

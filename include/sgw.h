@@ -523,6 +523,14 @@ int sgw_gather_rows(const float* src, int64_t row_elems, const int64_t* idx, int
  * the ring, by the device's own row count -> out [count][E][row_elems] (device, element type = sgw_set_obs_format's).  Same
  * arguments every turn: recordable.  The ring must be bound with states (sgw_turn_bind); 1 <= count <= capacity. */
 int sgw_turn_prev_rows(sgw_engine* eng, int32_t agent, int32_t count, void* out, void* stream);
+/* The speculative turn's form of SGW_ACT_QF32 (a policy that returns action VALUES, sorrel/models/pytorch/iqn.py:294-309): for k < n,
+ * out[k] = the action sgw_act(SGW_ACT_QF32) would take for agent a = row / E in env = row % E (row = idx[k]; idx NULL: row = k) from
+ * values[k][0 .. num_actions): the first index of the maximum (NaN = maximum) or -- with probability epsilon[a] (sgw_turn_epsilon) -- the
+ * engine's uniform draw for (env, `turn`, a) of `epoch`.  The draw is keyed, not consumed, so a window's action is a function of the
+ * window and the fixed point of sgw_turn_resolve stays the sequential turn with exploration.  values float32 [n][num_actions], idx / out
+ * int64 on the device; asynchronous on `stream`. */
+int sgw_choose_actions(sgw_engine* eng, const float* values, const int64_t* idx, int64_t n, uint32_t epoch, uint32_t turn, int64_t* out,
+                       void* stream);
 /* Exploration rate of SGW_ACT_QF32 acts under the turn protocol: `agent` in [0, A) or -1 for every agent; epsilon in [0, 1].
  * Stream-ordered and kept in the device's turn state, so a recorded turn follows a decaying epsilon without being recorded again. */
 int sgw_turn_epsilon(sgw_engine* eng, int32_t agent, double epsilon, void* stream);

@@ -82,6 +82,9 @@ class Buffer:
             raise ValueError(f"add_batch of {k} rows into a ring of {self.capacity}")
         if self._deferred:
             raise RuntimeError("add_batch inside a recorded turn")
+        per_row = torch.is_tensor(done) and done.dim() == 2          # [k, E]: a flag per row; a scalar or [E] broadcasts over the rows
+        if per_row and tuple(done.shape) != (k, self.num_envs):        # (checked before anything is written: the ring stays consistent)
+            raise ValueError(f"done must be a scalar, [{self.num_envs}] or [{k}, {self.num_envs}]; got {tuple(done.shape)}")
         first = min(k, self.capacity - self.idx)
         for lo, hi, at in ((0, first, self.idx), (first, k, 0)):
             if hi <= lo:
@@ -92,7 +95,7 @@ class Buffer:
             self.actions[at:at + n].copy_(actions[lo:hi])
             self.rewards[at:at + n].copy_(rewards[lo:hi])
             if torch.is_tensor(done) or done:
-                self.dones[at:at + n] = done
+                self.dones[at:at + n] = done[lo:hi] if per_row else done     # (a wrap-around splits the rows: each segment takes ITS flags)
                 self._dones_dirty = True
             elif self._dones_dirty:
                 self.dones[at:at + n] = 0

@@ -394,30 +394,32 @@ struct ActIO {                   // sgw_act's optional extras (see RowPtrs), pas
 // The caller's action of agent a in env: its tensor's element, or for SGW_ACT_QF32 the first index of the maximum of the env's row of
 // action values (np.argmax; NaN = maximum, as np / torch have it) -- and, under the turn protocol, with probability epsilon[a] the
 // engine's own uniform draw for (env, turn, agent) instead, the action SGW_STEP_RANDOM_ACTIONS takes (sorrel/models/pytorch/iqn.py:294-309: the two branches of take_action_from_policy).
+// (shared with sgw_choose_actions: the speculative turn's batched form of the same choice)
+__device__ __forceinline__ int argmax_explore(const float* q, const int nact, const uint64_t thr, const uint32_t env_id, const uint32_t turn,
+                                              const uint32_t ep4, const int a, const uint32_t seed_lo, const uint32_t seed_hi) {
+    float best = q[0];
+    int arg = 0;
+    for (int i = 1; i < nact; ++i) {
+        const float v = q[i];
+        if (best == best && (v > best || v != v)) { best = v; arg = i; }
+    }
+    if (thr) {
+        const U4 u = philox4x32_10((uint32_t)a >> 2, turn, env_id, ep4 | SGW_STREAM_EXPLORE, seed_lo, seed_hi);
+        if ((uint64_t)word_of(u, a & 3) < thr) {
+            const U4 w = philox4x32_10((uint32_t)a >> 2, turn, env_id, ep4 | SGW_STREAM_ACTION, seed_lo, seed_hi);
+            arg = (int)(((uint64_t)word_of(w, a & 3) * (uint32_t)nact) >> 32);
+        }
+    }
+    return arg;
+}
 __device__ __forceinline__ int64_t read_action(const Params& p, const void* agent_action, const int kind, const TurnState* ts,
                                                const int64_t env, const int a) {
     if (kind == SGW_ACT_I64) return reinterpret_cast<const int64_t*>(agent_action)[env];
     if (kind == SGW_ACT_I32) return (int64_t)reinterpret_cast<const int32_t*>(agent_action)[env];
     if (kind == SGW_ACT_U8) return (int64_t)reinterpret_cast<const uint8_t*>(agent_action)[env];
     const float* q = reinterpret_cast<const float*>(agent_action) + env * p.nact;
-    float best = q[0];
-    int arg = 0;
-    for (int i = 1; i < p.nact; ++i) {
-        const float v = q[i];
-        if (best == best && (v > best || v != v)) { best = v; arg = i; }
-    }
-    if (ts) {
-        const uint64_t thr = ts->eps_thr[a];
-        if (thr) {
-            const uint32_t env_id = p.first_env + (uint32_t)env, turn = ts->turn + 1u, ep4 = ts->epoch << 4;
-            const U4 u = philox4x32_10((uint32_t)a >> 2, turn, env_id, ep4 | SGW_STREAM_EXPLORE, p.seed_lo, p.seed_hi);
-            if ((uint64_t)word_of(u, a & 3) < thr) {
-                const U4 w = philox4x32_10((uint32_t)a >> 2, turn, env_id, ep4 | SGW_STREAM_ACTION, p.seed_lo, p.seed_hi);
-                arg = (int)(((uint64_t)word_of(w, a & 3) * (uint32_t)p.nact) >> 32);
-            }
-        }
-    }
-    return (int64_t)arg;
+    const uint64_t thr = ts ? ts->eps_thr[a] : 0ull;
+    return (int64_t)argmax_explore(q, p.nact, thr, p.first_env + (uint32_t)env, ts ? ts->turn + 1u : 0u, ts ? ts->epoch << 4 : 0u, a, p.seed_lo, p.seed_hi);
 }
 __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, uint8_t* g, const int64_t env, const int a,
                                         const double* wval, const bool writer, MoveOut& mo, const ActIO io = ActIO{}) {

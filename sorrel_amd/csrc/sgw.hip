@@ -1222,6 +1222,12 @@ int sgw_create(const sgw_config* cfg, sgw_engine** out) {
     if (err == hipSuccess) err = hipMalloc(&e->d_part, 2 * kRedBlocks * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&e->d_turn, sizeof(TurnState));
     if (err == hipSuccess) err = hipMemset(e->d_turn, 0, sizeof(TurnState));
+    if (e->cfg.num_envs >= 8192) {     // sgw_turn_resolve's scan-built dirty list (large batches): allocated HERE, not inside a stream-ordered (capturable) call
+        const size_t nb = (size_t)ceil_div(e->cfg.num_envs, 256);
+        if (err == hipSuccess) err = hipMalloc(&e->d_dcount, (size_t)e->cfg.num_envs);
+        if (err == hipSuccess) err = hipMalloc(&e->d_doffsets, 2 * nb * sizeof(uint32_t));      // block sums | block offsets
+        if (err == hipSuccess) err = hipMemset(e->d_doffsets, 0, 2 * nb * sizeof(uint32_t));
+    }
     if (err != hipSuccess) {
         sgw_destroy(e);
         return fail(SGW_EHIP, "device allocation failed: %s", hipGetErrorString(err));
@@ -1830,11 +1836,7 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
     // hundreds of microseconds), laid out afterwards by a scan over per-env counts
     const bool scan = dirty_list && pass >= 1 && c.num_envs >= 8192;
     const int nb = (int)ceil_div(c.num_envs, 256);
-    if (scan && !e->d_dcount) {
-        HIP_TRY(hipMalloc(&e->d_dcount, (size_t)c.num_envs));
-        HIP_TRY(hipMalloc(&e->d_doffsets, (size_t)2 * nb * sizeof(uint32_t)));      // block sums | block offsets
-        HIP_TRY(hipMemset(e->d_doffsets, 0, (size_t)2 * nb * sizeof(uint32_t)));
-    }
+    if (scan && (!e->d_dcount || !e->d_doffsets)) return fail(SGW_EINVAL, "sgw_turn_resolve: the scan buffers of this engine are missing");   // (sgw_create allocates both from 8 192 envs on)
     ra.list = (dirty_list && !scan) ? dirty_list + (pass & 1) * EA : nullptr;
     ra.count = (counters && !scan) ? counters + (pass & 7) : nullptr;
     ra.count_next = counters ? counters + ((pass + 1) & 7) : nullptr;
@@ -1872,6 +1874,19 @@ int sgw_gather_rows(const float* src, int64_t row_elems, const int64_t* idx, int
     const bool v2 = (row_elems & 1) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7) == 0;
     if (v2) hipLaunchKernelGGL(gather_rows_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, src, row_elems, idx, n, dst);
     else hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, src, row_elems, idx, n, dst);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_choose_actions(sgw_engine* e, const float* values, const int64_t* idx, int64_t n, uint32_t epoch, uint32_t turn, int64_t* out, void* stream) {
+    if (!e || !values || !out) return fail(SGW_EINVAL, "sgw_choose_actions: NULL argument");
+    if (n < 0 || n > (int64_t)e->cfg.num_envs * e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_choose_actions: n = %lld outside [0, E * A]", (long long)n);
+    if ((reinterpret_cast<uintptr_t>(values) & 3) || (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(idx) & 7))
+        return fail(SGW_EINVAL, "sgw_choose_actions: misaligned pointer");
+    if (n == 0) return SGW_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, kBlock), (int64_t)e->num_cus * 16);
+    hipLaunchKernelGGL(choose_actions_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), e->d_turn, values, (int)e->cfg.num_actions,
+                       idx, n, (int64_t)e->cfg.num_envs, (uint32_t)e->cfg.first_env_id, epoch, turn, (uint32_t)e->cfg.seed, (uint32_t)(e->cfg.seed >> 32), out);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
 }

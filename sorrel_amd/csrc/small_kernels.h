@@ -206,6 +206,19 @@ __global__ void turn_epsilon_kernel(TurnState* ts, const int agent, const int A,
     const int a = threadIdx.x;
     if (a < A && (agent < 0 || a == agent)) ts->eps_thr[a] = thr;
 }
+// sgw_choose_actions: out[k] = the action the sequential turn's sgw_act(SGW_ACT_QF32) takes for row idx[k] = agent * E + env, from that row's
+// action values q[k][:] -- first index of the maximum, or with probability epsilon[agent] the engine's own draw for (env, turn, agent).
+__global__ __launch_bounds__(kBlock) void choose_actions_kernel(const TurnState* __restrict__ ts, const float* __restrict__ q, const int nact,
+                                                                const int64_t* __restrict__ idx, const int64_t n, const int64_t E,
+                                                                const uint32_t first_env, const uint32_t epoch, const uint32_t turn,
+                                                                const uint32_t seed_lo, const uint32_t seed_hi, int64_t* __restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = idx ? idx[k] : k;
+        const int a = (int)(row / E);
+        const int64_t env = row - (int64_t)a * E;
+        out[k] = (int64_t)argmax_explore(q + k * nact, nact, ts->eps_thr[a], first_env + (uint32_t)env, turn, epoch << 4, a, seed_lo, seed_hi);
+    }
+}
 __global__ void turn_set_kernel(TurnState* ts, const uint32_t epoch, const uint32_t turn) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { ts->epoch = epoch; ts->turn = turn; }
 }

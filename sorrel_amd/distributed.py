@@ -40,8 +40,13 @@ def init_from_env(backend: str = None):
 def all_reduce_metrics(metrics: torch.Tensor) -> torch.Tensor:
     """SUM-all-reduce the metric vector ``[sum(total_reward), sum(total_reward^2), envs, 0]``.
     Rewards of the canonical worlds are integers, so the float64 sums are exact in any order."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+    if dist.is_available() and dist.is_initialized():      # (a group of ONE rank still runs the collective: RCCL on a one-GPU box)
+        if dist.get_backend() == "gloo" and metrics.is_cuda:   # gloo reduces host tensors (CPU rehearsals of the N > 1 path)
+            host = metrics.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            metrics.copy_(host)
+        else:
+            dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
     return metrics
 
 

@@ -8,6 +8,7 @@ device raises.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 from typing import Optional
 
 import torch
@@ -51,6 +52,7 @@ class GridEngine:
             raise N.SgwError("no HIP device visible to PyTorch; the step/observe path has no CPU fallback")
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._lib = N.load()
+        self.uid = next(GridEngine._uids)        # names this engine in caches (id() values are reused once an object is gone)
         E, A = self.num_envs, spec.num_agents
         dev = self.device
         tensors = tensors or {}
@@ -175,10 +177,32 @@ class GridEngine:
             raise ValueError(f"pos must be a contiguous uint8 tensor of shape {want} on {self.device}")
         return t
 
+    _pending_closes: list = []        # (library, handle) of engines dropped while a stream was capturing: destroyed by drain_pending_closes()
+    _uids = itertools.count(1)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.sgw_destroy(self._h)
-            self._h = C.c_void_p()
+            h, self._h = self._h, C.c_void_p()
+            # sgw_destroy frees device memory, which HIP forbids while a stream of the process is capturing (the capture fails and torch
+            # aborts while it unwinds): an engine that dies inside a capture -- the collector's doing or a plain refcount -- waits
+            try:
+                capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+            except Exception:
+                capturing = False
+            if capturing:
+                GridEngine._pending_closes.append((self._lib, h))
+            else:
+                self._lib.sgw_destroy(h)
+
+    @classmethod
+    def drain_pending_closes(cls) -> int:
+        """Destroy the engines whose ``close()`` came while a stream was capturing.  Called before and after ``capture_turn``'s capture."""
+        n = 0
+        while cls._pending_closes:
+            lib, h = cls._pending_closes.pop()
+            lib.sgw_destroy(h)
+            n += 1
+        return n
 
     def __del__(self):
         try:
@@ -471,6 +495,22 @@ class GridEngine:
         with self._on_device():
             N.check(self._lib.sgw_gather_rows(flat.data_ptr(), ne, idx.data_ptr(), n, buf.data_ptr(), self._stream()))
         return buf[:n]
+
+    def choose_actions(self, values: torch.Tensor, idx: Optional[torch.Tensor], epoch: int, turn: int) -> torch.Tensor:
+        """``sgw_choose_actions``: the actions ``sgw_act`` would take from these action values ``[n, num_actions]`` (row k belongs to the
+        (agent, env) pair ``idx[k] = agent * E + env``; ``idx`` None: ``k`` itself) -- argmax, or with probability epsilon[agent]
+        (``turn_epsilon``) the engine's keyed draw for (env, ``turn``, agent).  int64 ``[n]``."""
+        n = int(values.shape[0])
+        if values.dim() != 2 or values.shape[1] != self.spec.num_actions or not values.is_floating_point():
+            raise ValueError(f"action values must be floating point [n, {self.spec.num_actions}]; got {values.dtype} {tuple(values.shape)}")
+        values = values.to(device=self.device, dtype=torch.float32).contiguous()
+        if idx is not None and (idx.dtype != torch.int64 or idx.device != self.device or not idx.is_contiguous() or idx.numel() < n):
+            raise ValueError("choose_actions: idx must be a contiguous int64 vector of at least n entries on the engine's device")
+        out = torch.empty((n,), dtype=torch.int64, device=self.device)
+        with self._on_device():
+            N.check(self._lib.sgw_choose_actions(self._h, values.data_ptr(), idx.data_ptr() if idx is not None else None, n, int(epoch), int(turn),
+                                                 out.data_ptr(), self._stream()))
+        return out
 
     def speculation_windows(self, rows: Optional[torch.Tensor] = None, sweep_turn: Optional[int] = None) -> torch.Tensor:
         """Every agent's PRE-move window into ``speculation_rows(rows)``: ``sgw_observe_rows`` where the engine has a row kernel for the

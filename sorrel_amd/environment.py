@@ -127,8 +127,8 @@ class Environment:
         self._captured = None        # CapturedTurn: a whole policy turn recorded as one graph (capture_turn)
         self._turn_capture = False   # the turn protocol with device-side counters is in charge of this turn (recording or warming up)
         self._value_agents = set()   # slots whose get_action returns action values: the act launch takes the argmax / explores (SGW_ACT_QF32)
-        self._eps_pushed = {}        # slot -> (engine id, epsilon) last sent to the device's turn state
-        self._turn_state_at = {}     # engine id -> (epoch, turn) the device's turn state was last set for by the eager loop
+        self._eps_pushed = {}        # slot -> (engine uid, epsilon) last sent to the device's turn state
+        self._turn_state_at = {}     # engine uid -> (epoch, turn) the device's turn state was last set for by the eager loop
         self._engine = None
         self._engine_version = -1
         self._aux_engines = {}
@@ -514,7 +514,8 @@ class Environment:
         groups = self._speculation_groups_uncached(eng, N, Buffer)
         if groups is not None and self.speculate_turns != "always" and not self._speculation_pays(eng):
             groups = None
-        self.__dict__["_spec_groups"] = (key, groups)
+        # (the key names objects by id(): the entry holds them, so no id in it can be handed to a NEW engine / model / memory while it is cached)
+        self.__dict__["_spec_groups"] = (key, groups, (eng, [(a.model, getattr(a.model, "memory", None)) for a in self.agents]))
         return groups
 
     #: (fixed us of a speculative turn, us per MB of windows, us of host time per agent of the sequential loop, its fixed us): the sequential
@@ -576,16 +577,24 @@ class Environment:
         else:
             eng.speculation_windows(own, sweep_turn=self.turn)           # the sweep, then every agent's PRE-move window, once (one launch with CAP_SWEEP_ROWS)
 
-        def choose(model, x):
+        def choose(model, x, idx):
+            # idx: which (agent, env) pair each row of x belongs to (agent * E + env; None: the row's own number)
             out = model.take_action(x)
-            if out.dim() == 2:                                           # action values: greedy (an exploring policy draws inside take_action)
-                out = out.argmax(dim=1)
+            if out.dim() == 2:
+                # action values: what Agent.transition hands to sgw_act (SGW_ACT_QF32) -- the argmax, or with probability agent.epsilon the
+                # engine's draw for (env, turn, agent) (iqn.py:294-309).  The draw is keyed, so the choice stays a function of the window
+                # and the fixed point below is the sequential turn WITH its exploration.
+                self._push_epsilon(eng, range(A))
+                out = eng.choose_actions(out, idx, self.epoch, self.turn)
             return out.to(torch.int64)
 
         if len(groups) == 1:                                             # pass 1: one batch per model
-            fresh = choose(groups[0][2], flat)
+            fresh = choose(groups[0][2], flat, None)
         else:
-            fresh = torch.cat([choose(model, flat[a0 * E:a1 * E]) for a0, a1, model in groups])
+            every = self.__dict__.get("_spec_arange")
+            if every is None or every.numel() != A * E or every.device != eng.device:
+                every = self.__dict__["_spec_arange"] = torch.arange(A * E, dtype=torch.int64, device=eng.device)
+            fresh = torch.cat([choose(model, flat[a0 * E:a1 * E], every[a0 * E:a1 * E]) for a0, a1, model in groups])
         def bucket(n):
             # a batch of a few sizes only (the BLAS picks its kernel per shape: a new shape every turn costs more than the padding)
             return 64 if n <= 64 else (1 << (n - 1).bit_length() if n <= 4096 else -(-n // 4096) * 4096)
@@ -600,7 +609,7 @@ class Environment:
             ahead, m = None, 0
             if len(groups) == 1 and guess.get(k, 0) > 0:
                 m = min(bucket(int(guess[k] * 1.2) + 1), A * E)
-                ahead = choose(groups[0][2], eng.gather_rows(flat, eng._spec_list[k & 1, :m]))
+                ahead = choose(groups[0][2], eng.gather_rows(flat, eng._spec_list[k & 1, :m]), eng._spec_list[k & 1, :m])
             n = eng.spec_count(k)                                        # (synchronises)
             guess[k] = n
             if n == 0:
@@ -612,7 +621,7 @@ class Environment:
                 pad = eng._spec_list[k & 1, :m]
                 if m > n:
                     pad[n:m] = 0                                         # (row 0: evaluated again, the result thrown away)
-                fresh = choose(groups[0][2], eng.gather_rows(flat, pad))[:n]
+                fresh = choose(groups[0][2], eng.gather_rows(flat, pad), pad)[:n]
             else:
                 lst = eng._spec_list[k & 1, :n]
                 fresh = torch.empty_like(lst)
@@ -620,7 +629,7 @@ class Environment:
                 for a0, a1, model in groups:
                     sel = torch.nonzero((a_i >= a0) & (a_i < a1)).squeeze(1)
                     if sel.numel():
-                        fresh[sel] = choose(model, flat.index_select(0, lst[sel]))
+                        fresh[sel] = choose(model, flat.index_select(0, lst[sel]), lst[sel].contiguous())
             k += 1
             eng.turn_resolve(k, own, fresh.contiguous(), rrows, arows)
         self.speculation_passes = k
@@ -722,7 +731,7 @@ class Environment:
                tuple((id(a.model), id(getattr(a.model, "memory", None)), type(a)) for a in self.agents))
         cached = self.__dict__.get("_fast_plan_cache")
         if cached is None or cached[0] != key:
-            cached = (key, _FastPolicyTurn.build(self, eng))
+            cached = (key, _FastPolicyTurn.build(self, eng), (eng, [(a.model, getattr(a.model, "memory", None)) for a in self.agents]))   # (holds what its key names by id())
             self.__dict__["_fast_plan_cache"] = cached
         plan = cached[1]
         return plan if plan is not None and plan.still_valid() else None
@@ -1113,9 +1122,9 @@ class Environment:
         """The exploration rates of the agents that act through action values, to the device's turn state when they change."""
         for a in (self._value_agents if slots is None else slots):
             eps = min(1.0, max(0.0, self.agents[a].epsilon))
-            if self._eps_pushed.get(a) != (id(eng), eps):
+            if self._eps_pushed.get(a) != (eng.uid, eps):
                 eng.turn_epsilon(eps, a)
-                self._eps_pushed[a] = (id(eng), eps)
+                self._eps_pushed[a] = (eng.uid, eps)
 
     def _act(self, agent: Agent, action) -> torch.Tensor:
         eng = self._ensure_engine()
@@ -1135,9 +1144,9 @@ class Environment:
                 if self._captured is not None and self._captured.graph is not None:
                     raise RuntimeError("an agent switched to action values after its turn was recorded: capture_turn() again")
                 self._value_agents.add(a)
-            if not self._turn_capture and self._turn_state_at.get(id(eng)) != (self.epoch, self.turn):
+            if not self._turn_capture and self._turn_state_at.get(eng.uid) != (self.epoch, self.turn):
                 eng.turn_set(self.epoch, self.turn - 1)               # the exploration draws are keyed by the turn in flight
-                self._turn_state_at[id(eng)] = (self.epoch, self.turn)
+                self._turn_state_at[eng.uid] = (self.epoch, self.turn)
             if not (self._turn_capture and torch.cuda.is_current_stream_capturing()):
                 self._push_epsilon(eng, (a,))                         # (a recorded turn gets its epsilons before each replay)
         if self._mixed:                          # windows are rendered per agent at its pov: nothing to keep current
@@ -1516,9 +1525,9 @@ class _FastPolicyTurn:
                 if values and a in env._value_agents and action.dtype == torch.float32 and action.device == dev and action.is_contiguous() \
                         and tuple(action.shape) == (E, self.nact):
                     # action VALUES: the act launch takes the argmax / explores (SGW_ACT_QF32); the draws are keyed by the turn in flight
-                    if env._turn_state_at.get(id(eng)) != (env.epoch, env.turn):
+                    if env._turn_state_at.get(eng.uid) != (env.epoch, env.turn):
                         eng.turn_set(env.epoch, env.turn - 1)
-                        env._turn_state_at[id(eng)] = (env.epoch, env.turn)
+                        env._turn_state_at[eng.uid] = (env.epoch, env.turn)
                     env._push_epsilon(eng, (a,))
                     pa, kind = action.data_ptr(), self.qf32
                 elif not torch.is_tensor(action) or values:               # a plain int, or an agent's FIRST action values (or odd ones): the generic act
@@ -1602,8 +1611,13 @@ class CapturedTurn:
         # No garbage collection inside the capture: an unreachable engine or graph of an EARLIER environment that the collector happens to
         # free now would call hipFree / hipGraphDestroy while a stream is capturing, which HIP forbids -- the capture fails, and torch aborts
         # the process while it unwinds (seen under rocprofv3, where the timing differs; torch.cuda.graph no longer collects on entry itself)
+        # The window: process-wide and NOT thread-safe (another thread that re-enables the collector, or drops the last reference to an engine /
+        # graph between here and the end of the capture, still frees inside it) -- a capture is a single-threaded moment of the caller's program.
+        # Reference-counted frees of THIS thread are kept out explicitly: engines whose close() is pending are closed now, before the capture.
         import gc
+        from sorrel_amd.engine import GridEngine
         gc.collect()
+        GridEngine.drain_pending_closes()
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
@@ -1624,6 +1638,7 @@ class CapturedTurn:
                 mem.idx, mem.size = idx, size
                 mem._deferred_adds = 0
         self.graph = g
+        GridEngine.drain_pending_closes()
         self._expect, self._at = [mem.idx for mem in self.buffers], (env.epoch, env.turn)
 
     def abort(self) -> None:

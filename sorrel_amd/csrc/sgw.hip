@@ -1396,6 +1396,10 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
         k = &e->k_walk;
         blocks = e->walk_blocks;
     }
+    // (A/B option, off by default.  Measured on the kernel, config 5's shape: on one card the staged windows gain 1-3 % from it -- 185.5 -> 180.7 us at
+    //  4 096 envs -- and the direct dword stores lose 1-3 %; on the next card the staged windows LOSE 3-6 %: 213.8 -> 226.4; profiles/r06_c5_remap_ab.txt)
+    p.big_remap = (e->big && e->opt.big_remap && p.big_stage > 0 && blocks >= 64 && (blocks & 7) == 0) ? blocks / 8 : 0;
+    p.big_nt = e->opt.big_nt;
     if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, nullptr)) return rc;
     return time_end(e, s);
 }

@@ -142,6 +142,7 @@ struct sgw_engine {
     Kernel k_rows;        // phase_rows<L, NW, R>: a policy-driven phase with a lane per window row (one-hot, plain moves)
     Kernel k_obs_rows;    // observe_rows<L, NW, R>: a range of agents, per-agent destinations
     Kernel k_sweep_rows;  // step_fast_rows<L, C, R, H, W>: the sweep + every agent's window into per-agent destinations, one launch
+    bool sweep_rows_chunked = false;   // ... it is a step_fast_rowsx instance (a chunk-staging kernel: any env_stride, row tails)
     int walk_blocks = 0;                            // how many workgroups of the walking kernel the chip holds at once
     int64_t walk_min_envs = 0, walk_max_envs = 0;  // batches above min and up to max take it (multiples of what the plain kernel holds at once)
     int64_t big_stage_min_envs = 0;                // step_big stages its windows for batches above this
@@ -282,6 +283,12 @@ using RowsFn = void (*)(const Params, const RowPtrs);
         return reinterpret_cast<const void*>(static_cast<StepFn>(__VA_ARGS__)); \
     } while (0)
 
+#define PICK2(...)                                            \
+    do {                                                      \
+        *name = #__VA_ARGS__;                                 \
+        return reinterpret_cast<const void*>(static_cast<RowsFn>(__VA_ARGS__)); \
+    } while (0)
+
 // step_kernel<G, ONEHOT, L, C, RULE, r, H, W, MULTI>: the single-turn instance, or (multi) the one with sgw_rollout's turn loop.
 // A compile-time radius for the examples as shipped (Tag 11x11 / 9x9 windows 116-119 -> 107-108 us, Treasurehunt 5x5 51.0 -> 46.2 us at
 // 65 536 envs); everything else about a user's own world comes from the specialised instance (jit.h).
@@ -358,20 +365,20 @@ StepFn pick_reset(int wpe) { return wpe == 1 ? reset_kernel<1> : reset_kernel<4>
 const void* pick_big(bool onehot, int L, int C, int r, bool tag, int threads, const char** name) {
     if (tag) {   // TagAgent.act on the workgroup-per-env kernel (moves in registers, the "it" token walked by wave 0)
         if (threads == 256) {
-            if (onehot && L == 1 && C == 4 && r == 4) PICK(step_big<true, 1, 4, 4, false, false, true, 256>);
-            if (onehot) PICK(step_big<true, 0, 0, 0, false, false, true, 256>);
+            if (onehot && L == 1 && C == 4 && r == 4) PICK2(step_big<true, 1, 4, 4, false, false, true, 256>);
+            if (onehot) PICK2(step_big<true, 0, 0, 0, false, false, true, 256>);
         }
-        if (onehot && L == 1 && C == 4 && r == 4) PICK(step_big<true, 1, 4, 4, false, false, true>);   // the Tag example's tables and 9x9 window
-        if (onehot) PICK(step_big<true, 0, 0, 0, false, false, true>);
-        PICK(step_big<false, 0, 0, 0, false, false, true>);
+        if (onehot && L == 1 && C == 4 && r == 4) PICK2(step_big<true, 1, 4, 4, false, false, true>);   // the Tag example's tables and 9x9 window
+        if (onehot) PICK2(step_big<true, 0, 0, 0, false, false, true>);
+        PICK2(step_big<false, 0, 0, 0, false, false, true>);
     }
-    if (!onehot) PICK(step_big<false, 0, 0, 0>);
+    if (!onehot) PICK2(step_big<false, 0, 0, 0>);
     if (threads == 256) {   // up to 32 agents: four waves per workgroup
-        if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, false, false, 256>);
-        PICK(step_big<true, 0, 0, 0, false, false, false, 256>);
+        if (L == 2 && C == 6 && r == 5) PICK2(step_big<true, 2, 6, 5, false, false, false, 256>);
+        PICK2(step_big<true, 0, 0, 0, false, false, false, 256>);
     }
-    if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5>);   // BASELINE config 5
-    PICK(step_big<true, 0, 0, 0>);
+    if (L == 2 && C == 6 && r == 5) PICK2(step_big<true, 2, 6, 5>);   // BASELINE config 5
+    PICK2(step_big<true, 0, 0, 0>);
 }
 
 // which of pick_big's choices run 256 threads (the others: kBigThreads): worlds whose windows are little work for eight waves --
@@ -388,20 +395,20 @@ bool fixed_fast_shape(int L, int C, int r, int H, int W, bool tag) {   // = the 
 }
 
 const void* pick_big_multi(bool onehot, int L, int C, int r, const char** name) {
-    if (!onehot) PICK(step_big<false, 0, 0, 0, true>);
-    if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, true>);
+    if (!onehot) PICK2(step_big<false, 0, 0, 0, true>);
+    if (L == 2 && C == 6 && r == 5) PICK2(step_big<true, 2, 6, 5, true>);
     *name = "-";      // (round 5: the run-time-table turn-loop instance used 28 bytes of scratch per lane; without hipRTC such a world's rollout
     return nullptr;   // is a loop of single-turn launches)
 }
 
 const void* pick_big_walk(bool onehot, int L, int C, int r, int threads, const char** name) {
-    if (!onehot) PICK(step_big<false, 0, 0, 0, false, true>);
+    if (!onehot) PICK2(step_big<false, 0, 0, 0, false, true>);
     if (threads == 256) {
-        if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, true, false, 256>);
-        PICK(step_big<true, 0, 0, 0, false, true, false, 256>);
+        if (L == 2 && C == 6 && r == 5) PICK2(step_big<true, 2, 6, 5, false, true, false, 256>);
+        PICK2(step_big<true, 0, 0, 0, false, true, false, 256>);
     }
-    if (L == 2 && C == 6 && r == 5) PICK(step_big<true, 2, 6, 5, false, true>);
-    PICK(step_big<true, 0, 0, 0, false, true>);
+    if (L == 2 && C == 6 && r == 5) PICK2(step_big<true, 2, 6, 5, false, true>);
+    PICK2(step_big<true, 0, 0, 0, false, true>);
 }
 
 // phase_rows instances: layers x counter words (channels / 4) x vision radius.  Shapes outside the table are compiled on demand
@@ -468,8 +475,24 @@ std::string join_args(const char* tmpl, std::vector<std::string> a, size_t keep,
     return s + ">";
 }
 const char* tf(bool b) { return b ? "true" : "false"; }
-std::string fast_rows_id(int L, int C, int r, int H, int W) {
-    return "step_fast_rows<" + std::to_string(L) + ", " + std::to_string(C) + ", " + std::to_string(r) + ", " + std::to_string(H) + ", " + std::to_string(W) + ">";
+std::string fast_rows_id(int L, int C, int r, int H, int W, bool tag = false) {
+    return "step_fast_rows<" + std::to_string(L) + ", " + std::to_string(C) + ", " + std::to_string(r) + ", " + std::to_string(H) + ", " + std::to_string(W) + (tag ? ", true>" : ">");
+}
+// the ROWX twin of a chunk-staging instance `name` ("step_fast<true, ..., STAGE = true, ...>") for this engine's constants; "" if `name` is not one
+std::string fast_rowsx_id_like(const char* name, int L, int C, int r, int H, int W) {
+    std::vector<std::string> a;
+    const char* s = name ? strchr(name, '<') : nullptr;
+    if (!s) return "";
+    std::string cur;
+    for (++s; *s && *s != '>'; ++s) {
+        if (*s == ',') { a.push_back(cur); cur.clear(); }
+        else if (*s != ' ') cur += *s;
+    }
+    a.push_back(cur);
+    while (a.size() < 12) a.push_back("false");
+    if (a[0] != "true" || a[8] != "true" || a[9] == "true" || a[11] == "true") return "";     // one-hot, STAGE, single-turn, not the 16-bit colour instance
+    return "step_fast_rowsx<" + std::to_string(L) + ", " + std::to_string(C) + ", " + std::to_string(r) + ", " + std::to_string(H) + ", " + std::to_string(W) + ", " +
+           a[6] + ", " + a[7] + ", " + a[10] + ">";
 }
 std::string fast_id(bool onehot, int L, int C, int r, int H, int W, bool tag, bool rules, bool stage, bool multi, bool p3, bool i16) {
     return join_args("step_fast", {tf(onehot), std::to_string(L), std::to_string(C), std::to_string(r), std::to_string(H), std::to_string(W),
@@ -869,12 +892,19 @@ int plan_engine(sgw_engine* e, bool jit) {
             e->k_plain = Kernel();
         }
         // the policy turn's first launch into per-agent rows (sgw_sweep_observe_rows): plain movers whose env leaves as one burst
-        if (e->whole_env_burst && static_map && !tagk && !e->fast_rules && ((C * (2 * r + 1) * (2 * r + 1)) & 1) == 0) {
-            if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32) {
+        if (e->whole_env_burst && static_map && !e->fast_rules && ((C * (2 * r + 1) * (2 * r + 1)) & 1) == 0) {      // (round 6: Tag movers too)
+            if (L == 2 && C == 6 && r == 3 && H == 32 && W == 32 && !tagk) {
                 e->k_sweep_rows.host = reinterpret_cast<const void*>(&step_fast_rows<2, 6, 3, 32, 32>);
                 e->k_sweep_rows.host_name = "step_fast_rows<2, 6, 3, 32, 32>";
             }
-            if (jit) e->k_sweep_rows.want = fast_rows_id(L, C, r, H, W);
+            if (jit) e->k_sweep_rows.want = fast_rows_id(L, C, r, H, W, tagk);
+        }
+        // ... and on the chunk-staging instances (layered rule sets, Tag, run-time maps): the ROWX twin, specialised only (round 6)
+        e->sweep_rows_chunked = false;
+        if (jit && !e->whole_env_burst && stage_kernel && e->onehot && !e->rgb16 && e->stage_agents >= 1 && e->k_step.host_name) {
+            const int jh = static_map ? H : 0, jw = static_map ? W : 0;
+            e->k_sweep_rows.want = fast_rowsx_id_like(e->k_step.host_name, L, C, r, jh, jw);
+            e->sweep_rows_chunked = !e->k_sweep_rows.want.empty();
         }
     } else if (e->big) {
         e->k_step.host = pick_big(e->onehot, L, C, r, tag_move, e->big_threads, &e->k_step.host_name);
@@ -982,7 +1012,8 @@ int resolve_kernel(sgw_engine* e, Kernel& k) {
 int launch_kernel(sgw_engine* e, Kernel& k, unsigned blocks, unsigned threads, size_t lds, hipStream_t s, Params& p, RowPtrs* rp) {
     if (!k.jit && !k.want.empty() && !k.tried)
         if (int rc = resolve_kernel(e, k)) return rc;
-    void* args[2] = {&p, rp};
+    static RowPtrs no_rows{};                 // (kernels that take the row pointers read them only when Params says so: rows_on, ...)
+    void* args[2] = {&p, rp ? rp : &no_rows};
     if (k.jit) HIP_TRY(hipModuleLaunchKernel(k.jit, blocks, 1, 1, threads, 1, 1, (unsigned)lds, s, args, nullptr));
     else if (k.host) HIP_TRY(hipLaunchKernel(k.host, dim3(blocks), dim3(threads), args, lds, s));
     else return fail(SGW_EHIP, "no kernel to launch");
@@ -1340,7 +1371,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
     // step_big: the walking variant keeps the direct stores (measured faster there), and so does a launch whose observation
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
     const bool walk = e->big && p.nturns == 1 && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
-    p.big_stage = (e->big && p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0 && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
+    p.big_stage = (e->big && ((p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) || (sweep_rows && !p.obs_u8)) && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
     if (walk) {     // the walking workgroups: a static share each, the rest off a counter (step_big.h)
         p.walk_ctr = reinterpret_cast<uint32_t*>(e->d_status) + 1;
         p.walk_static = e->opt.big_walk_share > 0 ? e->opt.big_walk_share : (int)std::max<int64_t>(1, p.E / e->walk_blocks);
@@ -1353,12 +1384,14 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     // (the phase kernels take the acting agent's action from the tensor: a phase whose action is drawn on the device -- SGW_STEP_RANDOM_ACTIONS,
     // an agent with a RandomModel among agents that step one by one -- stays on the step kernel, which draws it)
-    if (sweep_rows) {
+    if (sweep_rows && !e->big) {
         if (p.obs_stage <= 0 || p.a0 != 0 || p.a1 != p.A || (p.flags & SGW_STEP_NO_OBS))      // (step_fast_rows has no other way to emit than its staged burst)
-            return fail(SGW_EINVAL, "sgw_sweep_observe_rows: this engine does not stage a whole env's windows");
+            return fail(SGW_EINVAL, "sgw_sweep_observe_rows: this engine does not stage its windows");
+        if (e->sweep_rows_chunked) p.stage_agents = 1;                                           // (ROWX: a chunk = one agent = one row)
         if (int rc = launch_kernel(e, e->k_sweep_rows, (unsigned)e->grid_blocks, kBlock, lds, s, p, sweep_rows)) return rc;
         return time_end(e, s);
     }
+    p.rows_on = sweep_rows ? 1 : 0;           // (step_big: the ordinary instances, windows to rp.p[a] + env * rp.stride; round 6)
     const bool one_phase = p.nturns == 1 && !(p.flags & (SGW_STEP_SWEEP | SGW_STEP_RANDOM_ACTIONS)) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
     if (e->k_rows.usable() && one_phase && !p.obs_u8) {
         // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
@@ -1400,7 +1433,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
     //  4 096 envs -- and the direct dword stores lose 1-3 %; on the next card the staged windows LOSE 3-6 %: 213.8 -> 226.4; profiles/r06_c5_remap_ab.txt)
     p.big_remap = (e->big && e->opt.big_remap && p.big_stage > 0 && blocks >= 64 && (blocks & 7) == 0) ? blocks / 8 : 0;
     p.big_nt = e->opt.big_nt;
-    if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, nullptr)) return rc;
+    if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, p.rows_on ? sweep_rows : nullptr)) return rc;
     return time_end(e, s);
 }
 
@@ -1534,7 +1567,8 @@ int sgw_capabilities(sgw_engine* e) {
         if (ok) caps |= SGW_CAP_RESOLVE;
     }
     if (e->big) caps |= SGW_CAP_OBS_AGENT_MAJOR;
-    if (e->k_sweep_rows.usable() && e->obs_format == SGW_OBS_F32 && e->tail_kind == SGW_TAIL_NONE) caps |= SGW_CAP_SWEEP_ROWS;
+    if (e->k_sweep_rows.usable() && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_SWEEP_ROWS;      // (round 6: row tails on every instance)
+    if (e->big && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_SWEEP_ROWS;      // (round 6: step_big renders into per-agent rows itself, row tails included)
     return caps;
 }
 
@@ -1618,13 +1652,16 @@ int sgw_sweep_observe_rows(sgw_engine* e, uint8_t* grid, const uint8_t* agent_po
     if (flags & ~(uint32_t)SGW_STEP_SWEEP) return fail(SGW_EINVAL, "sgw_sweep_observe_rows: flags may hold SGW_STEP_SWEEP only");
     if (epoch >= (1u << 28)) return fail(SGW_EINVAL, "epoch must be < 2^28");
     const int A = e->cfg.num_agents;
-    if (env_stride != (int64_t)e->base.C * e->base.VV) return fail(SGW_EINVAL, "sgw_sweep_observe_rows: env_stride must be exactly one window (C * V * V elements)");
+    if (env_stride != (int64_t)e->base.C * e->base.VV + e->tail_len)
+        return fail(SGW_EINVAL, "sgw_sweep_observe_rows: env_stride must be exactly one window (C * V * V elements) + the bound row tail (%d)", e->tail_len);
     RowPtrs rp;
     if (int rc = fill_rows(e, rows, env_stride, 0, A, true, &rp, "sgw_sweep_observe_rows")) return rc;
     Params p = e->base;
     p.grid = grid; p.pos = const_cast<uint8_t*>(agent_pos);
     p.actions = nullptr; p.obs = nullptr; p.rewards = nullptr; p.total = nullptr;
     p.epoch = epoch; p.turn = turn; p.a0 = 0; p.a1 = A; p.flags = flags & SGW_STEP_SWEEP; p.do_move = 0;
+    p.tail_kind = e->tail_kind; p.tail_len = e->tail_len; p.tail_table = e->tail_table;
+    if (p.tail_kind == SGW_TAIL_AGENT_IS_IT && !e->agent_state) return fail(SGW_EINVAL, "SGW_TAIL_AGENT_IS_IT needs sgw_bind_agent_state");
     return launch_step(e, p, static_cast<hipStream_t>(stream), &rp);
 }
 
@@ -2107,13 +2144,14 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
                           : (k.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.host, threads, lds) : hipErrorInvalidValue);
     if (oe != hipSuccess) per_cu = -1;
     const char* phase = e->k_rows.usable() ? e->k_rows.name() : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
-    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d specialised=%d",
+    const char* srows = e->big ? (e->obs_format == SGW_OBS_F32 ? "the-step-kernel" : "-") : (e->k_sweep_rows.usable() ? e->k_sweep_rows.name() : "-");   // what sgw_sweep_observe_rows launches
+    snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d specialised=%d sweep_rows=%s",
              k.name(),
              (e->fast || e->big) ? (e->big ? e->big_threads : e->wpe * kWave) : e->group,
              threads, lds, e->step_env_lds, e->obs_stage, e->stage_agents,
              walk ? e->walk_blocks : e->grid_blocks, per_cu,
              e->wg_per_cu == 0 ? "auto:" : (e->wg_per_cu < 0 ? "never:" : "forced:"), cap, phase, big_staged ? e->big_stage : 0,
-             k.jit ? 1 : 0);
+             k.jit ? 1 : 0, srows);
     return SGW_OK;
 }
 

@@ -60,7 +60,7 @@ constexpr int big_agent_lds(bool tag) { return kBigAgentLds + (tag ? kBigTagLds 
 // have one or two windows each and mostly wait at the barriers (round 3, 8 192 envs: 90x90x2 / 16 agents 122 -> 103 us, 100x100x2 / 8
 // agents / 11x11 104 -> 88, Tag 128x128 / 32 agents 145 -> 116; config 5 itself 352 -> 394: it keeps 512).
 template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false, int BT = kBigThreads>
-__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WAVES)) void step_big(const Params p) {
+__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WAVES)) void step_big(const Params p, const RowPtrs rp) {
     constexpr int kBT = BT, kBW = BT / 64;   // threads / waves of this instance
     static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
     // Philox key schedule per block (common.h): config 5's share on the walking variant 94 -> 90 us; the plain variant is indifferent at
@@ -551,8 +551,18 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     }
                 }
             }
-            float* obase = p.obs_ag ? p.obs + tix * p.ts_obs + (int64_t)a * p.obs_ag + env * (int64_t)(C * VV)       // [A][E][C][V][V]
+            float* obase = p.rows_on ? static_cast<float*>(rp.p[a]) + env * rp.stride                                   // sgw_sweep_observe_rows: the agent's own row
+                         : p.obs_ag ? p.obs + tix * p.ts_obs + (int64_t)a * p.obs_ag + env * (int64_t)(C * VV)       // [A][E][C][V][V]
                                     : p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
+            if (p.rows_on && p.tail_kind != SGW_TAIL_NONE) {     // what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds)
+                float* t = obase + C * VV;
+                if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {       // TagAgent.pov: [self.it] (nobody acts in this launch: the flag is the bound tensor's)
+                    if (lane == 0) t[0] = (p.agent_state && p.agent_state[env * p.A + a] == p.tag_it) ? 1.f : 0.f;
+                } else {                                         // CleanupObservation.observe: the positional code of the agent's cell
+                    const float* src = p.tail_table + ((int64_t)y * W + x) * p.tail_len;
+                    for (int k = lane; k < p.tail_len; k += 64) t[k] = src[k];
+                }
+            }
             if constexpr (ONEHOT) {
                 // the packed byte counts of window cell lane + 64 k: one table word per layer and group of four channels
                 auto counts = [&](const int k, uint32_t (&cq)[NW]) {
@@ -575,8 +585,10 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     typedef float vfloat4 __attribute__((ext_vector_type(4)));
                     uint8_t* ob = smem + p.big_stage_off + wv * p.big_stage;
                     const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
-                    const int64_t e0 = obase - p.obs;       // the window's first element in the tensor
-                    const int sh = (int)(e0 & 31);          // ... and its distance from a line boundary: staged byte s is element (e0 - sh) + s
+                    // the window's first element in the tensor and its distance from a line boundary: staged byte s is element (e0 - sh) + s
+                    // (a row of its own -- rows_on -- by its address: the row pointers are 4-byte aligned, no more)
+                    const int64_t e0 = p.rows_on ? (int64_t)(reinterpret_cast<uintptr_t>(obase) >> 2) : (int64_t)(obase - p.obs);
+                    const int sh = (int)(e0 & 31);
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         const int w = lane + 64 * k;
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     const int ie = lane == 0 ? i0 - 1 : i1;
                     const bool edge = lane == 0 ? (sh & 3) != 0 : (lane == 1 && (he & 3) != 0);
                     if (!p.obs_u8) {
-                        float* gb = p.obs + (e0 - sh);
+                        float* gb = p.rows_on ? obase - sh : p.obs + (e0 - sh);
                         for (int i = lane; i < i1; i += 64) {
                             if (i < i0) continue;
                             const uint32_t b = ob4[i];

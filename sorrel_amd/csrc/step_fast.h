@@ -188,15 +188,34 @@ __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* r
             if (re == kN) emit_run(ring, a, 0, live);
             else for (int k = 0; k < live; ++k) emit_run(ring + k * re, a, k, 1);
         }
+        // (round 6) what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds); nobody acts in this launch, so the
+        // agents' types and cells are the bound tensors'
+        if (p.tail_kind != SGW_TAIL_NONE && rp->stride >= kN + p.tail_len) {
+            for (int k = 0; k < live; ++k) {
+                float* t = base + k * rp->stride + kN;
+                const int64_t ea = (env_first + k) * p.A + a;
+                if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {
+                    if (lane == 0) t[0] = (p.agent_state && p.agent_state[ea] == p.tag_it) ? 1.f : 0.f;
+                } else {
+                    const uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[ea];
+                    const float* src = p.tail_table + ((int64_t)(yx & 0xFFu) * TW + (yx >> 8)) * p.tail_len;
+                    for (int j = lane; j < p.tail_len; j += 64) t[j] = src[j];
+                }
+            }
+        }
     }
 }
 
 // ROWS (round 5): the instance behind sgw_sweep_observe_rows -- the sweep and EVERY agent's window in one launch, each window going to
 // its agent's own destination (rp->p[a] + env * rp->stride: the row of that agent's replay buffer) instead of the [E][A][C][V][V] tensor.
 // Only the emit differs (see there); compiled for compile-time shapes with the whole-env burst.
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS>
+// ROWX (round 6): the same call on the instances that stage CHUNKS of agents (STAGE: layered rule sets -- Cleanup --, Tag, run-time maps and tables): the host
+// launches with one agent per chunk, and a chunk leaves for its agent's own row -- emit_chunk's line-aligned 16-byte streaming stores, the staging offset
+// taken from the ROW's address -- followed by the bound row tail (TagAgent.pov's flag, CleanupObservation's positional code).
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS, bool ROWX = false>
 __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] const RowPtrs* rp) {
-    static_assert(!ROWS || (ONEHOT && TL && TC && TH && TW && !TAG && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain movers, one-hot, compile-time shape");
+    static_assert(!ROWS || (ONEHOT && TL && TC && TH && TW && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain or Tag movers, one-hot, compile-time shape");
+    static_assert(!ROWX || (ONEHOT && STAGE && !MULTI && !I16 && !ROWS), "ROWX: a chunk-staging single-turn instance");
     // One wave = one env, one pass: no persistent loop (letting the dispatcher hand out
     // workgroups measured 17 % faster than a persistent grid with software prefetch),
     // wave-private LDS (grid slice + the table words this wave reads), no s_barrier.
@@ -326,6 +345,7 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
     [[maybe_unused]] uint32_t ch_shift = 0;    // staging byte of the chunk's first element = its offset (in elements) from a 128-byte line of global memory
     [[maybe_unused]] uint32_t ch_lo = 0;       // first staged byte that has not left yet (bytes carried over from the chunk before sit in front of ch_shift)
     if constexpr (kStageAlways) ch_lo = ch_shift = (uint32_t)(env * (int64_t)(p.A * C * VV)) & kLineMask;
+    [[maybe_unused]] float* row_dst = nullptr; // ROWX: where the chunk's (one) agent's window goes
 
     // per-lane window geometry: up to two cells per lane
     int wdi[2], wdj[2], woff[2];
@@ -537,8 +557,8 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
             // edge dwords (the env's first / last float4, partly another env's): element by element, by lanes 0 / 1
             const int ie = lane == 0 ? i0 - 1 : i1;
             const bool edge = lane == 0 ? (lo & 3) != 0 : (lane == 1 && (he & 3) != 0 && (i1 >= i0 || (lo & 3) == 0));
-            if (!p.obs_u8) {
-                float* gb = p.obs + (e0 - sh);
+            if (ROWX || !p.obs_u8) {
+                float* gb = ROWX ? row_dst - sh : p.obs + (e0 - sh);
                 for (int i = lane; i < i1; i += 64) {
                     if (i < i0) continue;
                     const uint32_t b = ob4[i];
@@ -572,6 +592,19 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
                         if (4 * ie + j >= lo && 4 * ie + j < he) gb[4 * ie + j] = (uint8_t)(b >> (8 * j));
                 }
             }
+            if constexpr (ROWX) {
+                if (p.tail_kind != SGW_TAIL_NONE) {      // what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds)
+                    float* t = row_dst + C * VV;
+                    if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {
+                        const uint32_t ty_ = (uint32_t)__builtin_amdgcn_readlane((int)atype, a_lo);
+                        if (lane == 0) t[0] = ty_ == p.tag_it ? 1.f : 0.f;
+                    } else {
+                        const int ay_ = __builtin_amdgcn_readlane((int)(yx & 0xFFu), a_lo), ax_ = __builtin_amdgcn_readlane((int)(yx >> 8), a_lo);
+                        const float* src = p.tail_table + ((int64_t)ay_ * W + ax_) * p.tail_len;
+                        for (int k = lane; k < p.tail_len; k += 64) t[k] = src[k];
+                    }
+                }
+            }
             if (!last) {   // the bytes behind the last line boundary: to the front, they leave with the next chunk
                 uint8_t t = 0;
                 if (lane < hi - he) t = ob[he + lane];
@@ -585,7 +618,12 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
         // ---- agents, strictly in list order (SGW_STEP_OBS_NEXT: one extra, observe-only iteration for agent a1)
         const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;
         for (int a = p.a0; a < a_end; ++a) {
-            if constexpr (kStageAlways) {
+            if constexpr (ROWX) {                    // a chunk = one agent = one row: the agent before leaves, this one's row sets the staging offset
+                if (a > p.a0 && write_obs) emit_chunk(a - 1, a, true);
+                ch_a0 = a;
+                row_dst = static_cast<float*>(rp->p[a]) + env * rp->stride;
+                ch_lo = ch_shift = (uint32_t)(reinterpret_cast<uintptr_t>(row_dst) >> 2) & kLineMask;
+            } else if constexpr (kStageAlways) {
                 if (a - ch_a0 == p.stage_agents) {   // the staging area is full: out with it, start the next chunk
                     if (write_obs) emit_chunk(ch_a0, a, false);   // (moves ch_shift / ch_lo on to the next chunk)
                     ch_a0 = a;
@@ -883,8 +921,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? SGW_FAST_MULTI_WAVES : (RULES ? (ST
     step_fast_body<ONEHOT, TL, TC, TR, TH, TW, TAG, RULES, STAGE, MULTI, P3, I16, false>(p, nullptr);
 }
 
+// ... on the chunk-staging instances (ROWX; specialised in-process only: the library holds no prebuilt twin)
+template <int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool P3>
+__global__ __launch_bounds__(kBlock, RULES ? 7 : 8) void step_fast_rowsx(const Params p, const RowPtrs rp) {
+    step_fast_body<true, TL, TC, TR, TH, TW, TAG, RULES, true, false, P3, false, false, true>(p, &rp);
+}
+
 // sweep + every agent's window into per-agent rows (sgw_sweep_observe_rows): nobody acts in this launch
-template <int TL, int TC, int TR, int TH, int TW>
+template <int TL, int TC, int TR, int TH, int TW, bool TAG = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast_rows(const Params p, const RowPtrs rp) {
-    step_fast_body<true, TL, TC, TR, TH, TW, false, false, false, false, false, false, true>(p, &rp);
+    step_fast_body<true, TL, TC, TR, TH, TW, TAG, false, false, false, false, false, true>(p, &rp);
 }

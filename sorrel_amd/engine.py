@@ -820,6 +820,6 @@ class GridEngine:
         N.check(self._lib.sgw_set_wg_per_cu(self._h, int(n)))
 
     def launch_info(self) -> str:
-        buf = C.create_string_buffer(512)
-        N.check(self._lib.sgw_launch_info(self._h, buf, 512))
+        buf = C.create_string_buffer(1024)
+        N.check(self._lib.sgw_launch_info(self._h, buf, 1024))
         return buf.value.decode()

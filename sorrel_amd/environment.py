@@ -760,7 +760,7 @@ class Environment:
                 self._tail_rows = [torch.zeros((eng.num_envs, per_env), dtype=torch.float32, device=eng.device) for _ in self.agents]
             dests = self._tail_rows
         rows = eng.window_rows(dests)
-        if dests is not None and self.fuse_sweep_and_rows and not eng.row_tail and caps & N.CAP_SWEEP_ROWS:
+        if dests is not None and self.fuse_sweep_and_rows and caps & N.CAP_SWEEP_ROWS:      # (round 6: row tails, Tag / Cleanup worlds and worlds above 4 KiB too)
             eng.sweep_observe_rows(rows, sweep=True, turn=self.turn)      # both in one launch (the grid read once, a burst per env)
         elif dests is not None:                 # the sweep alone, then every window into its agent's replay row
             eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
@@ -1479,7 +1479,7 @@ class _FastPolicyTurn:
         self.lib = eng._lib
         self.kinds = eng._ACTION_KINDS
         from sorrel_amd import _native as N
-        self.fused = bool(eng.capabilities() & N.CAP_SWEEP_ROWS) and not eng.row_tail
+        self.fused = bool(eng.capabilities() & N.CAP_SWEEP_ROWS)
         self.qf32, self.nact = N.ACT_QF32, eng.spec.num_actions
 
     def still_valid(self) -> bool:

@@ -855,13 +855,17 @@ def test_engines_without_the_fused_instance_say_so(torch_cuda):
 
     big = make_engine(treasurehunt_spec(72, 80, 6, 3), 5)                       # workgroup per env
     odd = make_engine(treasurehunt_spec(20, 20, 3, 1), 5)                       # 6 * 9 = 54 elements per window: even, offered; 3 agents * 54 % 4 != 0: no whole-env burst
-    for eng in (big, odd):
+    N.set_option("jit", 0)                                                      # (round 6: specialised chunk-staging instances have a fused twin; the prebuilt ones do not)
+    plain = make_engine(treasurehunt_spec(20, 20, 3, 1), 5)
+    N.reset_options()
+    for eng in (big, odd, plain):
         if eng.capabilities() & N.CAP_SWEEP_ROWS:
             continue
         rows = eng.window_rows([torch_cuda.zeros((5, int(np.prod(eng.spec.obs_shape[1:]))), device="cuda:0") for _ in range(eng.spec.num_agents)])
         with pytest.raises(ValueError):
             eng.sweep_observe_rows(rows)
-    assert not (big.capabilities() & N.CAP_SWEEP_ROWS)
+    assert big.capabilities() & N.CAP_SWEEP_ROWS                                # (round 6: step_big renders into per-agent rows itself)
+    assert not (plain.capabilities() & N.CAP_SWEEP_ROWS)
 
 
 def test_speculate_turns_true_follows_the_cost_model(torch_cuda):

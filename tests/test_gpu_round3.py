@@ -241,7 +241,8 @@ def test_sgw_act_and_observe_rows_reject_what_they_cannot_serve(torch_cuda):
 
     d, spec = H.load_golden("tag_9x9")
     tag = make_engine(H.world_spec(spec), 8)
-    assert tag.capabilities() == N.CAP_ACT | N.CAP_OBSERVE_ROWS   # (round 4: observe_rows renders windows whatever the agents' act rule is)
+    assert tag.capabilities() & ~N.CAP_SWEEP_ROWS == N.CAP_ACT | N.CAP_OBSERVE_ROWS   # (round 4: observe_rows renders windows whatever the agents' act rule is; round 6: where the
+    # world is on a wave-per-env instance -- a batch of 8 envs of a 9x9 map may be packed instead -- the fused sweep + rows launch as well; never the speculative resolve: Tag agents)
     ws = _move_world(16, 16, 2, 6, 4, 2, seed=1)
     u8 = make_engine(ws, 8, obs_dtype=torch.uint8)
     assert u8.capabilities() == N.CAP_ACT                # the row-load kernels write float32 windows only

@@ -71,7 +71,8 @@ extern "C" {
 #define SGW_MAX_CHANNELS 16
 #define SGW_MAX_CHOICES 8
 #define SGW_MAX_ACTIONS 16
-#define SGW_MAX_AGENTS 64
+#define SGW_MAX_AGENTS 128 /* round 6 (64 before): up to 64 agents every kernel family applies (lane = agent on the wave- / workgroup-per-env kernels); 65..128 run on
+                            * the ticket-ordered workgroup-per-env generic kernel, whatever the world's size (the reference steps any list: sorrel/environment.py:92-93) */
 #define SGW_MAX_LAYERS 7   /* numpy sums <= 7 layers left to right; 8+ pairwise */
 #define SGW_MAX_DIM 256    /* positions are uint8 */
 

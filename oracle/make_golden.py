@@ -849,6 +849,7 @@ def main() -> int:
     make_round2_fixtures(R)
     make_round3_fixtures(R)
     make_round5_fixtures(R)
+    make_round6_fixtures(R)
 
     print("stock_np_random: unmodified Treasurehunt classes + RandomModel on np.random.seed(0)")
     ref = run_reference_stock(R, 10, 10, 2, 2, 0.05, 60, np_seed=0)
@@ -1063,6 +1064,23 @@ def make_round5_fixtures(R):
     save("mixed_specs_treasurehunt", spec, ids, out, extra)
 
 
+def make_round6_fixtures(R):
+    """More than 64 agents (the reference steps any ``self.agents`` list, sorrel/environment.py:92-93): the reference's OWN take_turn over 80
+    Treasurehunt agents on a 24x26 map (contention: a seventh of the interior is agents) and 70 Tag agents on 20x21."""
+    print("many_agents_80_treasurehunt: 24x26, 80 agents, r=2, dense, 2 envs x 5 turns")
+    spec = O.treasurehunt_spec(24, 26, 80, 2, spawn_prob=0.03, seed=17, dense_prob=0.2)
+    ids = [0, 4099]
+    ref = run_reference_treasurehunt(R, spec, ids, 5)
+    check_against_oracle(spec, ids, 5, ref)
+    save("many_agents_80_treasurehunt", spec, ids, ref)
+    print("many_agents_70_tag: 20x21, 70 Tag agents, r=3, 1 env x 6 turns")
+    spec = tag_spec(20, 21, 70, 3, seed=23)
+    ids = [5]
+    ref = run_reference_tag(R, spec, ids, 6)
+    check_against_oracle(spec, ids, 6, ref)
+    save("many_agents_70_tag", spec, ids, ref)
+
+
 def make_buffer_fixture():
     """Replay ring semantics of the reference Buffer (sorrel/buffers.py:11-154): index arithmetic,
     n_frames stacking in current_state(), add_empty(), and sample() for given draws."""
@@ -1130,6 +1148,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["round5"]:       # only the fixture added in round 5
         make_round5_fixtures(_import_reference())
+        sys.exit(0)
+    if sys.argv[1:] == ["round6"]:       # only the fixtures added in round 6
+        make_round6_fixtures(_import_reference())
         sys.exit(0)
     if sys.argv[1:] == ["round3"]:       # only the fixtures added in round 3
         make_round3_fixtures(_import_reference())

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 64, 7, 256
+MAX_TYPES, MAX_CHANNELS, MAX_CHOICES, MAX_ACTIONS, MAX_AGENTS, MAX_LAYERS, MAX_DIM = 32, 16, 8, 16, 128, 7, 256
 RULE_NONE, RULE_SPAWN, RULE_BECOME_IF = 0, 1, 2
 NO_BORDER = 255
 STEP_SWEEP, STEP_RANDOM_ACTIONS, STEP_NO_OBS, STEP_OBS_NEXT, STEP_OBS_NEXT_PACKED, STEP_NO_MOVE, STEP_OBS_AGENT_MAJOR = 1, 2, 4, 8, 16, 32, 64

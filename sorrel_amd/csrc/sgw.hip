@@ -610,7 +610,8 @@ int plan_engine(sgw_engine* e, bool jit) {
     p.cells = c.layers * c.height * c.width;
     p.cells_pad = (p.cells + 15) & ~15;
     p.env_stride = c.grid_env_stride > 0 ? c.grid_env_stride : p.cells;
-    p.env_lds = p.cells_pad + kAgentLds;
+    p.agent_cap = c.num_agents > 64 ? SGW_MAX_AGENTS : 64;
+    p.env_lds = p.cells_pad + agent_lds_bytes(p.agent_cap);
     p.tab_bytes = onehot ? kTabFastBytes : (int)sizeof(DevTables);
     p.default_type = (uint32_t)c.default_type;
     p.fill_type = (uint32_t)c.fill_type;
@@ -714,6 +715,10 @@ int plan_engine(sgw_engine* e, bool jit) {
     if (o.force_generic) fast_8k = false;
     e->wpe = (p.cells_pad <= 4096 || rules_8k || fast_8k) ? 1 : 4;
     if (o.force_big && simple_rules && !o.force_generic) e->wpe = 4;
+    // More than 64 agents (round 6): the wave- and workgroup-per-env kernels keep an agent per LANE of one wave; such worlds run on the generic kernel
+    // with a workgroup per env (an agent phase = the work of one wave behind the LDS ticket, per-agent state in LDS arrays of SGW_MAX_AGENTS), any size
+    const bool many_agents = c.num_agents > 64;
+    if (many_agents) e->wpe = 4;
     const int epb = kBlock / (e->wpe * kWave);
     e->lds_bytes = (size_t)p.tab_bytes + (size_t)epb * p.env_lds;
     e->fast = e->wpe == 1 && vec16 && (p.cells_pad >> 4) <= 64 * (fast_8k ? kMaxUnitsPlain : kMaxUnits) && nspawn <= 1 && p.VV <= 128 && simple_rules;   // MovingAgent.act and TagAgent.act
@@ -722,6 +727,7 @@ int plan_engine(sgw_engine* e, bool jit) {
                     !tagk && (p.cells_pad <= 4096 || rules_8k);
     if (!o.fast_rules) e->fast_rules = false;   // test hook: generic kernel instead
     e->fast = e->fast || e->fast_rules;
+    if (many_agents) e->fast = e->fast_rules = false;
     // fast kernel: wave-private LDS = [one-hot counter words | appearance table][grid]
     // (the integer-table RGB instances exist for three channels, plain or Tag movers, worlds <= 4 KiB)
     const bool rgb16_fast = e->rgb16 && e->fast && !e->fast_rules && c.num_channels == 3;
@@ -730,7 +736,7 @@ int plan_engine(sgw_engine* e, bool jit) {
     bool agents_impassable = true;
     for (int a = 0; a < c.num_agents; ++a) agents_impassable = agents_impassable && !c.type_passable[c.agent_type[a]];
     const bool tag_move = tagk;      // TagAgent.act moves like MovingAgent.act; step_big<..., TAG> walks the "it" token
-    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && (plain_move || tag_move) && simple_rules;
+    e->big = e->wpe == 4 && vec16 && nspawn <= 1 && p.VV <= 128 && agents_impassable && (plain_move || tag_move) && simple_rules && !many_agents;
     e->big_threads = kBigThreads;
     if (e->big) e->big_threads = big_threads_for(o, onehot, c.num_agents, p.VV);
     bool stage_kernel = false;   // a STAGE kernel (bursts of agents) applies
@@ -1562,7 +1568,7 @@ int sgw_capabilities(sgw_engine* e) {
     if (e->k_obs_rows.usable() && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_OBSERVE_ROWS;
     caps |= SGW_CAP_ACT;      // MovingAgent.act, TagAgent.act and CleanupAgent.act all have an sgw_act instance
     {   // sgw_turn_resolve: plain movers with impassable agent types, float32 windows
-        bool ok = e->cfg.agent_rule == SGW_AGENT_RULE_MOVE && e->obs_format == SGW_OBS_F32;
+        bool ok = e->cfg.agent_rule == SGW_AGENT_RULE_MOVE && e->obs_format == SGW_OBS_F32 && e->cfg.num_agents <= 64;   // (the resolve kernel keeps an agent per lane)
         for (int a = 0; a < e->cfg.num_agents; ++a) ok = ok && !e->cfg.type_passable[e->cfg.agent_type[a]];
         if (ok) caps |= SGW_CAP_RESOLVE;
     }
@@ -1699,7 +1705,7 @@ static int act_impl(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* a
     const bool wide = A > 8 && A <= 16 && (e->opt.act_lanes == 16 || (e->opt.act_lanes == 0 && p.E <= 32768));   // (two agents per lane pay off once the waves outnumber the SIMDs' slots: profiles/r04_act_probe.txt)
     const int G = A <= 16 ? (wide ? 16 : 8) : (A <= 32 ? 32 : 64);      // lanes per env; 9..16 agents: two per lane
     const unsigned blocks = (unsigned)ceil_div(p.E, 4 * (64 / G));
-#define ACT_PICK(R, OH) (A <= 8 ? act_patch<8, 1, R, OH> : (A <= 16 ? (wide ? act_patch<16, 1, R, OH> : act_patch<8, 2, R, OH>) : (A <= 32 ? act_patch<32, 1, R, OH> : act_patch<64, 1, R, OH>)))
+#define ACT_PICK(R, OH) (A <= 8 ? act_patch<8, 1, R, OH> : (A <= 16 ? (wide ? act_patch<16, 1, R, OH> : act_patch<8, 2, R, OH>) : (A <= 32 ? act_patch<32, 1, R, OH> : (A <= 64 ? act_patch<64, 1, R, OH> : act_patch<64, 2, R, OH>))))
 #define ACT_RULE(OH) (e->cfg.agent_rule == SGW_AGENT_RULE_TAG ? ACT_PICK(SGW_AGENT_RULE_TAG, OH) \
                       : e->cfg.agent_rule == SGW_AGENT_RULE_CLEANUP ? ACT_PICK(SGW_AGENT_RULE_CLEANUP, OH) : ACT_PICK(SGW_AGENT_RULE_MOVE, OH))
     RowsFn fn = e->onehot ? ACT_RULE(true) : ACT_RULE(false);
@@ -1778,7 +1784,7 @@ int sgw_turn_epsilon(sgw_engine* e, int32_t agent, double epsilon, void* stream)
     if (!(epsilon >= 0.0 && epsilon <= 1.0)) return fail(SGW_EINVAL, "sgw_turn_epsilon: epsilon must be in [0, 1]");
     const double t = std::floor(epsilon * 4294967296.0);
     const uint64_t thr = t >= 4294967296.0 ? 4294967296ull : (uint64_t)t;
-    hipLaunchKernelGGL(turn_epsilon_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), e->d_turn, agent, e->cfg.num_agents, thr);
+    hipLaunchKernelGGL(turn_epsilon_kernel, dim3(1), dim3(SGW_MAX_AGENTS), 0, static_cast<hipStream_t>(stream), e->d_turn, agent, e->cfg.num_agents, thr);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
 }
@@ -1851,6 +1857,7 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
         return fail(SGW_EINVAL, "sgw_turn_resolve: NULL argument");
     const sgw_config& c = e->cfg;
     if (c.agent_rule != SGW_AGENT_RULE_MOVE) return fail(SGW_EINVAL, "sgw_turn_resolve: plain movers only (SGW_AGENT_RULE_MOVE)");
+    if (c.num_agents > 64) return fail(SGW_EINVAL, "sgw_turn_resolve: at most 64 agents (an agent per lane)");
     if (e->obs_format != SGW_OBS_F32) return fail(SGW_EINVAL, "sgw_turn_resolve: float32 windows only");
     for (int a = 0; a < c.num_agents; ++a)
         if (c.type_passable[c.agent_type[a]]) return fail(SGW_EINVAL, "sgw_turn_resolve: agent types must be impassable");
@@ -1971,7 +1978,7 @@ int sgw_turn_end(sgw_engine* e, const void* obs, void* stream) {
         }
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(turn_advance_kernel, dim3(1), dim3(64), 0, s, e->d_turn, A);   // every ring advances; the turn counts as completed
+    hipLaunchKernelGGL(turn_advance_kernel, dim3(1), dim3(SGW_MAX_AGENTS), 0, s, e->d_turn, A);   // every ring advances; the turn counts as completed
     HIP_TRY(hipGetLastError());
     return SGW_OK;
 }

@@ -58,30 +58,50 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Params p) {
         }
         gsync<WPE>();
     }
-    // agents: the first wave of the group, lane a = agent a
+    // agents: the first wave of the group, lane a = agent a (and, beyond 64 agents -- round 6 --, agent 64 + a in a second set of registers:
+    // the sorted list of taken cells is then 128 long, positions 0..63 in `taken`, 64..127 in `taken2`)
     if (gtid < kWave) {
-        uint32_t u = 0;
+        uint32_t u = 0, u2 = 0;
         if (lane < p.A) {
             const U4 w = philox4x32_10((uint32_t)lane >> 2, 0u, env_id, (p.epoch << 4) | SGW_STREAM_PLACE, p.seed_lo, p.seed_hi);
             u = word_of(w, lane & 3);
         }
+        if (64 + lane < p.A) {
+            const U4 w = philox4x32_10((uint32_t)(64 + lane) >> 2, 0u, env_id, (p.epoch << 4) | SGW_STREAM_PLACE, p.seed_lo, p.seed_hi);
+            u2 = word_of(w, lane & 3);
+        }
         const int n = (p.H - 2) * (p.W - 2);
         const int iw = p.W - 2;
-        int taken = 0x7FFFFFFF;                 // lane j: the j-th smallest taken interior index (valid for j < i)
-        int mine = 0;                           // lane i: agent i's interior index
+        int taken = 0x7FFFFFFF, taken2 = 0x7FFFFFFF;   // lane j: the j-th (64 + j-th) smallest taken interior index (valid below i)
+        int mine = 0, mine2 = 0;                       // lane i: agent i's (agent 64 + i's) interior index
         for (int i = 0; i < p.A; ++i) {
-            const uint32_t ui = (uint32_t)__builtin_amdgcn_readlane((int)u, i);
+            const uint32_t ui = i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)u, i) : (uint32_t)__builtin_amdgcn_readlane((int)u2, i - 64);
             const int d0 = (int)__umulhi(ui, (uint32_t)(n - i));
-            const int k = __popcll(__ballot(lane < i && taken - lane <= d0));
+            int k = __popcll(__ballot(lane < i && taken - lane <= d0));
+            if (i > 64) k += __popcll(__ballot(64 + lane < i && taken2 - (64 + lane) <= d0));
             const int d = d0 + k;
             const int below = __shfl_up(taken, 1);                               // lane j: taken[j - 1]
+            if (i >= 64) {                                                       // the upper half shifts too; taken[63] crosses over
+                const int below2 = __shfl_up(taken2, 1);
+                const int carry = __builtin_amdgcn_readlane(taken, 63);
+                const int pos2 = 64 + lane;
+                taken2 = pos2 > k ? (lane == 0 ? carry : below2) : (pos2 == k ? d : taken2);
+                mine2 = lane == i - 64 ? d : mine2;
+            } else {
+                mine = lane == i ? d : mine;
+            }
             taken = lane > k ? below : (lane == k ? d : taken);                  // insert d at sorted position k
-            mine = lane == i ? d : mine;
         }
         if (lane < p.A) {
             const int y = 1 + mine / iw, x = 1 + mine - (mine / iw) * iw;
             lg[zoff + y * p.W + x] = p.agent_state ? p.agent_state[env * p.A + lane] : p.tab->agent_type[lane];
             reinterpret_cast<uint16_t*>(p.pos)[env * p.A + lane] = (uint16_t)((uint32_t)y | ((uint32_t)x << 8));
+        }
+        if (64 + lane < p.A) {
+            const int a2 = 64 + lane;
+            const int y = 1 + mine2 / iw, x = 1 + mine2 - (mine2 / iw) * iw;
+            lg[zoff + y * p.W + x] = p.agent_state ? p.agent_state[env * p.A + a2] : p.tab->agent_type[a2];
+            reinterpret_cast<uint16_t*>(p.pos)[env * p.A + a2] = (uint16_t)((uint32_t)y | ((uint32_t)x << 8));
         }
         if (lane == 0) p.total[env] = 0.0;
     }

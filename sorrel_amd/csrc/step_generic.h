@@ -4,15 +4,9 @@
 #pragma once
 
 // ---------------------------------------------------------------- step kernel
-// Per-env LDS slice: [grid cells_pad][pos 2*64][act 64][rew f32 x64]
-constexpr int kPosOff = 0;
-constexpr int kActOff = 2 * SGW_MAX_AGENTS;
-constexpr int kRewOff = kActOff + SGW_MAX_AGENTS;
-constexpr int kTypeOff = kRewOff + 4 * SGW_MAX_AGENTS;   // current type of each agent
-constexpr int kPovOff = kTypeOff + SGW_MAX_AGENTS;      // its type when it observed
-constexpr int kDirOff = kPovOff + SGW_MAX_AGENTS;       // its facing (Cleanup)
-constexpr int kTicketOff = kDirOff + SGW_MAX_AGENTS;    // G = 256: whose turn it is (u32), the env's running total (f64 at + 8)
-constexpr int kAgentLds = kTicketOff + 16;              // 656 bytes, multiple of 16
+// Per-env LDS slice: [grid cells_pad][pos 2 x AC][act AC][rew f32 x AC][type AC][pov type AC][facing AC][ticket + total 16], AC = Params::agent_cap:
+// 64, or 128 for engines with more than 64 agents (round 6) -- every other engine keeps the 656 bytes it had
+__host__ __device__ constexpr int agent_lds_bytes(int cap) { return 10 * cap + 16; }
 
 #ifndef SGW_GENERIC_WAVES
 #define SGW_GENERIC_WAVES 6
@@ -47,12 +41,13 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
     uint8_t* slice = smem + p.tab_bytes + sub * p.env_lds;
     uint8_t* lg = slice;                              // grid
-    uint8_t* s_pos = slice + p.cells_pad + kPosOff;   // [A][2]
-    uint8_t* s_act = slice + p.cells_pad + kActOff;   // [A]
-    float* s_rew = reinterpret_cast<float*>(slice + p.cells_pad + kRewOff);
-    uint8_t* s_type = slice + p.cells_pad + kTypeOff;   // [A] current entity type of each agent
-    uint8_t* s_pov = slice + p.cells_pad + kPovOff;     // [A] its type when it observed
-    uint8_t* s_dir = slice + p.cells_pad + kDirOff;     // [A] its facing
+    const int AC = p.agent_cap;
+    uint8_t* s_pos = slice + p.cells_pad;             // [A][2]
+    uint8_t* s_act = s_pos + 2 * AC;                  // [A]
+    float* s_rew = reinterpret_cast<float*>(s_act + AC);
+    uint8_t* s_type = s_act + 5 * AC;                   // [A] current entity type of each agent
+    uint8_t* s_pov = s_type + AC;                       // [A] its type when it observed
+    uint8_t* s_dir = s_pov + AC;                        // [A] its facing
     // G = 256 (worlds above 4 KiB): the load, the sweep and the write-back use the whole workgroup, but an AGENT PHASE is the
     // work of one wave, and the four waves take the agents in turn behind a ticket in LDS: wave (a - a0) mod 4 waits
     // until agent a - 1 has acted, captures agent a's window bytes in registers, acts (Tag / Cleanup / move: the same code
@@ -63,8 +58,8 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     constexpr int GA = kTicket ? kWave : G;            // threads that cooperate on one agent
     constexpr int WPA = kTicket ? 1 : WPE;             // waves that synchronise inside an agent phase
     const int atid = kTicket ? (tid & 63) : gtid;      // index inside that group
-    volatile uint32_t* s_ticket = reinterpret_cast<volatile uint32_t*>(slice + p.cells_pad + kTicketOff);
-    double* s_tot = reinterpret_cast<double*>(slice + p.cells_pad + kTicketOff + 8);
+    volatile uint32_t* s_ticket = reinterpret_cast<volatile uint32_t*>(s_dir + AC);     // G = 256: whose turn it is (u32), the env's running total (f64 at + 8)
+    double* s_tot = reinterpret_cast<double*>(s_dir + AC + 8);
 
     const int r = TR ? TR : p.r, V = TR ? 2 * TR + 1 : p.V, VV = TR ? (2 * TR + 1) * (2 * TR + 1) : p.VV;
     const int H = TH ? TH : p.H, W = TW ? TW : p.W;

@@ -1,0 +1,159 @@
+"""More than 64 agents (round 6; SGW_MAX_AGENTS = 128).  The reference steps any ``self.agents`` list (``sorrel/environment.py:92-93``); the engine
+keeps an agent per lane on its wave- and workgroup-per-env kernels, so 65..128 agents run on the ticket-ordered generic kernel (``step_kernel<256>``),
+whatever the world's size.  Pinned by two fixtures the reference's own ``take_turn`` produced (80 Treasurehunt agents, 70 Tag agents:
+``oracle/make_golden.py round6``; they also run in ``test_gpu_parity.py::test_hip_matches_reference_golden``), and checked against the C oracle
+at batch sizes -- reset (the wave-parallel placement's second register set), fused and phased turns, ``sgw_observe_rows`` + ``sgw_act``, rollouts."""
+import numpy as np
+import pytest
+
+from sorrel_amd import _native as N
+from tests import helpers as H
+from tests.test_gpu_parity import assert_same, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no silent CPU fallback)")
+    return torch
+
+
+def _th(h, w, a, r, **kw):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    return treasurehunt_spec(h, w, a, r, spawn_prob=0.04, seed=31, dense_prob=0.2, **kw)
+
+
+def _tag(h, w, a, r):
+    from tests.test_gpu_round2 import _tag_spec
+
+    return _tag_spec(h, w, a, r)
+
+
+CASES = [
+    ("th_128x128_A128_r5", lambda: _th(128, 128, 128, 5), 9),          # the review's target: 128 agents on config 5's map
+    ("th_128x128_A65_r5", lambda: _th(128, 128, 65, 5), 6),            # one more than a wave holds
+    ("th_24x26_A80_r2", lambda: _th(24, 26, 80, 2), 70),               # a small, crowded world (1.2 KB per env) on the workgroup-per-env kernel
+    ("th_14x14_A100_r1", lambda: _th(14, 14, 100, 1), 33),             # 100 agents on 144 interior cells: nearly every move is contested
+    ("tag_40x42_A96_r4", lambda: _tag(40, 42, 96, 4), 12),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_more_than_64_agents_vs_the_c_oracle(torch_cuda, case):
+    torch = torch_cuda
+    name, mk, E = case
+    ws = mk()
+    A = ws.num_agents
+    eng, co = make_engine(ws, E, first=11), H.COracle(ws, E, first_env_id=11)
+    assert "step_kernel<256" in eng.launch_info(), eng.launch_info()
+    assert not (eng.capabilities() & N.CAP_RESOLVE)                    # (the speculative resolve keeps an agent per lane)
+    eng.reset(epoch=2)
+    co.reset(2)
+    if eng.agent_state is not None:
+        co.agent_state[...] = eng.agent_state.cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.grid.cpu().numpy(), co.grid) and np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), f"{name}: reset"
+    pos = co.pos.astype(np.int64)
+    assert all(len({(int(y), int(x)) for y, x in pos[e]}) == A for e in range(E)), "agents on distinct cells"
+    for t in range(1, 5):                                               # fused turns, actions drawn on the device
+        eng.step(random_actions=True, turn=t)
+        assert co.step(2, t, random_actions=True) == 0
+        assert_same(eng, co, ctx=f"{name} fused turn {t}")
+    gen = np.random.default_rng(3)
+    nact = len(ws.action_dy)
+    for t in range(5, 8):                                               # given actions, agent after agent (1 + A launches), windows at pov time
+        acts = gen.integers(0, nact, (E, A)).astype(np.uint8)
+        ta = torch.from_numpy(acts).cuda()
+        assert co.step(2, t, actions=acts) == 0
+        seen = torch.zeros_like(eng.obs)
+        eng.step(ta, sweep=True, agent_begin=0, agent_end=0, turn=t, obs_next=True)
+        for a in range(A):
+            seen[:, a] = eng.obs[:, a]
+            eng.step(ta, sweep=False, agent_begin=a, agent_end=a + 1, turn=t, obs_next=a + 1 < A, write_obs=False)
+        torch.cuda.synchronize()
+        assert np.array_equal(seen.cpu().numpy(), co.obs), f"{name} phased turn {t}: windows"
+        assert_same(eng, co, what=("grid", "pos", "rewards", "total"), ctx=f"{name} phased turn {t}")
+    if eng.capabilities() & N.CAP_OBSERVE_ROWS:                         # windows once + sgw_act per agent (act_patch<64, 2>: two agents per lane)
+        Nw = int(np.prod(ws.obs_shape[1:]))
+        dests = [torch.full((E, Nw), -5.0, device="cuda:0") for _ in range(A)]
+        rows = eng.window_rows(dests)
+        for t in range(8, 11):
+            acts = gen.integers(0, nact, (E, A)).astype(np.uint8)
+            ta = torch.from_numpy(acts).cuda()
+            assert co.step(2, t, actions=acts) == 0
+            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=t)
+            eng.observe_rows(rows)
+            seen = []
+            for a in range(A):
+                seen.append(dests[a].clone())
+                eng.act(a, rows, action=ta[:, a].to(torch.int64).contiguous())
+            torch.cuda.synchronize()
+            got = torch.stack(seen, dim=1).view(E, A, *ws.obs_shape[1:]).cpu().numpy()
+            assert np.array_equal(got, co.obs), f"{name} sgw_act turn {t}: windows at pov time"
+            assert_same(eng, co, what=("grid", "pos", "rewards", "total"), ctx=f"{name} sgw_act turn {t}")
+    eng.rollout(4)                                                      # sgw_rollout continues from here
+    for t in range(eng.turn - 3, eng.turn + 1):
+        assert co.step(2, t, random_actions=True) == 0
+    assert_same(eng, co, ctx=f"{name} rollout")
+    assert eng.status() == 0
+
+
+def test_agent_limit_is_128_and_said_so(torch_cuda):
+    from sorrel_amd.spec import treasurehunt_spec
+
+    assert N.MAX_AGENTS == 128
+    with pytest.raises(ValueError):
+        treasurehunt_spec(64, 64, 129, 2).to_config(4, 0)
+    ok = make_engine(treasurehunt_spec(64, 64, 128, 2), 3)
+    ok.reset(0)
+    ok.step(random_actions=True)
+    assert ok.status() == 0
+
+
+def test_environment_with_96_policy_driven_agents(torch_cuda):
+    """The Python API: 96 agents with a shared linear policy and a shared replay ring through Environment.take_turn (the eager loops), against
+    the C oracle stepping the actions taken."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.models import BaseModel
+    from tests.test_gpu_round2 import make_env
+
+    E, A = 17, 96
+    one = []
+
+    class Shared(BaseModel):
+        def __init__(self, input_size, action_space):
+            super().__init__(input_size, action_space, memory_size=0, num_envs=E, device="cuda:0")
+            self.memory = Buffer(capacity=2 * A, obs_shape=tuple(input_size), num_envs=E, device="cuda:0")
+            self.w = torch.randn(int(np.prod(input_size)), action_space, generator=torch.Generator().manual_seed(4)).cuda()
+
+        def take_action(self, state):
+            return (state.reshape(state.shape[0], -1) @ self.w).argmax(dim=1)
+
+    def factory(input_size, action_space):
+        if not one:
+            one.append(Shared(input_size, action_space))
+        return one[0]
+
+    env = make_env(30, 31, A, 2, E, p=0.05, seed=9, model_factory=factory)
+    env.speculate_turns = "always"                                     # (not possible with more than 64 agents: the sequential loop plays)
+    co = H.COracle(env.compile_spec(), E)
+    co.grid[...] = env.world.grid.cpu().numpy()
+    co.pos[...] = env.world.agent_pos.cpu().numpy()
+    for t in range(1, 5):
+        env.take_turn()
+        torch.cuda.synchronize()
+        assert env.turn_plan()["loop"] in ("fast", "generic")
+        assert co.step(0, t, actions=env.actions.cpu().numpy()) == 0
+        assert np.array_equal(env.world.grid.cpu().numpy(), co.grid) and np.array_equal(env.rewards.cpu().numpy(), co.rewards), t
+        assert np.array_equal(env.world.total_reward.cpu().numpy(), co.total), t
+        mem = one[0].memory
+        rows = [(mem.idx - A + a) % mem.capacity for a in range(A)]
+        got = torch.stack([mem.states[r] for r in rows], dim=1).cpu().numpy().reshape(co.obs.shape)
+        assert np.array_equal(got, co.obs), (t, "the windows the agents acted on")
+    env.raise_on_status()

@@ -54,6 +54,9 @@ def cases():
         out.append((f"mid_72x72_E{E}", th(72, 72, 8, 5), E, {}))
     for E in (1536, 1537, 1792, 1793, 2304, 2305):                        # step_big: walk window (1.5x .. 2.25x resident), staging above 1.75x
         out.append((f"c5_E{E}", th(128, 128, 64, 5, dense_prob=0.25), E, {}))
+    # more than 64 agents (round 6): the ticket-ordered generic kernel whatever the size; 64 agents keep their kernels
+    out += [("agents_65_of_128x128", th(128, 128, 65, 5), 2048, {}), ("agents_128_of_128x128", th(128, 128, 128, 5), 2048, {}),
+            ("agents_80_of_40x40", th(40, 40, 80, 2), 4096, {}), ("agents_64_of_40x40", th(40, 40, 64, 2), 4096, {})]
     out += [("big_256_threads", th(100, 100, 8, 5), 8192, {}), ("big_512_threads", th(128, 128, 32, 5), 8192, {}),
             ("avv_100", th(24, 24, 4, 2), 65536, {}), ("avv_101", th(24, 24, 5, 2), 65536, {}), ("avv_200", th(30, 30, 8, 2), 65536, {}),
             ("cells_1024_pack", th(22, 23, 2, 2), 65536, {}), ("cells_1040_nopack", th(22, 24, 3, 3), 65536, {})]

@@ -615,9 +615,9 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                                 lg[zoff + ay * W + ax] = (uint8_t)p.tag_it;
                                 s_type[a] = (uint8_t)p.tag_notit;
                             }
-                            // the neighbour's slot: the agent standing on (ay, ax)
-                            if (atid < p.A && atid != a && s_pos[2 * atid] == ay && s_pos[2 * atid + 1] == ax)
-                                s_type[atid] = (uint8_t)p.tag_it;
+                            // the neighbour's slot: the agent standing on (ay, ax) (more than 64 agents: a second round of the wave's lanes)
+                            for (int b = atid; b < p.A; b += GA)
+                                if (b != a && s_pos[2 * b] == ay && s_pos[2 * b + 1] == ax) s_type[b] = (uint8_t)p.tag_it;
                         }
                     }
                     val = mine_now != p.tag_it ? p.tag_reward : 0.0;

@@ -390,6 +390,11 @@ struct ActIO {                   // sgw_act's optional extras (see RowPtrs), pas
     int64_t* action_row = nullptr;
     const TurnState* ts = nullptr;
     bool want_cols = false;      // sgw_act: the whole columns of the mover's two cells (window repairs need the other layers)
+    // sgw_act (round 6): the act's inputs, loaded by the caller BEFORE its table staging and barrier (addresses that need only the launch arguments)
+    bool pre = false;
+    uint32_t yx_pre = 0, type_pre = 0;
+    int64_t act_pre = 0;
+    double tot_pre = 0.0;
 };
 // The caller's action of agent a in env: its tensor's element, or for SGW_ACT_QF32 the first index of the maximum of the env's row of
 // action values (np.argmax; NaN = maximum, as np / torch have it) -- and, under the turn protocol, with probability epsilon[a] the
@@ -425,18 +430,21 @@ __device__ __forceinline__ int move_one(const Params& p, const DevTables* gtab, 
                                         const double* wval, const bool writer, MoveOut& mo, const ActIO io = ActIO{}) {
     const int H = p.H, W = p.W, HW = H * W;
     int st = 0;
-    uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
+    uint32_t yx = io.pre ? io.yx_pre : (uint32_t)reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
     uint32_t act;
     int64_t act_raw;
-    if (io.agent_action) {                               // the policy's own output tensor: one action per env
+    if (io.pre) {
+        act_raw = io.act_pre;
+        act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;
+    } else if (io.agent_action) {                        // the policy's own output tensor: one action per env
         act_raw = read_action(p, io.agent_action, io.action_kind, io.ts, env, a);
         act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;     // out of range either way: SGW_STATUS_BAD_ACTION
     } else {
         act = p.actions[env * p.A + a];
         act_raw = act;
     }
-    const uint32_t my_type = p.agent_state ? p.agent_state[env * p.A + a] : gtab->agent_type[a];
-    const double tot = p.total[env];
+    const uint32_t my_type = io.pre ? io.type_pre : (p.agent_state ? p.agent_state[env * p.A + a] : gtab->agent_type[a]);
+    const double tot = io.pre ? io.tot_pre : p.total[env];
     if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
     const int my = (int)(yx & 0xFFu), mx = (int)(yx >> 8);
     const bool act_ok = act < (uint32_t)p.nact;
@@ -688,6 +696,14 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 4 : 8) voi
         if (rp.ts->rewards[a]) reward_row = rp.ts->rewards[a] + rp.ts->row[a] * p.E;
         if (rp.ts->actions[a]) action_row = rp.ts->actions[a] + rp.ts->row[a] * p.E;
     }
+    // ... and the act's own inputs (the acting agent's cell, type, action, the env's total): a policy's fresh output comes from the memory side,
+    // ~2 us away -- behind the barrier below it headed the act's chain of dependent loads (profiles/r06_act_after_probe.txt)
+    const uint32_t yx_pre = (uint32_t)reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
+    const uint32_t type_pre = p.agent_state ? (uint32_t)p.agent_state[env * p.A + a] : (uint32_t)gtab->agent_type[a];
+    const double tot_pre = p.total[env];
+    int64_t act_pre;
+    if (rp.agent_action) act_pre = read_action(p, rp.agent_action, rp.action_kind, rp.ets, env, a);
+    else act_pre = (int64_t)p.actions[env * p.A + a];
     if (tid >= 128 && tid < 128 + SGW_MAX_TYPES) s_value[tid - 128] = gtab->value[tid - 128];
     if constexpr (ONEHOT) {
         if (tid < SGW_MAX_TYPES) {
@@ -793,7 +809,9 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 4 : 8) voi
 
     if constexpr (RULE == SGW_AGENT_RULE_MOVE) {
         MoveOut mo;
-        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, ActIO{rp.agent_action, rp.action_kind, reward_row, action_row, rp.ets, true});
+        ActIO io{rp.agent_action, rp.action_kind, reward_row, action_row, rp.ets, true};
+        io.pre = true; io.yx_pre = yx_pre; io.type_pre = type_pre; io.act_pre = act_pre; io.tot_pre = tot_pre;
+        const int st = move_one(p, gtab, g, env, a, s_value, writer, mo, io);
         if (st && writer) atomicOr(p.status, st);
         if (mo.old_y < 0) return;
         patch(mo.old_y, mo.old_x, p.zA, mo.left, p.default_type, mo.col_old);
@@ -802,18 +820,11 @@ __global__ __launch_bounds__(kBlock, RULE == SGW_AGENT_RULE_CLEANUP ? 4 : 8) voi
     } else {
         // ---- inputs of the act (same-address loads in every lane of the group)
         int st = 0;
-        uint32_t yx = reinterpret_cast<const uint16_t*>(p.pos)[env * p.A + a];
-        uint32_t act;
-        int64_t act_raw;
-        if (rp.agent_action) {
-            act_raw = read_action(p, rp.agent_action, rp.action_kind, rp.ets, env, a);
-            act = (act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw;
-        } else {
-            act = p.actions[env * p.A + a];
-            act_raw = act;
-        }
-        const uint32_t my_type = p.agent_state ? p.agent_state[env * p.A + a] : gtab->agent_type[a];
-        const double tot = p.total[env];
+        uint32_t yx = yx_pre;                                             // (loaded ahead of the barrier, above)
+        const int64_t act_raw = act_pre;
+        const uint32_t act = rp.agent_action ? ((act_raw < 0 || act_raw > 255) ? 255u : (uint32_t)act_raw) : (uint32_t)act_raw;
+        const uint32_t my_type = type_pre;
+        const double tot = tot_pre;
         if ((yx & 0xFFu) >= (uint32_t)H || (yx >> 8) >= (uint32_t)W) { yx = 0; st |= SGW_STATUS_BAD_POS; }
         const int y = (int)(yx & 0xFFu), x = (int)(yx >> 8);
         const bool act_ok = act < (uint32_t)p.nact;

@@ -516,6 +516,18 @@ int sgw_turn_state(sgw_engine* eng, uint32_t* epoch_turn, int64_t* rows, void* s
 int sgw_turn_resolve(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, float* rows, int64_t row_elems,
                      float* rewards, double* total_reward, uint8_t* scratch, int64_t* dirty_list, uint32_t* counters,
                      const int64_t* new_actions, int64_t n_new, float* reward_rows, int64_t* action_rows, int32_t pass, void* stream);
+/* The resolve of a speculative turn for ANY agent rule (round 6; Tag, Cleanup, whatever rule comes next): play the current actions as ONE sequential turn on
+ * a scratch copy of the state -- sgw_step with given actions, no sweep, observations on: its `obs` [E][A][C][V][V] are the windows the agents really have
+ * when their turn comes (Agent.transition, sorrel/agents/agent.py:155-173), its state_at_pov Tag's "it" flags at pov time -- then sgw_verify_rows: row
+ * (a, e) of `rows` [A][E][row_elems] (window + the bound row tail) that differs from that is rewritten from it and its index a * E + e appended to `list`
+ * (*count = how many; zeroed by the call).  Evaluate the policy on those rows, sgw_apply_actions, play again -- until *count == 0: the scratch state then
+ * IS the sequential turn's result (copy it over the state).  A positional tail (SGW_TAIL_POSITION_TABLE) is not compared: an agent's own cell does not
+ * change before its own act.  Pays where the sequential loop is host-bound and the agents many (profiles/r06_speculation_study_rules.txt). */
+int sgw_verify_rows(sgw_engine* eng, const float* obs, const uint8_t* state_at_pov, float* rows, int64_t row_elems, int64_t* list, uint32_t* count,
+                    void* stream);
+/* actions[e][a] = new_actions[k] for the k-th entry a * E + e of `list` (NULL: k itself), k < n; values outside [0, 255) become 255 (no ActionSpec has
+ * it: SGW_STATUS_BAD_ACTION when played).  The dirty rows' fresh policy outputs into the [E][A] action tensor. */
+int sgw_apply_actions(sgw_engine* eng, uint8_t* actions, const int64_t* list, const int64_t* new_actions, int64_t n, void* stream);
 /* dst[k][:] = src[idx[k]][:] for k < n: rows of `row_elems` float32 (the dirty rows of a speculative pass as ONE contiguous batch for the
  * policy); src / dst 4-byte aligned device pointers, idx int64 on the device.  Asynchronous on `stream`; needs no engine. */
 int sgw_gather_rows(const float* src, int64_t row_elems, const int64_t* idx, int64_t n, float* dst, void* stream);

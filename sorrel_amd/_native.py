@@ -109,7 +109,7 @@ EXPORTS = (
     "sgw_algorithmic_bytes_per_env_step", "sgw_set_timing", "sgw_get_step_time_ms", "sgw_get_step_times_ms",
     "sgw_set_auto_reset", "sgw_set_wg_per_cu", "sgw_launch_info", "sgw_capabilities", "sgw_observe_rows", "sgw_act", "sgw_observe_full",
     "sgw_set_option", "sgw_plan", "sgw_jit_stats", "sgw_jit_compile", "sgw_bind_row_tail",
-    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state", "sgw_turn_begin_rows", "sgw_turn_act_rows", "sgw_turn_epsilon", "sgw_turn_prev_rows", "sgw_turn_resolve", "sgw_gather_rows", "sgw_sweep_observe_rows", "sgw_choose_actions",
+    "sgw_turn_bind", "sgw_turn_set", "sgw_turn_begin", "sgw_turn_act", "sgw_turn_end", "sgw_turn_state", "sgw_turn_begin_rows", "sgw_turn_act_rows", "sgw_turn_epsilon", "sgw_turn_prev_rows", "sgw_turn_resolve", "sgw_gather_rows", "sgw_sweep_observe_rows", "sgw_choose_actions", "sgw_verify_rows", "sgw_apply_actions",
     "sgw_last_error", "sgw_version",
 )
 
@@ -233,6 +233,10 @@ def load():
     lib.sgw_turn_resolve.restype = C.c_int
     lib.sgw_gather_rows.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp]
     lib.sgw_gather_rows.restype = C.c_int
+    lib.sgw_verify_rows.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+    lib.sgw_verify_rows.restype = C.c_int
+    lib.sgw_apply_actions.argtypes = [vp, vp, vp, vp, C.c_int64, vp]
+    lib.sgw_apply_actions.restype = C.c_int
     lib.sgw_choose_actions.argtypes = [vp, vp, vp, C.c_int64, C.c_uint32, C.c_uint32, vp, vp]
     lib.sgw_choose_actions.restype = C.c_int
     lib.sgw_turn_prev_rows.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]

@@ -53,6 +53,35 @@ __global__ __launch_bounds__(kBlock) void resolve_apply_actions(uint8_t* actions
     }
 }
 
+// sgw_verify_rows (round 6): the resolve of a speculative turn for ANY agent rule.  `obs` [E][A][N] holds the windows a sequential turn with the
+// current actions showed its agents at their pov (sgw_step with given actions on a scratch copy of the state), `rows` [A][E][R] what the actions were
+// computed on (window + tail).  A wave per (env, agent): where the window -- or Tag's "it" flag behind it -- differs, the row is rewritten, its index
+// a * E + env appended to `list` (one atomic per dirty row: this path is for the small batches where a speculative turn pays at all).
+__global__ __launch_bounds__(kBlock) void verify_rows_kernel(const float* __restrict__ obs, const uint8_t* __restrict__ state_at_pov, float* __restrict__ rows,
+                                                             const int64_t R, const int N, const int64_t E, const int A, const int tail_it, const uint32_t it_type,
+                                                             int64_t* __restrict__ list, uint32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (w >= E * A) return;
+    const int64_t env = w / A;
+    const int a = (int)(w - env * A);
+    const float* src = obs + w * N;
+    float* dst = rows + ((int64_t)a * E + env) * R;
+    bool diff = false;
+    for (int i = lane; i < N; i += 64) diff = diff || src[i] != dst[i];
+    float flag = 0.f;
+    if (tail_it) {
+        flag = state_at_pov[w] == it_type ? 1.f : 0.f;
+        diff = diff || (lane == 0 && dst[N] != flag);
+    }
+    if (__ballot(diff) == 0ull) return;
+    for (int i = lane; i < N; i += 64) dst[i] = src[i];
+    if (lane == 0) {
+        if (tail_it) dst[N] = flag;
+        list[atomicAdd(count, 1u)] = (int64_t)a * E + env;
+    }
+}
+
 // Large batches: the dirty list without tens of thousands of atomics on one counter.  The resolve kernel leaves the number of dirty rows of each
 // env in dcount[env] and adds it to the sum of its block of 256 envs (256 envs share a counter: the atomics spread over E / 256 addresses);
 // one workgroup turns the block sums into block offsets (and the total); a workgroup per block then scans its 256 counts and writes the

@@ -1917,6 +1917,33 @@ int sgw_turn_resolve(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_t* 
     return time_end(e, s);
 }
 
+int sgw_verify_rows(sgw_engine* e, const float* obs, const uint8_t* state_at_pov, float* rows, int64_t row_elems, int64_t* list, uint32_t* count, void* stream) {
+    if (!e || !obs || !rows || !list || !count) return fail(SGW_EINVAL, "sgw_verify_rows: NULL argument");
+    if (e->obs_format != SGW_OBS_F32) return fail(SGW_EINVAL, "sgw_verify_rows: float32 windows only");
+    const int N = e->base.C * e->base.VV;
+    const bool tail_it = e->tail_kind == SGW_TAIL_AGENT_IS_IT;
+    if (row_elems < N + e->tail_len) return fail(SGW_EINVAL, "sgw_verify_rows: row_elems is smaller than one window + the bound row tail");
+    if (tail_it && !state_at_pov) return fail(SGW_EINVAL, "sgw_verify_rows: SGW_TAIL_AGENT_IS_IT needs the scratch turn's state_at_pov");
+    if ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(count)) & 3u) return fail(SGW_EINVAL, "sgw_verify_rows: misaligned pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+    const int64_t waves = (int64_t)e->cfg.num_envs * e->cfg.num_agents;
+    hipLaunchKernelGGL(verify_rows_kernel, dim3((unsigned)ceil_div(waves, kBlock / 64)), dim3(kBlock), 0, s, obs, state_at_pov, rows, row_elems, N, (int64_t)e->cfg.num_envs,
+                       e->cfg.num_agents, tail_it ? 1 : 0, (uint32_t)e->cfg.tag_it_type, list, count);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
+int sgw_apply_actions(sgw_engine* e, uint8_t* actions, const int64_t* list, const int64_t* new_actions, int64_t n, void* stream) {
+    if (!e || !actions || !new_actions) return fail(SGW_EINVAL, "sgw_apply_actions: NULL argument");
+    if (n < 0 || n > (int64_t)e->cfg.num_envs * e->cfg.num_agents) return fail(SGW_EINVAL, "sgw_apply_actions: n = %lld outside [0, E * A]", (long long)n);
+    if (n == 0) return SGW_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, kBlock), (int64_t)e->num_cus * 8);
+    hipLaunchKernelGGL(resolve_apply_actions, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), actions, list, new_actions, n, (int64_t)e->cfg.num_envs, e->cfg.num_agents);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+}
+
 int sgw_gather_rows(const float* src, int64_t row_elems, const int64_t* idx, int64_t n, float* dst, void* stream) {
     if (!src || !idx || !dst || row_elems < 1 || n < 0) return fail(SGW_EINVAL, "sgw_gather_rows: bad argument");
     if (n == 0) return SGW_OK;

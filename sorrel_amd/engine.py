@@ -512,6 +512,31 @@ class GridEngine:
                                                  out.data_ptr(), self._stream()))
         return out
 
+    def verify_rows(self, played: "GridEngine", rows: torch.Tensor) -> None:
+        """``sgw_verify_rows``: ``played`` is a scratch engine that has just played this turn's current actions as ONE sequential turn
+        (``step(actions, sweep=False)``: its ``obs`` are the windows the agents really had, its ``state_at_pov`` Tag's flags); every row of
+        ``rows`` ``[A, E, C*V*V + tail]`` that differs is rewritten and listed (``verify_count`` / ``verify_list``)."""
+        A, E = self.spec.num_agents, self.num_envs
+        if rows.dtype != torch.float32 or rows.device != self.device or not rows.is_contiguous() or rows.dim() != 3 or tuple(rows.shape[:2]) != (A, E):
+            raise ValueError(f"rows must be a contiguous float32 [{A}, {E}, row] tensor on {self.device}")
+        if getattr(self, "_verify_list", None) is None:
+            self._verify_list = torch.zeros((E * A,), dtype=torch.int64, device=self.device)
+            self._verify_ctr = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        with self._on_device():
+            N.check(self._lib.sgw_verify_rows(self._h, played.obs.data_ptr(), self._ptr(played.state_at_pov), rows.data_ptr(), int(rows.shape[2]),
+                                              self._verify_list.data_ptr(), self._verify_ctr.data_ptr(), self._stream()))
+
+    def verify_count(self) -> int:
+        """How many rows the last ``verify_rows`` rewrote (synchronises: the one read-back per pass)."""
+        return int(self._verify_ctr.item())
+
+    def apply_actions(self, idx: Optional[torch.Tensor], fresh: torch.Tensor, n: int) -> None:
+        """``sgw_apply_actions``: ``actions[e, a] = fresh[k]`` for the k-th row index ``a * E + e`` of ``idx`` (None: k itself), k < n."""
+        if fresh.dtype != torch.int64 or fresh.device != self.device or not fresh.is_contiguous() or fresh.numel() < n:
+            raise ValueError("apply_actions: fresh must be a contiguous int64 vector of at least n entries on the engine's device")
+        with self._on_device():
+            N.check(self._lib.sgw_apply_actions(self._h, self.actions.data_ptr(), None if idx is None else idx.data_ptr(), fresh.data_ptr(), int(n), self._stream()))
+
     def speculation_windows(self, rows: Optional[torch.Tensor] = None, sweep_turn: Optional[int] = None) -> torch.Tensor:
         """Every agent's PRE-move window into ``speculation_rows(rows)``: ``sgw_observe_rows`` where the engine has a row kernel for the
         world (one-hot tables), else ``sgw_turn_resolve``'s render mode (any table).  ``sweep_turn``: the entity sweep of that turn runs

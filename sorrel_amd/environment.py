@@ -524,19 +524,32 @@ class Environment:
     #: turn, speculative / sequential): 8 agents 235 / 281 at 2 048 envs, 244 / 277 at 4 096, 306 / 304 at 8 192, 406 / 292 at 16 384;
     #: 16 agents 237 / 479 at 1 024, 459 / 552 at 8 192; config 5's 64 agents 546 / 2 190 at 2 048.
     speculation_cost_model = (200.0, 1.6, 33.0, 20.0)
+    #: ... of the generic form (Tag, Cleanup, tailed rows): every pass plays a whole turn on the scratch state and reads all windows twice, and the
+    #: examples' windows cover a fifth to most of their maps, so pass 2 re-evaluates ~60 % of the rows (profiles/r06_speculation_study_rules.txt:
+    #: 2.3-2.6 passes per env on average, 99th percentile 4, 1.7 evaluations per agent-step; a BATCH needs the passes of its slowest env: 3-5).
+    #: Measured, wall us per turn, generic speculative / eager (profiles/r06_speculative_generic.txt): Tag 5 agents 410 / 182 at 1 024 envs, Tag 16
+    #: agents 858 / 566, Cleanup 10 agents 785 / 358, 96 plain movers 2 059 / 2 803 at 1 024 envs and 6 239 / 2 768 at 4 096 -- the shipped
+    #: examples keep the eager loop; it pays for very many agents over small batches.
+    speculation_cost_model_generic = (600.0, 24.0, 33.0, 20.0)
 
     def _speculation_pays(self, eng) -> bool:
         """``speculate_turns = True`` speculates where the model above says it is the faster turn (``"always"``: wherever it is possible)."""
-        fixed, per_mb, per_agent, seq_fixed = self.speculation_cost_model
+        fixed, per_mb, per_agent, seq_fixed = self.speculation_cost_model_generic if getattr(self, "_spec_generic", False) else self.speculation_cost_model
         A = len(self.agents)
         per_env = int(np.prod(eng.spec.obs_shape[1:]))
         mb = eng.num_envs * A * per_env * 4 / 1e6
         return per_agent * A + seq_fixed > fixed + per_mb * mb
 
     def _speculation_groups_uncached(self, eng, N, Buffer):
-        if self._mixed or eng.obs_dtype != torch.float32 or not (eng.capabilities() & N.CAP_RESOLVE) or eng.row_tail:
+        if self._mixed or eng.obs_dtype != torch.float32:
             return None
-        per_env = int(np.prod(eng.spec.obs_shape[1:]))
+        # plain movers without row tails: the resolve kernel (sgw_turn_resolve).  Everything else -- Tag, Cleanup, agents beyond the 64 a wave
+        # holds, tailed rows -- : the generic form (round 6), which plays the current actions as one sequential turn on a scratch copy of the
+        # state and compares what the agents saw (sgw_verify_rows); it needs the windows in rows the row kernels can write
+        self._spec_generic = not (eng.capabilities() & N.CAP_RESOLVE) or bool(eng.row_tail)
+        if self._spec_generic and not (eng.capabilities() & N.CAP_OBSERVE_ROWS):
+            return None
+        per_env = int(np.prod(eng.spec.obs_shape[1:])) + (eng.row_tail if self._spec_generic else 0)
         groups = []
         for a, agent in enumerate(self.agents):
             model = agent.model
@@ -558,7 +571,109 @@ class Environment:
             return None                                # -- measured 17 ms against 3.3 ms for 64 agents with 64 models (profiles/r05_speculative_turn.txt)
         return groups
 
+    def _spec_scratch_engine(self, eng):
+        """A second handle over scratch copies of the state tensors (same spec, same global env ids): where a speculative pass plays its turn."""
+        scr = self.__dict__.get("_spec_scratch")
+        if scr is not None and scr[0] is eng:
+            return scr[1]
+        from sorrel_amd.engine import GridEngine
+
+        t = dict(agent_pos=torch.zeros_like(eng.agent_pos), total_reward=torch.zeros_like(eng.total_reward))
+        if eng.agent_state is not None:
+            t["agent_state"] = eng.agent_state.clone()
+        if eng.agent_dir is not None:
+            t["agent_dir"] = eng.agent_dir.clone()
+        played = GridEngine(eng.spec, eng.num_envs, device=eng.device, first_env_id=eng.first_env_id, tensors=t, obs_dtype=eng.obs_dtype)
+        self.__dict__["_spec_scratch"] = (eng, played)
+        self._aux_engines[("speculation scratch", eng.uid)] = played      # (raise_on_status polls it; closed with the others)
+        return played
+
+    def _take_turn_speculative_generic(self, eng, groups) -> None:
+        """The speculative turn for any agent rule (``sgw_verify_rows``): pass 1 evaluates every agent on what its ``pov`` returns BEFORE anyone acts
+        (window + tail, one batch per model); a pass then plays the current actions as ONE sequential turn on a scratch copy of the state -- the
+        ordinary fused step kernel -- and compares what every agent really saw with what its action was computed on; the rows that differ are
+        evaluated again, until none does.  The scratch state of that last pass is the reference's agent-after-agent turn, bit for bit."""
+        E, A = eng.num_envs, len(self.agents)
+        self._turn_windows = None
+        played = self._spec_scratch_engine(eng)
+        per_env = int(np.prod(eng.spec.obs_shape[1:])) + eng.row_tail
+        rows = self.__dict__.get("_spec_rows_generic")
+        if rows is None or tuple(rows.shape) != (A, E, per_env) or rows.device != eng.device:
+            rows = self.__dict__["_spec_rows_generic"] = torch.zeros((A, E, per_env), dtype=torch.float32, device=eng.device)
+            self.__dict__["_spec_rows_generic_wr"] = eng.window_rows([rows[a] for a in range(A)])
+        wr = self.__dict__["_spec_rows_generic_wr"]
+        flat = rows.view(A * E, per_env)
+        from sorrel_amd import _native as N
+
+        if eng.capabilities() & N.CAP_SWEEP_ROWS and self.fuse_sweep_and_rows:     # the sweep and every agent's PRE-act window (+ tail), one launch
+            eng.sweep_observe_rows(wr, sweep=True, turn=self.turn)
+        else:
+            eng.step(sweep=True, agent_begin=0, agent_end=0, write_obs=False, turn=self.turn)
+            eng.observe_rows(wr)
+
+        def choose(model, x, idx):
+            out = model.take_action(x)
+            if out.dim() == 2:                                           # action values: the act launch's choice, exploration included (sgw_choose_actions)
+                self._push_epsilon(eng, range(A))
+                out = eng.choose_actions(out, idx, self.epoch, self.turn)
+            return out.to(torch.int64)
+
+        every = self.__dict__.get("_spec_arange")
+        if every is None or every.numel() != A * E or every.device != eng.device:
+            every = self.__dict__["_spec_arange"] = torch.arange(A * E, dtype=torch.int64, device=eng.device)
+        fresh = torch.cat([choose(model, flat[a0 * E:a1 * E], every[a0 * E:a1 * E]) for a0, a1, model in groups]) if len(groups) > 1 \
+            else choose(groups[0][2], flat, None)
+        eng.apply_actions(None, fresh.contiguous(), A * E)
+        state = [("grid", eng.grid, played.grid), ("agent_pos", eng.agent_pos, played.agent_pos), ("total_reward", eng.total_reward, played.total_reward)]
+        if eng.agent_state is not None:
+            state.append(("agent_state", eng.agent_state, played.agent_state))
+        if eng.agent_dir is not None:
+            state.append(("agent_dir", eng.agent_dir, played.agent_dir))
+        k = 0
+        while True:
+            k += 1
+            for _name, real, scratch in state:
+                scratch.copy_(real)
+            played.epoch = eng.epoch
+            played.step(eng.actions, sweep=False, turn=self.turn)        # the whole turn, agent after agent, with the current actions
+            eng.verify_rows(played, rows)
+            n = eng.verify_count()                                       # (synchronises)
+            if n == 0:
+                break
+            if k > A + 1:
+                raise RuntimeError("speculative turn did not converge (a policy that is not a function of its observation?)")
+            lst = eng._verify_list[:n]
+            if len(groups) == 1:
+                new = choose(groups[0][2], eng.gather_rows(flat, lst), lst)
+            else:
+                new = torch.empty_like(lst)
+                a_i = torch.div(lst, E, rounding_mode="floor")
+                for a0, a1, model in groups:
+                    sel = torch.nonzero((a_i >= a0) & (a_i < a1)).squeeze(1)
+                    if sel.numel():
+                        new[sel] = choose(model, flat.index_select(0, lst[sel]), lst[sel].contiguous())
+            eng.apply_actions(lst, new.contiguous(), n)
+        for _name, real, scratch in state:                               # the last pass played the sequential turn: its state is the turn's
+            real.copy_(scratch)
+        eng.rewards.copy_(played.rewards)
+        if eng.state_at_pov is not None:
+            eng.state_at_pov.copy_(played.state_at_pov)
+        self.speculation_passes = k
+        self._spec_seen = (self.epoch, self.turn, rows)
+        taken = eng.actions.t().to(torch.int64)                          # [A, E]
+        rew = eng.rewards.t().contiguous()
+        for a0, a1, model in groups:                                     # add_memory of every agent, in list order
+            mem = getattr(model, "memory", None)
+            if mem is None:
+                continue
+            dones = [self.agents[a].is_done(self.world) for a in range(a0, a1)]
+            done = False if not any(torch.is_tensor(d) or d for d in dones) else \
+                torch.stack([torch.as_tensor(d, dtype=torch.float32, device=eng.device).expand(E) for d in dones])
+            mem.add_batch(rows[a0:a1], taken[a0:a1].contiguous(), rew[a0:a1], done)
+
     def _take_turn_speculative(self, eng, groups) -> None:
+        if getattr(self, "_spec_generic", False):
+            return self._take_turn_speculative_generic(eng, groups)
         E, A = eng.num_envs, len(self.agents)
         self._turn_windows = None
         # what the policies read, [A, E, N]: where ONE model (and so one replay ring) serves every agent and the ring's rows of this turn
@@ -708,7 +823,8 @@ class Environment:
             eng = self._ensure_engine()
             seen = getattr(self, "_spec_seen", None)
             if seen is not None and seen[:2] == (self.epoch, self.turn):      # the last turn was a speculative one
-                return seen[2][a].view((eng.num_envs,) + tuple(eng.spec.obs_shape[1:]))
+                nw = int(np.prod(eng.spec.obs_shape[1:]))                      # (rows of the generic form carry the pov's tail behind the window)
+                return seen[2][a][:, :nw].reshape((eng.num_envs,) + tuple(eng.spec.obs_shape[1:]))
             return eng.obs[:, a]
         t = self._mixed_obs[a]
         g = self._agent_engine[a]

@@ -117,3 +117,94 @@ def test_choose_actions_is_the_choice_of_the_act_launch(torch_cuda):
     with pytest.raises(ValueError):
         eng.choose_actions(q[:, :2], None, 2, 7)
     eng.close()
+
+
+@pytest.mark.parametrize("values", [False, True], ids=["int_actions", "action_values_eps"])
+@pytest.mark.parametrize("which", ["tag", "cleanup", "tag_shared_two_models", "plain_80_agents"])
+def test_generic_speculative_turn_equals_the_sequential_turn(torch_cuda, which, values):
+    """``Environment.speculate_turns`` for agent rules the resolve kernel does not know (round 6, ``sgw_verify_rows``): Tag ("it" flag in the row,
+    tags flip victims' flags and cells), Cleanup (beams on the layer above, facing, all-layer rewards, a 12-element positional tail) and plain
+    movers beyond 64 agents -- one model shared by all agents (or two) with a shared replay ring.  World, agent state, step outputs and every
+    replay row (tails included) equal the eager agent-after-agent loop's, turn after turn, through ring wrap-arounds and a reset; with action
+    values and epsilon > 0 the exploration draws are the sequential turn's."""
+    torch = torch_cuda
+    from sorrel_amd.buffers import Buffer
+    from sorrel_amd.models import BaseModel
+
+    E = 21
+    n_models = 2 if which == "tag_shared_two_models" else 1
+
+    def make(speculate):
+        made = []
+
+        class Shared(BaseModel):
+            def __init__(self, input_size, n_actions, cap):
+                n = int(np.prod(input_size))
+                super().__init__((n,), n_actions, memory_size=0, num_envs=E, device="cuda:0")
+                self.memory = Buffer(capacity=cap, obs_shape=(n,), num_envs=E, device="cuda:0")
+                self.weight = torch.randn((n, n_actions), generator=torch.Generator().manual_seed(3 + n + len(made))).cuda()
+                self.epsilon = 0.3 if values else 0.0
+
+            def take_action(self, state):
+                q = state.reshape(state.shape[0], -1) @ self.weight
+                return q if values else q.argmax(dim=1)
+
+        count = [0]
+
+        def factory(input_size, n_actions):
+            A = agents_of[which]
+            k = count[0] * n_models // A
+            count[0] += 1
+            while len(made) <= k:
+                made.append(Shared(input_size, n_actions, 3 * A + 1))
+            return made[k]
+
+        if which.startswith("tag"):
+            from sorrel_amd.entities import EmptyEntity
+            from sorrel_amd.examples.tag.env import TagEnv
+            from sorrel_amd.worlds import Gridworld
+
+            cfg = {"agent": {"num_agents": 6, "vision_radius": 2, "reward_per_turn": 10}, "experiment": {"epochs": 1, "max_turns": 50}}
+            env = TagEnv(Gridworld(8, 9, 1, EmptyEntity(), num_envs=E, device="cuda:0", seed=31), cfg, model_factory=factory)
+        elif which == "cleanup":
+            from tests.test_api_host import make_cleanup_env
+
+            env = make_cleanup_env(E=E, seed=7, device="cuda:0", model_factory=factory)
+        else:
+            from tests.test_gpu_round2 import make_env
+
+            env = make_env(26, 27, 80, 2, E, p=0.05, seed=9, model_factory=factory)
+        env.speculate_turns = "always" if speculate else False
+        return env, made
+
+    agents_of = {"tag": 6, "tag_shared_two_models": 6, "cleanup": None, "plain_80_agents": 80}
+    if which == "cleanup":
+        from tests.test_api_host import make_cleanup_env
+
+        agents_of["cleanup"] = len(make_cleanup_env(E=2, seed=7, device="cuda:0").agents)
+    (a, ma), (b, mb) = make(False), make(True)
+    A = len(a.agents)
+    assert len(ma) == len(mb) == n_models
+    passes = []
+    for t in range(14):
+        if t == 9:
+            a.reset(); b.reset()
+        for m in ma + mb:
+            m.epsilon *= 0.95
+        a.take_turn()
+        b.take_turn()
+        assert b.turn_plan()["loop"] == "speculative", b.turn_plan()
+        passes.append(b.speculation_passes)
+        torch.cuda.synchronize()
+        names = ("grid", "agent_pos", "total_reward") + (("agent_state",) if which.startswith("tag") else ()) + (("agent_dir",) if which == "cleanup" else ())
+        for name in names:
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert torch.equal(a.rewards, b.rewards) and torch.equal(a.actions, b.actions), t
+    assert b._spec_generic is True and max(passes) >= 2 and max(passes) <= A + 1
+    for x, y in zip(ma, mb):
+        assert (x.memory.idx, x.memory.size) == (y.memory.idx, y.memory.size)
+        for name in ("states", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(x.memory, name), getattr(y.memory, name)), name
+    assert float(b.world.total_reward.abs().sum()) > 0
+    a.raise_on_status()
+    b.raise_on_status()

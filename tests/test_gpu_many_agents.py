@@ -141,14 +141,17 @@ def test_environment_with_96_policy_driven_agents(torch_cuda):
         return one[0]
 
     env = make_env(30, 31, A, 2, E, p=0.05, seed=9, model_factory=factory)
-    env.speculate_turns = "always"                                     # (not possible with more than 64 agents: the sequential loop plays)
+    env.speculate_turns = "always"                                     # (the resolve kernel keeps an agent per lane: the generic speculative turn plays, sgw_verify_rows)
     co = H.COracle(env.compile_spec(), E)
     co.grid[...] = env.world.grid.cpu().numpy()
     co.pos[...] = env.world.agent_pos.cpu().numpy()
     for t in range(1, 5):
         env.take_turn()
         torch.cuda.synchronize()
-        assert env.turn_plan()["loop"] in ("fast", "generic")
+        assert env.turn_plan()["loop"] == ("speculative" if t < 4 else "fast"), env.turn_plan()
+        if t == 3:
+            assert env._spec_generic is True
+            env.speculate_turns = False                                # ... and the eager loop for the last turn
         assert co.step(0, t, actions=env.actions.cpu().numpy()) == 0
         assert np.array_equal(env.world.grid.cpu().numpy(), co.grid) and np.array_equal(env.rewards.cpu().numpy(), co.rewards), t
         assert np.array_equal(env.world.total_reward.cpu().numpy(), co.total), t

@@ -29,7 +29,7 @@ def _th(h, w, a, r, **kw):
 
 
 def _tag(h, w, a, r):
-    from tests.test_gpu_round2 import _tag_spec
+    from tests.gpu_common import _tag_spec
 
     return _tag_spec(h, w, a, r)
 
@@ -121,7 +121,7 @@ def test_environment_with_96_policy_driven_agents(torch_cuda):
     torch = torch_cuda
     from sorrel_amd.buffers import Buffer
     from sorrel_amd.models import BaseModel
-    from tests.test_gpu_round2 import make_env
+    from tests.gpu_common import make_env
 
     E, A = 17, 96
     one = []

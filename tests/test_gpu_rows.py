@@ -217,6 +217,8 @@ import subprocess  # noqa: E402,F401
 import sys  # noqa: E402,F401
 
 from oracle import gridstep_oracle as O  # noqa: E402,F401
+from sorrel_amd import _native as N  # noqa: E402,F401
+from tests import helpers as H  # noqa: E402,F401
 from tests.gpu_common import *  # noqa: E402,F401,F403
 
 

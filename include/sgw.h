@@ -383,7 +383,7 @@ int sgw_launch_info(sgw_engine* eng, char* buf, int64_t capacity);
  * engine only the keys that do not shape its plan are accepted ("rows_mode", "act_lanes", "jit_verbose").  Keys (sorrel_amd/csrc/
  * options.h holds the table): jit, jit_cache, jit_cache_dir, jit_verbose, jit_own_rtc, jit_refuse (test hook), burst, pack3,
  * force_generic, fast_rules, rules_11k, fast_8k, force_big, group, phase_kernel, phase_rows, stage, stage_agents, fast_wg_per_cu,
- * big_threads, big_stage, big_wg_per_cu, big_remap, big_nt, big_walk, big_walk_blocks, big_walk_share, resolve_diag, rows_mode, act_lanes.  (Round 5
+ * big_threads, big_stage, big_wg_per_cu, big_walk, big_walk_blocks, big_walk_share, resolve_diag, rows_mode, act_lanes.  (Round 5
  * retired ten A/B hooks of closed experiments: static_radius, static_cleanup, rgb16, rules_8k, big_tag, stage_bytes, big_pad,
  * big_rot, big_walk_static, big_walk_stage -- an unknown key is SGW_EINVAL.)  No dispatcher knob is
  * an environment variable; the library reads SGW_DEBUG=1 (log lines of the specialiser on stderr), ROCM_PATH (which installation's

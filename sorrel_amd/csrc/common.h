@@ -127,12 +127,6 @@ struct Params {
     int obs_A, obs_a0; // where agent a's window goes: obs + ((env * obs_A + (a - obs_a0)) * C) * V * V.  (A, 0): the [E][A][C][V][V]
                       // tensor; (1, a1) with SGW_STEP_OBS_NEXT_PACKED: one window per env, [E][C][V][V] (an agent's replay slot)
     int64_t obs_ag;   // step_big, SGW_STEP_OBS_AGENT_MAJOR: elements between two agents' rows of an [A][E][C][V][V] observation tensor (0: [E][A][C][V][V])
-    int big_remap;    // step_big: 0, or blocks / 8 -- workgroup b then plays env (b % 8) * big_remap + b / 8 of its round, so the workgroups that share an
-                      // XCD (round-robin dispatch: b, b + 8, ...) write a CONTIGUOUS range of the observation tensor (round 6; speed only)
-    int agent_cap;    // step_kernel: entries of its per-agent LDS arrays (64; 128 for engines with more than 64 agents)
-    int rows_on;      // step_big / step_fast<..., RULES> behind sgw_sweep_observe_rows (round 6): agent a's window of env e goes to rp.p[a] + e * rp.stride (the kernel's
-                      // second argument) instead of the observation tensor, followed by the bound row tail
-    int big_nt;       // step_big, staged windows: 1 = streaming (non-temporal) 16-byte stores, 0 = ordinary ones
     int big_pitch;    // step_big: bytes between grid rows in LDS (W, or W + 16 to spread window rows over the banks)
     int big_stage;    // step_big: bytes of LDS observation staging per wave (0: windows go straight to HBM, a dword store per lane and channel)
     int big_stage_off; // ... and where the first wave's area starts (behind the grid image)

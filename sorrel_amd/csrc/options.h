@@ -35,9 +35,6 @@ struct Options {
     int big_threads = 0;      // step_big workgroup: 0 auto, 256, 512
     int big_stage = -1;       // step_big window staging: -1 by batch size, 0 never, 1 always
     int big_wg_per_cu = 0;    // step_big workgroups per CU: 0 = what the code object admits, 1..3 = capped through the LDS request (A/B)
-    int big_remap = 0;        // step_big, staged windows: 1 = the workgroups of an XCD play a contiguous range of envs (Params::big_remap); 0: workgroup b plays env b.
-                              // Off: +1-3 % on one card (185.5 -> 180.7 us at 4 096 envs of config 5), -3-6 % on the next (213.8 -> 226.4): profiles/r06_c5_remap_ab.txt
-    int big_nt = 1;           // step_big's staged windows leave as streaming (1) or ordinary (0) 16-byte stores
     int big_walk = 1;         // step_big<..., WALK>
     int big_walk_blocks = 0;  // ... this many workgroups whatever the batch (0 auto)
     int big_walk_share = 0;   // ... envs per workgroup assigned statically before the shared counter takes over (0 auto)
@@ -75,8 +72,6 @@ const OptKey kOptKeys[] = {
     {"big_threads", &Options::big_threads, 0, 512, false},
     {"big_stage", &Options::big_stage, -1, 1, false},
     {"big_wg_per_cu", &Options::big_wg_per_cu, 0, 8, false},
-    {"big_remap", &Options::big_remap, 0, 1, false},
-    {"big_nt", &Options::big_nt, 0, 1, false},
     {"big_walk", &Options::big_walk, 0, 1, false},
     {"big_walk_blocks", &Options::big_walk_blocks, 0, 1 << 20, false},
     {"big_walk_share", &Options::big_walk_share, 0, 1 << 20, false},

@@ -141,7 +141,8 @@ struct sgw_engine {
     Kernel k_walk;        // step_big<..., WALK>: resident workgroups walking the batch
     Kernel k_rows;        // phase_rows<L, NW, R>: a policy-driven phase with a lane per window row (one-hot, plain moves)
     Kernel k_obs_rows;    // observe_rows<L, NW, R>: a range of agents, per-agent destinations
-    Kernel k_sweep_rows;  // step_fast_rows<L, C, R, H, W>: the sweep + every agent's window into per-agent destinations, one launch
+    Kernel k_sweep_rows;  // step_fast_rows<L, C, R, H, W>: the sweep + every agent's window into per-agent destinations, one launch (step_big<..., ROWS> for worlds above 4 KiB)
+    Kernel k_sweep_rows_tail;          // ... step_fast_rows<..., TAIL = true>: the same with the bound row tail behind every window (resolved by sgw_bind_row_tail)
     bool sweep_rows_chunked = false;   // ... it is a step_fast_rowsx instance (a chunk-staging kernel: any env_stride, row tails)
     int walk_blocks = 0;                            // how many workgroups of the walking kernel the chip holds at once
     int64_t walk_min_envs = 0, walk_max_envs = 0;  // batches above min and up to max take it (multiples of what the plain kernel holds at once)
@@ -339,6 +340,21 @@ const void* pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W
 #undef PICK_SK
 #undef PICK_SK1
 
+// more than 64 agents (round 6): the workgroup-per-env instances with 128-entry per-agent arrays; prebuilt with run-time shapes only (single-turn: a rollout
+// is a loop of launches without hipRTC)
+const void* pick_step_many(bool onehot, int rule, bool multi, const char** name) {
+    if (multi) return nullptr;
+    if (rule == SGW_AGENT_RULE_CLEANUP) {
+        if (onehot) PICK(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_CLEANUP, 0, 0, 0, false, SGW_MAX_AGENTS>);
+        PICK(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_CLEANUP, 0, 0, 0, false, SGW_MAX_AGENTS>);
+    }
+    if (rule == SGW_AGENT_RULE_TAG) {
+        if (onehot) PICK(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_TAG, 0, 0, 0, false, SGW_MAX_AGENTS>);
+        PICK(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_TAG, 0, 0, 0, false, SGW_MAX_AGENTS>);
+    }
+    if (onehot) PICK(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_MOVE, 0, 0, 0, false, SGW_MAX_AGENTS>);
+    PICK(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_MOVE, 0, 0, 0, false, SGW_MAX_AGENTS>);
+}
 const void* pick_step(const Options& o, int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
     if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, multi, name);
     if (group == 32) return pick_step_g<32>(onehot, L, C, rule, r, H, W, multi, name);
@@ -475,8 +491,9 @@ std::string join_args(const char* tmpl, std::vector<std::string> a, size_t keep,
     return s + ">";
 }
 const char* tf(bool b) { return b ? "true" : "false"; }
-std::string fast_rows_id(int L, int C, int r, int H, int W, bool tag = false) {
-    return "step_fast_rows<" + std::to_string(L) + ", " + std::to_string(C) + ", " + std::to_string(r) + ", " + std::to_string(H) + ", " + std::to_string(W) + (tag ? ", true>" : ">");
+std::string fast_rows_id(int L, int C, int r, int H, int W, bool tag = false, bool tail = false) {
+    return "step_fast_rows<" + std::to_string(L) + ", " + std::to_string(C) + ", " + std::to_string(r) + ", " + std::to_string(H) + ", " + std::to_string(W) +
+           (tail ? (tag ? ", true, true>" : ", false, true>") : (tag ? ", true>" : ">"));
 }
 // the ROWX twin of a chunk-staging instance `name` ("step_fast<true, ..., STAGE = true, ...>") for this engine's constants; "" if `name` is not one
 std::string fast_rowsx_id_like(const char* name, int L, int C, int r, int H, int W) {
@@ -514,12 +531,16 @@ std::string fast_id_like(const char* name, int L, int C, int r, int H, int W, in
     return fast_id(a[0] == "true", L, C, r, i16 ? 0 : H, i16 ? 0 : W, a[6] == "true", a[7] == "true", stage < 0 ? a[8] == "true" : stage != 0,
                    multi < 0 ? a[9] == "true" : multi != 0, a[10] == "true", i16);
 }
-std::string generic_id(int G, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi) {
+std::string generic_id(int G, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, bool many = false) {
+    if (many)        // (128-entry per-agent arrays: every argument spelled)
+        return join_args("step_kernel", {std::to_string(G), tf(onehot), std::to_string(L), std::to_string(C), std::to_string(rule), std::to_string(r),
+                                         std::to_string(H), std::to_string(W), tf(multi), std::to_string(SGW_MAX_AGENTS)}, 10, "");
     return join_args("step_kernel", {std::to_string(G), tf(onehot), std::to_string(L), std::to_string(C), std::to_string(rule), std::to_string(r),
                                      std::to_string(H), std::to_string(W), tf(multi)}, 8, "false");
 }
-std::string big_id(bool onehot, int L, int C, int r, bool multi, bool walk, bool tag, int threads) {
+std::string big_id(bool onehot, int L, int C, int r, bool multi, bool walk, bool tag, int threads, bool rows = false) {
     std::vector<std::string> a = {tf(onehot), std::to_string(L), std::to_string(C), std::to_string(r), tf(multi), tf(walk), tf(tag), std::to_string(threads)};
+    if (rows) { a.push_back("true"); return join_args("step_big", a, 9, ""); }      // (the ROWS instance: every argument spelled)
     if (threads == kBigThreads) a.pop_back();
     return join_args("step_big", a, 4, threads == kBigThreads ? "false" : "");
 }
@@ -546,7 +567,7 @@ int plan_engine(sgw_engine* e, bool jit) {
     const sgw_config& c = e->cfg;
     const Options& o = e->opt;
     e->jit = jit;
-    e->k_step = e->k_plain = e->k_multi = e->k_walk = e->k_rows = e->k_obs_rows = e->k_sweep_rows = Kernel();
+    e->k_step = e->k_plain = e->k_multi = e->k_walk = e->k_rows = e->k_obs_rows = e->k_sweep_rows = e->k_sweep_rows_tail = Kernel();
     e->stage_agents = 0;
     e->walk_blocks = 0;
     e->walk_min_envs = e->walk_max_envs = e->big_stage_min_envs = 0;
@@ -610,8 +631,7 @@ int plan_engine(sgw_engine* e, bool jit) {
     p.cells = c.layers * c.height * c.width;
     p.cells_pad = (p.cells + 15) & ~15;
     p.env_stride = c.grid_env_stride > 0 ? c.grid_env_stride : p.cells;
-    p.agent_cap = c.num_agents > 64 ? SGW_MAX_AGENTS : 64;
-    p.env_lds = p.cells_pad + agent_lds_bytes(p.agent_cap);
+    p.env_lds = p.cells_pad + agent_lds_bytes(c.num_agents > 64 ? SGW_MAX_AGENTS : 64);      // (the generic kernel's per-agent LDS arrays: its AC template argument)
     p.tab_bytes = onehot ? kTabFastBytes : (int)sizeof(DevTables);
     p.default_type = (uint32_t)c.default_type;
     p.fill_type = (uint32_t)c.fill_type;
@@ -904,6 +924,7 @@ int plan_engine(sgw_engine* e, bool jit) {
                 e->k_sweep_rows.host_name = "step_fast_rows<2, 6, 3, 32, 32>";
             }
             if (jit) e->k_sweep_rows.want = fast_rows_id(L, C, r, H, W, tagk);
+            if (jit) e->k_sweep_rows_tail.want = fast_rows_id(L, C, r, H, W, tagk, true);       // (compiled when a tail is bound: sgw_bind_row_tail)
         }
         // ... and on the chunk-staging instances (layered rule sets, Tag, run-time maps): the ROWX twin, specialised only (round 6)
         e->sweep_rows_chunked = false;
@@ -918,16 +939,22 @@ int plan_engine(sgw_engine* e, bool jit) {
         if (!tag_move && ((p.cells + 15) >> 4) <= 4 * e->big_threads)   // the prefetch holds one 4-unit round per thread
             e->k_walk.host = pick_big_walk(e->onehot, L, C, r, e->big_threads, &e->k_walk.host_name);
         if (jit) {
+            e->k_sweep_rows.want = big_id(e->onehot, L, C, r, false, false, tag_move, e->big_threads, true);   // (round 6: the fused sweep + rows launch; specialised only)
             e->k_step.want = big_id(e->onehot, L, C, r, false, false, tag_move, e->big_threads);
             if (!tag_move) e->k_multi.want = big_id(e->onehot, L, C, r, true, false, false, kBigThreads);   // (whether or not the library holds a twin)
             if (e->k_walk.host) e->k_walk.want = big_id(e->onehot, L, C, r, false, true, false, e->big_threads);
         }
     } else {
-        e->k_step.host = pick_step(o, e->group, e->onehot, L, C, c.agent_rule, r, H, W, false, &e->k_step.host_name);
-        e->k_multi.host = pick_step(o, e->group, e->onehot, L, C, c.agent_rule, r, H, W, true, &e->k_multi.host_name);   // the generic kernel's instance with the turn loop
+        if (many_agents) {      // (group == 256: set above)
+            e->k_step.host = pick_step_many(e->onehot, c.agent_rule, false, &e->k_step.host_name);
+            e->k_multi.host = nullptr;
+        } else {
+            e->k_step.host = pick_step(o, e->group, e->onehot, L, C, c.agent_rule, r, H, W, false, &e->k_step.host_name);
+            e->k_multi.host = pick_step(o, e->group, e->onehot, L, C, c.agent_rule, r, H, W, true, &e->k_multi.host_name);   // the generic kernel's instance with the turn loop
+        }
         if (jit) {
-            e->k_step.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, false);
-            e->k_multi.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, true);
+            e->k_step.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, false, many_agents);
+            e->k_multi.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, true, many_agents);
         }
     }
     if (!o.big_walk) e->k_walk = Kernel();   // A/B hook
@@ -1376,7 +1403,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
     size_t lds = step_lds_request(e, p, &cap);
     // step_big: the walking variant keeps the direct stores (measured faster there), and so does a launch whose observation
     // pointer is not 16-byte aligned; such a launch does not ask for the staging area either
-    const bool walk = e->big && p.nturns == 1 && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
+    const bool walk = e->big && p.nturns == 1 && !sweep_rows && e->k_walk.usable() && p.E > e->walk_min_envs && p.E <= e->walk_max_envs;
     p.big_stage = (e->big && ((p.obs && (reinterpret_cast<uintptr_t>(p.obs) & 15) == 0) || (sweep_rows && !p.obs_u8)) && !walk && p.E > e->big_stage_min_envs) ? e->big_stage : 0;
     if (walk) {     // the walking workgroups: a static share each, the rest off a counter (step_big.h)
         p.walk_ctr = reinterpret_cast<uint32_t*>(e->d_status) + 1;
@@ -1394,10 +1421,10 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
         if (p.obs_stage <= 0 || p.a0 != 0 || p.a1 != p.A || (p.flags & SGW_STEP_NO_OBS))      // (step_fast_rows has no other way to emit than its staged burst)
             return fail(SGW_EINVAL, "sgw_sweep_observe_rows: this engine does not stage its windows");
         if (e->sweep_rows_chunked) p.stage_agents = 1;                                           // (ROWX: a chunk = one agent = one row)
-        if (int rc = launch_kernel(e, e->k_sweep_rows, (unsigned)e->grid_blocks, kBlock, lds, s, p, sweep_rows)) return rc;
+        Kernel& kr = (p.tail_kind != SGW_TAIL_NONE && !e->sweep_rows_chunked) ? e->k_sweep_rows_tail : e->k_sweep_rows;
+        if (int rc = launch_kernel(e, kr, (unsigned)e->grid_blocks, kBlock, lds, s, p, sweep_rows)) return rc;
         return time_end(e, s);
     }
-    p.rows_on = sweep_rows ? 1 : 0;           // (step_big: the ordinary instances, windows to rp.p[a] + env * rp.stride; round 6)
     const bool one_phase = p.nturns == 1 && !(p.flags & (SGW_STEP_SWEEP | SGW_STEP_RANDOM_ACTIONS)) && p.a1 - p.a0 <= 1 && (p.do_move || p.a1 - p.a0 == 1);
     if (e->k_rows.usable() && one_phase && !p.obs_u8) {
         // one window per env: contiguous for all envs only in the packed destination ([E][C][V][V])
@@ -1435,11 +1462,8 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
         k = &e->k_walk;
         blocks = e->walk_blocks;
     }
-    // (A/B option, off by default.  Measured on the kernel, config 5's shape: on one card the staged windows gain 1-3 % from it -- 185.5 -> 180.7 us at
-    //  4 096 envs -- and the direct dword stores lose 1-3 %; on the next card the staged windows LOSE 3-6 %: 213.8 -> 226.4; profiles/r06_c5_remap_ab.txt)
-    p.big_remap = (e->big && e->opt.big_remap && p.big_stage > 0 && blocks >= 64 && (blocks & 7) == 0) ? blocks / 8 : 0;
-    p.big_nt = e->opt.big_nt;
-    if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, p.rows_on ? sweep_rows : nullptr)) return rc;
+    if (sweep_rows) k = &e->k_sweep_rows;     // (step_big<..., ROWS>: the plain single-turn variant with the row pointers as its second argument; `walk` is off above)
+    if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, sweep_rows)) return rc;
     return time_end(e, s);
 }
 
@@ -1573,8 +1597,9 @@ int sgw_capabilities(sgw_engine* e) {
         if (ok) caps |= SGW_CAP_RESOLVE;
     }
     if (e->big) caps |= SGW_CAP_OBS_AGENT_MAJOR;
-    if (e->k_sweep_rows.usable() && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_SWEEP_ROWS;      // (round 6: row tails on every instance)
-    if (e->big && e->obs_format == SGW_OBS_F32) caps |= SGW_CAP_SWEEP_ROWS;      // (round 6: step_big renders into per-agent rows itself, row tails included)
+    // (round 6: also step_big<..., ROWS> and the chunk-staging twins, which write the bound row tail themselves; the whole-env instance has a TAIL twin)
+    if (e->k_sweep_rows.usable() && e->obs_format == SGW_OBS_F32 &&
+        (e->tail_kind == SGW_TAIL_NONE || e->big || e->sweep_rows_chunked || e->k_sweep_rows_tail.jit)) caps |= SGW_CAP_SWEEP_ROWS;
     return caps;
 }
 
@@ -2041,14 +2066,26 @@ int sgw_bind_agent_state(sgw_engine* e, uint8_t* agent_state, uint8_t* state_at_
 int sgw_bind_row_tail(sgw_engine* e, int kind, int tail_len, const float* table) {
     if (!e) return fail(SGW_EINVAL, "sgw_bind_row_tail: NULL engine");
     if (kind == SGW_TAIL_NONE) { e->tail_kind = SGW_TAIL_NONE; e->tail_len = 0; e->tail_table = nullptr; return SGW_OK; }
+    // the whole-env instance of sgw_sweep_observe_rows has a twin that writes the tail (round 6): compiled / loaded HERE, not inside a stream-ordered call; a
+    // refusal only costs the capability bit (the sweep alone + sgw_observe_rows do the same in two launches)
+    auto tail_twin = [&]() {
+        Kernel& k = e->k_sweep_rows_tail;
+        if (!k.jit && !k.want.empty() && !k.tried) {
+            k.tried = true;
+            std::string err;
+            k.jit = jit_get(k.want, e->opt, e->arch.c_str(), e->dev, &err);
+        }
+    };
     if (kind == SGW_TAIL_AGENT_IS_IT) {
         if (e->cfg.agent_rule != SGW_AGENT_RULE_TAG) return fail(SGW_EINVAL, "SGW_TAIL_AGENT_IS_IT is the tail of SGW_AGENT_RULE_TAG agents");
         e->tail_kind = kind; e->tail_len = 1; e->tail_table = nullptr;
+        tail_twin();
         return SGW_OK;
     }
     if (kind != SGW_TAIL_POSITION_TABLE) return fail(SGW_EINVAL, "sgw_bind_row_tail: unknown kind %d", kind);
     if (tail_len < 1 || tail_len > 4096 || !table) return fail(SGW_EINVAL, "SGW_TAIL_POSITION_TABLE needs a device table of [H][W][tail_len] floats, 1 <= tail_len <= 4096");
     e->tail_kind = kind; e->tail_len = tail_len; e->tail_table = table;
+    tail_twin();
     return SGW_OK;
 }
 
@@ -2181,7 +2218,8 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
                           : (k.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.host, threads, lds) : hipErrorInvalidValue);
     if (oe != hipSuccess) per_cu = -1;
     const char* phase = e->k_rows.usable() ? e->k_rows.name() : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
-    const char* srows = e->big ? (e->obs_format == SGW_OBS_F32 ? "the-step-kernel" : "-") : (e->k_sweep_rows.usable() ? e->k_sweep_rows.name() : "-");   // what sgw_sweep_observe_rows launches
+    const char* srows = e->k_sweep_rows.usable() ? ((e->tail_kind != SGW_TAIL_NONE && !e->big && !e->sweep_rows_chunked && e->k_sweep_rows_tail.jit) ? e->k_sweep_rows_tail.name()
+                                                                                                                                                   : e->k_sweep_rows.name()) : "-";   // what sgw_sweep_observe_rows launches
     snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d specialised=%d sweep_rows=%s",
              k.name(),
              (e->fast || e->big) ? (e->big ? e->big_threads : e->wpe * kWave) : e->group,

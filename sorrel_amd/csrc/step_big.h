@@ -59,8 +59,12 @@ constexpr int big_agent_lds(bool tag) { return kBigAgentLds + (tag ? kBigTagLds 
 // BT: threads per workgroup.  512 (eight waves) for worlds with many agents (config 5: 64); 256 for up to 32 agents, where eight waves
 // have one or two windows each and mostly wait at the barriers (round 3, 8 192 envs: 90x90x2 / 16 agents 122 -> 103 us, 100x100x2 / 8
 // agents / 11x11 104 -> 88, Tag 128x128 / 32 agents 145 -> 116; config 5 itself 352 -> 394: it keeps 512).
-template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false, int BT = kBigThreads>
-__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WAVES)) void step_big(const Params p, const RowPtrs rp) {
+// ROWS (round 6): the instance behind sgw_sweep_observe_rows -- agent a's window of env e goes to rp.p[a] + e * rp.stride (its own row, e.g. of its replay buffer),
+// followed by the bound row tail; a separate instantiation (specialised in-process only): in the ordinary instances the extra addressing cost the walking variant
+// 37 spilled scalars and 8 bytes of scratch per lane.  Every instance takes the row pointers as its second argument (read by ROWS instances only).
+template <bool ONEHOT, int TL, int TC, int TR, bool MULTI = false, bool WALK = false, bool TAG = false, int BT = kBigThreads, bool ROWS = false>
+__global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WAVES)) void step_big(const Params p, [[maybe_unused]] const RowPtrs rp) {
+    static_assert(!ROWS || (!MULTI && !WALK), "ROWS: the plain single-turn variant");
     constexpr int kBT = BT, kBW = BT / 64;   // threads / waves of this instance
     static_assert(!(MULTI && WALK), "a rollout keeps one env per workgroup");
     // Philox key schedule per block (common.h): config 5's share on the walking variant 94 -> 90 us; the plain variant is indifferent at
@@ -69,9 +73,9 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
     static_assert(!(TAG && (MULTI || WALK)), "Tag: single-turn, one env per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid0 = threadIdx.x;
-    // which env of its round this workgroup plays: its own number, or -- big_remap -- the transposed one, which gives every XCD (blocks b, b + 8,
-    // ...) one contiguous eighth of the round's envs: 380 MB of config 5's windows alone leave in 73.3 instead of 75.9 us (profiles/r06_c5_emit_micro.txt)
-    int64_t env = p.big_remap ? (int64_t)(blockIdx.x & 7u) * p.big_remap + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    // (Round 6 measured the transposed assignment -- workgroup b plays env (b % 8) * (blocks / 8) + b / 8, so that the workgroups of an XCD write one contiguous
+    // eighth of the round's windows: + 1-3 % for the staged windows on one card, - 3-6 % on the next, - 1-3 % for the direct stores; not kept: profiles/r06_c5_remap_ab.txt)
+    int64_t env = blockIdx.x;
 #ifdef SGW_STAMPS
     unsigned long long tprev_ = 0;
 #define STAMPB(i)                                                                                            \
@@ -551,17 +555,21 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     }
                 }
             }
-            float* obase = p.rows_on ? static_cast<float*>(rp.p[a]) + env * rp.stride                                   // sgw_sweep_observe_rows: the agent's own row
-                         : p.obs_ag ? p.obs + tix * p.ts_obs + (int64_t)a * p.obs_ag + env * (int64_t)(C * VV)       // [A][E][C][V][V]
-                                    : p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
-            if (p.rows_on && p.tail_kind != SGW_TAIL_NONE) {     // what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds)
-                float* t = obase + C * VV;
-                if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {       // TagAgent.pov: [self.it] (nobody acts in this launch: the flag is the bound tensor's)
-                    if (lane == 0) t[0] = (p.agent_state && p.agent_state[env * p.A + a] == p.tag_it) ? 1.f : 0.f;
-                } else {                                         // CleanupObservation.observe: the positional code of the agent's cell
-                    const float* src = p.tail_table + ((int64_t)y * W + x) * p.tail_len;
-                    for (int k = lane; k < p.tail_len; k += 64) t[k] = src[k];
+            float* obase;
+            if constexpr (ROWS) {
+                obase = static_cast<float*>(rp.p[a]) + env * rp.stride;                                             // sgw_sweep_observe_rows: the agent's own row
+                if (p.tail_kind != SGW_TAIL_NONE) {              // what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds)
+                    float* t = obase + C * VV;
+                    if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {   // TagAgent.pov: [self.it] (nobody acts in this launch: the flag is the bound tensor's)
+                        if (lane == 0) t[0] = (p.agent_state && p.agent_state[env * p.A + a] == p.tag_it) ? 1.f : 0.f;
+                    } else {                                     // CleanupObservation.observe: the positional code of the agent's cell
+                        const float* src = p.tail_table + ((int64_t)y * W + x) * p.tail_len;
+                        for (int k = lane; k < p.tail_len; k += 64) t[k] = src[k];
+                    }
                 }
+            } else {
+                obase = p.obs_ag ? p.obs + tix * p.ts_obs + (int64_t)a * p.obs_ag + env * (int64_t)(C * VV)           // [A][E][C][V][V]
+                                 : p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)C) * VV;
             }
             if constexpr (ONEHOT) {
                 // the packed byte counts of window cell lane + 64 k: one table word per layer and group of four channels
@@ -586,8 +594,8 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     uint8_t* ob = smem + p.big_stage_off + wv * p.big_stage;
                     const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
                     // the window's first element in the tensor and its distance from a line boundary: staged byte s is element (e0 - sh) + s
-                    // (a row of its own -- rows_on -- by its address: the row pointers are 4-byte aligned, no more)
-                    const int64_t e0 = p.rows_on ? (int64_t)(reinterpret_cast<uintptr_t>(obase) >> 2) : (int64_t)(obase - p.obs);
+                    // (a row of its own -- ROWS -- by its address: the row pointers are 4-byte aligned, no more)
+                    const int64_t e0 = ROWS ? (int64_t)(reinterpret_cast<uintptr_t>(obase) >> 2) : (int64_t)(obase - p.obs);
                     const int sh = (int)(e0 & 31);
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                     const int ie = lane == 0 ? i0 - 1 : i1;
                     const bool edge = lane == 0 ? (sh & 3) != 0 : (lane == 1 && (he & 3) != 0);
                     if (!p.obs_u8) {
-                        float* gb = p.rows_on ? obase - sh : p.obs + (e0 - sh);
+                        float* gb = ROWS ? obase - sh : p.obs + (e0 - sh);
                         for (int i = lane; i < i1; i += 64) {
                             if (i < i0) continue;
                             const uint32_t b = ob4[i];
@@ -616,8 +624,7 @@ __global__ __launch_bounds__(BT, WALK ? SGW_WALK_WAVES : (MULTI ? 6 : SGW_BIG_WA
                             v.y = (float)((b >> 8) & 0xFFu);
                             v.z = (float)((b >> 16) & 0xFFu);
                             v.w = (float)(b >> 24);
-                            if (p.big_nt) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));
-                            else *reinterpret_cast<vfloat4*>(gb + 4 * i) = v;
+                            __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(gb + 4 * i));      // (ordinary stores: no difference on the kernel, profiles/r06_c5_remap_ab.txt)
                         }
                         if (edge) {
                             const uint32_t b = ob4[ie];

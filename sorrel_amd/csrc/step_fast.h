@@ -116,7 +116,7 @@ __device__ unsigned long long g_stamps[kStampEnvs * 8];
 // makes it a byte, the byte is staged, and the burst turns it into (float)(k / 255.0) through a 256-entry table of exactly those
 // floats (DevTables::post_lut, one copy per workgroup in LDS) instead of a float64 sum, clip and DIVISION per cell and channel.
 // step_fast_rows' emit (called once by EVERY wave of the workgroup, also one whose env lies beyond the batch):
-template <int TL, int TC, int TR, int TH, int TW>
+template <int TL, int TC, int TR, int TH, int TW, bool TAIL = false>
 __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* rp, uint8_t* smem, const int sub, const int lane) {
     // Agent a's C * V * V staged bytes of env e -> floats at rp->p[a] + e * rp->stride.  The workgroup's four envs are consecutive,
     // so with stride = C * V * V their windows of ONE agent are one run of 4 C V V floats: the waves meet (the only barrier of
@@ -190,7 +190,8 @@ __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* r
         }
         // (round 6) what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds); nobody acts in this launch, so the
         // agents' types and cells are the bound tensors'
-        if (p.tail_kind != SGW_TAIL_NONE && rp->stride >= kN + p.tail_len) {
+        // (the TAIL twin only: in the instance without it this code cost 41 spilled scalars -- vector instructions, on a kernel that is bound by them)
+        if constexpr (TAIL) if (p.tail_kind != SGW_TAIL_NONE && rp->stride >= kN + p.tail_len) {
             for (int k = 0; k < live; ++k) {
                 float* t = base + k * rp->stride + kN;
                 const int64_t ea = (env_first + k) * p.A + a;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void fast_rows_emit(const Params& p, const RowPtrs* r
 // ROWX (round 6): the same call on the instances that stage CHUNKS of agents (STAGE: layered rule sets -- Cleanup --, Tag, run-time maps and tables): the host
 // launches with one agent per chunk, and a chunk leaves for its agent's own row -- emit_chunk's line-aligned 16-byte streaming stores, the staging offset
 // taken from the ROW's address -- followed by the bound row tail (TagAgent.pov's flag, CleanupObservation's positional code).
-template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS, bool ROWX = false>
+template <bool ONEHOT, int TL, int TC, int TR, int TH, int TW, bool TAG, bool RULES, bool STAGE, bool MULTI, bool P3, bool I16, bool ROWS, bool ROWX = false, bool TAIL = false>
 __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] const RowPtrs* rp) {
     static_assert(!ROWS || (ONEHOT && TL && TC && TH && TW && !RULES && !STAGE && !MULTI && !P3 && !I16), "ROWS: plain or Tag movers, one-hot, compile-time shape");
     static_assert(!ROWX || (ONEHOT && STAGE && !MULTI && !I16 && !ROWS), "ROWX: a chunk-staging single-turn instance");
@@ -227,7 +228,7 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
     if (env >= p.E) {         // whole wave exits together
         if constexpr (ROWS)      // (the workgroup's waves meet once, in the emit, and every wave writes its share of the agents)
             if (p.obs_stage > 0 && p.a0 == 0 && p.a1 == p.A && !(p.flags & SGW_STEP_NO_OBS))   // (= `stage && write_obs` of the waves that have an env)
-                fast_rows_emit<TL, TC, TR, TH, TW>(p, rp, smem, sub, lane);
+                fast_rows_emit<TL, TC, TR, TH, TW, TAIL>(p, rp, smem, sub, lane);
         return;
     }
 #ifdef SGW_STAMPS
@@ -836,7 +837,7 @@ __device__ __forceinline__ void step_fast_body(const Params p, [[maybe_unused]] 
             const int nd = (p.A * C * VV) >> 2;   // dwords of staged bytes (the host stages only multiples of 4 elements)
             const uint32_t* ob4 = reinterpret_cast<const uint32_t*>(ob);
             if constexpr (ROWS) {
-                fast_rows_emit<TL, TC, TR, TH, TW>(p, rp, smem, sub, lane);
+                fast_rows_emit<TL, TC, TR, TH, TW, TAIL>(p, rp, smem, sub, lane);
             } else if (!p.obs_u8) {
                 // Non-temporal (streaming) stores: every wave instruction here writes eight whole 128-byte lines that
                 // nothing reads again in this launch; keeping them out of the caches leaves those to the grids (134 MB,
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(kBlock, RULES ? 7 : 8) void step_fast_rowsx(const P
 }
 
 // sweep + every agent's window into per-agent rows (sgw_sweep_observe_rows): nobody acts in this launch
-template <int TL, int TC, int TR, int TH, int TW, bool TAG = false>
+template <int TL, int TC, int TR, int TH, int TW, bool TAG = false, bool TAIL = false>
 __global__ __launch_bounds__(kBlock, 8) void step_fast_rows(const Params p, const RowPtrs rp) {
-    step_fast_body<true, TL, TC, TR, TH, TW, TAG, false, false, false, false, false, true>(p, &rp);
+    step_fast_body<true, TL, TC, TR, TH, TW, TAG, false, false, false, false, false, true, false, TAIL>(p, &rp);
 }

@@ -22,8 +22,11 @@ __host__ __device__ constexpr int agent_lds_bytes(int cap) { return 10 * cap + 1
 // MULTI: sgw_rollout's instance (the turn loop; nturns > 1).  The single-turn instances are compiled without the loop: its
 // loop-carried state cost the small-world kernels a fifth of their speed when it was added to the one kernel (round 2: 16x16 / 4
 // agents, 32 lanes per env, 54 -> 67 us; found in round 3 by bisecting tools/group_sweep.py).
-template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0, bool MULTI = false>
+// AC: entries of the per-agent LDS arrays -- 64, or 128 for engines with more than 64 agents (round 6; workgroup-per-env instances only: a group of G < 256
+// threads holds at most G agents).  A compile-time constant: as a launch parameter it cost the small-world instances 2-4 VGPRs, three of them a wave of occupancy.
+template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0, bool MULTI = false, int AC = 64>
 __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p) {
+    static_assert(AC == 64 || (AC == SGW_MAX_AGENTS && G == 256), "more than 64 agents: the workgroup-per-env instances");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
     constexpr int EPB = kBlock / G;    // envs per workgroup
@@ -41,7 +44,6 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
     const DevTables* tab = reinterpret_cast<const DevTables*>(smem);
     uint8_t* slice = smem + p.tab_bytes + sub * p.env_lds;
     uint8_t* lg = slice;                              // grid
-    const int AC = p.agent_cap;
     uint8_t* s_pos = slice + p.cells_pad;             // [A][2]
     uint8_t* s_act = s_pos + 2 * AC;                  // [A]
     float* s_rew = reinterpret_cast<float*>(s_act + AC);

@@ -71,15 +71,15 @@ def _rule_world(seed, mode):
 CASES = [
     ("c5_shape_direct", lambda: _th(128, 128, 64, 5), 6, {"big_stage": 0, "big_walk": 0}, "step_big<true, 2, 6, 5", None),
     ("c5_shape_staged", lambda: _th(128, 128, 64, 5), 6, {"big_stage": 1, "big_walk": 0}, "step_big<true, 2, 6, 5", None),
-    ("c5_shape_walking", lambda: _th(128, 128, 64, 5), 23, {"big_walk_blocks": 5}, "step_big<true, 2, 6, 5, false, true", None),
-    ("c5_shape_prebuilt", lambda: _th(128, 128, 64, 5), 5, {"jit": 0}, "step_big<true, 2, 6, 5", None),
+    ("c5_shape_walk_window", lambda: _th(128, 128, 64, 5), 23, {"big_walk_blocks": 5}, "step_big<true, 2, 6, 5", None),      # (a batch the step itself would walk: the rows launch does not)
+    ("c5_shape_prebuilt_has_none", lambda: _th(128, 128, 64, 5), 5, {"jit": 0}, None, None),      # (the ROWS instances are specialised only)
     ("big_72x80_r3_tail7", lambda: _th(72, 80, 6, 3), 9, {"big_stage": 1}, "step_big<", 7),
     ("big_70x66_r4_256_threads", lambda: _th(70, 66, 10, 4), 11, {}, "step_big<", None),
     ("big_float_table", lambda: _float_table(_th(72, 80, 6, 3)), 7, {}, "step_big<false", None),
     ("big_tag_70x80_it", lambda: _tag(70, 80, 9, 4), 8, {}, "step_big<", "it"),
     ("cleanup_15x16_rules_table12", _cleanup, 19, {}, "step_fast_rowsx<", 12),
     ("cleanup_15x16_rules_no_tail", _cleanup, 19, {}, "step_fast_rowsx<", None),
-    ("tag_11x11_it_whole_env", lambda: _tag(11, 11, 5, 4), 37, {"group": 64}, "step_fast_rows<1, 4, 4, 11, 11, true>", "it"),
+    ("tag_11x11_it_whole_env", lambda: _tag(11, 11, 5, 4), 37, {"group": 64}, "step_fast_rows<1, 4, 4, 11, 11, true, true>", "it"),
     ("tag_70x60_it_chunked", lambda: _tag(70, 60, 7, 4), 14, {"fast_8k": 1}, "step_fast_rowsx<", "it"),
     ("tag_13x12_prebuilt_has_none", lambda: _tag(13, 12, 4, 2), 9, {"group": 64, "jit": 0}, None, "it"),
     ("runtime_map_33x35_r3", lambda: _th(33, 35, 7, 3), 21, {"burst": 2}, "step_fast_rowsx<", None),
@@ -145,7 +145,8 @@ def test_sweep_and_rows_in_one_launch_on_the_big_and_the_chunk_staging_kernels(t
         torch.cuda.synchronize()
         if t == 1:
             info = a.launch_info()
-            assert (inst in info.split("sweep_rows=")[1]) if inst.startswith("step_fast_rows") else (inst in info and "sweep_rows=the-step-kernel" in info), (name, info)
+            srows = info.split("sweep_rows=")[1]
+            assert (inst in srows) if inst.startswith("step_fast_rows") else (srows.startswith(inst) and srows.rstrip().endswith(", true>")), (name, info)
         assert np.array_equal(a.grid.cpu().numpy(), co.grid) and torch.equal(a.grid, b.grid), (name, t, "grid after the sweep")
         pos = a.agent_pos.cpu().numpy()
         for k in range(A):

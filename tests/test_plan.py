@@ -107,14 +107,15 @@ def _canonical(name: str, lanes: int):
     m = re.fullmatch(r"(\w+)<(.*)>", name)
     assert m, name
     tmpl, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    rules = {"SGW_AGENT_RULE_MOVE": "0", "SGW_AGENT_RULE_TAG": "1", "SGW_AGENT_RULE_CLEANUP": "2"}
+    rules = {"SGW_AGENT_RULE_MOVE": "0", "SGW_AGENT_RULE_TAG": "1", "SGW_AGENT_RULE_CLEANUP": "2", "SGW_MAX_AGENTS": str(__import__("sorrel_amd._native", fromlist=["x"]).MAX_AGENTS)}
     args = [rules.get(a, str(lanes) if a == "G" else a) for a in args]
-    defaults = {"step_fast": ["?"] * 6 + ["false"] * 6, "step_big": ["?"] * 4 + ["false", "false", "false", "512"],
-                "step_kernel": ["?", "?", "0", "0", "0", "0", "0", "0", "false"]}.get(tmpl)
+    # (round 6: step_big has a ninth argument -- ROWS --, step_kernel a tenth -- the capacity of its per-agent LDS arrays)
+    defaults = {"step_fast": ["?"] * 6 + ["false"] * 6, "step_big": ["?"] * 4 + ["false", "false", "false", "512", "false"],
+                "step_kernel": ["?", "?", "0", "0", "0", "0", "0", "0", "false", "64"]}.get(tmpl)
     if defaults:
         args += defaults[len(args):]
         if multi:
-            args[-1] = "true"
+            args[{"step_kernel": 8, "step_big": 4}.get(tmpl, -1)] = "true"
     return tmpl, tuple(args)
 
 
@@ -147,4 +148,4 @@ def test_every_plan_without_specialised_instances_names_kernels_the_library_hold
             checked += 1
     assert checked > 100
     # ... and the count the round ended on (tools/regs.py lists them with registers / scratch): 177 before, 151 now
-    assert len([h for h in have if h[0].startswith("step_")]) == 93      # (round 5: + step_fast_rows<2, 6, 3, 32, 32>)
+    assert len([h for h in have if h[0].startswith("step_")]) == 99      # (round 5: + step_fast_rows<2, 6, 3, 32, 32>; round 6: + six run-time-shape step_kernel<256, ..., 128> for > 64 agents)

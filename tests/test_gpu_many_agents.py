@@ -103,6 +103,45 @@ def test_more_than_64_agents_vs_the_c_oracle(torch_cuda, case):
     assert eng.status() == 0
 
 
+def test_cleanup_rules_with_more_than_64_agents_vs_the_c_oracle(torch_cuda):
+    """The layered rule set (BECOME_IF sweeps, beams on the layer above, facing, all-layer rewards: examples/cleanup) with 72 agents on a 30x34x3
+    map -- the generic kernel's Cleanup instance with 128-entry per-agent arrays --, fused turns and sgw_act turns against the C oracle."""
+    torch = torch_cuda
+    from tests.gpu_common import _cleanup_spec
+
+    ws, _d = _cleanup_spec()
+    A = 72
+    ws.height, ws.width, ws.num_agents, ws.agent_type = 30, 34, A, [ws.agent_type[0]] * A
+    E = 10
+    eng, co = make_engine(ws, E, first=2), H.COracle(ws, E, first_env_id=2)
+    assert "step_kernel<256" in eng.launch_info() and "128" in eng.launch_info().split(" group")[0], eng.launch_info()
+    eng.reset(epoch=1)
+    co.reset(1)
+    co.agent_dir[...] = eng.agent_dir.cpu().numpy()
+    nact = len(ws.action_dy)
+    for t in range(1, 6):
+        eng.step(random_actions=True, turn=t)
+        assert co.step(1, t, random_actions=True) == 0
+        assert_same(eng, co, ctx=f"cleanup 72 agents, fused turn {t}")
+        assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), t
+    gen = np.random.default_rng(8)
+    rows = eng.window_rows(None)
+    for t in range(6, 9):                                               # windows once (NO_MOVE) + sgw_act per agent: beams repaired in later windows
+        acts = gen.integers(0, nact, (E, A)).astype(np.uint8)
+        ta = torch.from_numpy(acts).cuda()
+        assert co.step(1, t, actions=acts) == 0
+        eng.step(ta, sweep=True, no_move=True, turn=t)
+        seen = torch.zeros_like(eng.obs)
+        for a in range(A):
+            seen[:, a] = eng.obs[:, a]
+            eng.act(a, rows, action=ta[:, a].to(torch.int64).contiguous())
+        torch.cuda.synchronize()
+        assert np.array_equal(seen.cpu().numpy(), co.obs), f"sgw_act turn {t}: windows at pov time"
+        assert_same(eng, co, what=("grid", "pos", "rewards", "total"), ctx=f"cleanup 72 agents, sgw_act turn {t}")
+        assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), t
+    assert eng.status() == 0
+
+
 def test_agent_limit_is_128_and_said_so(torch_cuda):
     from sorrel_amd.spec import treasurehunt_spec
 

@@ -458,7 +458,9 @@ class Environment(SpeculativeTurns, MixedSpecTurns, PolicyTurns, RecordedTurns, 
         out = {}
         if self.speculate_turns:
             if self._speculation_groups(eng) is not None:
-                return {"loop": "speculative", "models": len(self._speculation_groups(eng))}
+                return {"loop": "speculative", "models": len(self._speculation_groups(eng)),
+                        "resolve": "sgw_verify_rows (any agent rule: a whole turn per pass on a scratch state)" if getattr(self, "_spec_generic", False)
+                        else "sgw_turn_resolve (plain movers)"}
             out["speculative"] = "not possible for these agents, or the cost model keeps the sequential loop (speculate_turns = 'always' overrides it)"
         plan = self._fast_plan(eng) if self.fast_policy_loop else None
         caps = eng.capabilities()
@@ -682,11 +684,20 @@ class Environment(SpeculativeTurns, MixedSpecTurns, PolicyTurns, RecordedTurns, 
 
     def _push_epsilon(self, eng, slots=None) -> None:
         """The exploration rates of the agents that act through action values, to the device's turn state when they change."""
+        todo = {}
         for a in (self._value_agents if slots is None else slots):
             eps = min(1.0, max(0.0, self.agents[a].epsilon))
             if self._eps_pushed.get(a) != (eng.uid, eps):
+                todo[a] = eps
+        if not todo:
+            return
+        if len(todo) == len(self.agents) and len(set(todo.values())) == 1:      # every agent, one rate (agents that share a model): ONE launch, not A
+            eng.turn_epsilon(next(iter(todo.values())), -1)
+        else:
+            for a, eps in todo.items():
                 eng.turn_epsilon(eps, a)
-                self._eps_pushed[a] = (eng.uid, eps)
+        for a, eps in todo.items():
+            self._eps_pushed[a] = (eng.uid, eps)
 
     def _act(self, agent: Agent, action) -> torch.Tensor:
         eng = self._ensure_engine()

@@ -169,7 +169,7 @@ def test_sweep_and_rows_in_one_launch_on_the_big_and_the_chunk_staging_kernels(t
 
 
 @pytest.mark.parametrize("mode", ["cleanup", "tag", "move"])
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, int(__import__("os").environ.get("SGW_SOAK", "0")) // 4)))
 def test_fused_rows_soak_random_rule_worlds(torch_cuda, mode, seed):
     """Random layered rule worlds (tests/helpers.random_rule_world: BECOME_IF tables, timers, spawners; Cleanup / Tag / plain agents) from an
     injected grid: the fused launch where the engine offers it == sweep alone + sgw_observe_rows == the oracle."""

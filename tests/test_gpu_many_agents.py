@@ -199,3 +199,48 @@ def test_environment_with_96_policy_driven_agents(torch_cuda):
         got = torch.stack([mem.states[r] for r in rows], dim=1).cpu().numpy().reshape(co.obs.shape)
         assert np.array_equal(got, co.obs), (t, "the windows the agents acted on")
     env.raise_on_status()
+
+
+@pytest.mark.parametrize("layout", ["rows", "tensor"])
+def test_recorded_turn_with_72_agents_equals_the_eager_loop(torch_cuda, layout):
+    """``Environment.capture_turn()`` beyond 64 agents (the device-side turn state holds 128 rings): 72 agents with a linear policy and a replay ring
+    each, one graph replay per turn against the eager loop and the C oracle -- state, step outputs, every ring, across a reset."""
+    torch = torch_cuda
+    from tests.gpu_common import _policy_env
+
+    E, shape = 11, (24, 25, 72, 2)
+    a, b = _policy_env(E, shape=shape, memory=4), _policy_env(E, shape=shape, memory=4)
+    b.capture_layout = layout
+    cap = b.capture_turn(warmup=2, force=True)
+    assert cap is not None, getattr(b, "capture_error", None)
+    for _ in range(2):
+        a.take_turn()
+    co = H.COracle(a._engine.spec, E, first_env_id=0)
+
+    def sync_oracle():
+        co.grid[...] = a.world.grid.cpu().numpy()
+        co.pos[...] = a.world.agent_pos.cpu().numpy()
+        co.total[...] = a.world.total_reward.cpu().numpy()
+
+    sync_oracle()
+    for t in range(9):
+        if t == 5:
+            a.reset()
+            b.reset()
+            sync_oracle()
+        a.take_turn()
+        b.take_turn()
+        torch.cuda.synchronize()
+        assert b.turn_plan()["loop"] == "recorded"
+        assert co.step(a.epoch, a.turn, actions=a.actions.cpu().numpy()) == 0
+        for name in ("grid", "agent_pos", "total_reward"):
+            assert torch.equal(getattr(a.world, name), getattr(b.world, name)), (t, name)
+        assert torch.equal(a.rewards, b.rewards) and torch.equal(a.actions, b.actions), t
+        assert np.array_equal(b.world.grid.cpu().numpy(), co.grid) and np.array_equal(b.rewards.cpu().numpy(), co.rewards), t
+        for k, (x, y) in enumerate(zip(a.agents, b.agents)):
+            mx, my = x.model.memory, y.model.memory
+            assert (mx.idx, mx.size) == (my.idx, my.size), (t, k)
+            for name in ("states", "actions", "rewards", "dones"):
+                assert torch.equal(getattr(mx, name), getattr(my, name)), (t, k, name)
+    a.raise_on_status()
+    b.raise_on_status()

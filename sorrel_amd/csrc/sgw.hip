@@ -296,8 +296,8 @@ using RowsFn = void (*)(const Params, const RowPtrs);
 #define PICK_SK(G_, OH, L_, C_, RULE_, R_, H_, W_, NAME)                          \
     do {                                                                          \
         *name = multi ? NAME " (turn loop)" : NAME;                               \
-        return multi ? reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, true>)) \
-                     : reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
+        return multi ? reinterpret_cast<const void*>(static_cast<RowsFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, true>)) \
+                     : reinterpret_cast<const void*>(static_cast<RowsFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
     } while (0)
 // (round 5) The library holds the turn-loop (sgw_rollout) instance of the packed / wave-per-env kernels for plain movers only, plus the Tag
 // example as shipped: every run-time-shape turn-loop instance of the Tag / Cleanup rules and every one of the workgroup-per-env form
@@ -306,7 +306,7 @@ using RowsFn = void (*)(const Params, const RowPtrs);
 #define PICK_SK1(G_, OH, L_, C_, RULE_, R_, H_, W_, NAME)                         \
     do {                                                                          \
         *name = multi ? "-" : NAME;                                               \
-        return multi ? nullptr : reinterpret_cast<const void*>(static_cast<StepFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
+        return multi ? nullptr : reinterpret_cast<const void*>(static_cast<RowsFn>(step_kernel<G_, OH, L_, C_, RULE_, R_, H_, W_, false>)); \
     } while (0)
 template <int G>
 const void* pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
@@ -345,15 +345,15 @@ const void* pick_step_g(bool onehot, int L, int C, int rule, int r, int H, int W
 const void* pick_step_many(bool onehot, int rule, bool multi, const char** name) {
     if (multi) return nullptr;
     if (rule == SGW_AGENT_RULE_CLEANUP) {
-        if (onehot) PICK(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_CLEANUP, 0, 0, 0, false, SGW_MAX_AGENTS>);
-        PICK(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_CLEANUP, 0, 0, 0, false, SGW_MAX_AGENTS>);
+        if (onehot) PICK2(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_CLEANUP, 0, 0, 0, false, SGW_MAX_AGENTS>);
+        PICK2(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_CLEANUP, 0, 0, 0, false, SGW_MAX_AGENTS>);
     }
     if (rule == SGW_AGENT_RULE_TAG) {
-        if (onehot) PICK(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_TAG, 0, 0, 0, false, SGW_MAX_AGENTS>);
-        PICK(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_TAG, 0, 0, 0, false, SGW_MAX_AGENTS>);
+        if (onehot) PICK2(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_TAG, 0, 0, 0, false, SGW_MAX_AGENTS>);
+        PICK2(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_TAG, 0, 0, 0, false, SGW_MAX_AGENTS>);
     }
-    if (onehot) PICK(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_MOVE, 0, 0, 0, false, SGW_MAX_AGENTS>);
-    PICK(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_MOVE, 0, 0, 0, false, SGW_MAX_AGENTS>);
+    if (onehot) PICK2(step_kernel<256, true, 0, 0, SGW_AGENT_RULE_MOVE, 0, 0, 0, false, SGW_MAX_AGENTS>);
+    PICK2(step_kernel<256, false, 0, 0, SGW_AGENT_RULE_MOVE, 0, 0, 0, false, SGW_MAX_AGENTS>);
 }
 const void* pick_step(const Options& o, int group, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, const char** name) {
     if (group == 16) return pick_step_g<16>(onehot, L, C, rule, r, H, W, multi, name);
@@ -531,7 +531,10 @@ std::string fast_id_like(const char* name, int L, int C, int r, int H, int W, in
     return fast_id(a[0] == "true", L, C, r, i16 ? 0 : H, i16 ? 0 : W, a[6] == "true", a[7] == "true", stage < 0 ? a[8] == "true" : stage != 0,
                    multi < 0 ? a[9] == "true" : multi != 0, a[10] == "true", i16);
 }
-std::string generic_id(int G, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, bool many = false) {
+std::string generic_id(int G, bool onehot, int L, int C, int rule, int r, int H, int W, bool multi, bool many = false, bool rows = false) {
+    if (rows)        // (the ROWS instance: every argument spelled)
+        return join_args("step_kernel", {std::to_string(G), tf(onehot), std::to_string(L), std::to_string(C), std::to_string(rule), std::to_string(r),
+                                         std::to_string(H), std::to_string(W), "false", std::to_string(many ? SGW_MAX_AGENTS : 64), "true"}, 11, "");
     if (many)        // (128-entry per-agent arrays: every argument spelled)
         return join_args("step_kernel", {std::to_string(G), tf(onehot), std::to_string(L), std::to_string(C), std::to_string(rule), std::to_string(r),
                                          std::to_string(H), std::to_string(W), tf(multi), std::to_string(SGW_MAX_AGENTS)}, 10, "");
@@ -955,6 +958,7 @@ int plan_engine(sgw_engine* e, bool jit) {
         if (jit) {
             e->k_step.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, false, many_agents);
             e->k_multi.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, true, many_agents);
+            e->k_sweep_rows.want = generic_id(e->group, e->onehot, L, C, c.agent_rule, r, H, W, false, many_agents, true);   // (round 6: the fused sweep + rows launch)
         }
     }
     if (!o.big_walk) e->k_walk = Kernel();   // A/B hook
@@ -1417,7 +1421,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
     // world whose (layers, channels, radius) has a phase_rows instance: a lane per window row, no staging, any world size.
     // (the phase kernels take the acting agent's action from the tensor: a phase whose action is drawn on the device -- SGW_STEP_RANDOM_ACTIONS,
     // an agent with a RandomModel among agents that step one by one -- stays on the step kernel, which draws it)
-    if (sweep_rows && !e->big) {
+    if (sweep_rows && e->fast) {
         if (p.obs_stage <= 0 || p.a0 != 0 || p.a1 != p.A || (p.flags & SGW_STEP_NO_OBS))      // (step_fast_rows has no other way to emit than its staged burst)
             return fail(SGW_EINVAL, "sgw_sweep_observe_rows: this engine does not stage its windows");
         if (e->sweep_rows_chunked) p.stage_agents = 1;                                           // (ROWX: a chunk = one agent = one row)
@@ -1462,7 +1466,7 @@ static int launch_step(sgw_engine* e, Params& p, hipStream_t s, RowPtrs* sweep_r
         k = &e->k_walk;
         blocks = e->walk_blocks;
     }
-    if (sweep_rows) k = &e->k_sweep_rows;     // (step_big<..., ROWS>: the plain single-turn variant with the row pointers as its second argument; `walk` is off above)
+    if (sweep_rows) k = &e->k_sweep_rows;     // (step_big<..., ROWS> / step_kernel<..., ROWS>: the plain single-turn variant with the row pointers as its second argument; `walk` is off above)
     if (int rc = launch_kernel(e, *k, (unsigned)blocks, e->big ? (p.nturns > 1 ? kBigThreads : e->big_threads) : kBlock, lds, s, p, sweep_rows)) return rc;
     return time_end(e, s);
 }
@@ -1599,7 +1603,7 @@ int sgw_capabilities(sgw_engine* e) {
     if (e->big) caps |= SGW_CAP_OBS_AGENT_MAJOR;
     // (round 6: also step_big<..., ROWS> and the chunk-staging twins, which write the bound row tail themselves; the whole-env instance has a TAIL twin)
     if (e->k_sweep_rows.usable() && e->obs_format == SGW_OBS_F32 &&
-        (e->tail_kind == SGW_TAIL_NONE || e->big || e->sweep_rows_chunked || e->k_sweep_rows_tail.jit)) caps |= SGW_CAP_SWEEP_ROWS;
+        (e->tail_kind == SGW_TAIL_NONE || !e->fast || e->sweep_rows_chunked || e->k_sweep_rows_tail.jit)) caps |= SGW_CAP_SWEEP_ROWS;
     return caps;
 }
 
@@ -2218,7 +2222,7 @@ int sgw_launch_info(sgw_engine* e, char* buf, int64_t capacity) {
                           : (k.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.host, threads, lds) : hipErrorInvalidValue);
     if (oe != hipSuccess) per_cu = -1;
     const char* phase = e->k_rows.usable() ? e->k_rows.name() : (e->phase_ok ? (e->onehot ? "phase_kernel<true>" : "phase_kernel<false>") : "the step kernel");
-    const char* srows = e->k_sweep_rows.usable() ? ((e->tail_kind != SGW_TAIL_NONE && !e->big && !e->sweep_rows_chunked && e->k_sweep_rows_tail.jit) ? e->k_sweep_rows_tail.name()
+    const char* srows = e->k_sweep_rows.usable() ? ((e->tail_kind != SGW_TAIL_NONE && e->fast && !e->sweep_rows_chunked && e->k_sweep_rows_tail.jit) ? e->k_sweep_rows_tail.name()
                                                                                                                                                    : e->k_sweep_rows.name()) : "-";   // what sgw_sweep_observe_rows launches
     snprintf(buf, (size_t)capacity, "%s group=%d threads=%d lds=%zu env_lds=%d obs_stage=%d stage_agents=%d grid=%d wg_per_cu=%d cap=%s%d phase=%s big_stage=%d specialised=%d sweep_rows=%s",
              k.name(),

@@ -24,9 +24,13 @@ __host__ __device__ constexpr int agent_lds_bytes(int cap) { return 10 * cap + 1
 // agents, 32 lanes per env, 54 -> 67 us; found in round 3 by bisecting tools/group_sweep.py).
 // AC: entries of the per-agent LDS arrays -- 64, or 128 for engines with more than 64 agents (round 6; workgroup-per-env instances only: a group of G < 256
 // threads holds at most G agents).  A compile-time constant: as a launch parameter it cost the small-world instances 2-4 VGPRs, three of them a wave of occupancy.
-template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0, bool MULTI = false, int AC = 64>
-__global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p) {
+// ROWS (round 6): the instance behind sgw_sweep_observe_rows on the worlds this kernel serves (small worlds packed two or four to a wave, rule worlds above 8 KiB,
+// more than 64 agents) -- agent a's window of env e goes to rp.p[a] + e * rp.stride, the bound row tail behind it; specialised in-process only.  Every instance
+// takes the row pointers as its second argument (read by ROWS instances only).
+template <int G, bool ONEHOT, int TL = 0, int TC = 0, int RULE = SGW_AGENT_RULE_MOVE, int TR = 0, int TH = 0, int TW = 0, bool MULTI = false, int AC = 64, bool ROWS = false>
+__global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const Params p, [[maybe_unused]] const RowPtrs rp) {
     static_assert(AC == 64 || (AC == SGW_MAX_AGENTS && G == 256), "more than 64 agents: the workgroup-per-env instances");
+    static_assert(!ROWS || !MULTI, "ROWS: a single-turn instance");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WPE = G <= kWave ? 1 : G / kWave;   // waves that must synchronise
     constexpr int EPB = kBlock / G;    // envs per workgroup
@@ -135,6 +139,17 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
             }
         }
 
+        // ROWS: what pov() appends behind the flattened window (phase.h, observe_rows: the same two kinds) -- by the `n` threads that render the window
+        [[maybe_unused]] auto row_tail = [&](float* row, const int a, const int y, const int x, const int me, const int n) {
+            if (p.tail_kind == SGW_TAIL_NONE) return;
+            float* t = row + (TC ? TC : p.C) * VV;
+            if (p.tail_kind == SGW_TAIL_AGENT_IS_IT) {
+                if (me == 0) t[0] = s_type[a] == p.tag_it ? 1.f : 0.f;
+            } else {
+                const float* src = p.tail_table + ((int64_t)y * W + x) * p.tail_len;
+                for (int k = me; k < p.tail_len; k += n) t[k] = src[k];
+            }
+        };
         const int a_end = (p.obs_next && p.a1 < p.A) ? p.a1 + 1 : p.a1;   // OBS_NEXT: one extra, observe-only iteration
         if constexpr (!kTicket) {
         // ---- a wave (or part of one) per env: the agents one after the other, the whole group on each
@@ -142,7 +157,13 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                 const int y = s_pos[2 * a], x = s_pos[2 * a + 1];
                 // ---- pov: egocentric window (visual_field.py:9-101)
                 if (p.obs_next ? a == p.a1 : write_obs) {
-                    float* obase = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
+                    float* obase;
+                    if constexpr (ROWS) {
+                        obase = static_cast<float*>(rp.p[a]) + env * rp.stride;
+                        row_tail(obase, a, y, x, gtid, G);
+                    } else {
+                        obase = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
+                    }
                     auto render = [&](const int w, const int i, const int j) {
                         const int gy = y - r + i, gx = x - r + j;
                         const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -348,7 +369,11 @@ __global__ __launch_bounds__(kBlock, SGW_GENERIC_WAVES) void step_kernel(const P
                     pend[npend++] = v;
                 };
                 const bool observe = p.obs_next ? a == p.a1 : write_obs;
-                float* const obase0 = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
+                float* obase0_;
+                if constexpr (ROWS) obase0_ = static_cast<float*>(rp.p[a]) + env * rp.stride;
+                else obase0_ = p.obs + tix * p.ts_obs + ((env * p.obs_A + (a - p.obs_a0)) * (int64_t)p.C) * VV;
+                float* const obase0 = obase0_;
+                if constexpr (ROWS) if (observe) row_tail(obase0, a, y, x, atid, GA);   // (nobody acts in a ROWS launch: the agent's type and cell are the turn's)
                 uint32_t clo[kMaxPass], chi[kMaxPass];      // G = 256: the captured window bytes (layers 0-3 | 4-6, five bits each)
                 bool cin[kMaxPass];
                 int coff[kMaxPass];

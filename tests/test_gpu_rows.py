@@ -57,6 +57,12 @@ def _cleanup():
     return _cleanup_spec()[0]
 
 
+def _big_cleanup():
+    ws = _cleanup()
+    ws.height, ws.width = 40, 44
+    return ws
+
+
 def _rule_world(seed, mode):
     rng = np.random.default_rng(seed)
     while True:
@@ -83,6 +89,11 @@ CASES = [
     ("tag_70x60_it_chunked", lambda: _tag(70, 60, 7, 4), 14, {"fast_8k": 1}, "step_fast_rowsx<", "it"),
     ("tag_13x12_prebuilt_has_none", lambda: _tag(13, 12, 4, 2), 9, {"group": 64, "jit": 0}, None, "it"),
     ("runtime_map_33x35_r3", lambda: _th(33, 35, 7, 3), 21, {"burst": 2}, "step_fast_rowsx<", None),
+    ("packed_tag_11x11_it", lambda: _tag(11, 11, 5, 4), 70, {"group": 32}, "step_kernel<32, true, 1, 4, 1, 4, 11, 11, false, 64, true>", "it"),      # two envs to a wave
+    ("packed_th_10x10_tail4", lambda: _th(10, 10, 2, 2), 133, {"group": 16}, "step_kernel<16, ", 4),                                              # four envs to a wave
+    ("generic_wave_per_env_18x14", lambda: _th(18, 14, 4, 3), 21, {"force_generic": 1}, "step_kernel<64, ", None),
+    ("ticket_kernel_80_agents_tail5", lambda: _th(40, 42, 80, 2), 9, {}, "step_kernel<256, ", 5),                                              # > 64 agents: 128-entry arrays
+    ("ticket_kernel_big_cleanup", lambda: _big_cleanup(), 7, {"fast_rules": 0}, "step_kernel<256, ", 12),
     ("chunked_20x20_r1_odd", lambda: _th(20, 20, 3, 1), 26, {}, "step_fast_rowsx<", 3),
 ]
 

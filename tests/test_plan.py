@@ -109,9 +109,9 @@ def _canonical(name: str, lanes: int):
     tmpl, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     rules = {"SGW_AGENT_RULE_MOVE": "0", "SGW_AGENT_RULE_TAG": "1", "SGW_AGENT_RULE_CLEANUP": "2", "SGW_MAX_AGENTS": str(__import__("sorrel_amd._native", fromlist=["x"]).MAX_AGENTS)}
     args = [rules.get(a, str(lanes) if a == "G" else a) for a in args]
-    # (round 6: step_big has a ninth argument -- ROWS --, step_kernel a tenth -- the capacity of its per-agent LDS arrays)
+    # (round 6: step_big has a ninth argument -- ROWS --, step_kernel a tenth -- the capacity of its per-agent LDS arrays -- and an eleventh -- ROWS)
     defaults = {"step_fast": ["?"] * 6 + ["false"] * 6, "step_big": ["?"] * 4 + ["false", "false", "false", "512", "false"],
-                "step_kernel": ["?", "?", "0", "0", "0", "0", "0", "0", "false", "64"]}.get(tmpl)
+                "step_kernel": ["?", "?", "0", "0", "0", "0", "0", "0", "false", "64", "false"]}.get(tmpl)
     if defaults:
         args += defaults[len(args):]
         if multi:

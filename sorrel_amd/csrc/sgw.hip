@@ -1849,8 +1849,8 @@ int sgw_turn_begin_rows(sgw_engine* e, uint8_t* grid, uint8_t* agent_pos, uint8_
     if (!(sgw_capabilities(e) & SGW_CAP_OBSERVE_ROWS)) return fail(SGW_EINVAL, "sgw_turn_begin_rows needs SGW_CAP_OBSERVE_ROWS (one-hot float32 windows); use sgw_turn_begin");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // both steps in one launch -- on the whole-env instance, whose emit also writes the recorded turn's second copy (the ring rows by the device's
-    // row count); step_big and the chunk-staging instances (round 6) render into the rows alone, so a recorded turn keeps the two launches there
-    if ((sgw_capabilities(e) & SGW_CAP_SWEEP_ROWS) && !e->big && !e->sweep_rows_chunked && e->tail_kind == SGW_TAIL_NONE &&
+    // row count); step_big, the chunk-staging and the generic instances (round 6) render into the rows alone, so a recorded turn keeps the two launches there
+    if ((sgw_capabilities(e) & SGW_CAP_SWEEP_ROWS) && e->fast && !e->sweep_rows_chunked && e->tail_kind == SGW_TAIL_NONE &&
         env_stride == (int64_t)e->base.C * e->base.VV) {
         RowPtrs rp;
         if (int rc = fill_rows(e, rows, env_stride, 0, e->cfg.num_agents, true, &rp, "sgw_turn_begin_rows")) return rc;

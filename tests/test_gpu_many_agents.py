@@ -244,3 +244,59 @@ def test_recorded_turn_with_72_agents_equals_the_eager_loop(torch_cuda, layout):
                 assert torch.equal(getattr(mx, name), getattr(my, name)), (t, k, name)
     a.raise_on_status()
     b.raise_on_status()
+
+
+@pytest.mark.parametrize("case", range(max(6, int(__import__("os").environ.get("SGW_SOAK", "0")) // 8)))
+def test_many_agents_soak_random_worlds(torch_cuda, case):
+    """Random worlds with 65 ... 128 agents -- Treasurehunt, Tag or Cleanup rules, map, radius, batch and global env ids drawn per case -- on the generic
+    workgroup-per-env kernel: reset, fused turns with device-drawn actions, a turn of sgw_act launches (windows at pov time), against the C oracle."""
+    torch = torch_cuda
+    from tests.gpu_common import _cleanup_spec
+
+    rng = np.random.default_rng(9000 + case)
+    kind = ("move", "tag", "cleanup")[case % 3]
+    A = int(rng.integers(65, 129))
+    side = int(np.ceil(np.sqrt(A * rng.uniform(1.3, 6.0)))) + 2
+    h, w = side + int(rng.integers(0, 9)), side + int(rng.integers(0, 9))
+    r = int(rng.integers(1, min(5, (min(h, w) - 1) // 2) + 1))
+    E, first = int(rng.integers(3, 14)), int(rng.integers(0, 5000))
+    if kind == "move":
+        ws = _th(h, w, A, r)
+    elif kind == "tag":
+        ws = _tag(h, w, A, r)
+    else:
+        ws, _d = _cleanup_spec()
+        ws.height, ws.width, ws.num_agents, ws.vision_radius, ws.agent_type = h, w, A, r, [ws.agent_type[0]] * A
+    eng, co = make_engine(ws, E, first=first), H.COracle(ws, E, first_env_id=first)
+    assert "step_kernel<256" in eng.launch_info(), eng.launch_info()
+    epoch = int(rng.integers(0, 4))
+    eng.reset(epoch=epoch)
+    co.reset(epoch)
+    if eng.agent_state is not None:
+        co.agent_state[...] = eng.agent_state.cpu().numpy()
+    if eng.agent_dir is not None:
+        co.agent_dir[...] = eng.agent_dir.cpu().numpy()
+    ctx = f"case {case}: {kind} {h}x{w} A={A} r={r} E={E}"
+    assert np.array_equal(eng.grid.cpu().numpy(), co.grid) and np.array_equal(eng.agent_pos.cpu().numpy(), co.pos), ctx + " reset"
+    for t in range(1, 4):
+        eng.step(random_actions=True, turn=t)
+        assert co.step(epoch, t, random_actions=True) == 0
+        assert_same(eng, co, ctx=ctx + f" fused turn {t}")
+    nact = len(ws.action_dy)
+    acts = rng.integers(0, nact, (E, A)).astype(np.uint8)
+    ta = torch.from_numpy(acts).cuda()
+    assert co.step(epoch, 4, actions=acts) == 0
+    rows = eng.window_rows(None)
+    eng.step(ta, sweep=True, no_move=True, turn=4)
+    seen = torch.zeros_like(eng.obs)
+    for a in range(A):
+        seen[:, a] = eng.obs[:, a]
+        eng.act(a, rows, action=ta[:, a].to(torch.int64).contiguous())
+    torch.cuda.synchronize()
+    assert np.array_equal(seen.cpu().numpy(), co.obs), ctx + " sgw_act turn: windows at pov time"
+    assert_same(eng, co, what=("grid", "pos", "rewards", "total"), ctx=ctx + " sgw_act turn")
+    if eng.agent_state is not None:
+        assert np.array_equal(eng.agent_state.cpu().numpy(), co.agent_state), ctx
+    if eng.agent_dir is not None:
+        assert np.array_equal(eng.agent_dir.cpu().numpy(), co.agent_dir), ctx
+    assert eng.status() == 0

@@ -55,16 +55,8 @@ if "--thresholds" in sys.argv:      # the dispatcher's choice against each force
     VARIANTS = [v for v in VARIANTS if v[0] in ("default dispatch", "walking", "plain direct, 4/CU", "plain staged, 4/CU")]
 
 
-if "--remap" in sys.argv:           # (the options big_remap / big_nt existed for this A/B in round 6 only: profiles/r06_c5_remap_ab.txt; a build without them rejects the keys)
-    pass
-if False and "--remap" in sys.argv:           # round 6: the XCD-contiguous env assignment (option big_remap) against workgroup b = env b, variant by variant
-    VARIANTS = [(n + (", remap" if r else ", b = env"), dict(o, big_remap=r)) for n, o in VARIANTS[:3] + VARIANTS[4:5] for r in (1, 0)]
-
-
-if False and "--nt" in sys.argv:              # round 6: the staged windows as ordinary instead of streaming stores
-    VARIANTS = [("default dispatch", {}), ("walking", dict(big_walk_blocks=-1)), ("plain staged, nt", dict(big_walk=0, big_stage=1, big_nt=1)),
-                ("plain staged, ordinary", dict(big_walk=0, big_stage=1, big_nt=0)), ("plain staged, ordinary, b = env", dict(big_walk=0, big_stage=1, big_nt=0, big_remap=0)),
-                ("plain staged, ordinary, 3/CU", dict(big_walk=0, big_stage=1, big_nt=0, big_wg_per_cu=3))]
+# (Round 6 ran two more A/Bs with this tool -- the XCD-contiguous env assignment and ordinary instead of streaming stores for the staged windows, through options
+#  `big_remap` / `big_nt` that existed for the measurement only: profiles/r06_c5_remap_ab.txt.)
 
 
 def main():

@@ -53,6 +53,8 @@ class GridEngine:
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._lib = N.load()
         self.uid = next(GridEngine._uids)        # names this engine in caches (id() values are reused once an object is gone)
+        if GridEngine._pending_closes and not torch.cuda.is_current_stream_capturing():
+            GridEngine.drain_pending_closes()    # (engines dropped inside an earlier capture: their handles are destroyed no later than here)
         E, A = self.num_envs, spec.num_agents
         dev = self.device
         tensors = tensors or {}

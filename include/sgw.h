@@ -255,9 +255,11 @@ int sgw_step(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* action
  * a policy-driven epoch loop resets with sgw_reset, as Environment.run_experiment does. */
 #define SGW_CAP_OBSERVE_ROWS 1
 #define SGW_CAP_ACT 2
-#define SGW_CAP_RESOLVE 4      /* sgw_turn_resolve (speculative policy turns): plain movers, impassable agent types, float32 windows */
+#define SGW_CAP_RESOLVE 4      /* sgw_turn_resolve (speculative policy turns): plain movers, impassable agent types, float32 windows, at most 64 agents
+                                * (any other rule set or agent count: sgw_verify_rows) */
 #define SGW_CAP_OBS_AGENT_MAJOR 8   /* sgw_step accepts SGW_STEP_OBS_AGENT_MAJOR */
-#define SGW_CAP_SWEEP_ROWS 16       /* sgw_sweep_observe_rows: steps 1 and 2 of the patched-window protocol in ONE launch */
+#define SGW_CAP_SWEEP_ROWS 16       /* sgw_sweep_observe_rows: steps 1 and 2 of the patched-window protocol in ONE launch (round 6: every kernel family where the
+                                     * in-process specialiser is available; without hipRTC the headline's prebuilt instance only) */
 #define SGW_ACT_U8 0
 #define SGW_ACT_I32 1
 #define SGW_ACT_I64 2
@@ -278,10 +280,12 @@ int sgw_observe_rows(sgw_engine* eng, const uint8_t* grid, const uint8_t* agent_
 int sgw_act(sgw_engine* eng, uint8_t* grid, uint8_t* agent_pos, uint8_t* actions, void* const* rows, int64_t env_stride,
             float* rewards, double* total_reward, int32_t agent, const void* agent_action, int32_t action_kind,
             float* reward_row, int64_t* action_row, void* stream);
-/* Steps 1 and 2 of that protocol in one launch (SGW_CAP_SWEEP_ROWS: plain movers, one-hot float32 windows, a world the wave-per-env
- * kernel holds with a compile-time shape -- the headline's among them): the entity sweep of Environment.take_turn
+/* Steps 1 and 2 of that protocol in one launch (SGW_CAP_SWEEP_ROWS; float32 windows): the entity sweep of Environment.take_turn
  * (sorrel/environment.py:84-90; flags = SGW_STEP_SWEEP, or 0 for none) and then EVERY agent's window of the grid after the sweep
- * (Agent.pov, sorrel/agents/agent.py:158) into rows[a] + env * env_stride, env_stride == C * V * V exactly (no row tail).  Same
+ * (Agent.pov, sorrel/agents/agent.py:158) into rows[a] + env * env_stride, env_stride == C * V * V + the bound row tail exactly; the tail
+ * (sgw_bind_row_tail: what TagAgent.pov / CleanupObservation.observe append) is written behind every window.  Round 5: the wave-per-env
+ * kernel's compile-time-shape instances of plain movers; round 6: every family -- step_big<..., ROWS>, the chunk-staging instances
+ * (step_fast_rowsx), the generic kernel (step_kernel<..., ROWS>), Tag's whole-env instances -- as instances of their own.  Same
  * results as sgw_step(SGW_STEP_SWEEP | SGW_STEP_NO_OBS, agents [0, 0)) followed by sgw_observe_rows; the grid is read once and the
  * windows leave as the step kernel's one burst per env (config 3 at 65 536 envs: 183 us in two launches). */
 int sgw_sweep_observe_rows(sgw_engine* eng, uint8_t* grid, const uint8_t* agent_pos, void* const* rows, int64_t env_stride,

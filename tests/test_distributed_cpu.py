@@ -69,3 +69,24 @@ def test_two_rank_sharding_equals_single_process():
     assert np.array_equal(metrics, ref)                         # integer rewards: exact in any order
     assert np.array_equal(total0, whole.total[: E // 2])        # rank 0's shard == first half of the batch
     assert np.array_equal(grid0, whole.grid[: E // 2])
+
+
+def test_bench_starts_its_own_ranks_before_touching_a_gpu():
+    """``python bench.py --gpus 2`` without a launcher's WORLD_SIZE (round 6): the parent starts ``torch.distributed.run`` with two ranks as a CHILD process and relays
+    its exit code -- here, without a GPU, every rank stops at "no HIP device" (rc 2), the launcher reports the failure and the parent hands it on.  The parent itself never
+    imports torch (nothing in it can touch a GPU): checked on the module."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    if torch.cuda.is_available():           # (on a GPU box this is the real two-rank run of the GPU tests; nothing to assert here)
+        return
+    assert out.returncode != 0
+    assert out.stderr.count("no HIP device") >= 2, out.stderr[-1500:]          # both ranks were started, and each said why it stopped
+    src = open(os.path.join(root, "bench.py")).read()
+    head = src[src.index("def launch_ranks"):src.index("def series_stats")]
+    import re
+    assert not re.search(r"^\s*(import|from)\s+torch", head, re.M) and "os.exec" not in head and "execv" not in head
